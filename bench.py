@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py — million rays/s of the batched lidar scan on MI355X, with roofline and CPU baseline.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 launched under
+``torch.distributed.run`` with one rank per GPU (RCCL).  Prints ONE JSON line on rank 0.
+
+A "step" is one pass of the hot path over one synthetic pose batch: the fan-expanding ray
+march of ``n_poses x num_rays`` rays (ScanSimulator2D.scanMany -> calc_range_many,
+/root/reference/scripts/scan_simulator.py:113-135) with poses and ranges resident in HBM.
+For N>1 every rank scans its own ``n_poses`` block (weak scaling) and the ranges are
+all-gathered over xGMI, chunk-overlapped with the march (BASELINE.json north_star).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2",
+                    help="cfg2 (default: 2049^2 maze, 4096x1081, RMGPU) | cfg3 | cfg4 | cfg5")
+    ap.add_argument("--poses", type=int, default=0, help="poses per GPU (0 = workload default)")
+    ap.add_argument("--method", default="", help="override: RM | RMGPU | BL | CDDT | GLT")
+    ap.add_argument("--chunks", type=int, default=4, help="all-gather overlap chunks (N>1)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the range all-gather")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
+    return ap.parse_args()
+
+
+def make_method(range_libc, omap, w, method):
+    if method == "RM":
+        return range_libc.PyRayMarching(omap, w.max_range_px)
+    if method == "RMGPU":
+        return range_libc.PyRayMarchingGPU(omap, w.max_range_px)
+    if method == "BL":
+        return range_libc.PyBresenhamsLine(omap, w.max_range_px)
+    if method == "CDDT":
+        return range_libc.PyCDDTCast(omap, w.max_range_px, w.theta_disc or 108)
+    if method == "GLT":
+        return range_libc.PyGiantLUTCast(omap, w.max_range_px, w.theta_disc or 1442)
+    raise SystemExit("unknown method %r" % method)
+
+
+def algorithmic_bytes_per_ray(method, mean_steps, num_rays, w):
+    """bytes a ray must move, per kernel family."""
+    pose = 12.0 / num_rays
+    if method in ("RM", "RMGPU"):
+        return mean_steps * 4.0 + 4.0 + pose            # S̄ EDT samples (f32) + range out + pose
+    if method == "BL":
+        win = 2 * w.max_range_px + 1
+        return (win * win / 8.0) / num_rays + 4.0 + pose  # bit-packed window per pose + out
+    if method == "GLT":
+        return 2.0 + 4.0 + pose                          # one u16 entry + range out
+    if method == "CDDT":
+        return 4.0 * max(1.0, mean_steps) + 8.0 + 4.0 + pose
+    return 4.0 + pose
+
+
+def cpu_baseline(w, gmap, poses_all, method, seconds):
+    """Oracle (kind "port": range_libc's CPU classes are absent from the reference mount) timed
+    on this host's cores over a bounded sample of the same poses."""
+    from oracle import oracle as O
+    om = O.OracleMap.from_gridmap(gmap, w.max_range_px)
+    _ = om.dt
+    nthr = O.max_threads()
+    step = 1.0 if method == "RMGPU" else 0.999
+    B = w.num_rays
+
+    def run(poses, nt):
+        t = time.perf_counter()
+        if method == "BL":
+            om.bl_fan(poses, w.fov, B, nthreads=nt)
+        else:
+            om.rm_fan(poses, w.fov, B, step_coeff=step, nthreads=nt, want_hits=False,
+                      want_steps=False)
+        return time.perf_counter() - t
+
+    # 1 thread: faithful to range_libc's serial loop; bounded sample
+    n1 = min(len(poses_all), 512)
+    run(poses_all[:64], 1)
+    t1 = run(poses_all[:n1], 1)
+    rate1 = n1 * B / t1
+    # all cores: repeat the whole batch until ~seconds elapsed (threads ramp up slowly in VMs)
+    reps, tot, t_all = 0, 0, 0.0
+    run(poses_all, nthr)
+    while t_all < seconds and reps < 200:
+        t_all += run(poses_all, nthr)
+        tot += len(poses_all) * B
+        reps += 1
+    rate = tot / t_all
+    name = "BresenhamsLine" if method == "BL" else "RayMarching"
+    return {"value": round(rate / 1e6, 3), "unit": "Mrays/s", "cores": nthr, "kind": "port",
+            "sample": "%s oracle (oracle/rangelib_oracle.c, OpenMP over poses), %d x (%d poses x %d "
+                      "beams) of the same workload in %.1f s" % (name, reps, len(poses_all), B, t_all),
+            "single_thread_Mrays_s": round(rate1 / 1e6, 3),
+            "single_thread_sample": "%d poses x %d beams" % (n1, B)}
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...")
+
+    import torch
+    import torch.distributed as dist
+    from pyracecarsimulator_amd import range_libc, workloads
+    from pyracecarsimulator_amd.distributed import ShardedScan, broadcast_map
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w = workloads.CONFIGS[a.workload]()
+    if a.poses:
+        w.n_poses = a.poses
+    method = a.method or w.method
+    B = w.num_rays
+
+    # map: built on rank 0, broadcast over RCCL (north_star), tables built per GPU
+    gmap = w.gmap
+    if world > 1:
+        gmap = broadcast_map(w.gmap if rank == 0 else None, 0, dev)
+    omap = range_libc.PyOMap(gmap, device=local_rank)
+    meth = make_method(range_libc, omap, w, method)
+    if a.variant >= 0:
+        meth.set_option("variant", a.variant)
+    if w.noise_std > 0:
+        meth.set_noise(w.noise_std, w.noise_seed, rank * w.n_poses * B)
+
+    # poses: one seeded global batch of world*n_poses, rank r takes block r (weak scaling)
+    dt = omap.distance_transform()
+    w_global = workloads.Workload(**{**w.__dict__, "n_poses": w.n_poses * world})
+    poses_all = workloads.make_poses(w_global, dt=dt)
+    lo, hi = workloads.shard_range(len(poses_all), rank, world)
+    poses = np.ascontiguousarray(poses_all[lo:hi])
+    d_poses = torch.from_numpy(poses).to(dev)
+    n = len(poses)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    scan = ShardedScan(n, B, dev, n_chunks=a.chunks, gather=not a.no_gather)
+
+    def compute(clo, chi, view):
+        meth.calc_range_fan_device(d_poses.data_ptr() + clo * 12, chi - clo, w.fov, B,
+                                   view.data_ptr(), stream=stream)
+
+    # untimed diagnostics launch: mean samples per ray (feeds the algorithmic-bytes figure)
+    mean_steps = 0.0
+    if method in ("RM", "RMGPU", "BL"):
+        d_steps = torch.empty(n * B, dtype=torch.int16, device=dev)
+        meth.calc_range_fan_device(d_poses.data_ptr(), n, w.fov, B, scan.local.data_ptr(),
+                                   d_steps_ptr=d_steps.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        mean_steps = float(d_steps.to(torch.int32).bitwise_and(0xFFFF).float().mean().item())
+        del d_steps
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        scan.step(compute)
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()
+        scan.step(compute)
+        ev[i][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    rays_per_step = n * B * world
+    value = rays_per_step * a.steps / elapsed / 1e6
+    # dominant kernel: average launch duration from HIP events on the launch stream
+    k_ms = float(np.mean(dev_ms))
+    bpr = algorithmic_bytes_per_ray(method, mean_steps, B, w)
+    achieved = bpr * n * B / (k_ms * 1e-3) / 1e9 if world == 1 else None
+
+    out = {
+        "metric": "million rays/sec, 1081-beam scans" if B == 1081 else
+                  "million rays/sec, %d-beam scans" % B,
+        "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seeded maze + seeded free-space poses; maps/map.pgm is missing from "
+                "the reference mount)" if "maze" in gmap.name else "reference map fixture + "
+                "seeded poses",
+        "config": {"workload": w.describe(), "method": method, "poses_per_gpu": n,
+                   "global_poses": n * world, "num_rays": B, "fov": w.fov,
+                   "max_range_px": w.max_range_px, "map": "%dx%d" % (gmap.rows, gmap.cols),
+                   "parallelism": "pose-batch dp%d" % world,
+                   "gather": "none" if (world == 1 or a.no_gather) else
+                             "all-gather ranges, %d overlap chunks" % len(scan.chunks)},
+        "kernel_ms_avg": round(k_ms, 4), "kernel_ms_min": round(float(np.min(dev_ms)), 4),
+        "mean_samples_per_ray": round(mean_steps, 3),
+    }
+    if world == 1:
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                           "traffic": _pmc_traffic(a.workload, method),
+                           "bytes_per_ray": round(bpr, 3),
+                           "kernel": "rm_fan_kernel" if method in ("RM", "RMGPU") else method}
+        if rank == 0 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, gmap, poses_all, method, a.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(workload, method):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*.json), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("%s/%s" % (workload, method))
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+/*
+ * scanlib.h — C ABI of libscan_amd.so: the MI355X (gfx950) 2D lidar range library.
+ *
+ * Drop-in boundary for the ONE hot path of felrock/PyRacecarSimulator:
+ *   ScanSimulator2D.scan / scanMany            scripts/scan_simulator.py:88-135
+ *     -> range_libc.PyOMap / PyRayMarching / PyRayMarchingGPU / PyCDDTCast
+ *        .calc_range_many(...)                  scripts/scan_simulator.py:72-76,103-106,130-133
+ *                                               scripts/two_player/scan.py:45-46,69-70
+ * range_libc is a Cython module; its FFI for this path is "float32 C-contiguous
+ * numpy buffers + scalars" (SURVEY.md §8b).  Every entry point below is what a
+ * ctypes / Cython stub for that path binds (INTEGRATION.md shows the stubs).
+ *
+ * Rules of the boundary
+ *   - plain pointers and sizes only; no C++/torch types; nothing throws across it;
+ *   - every function returns RL_OK (0) or a negative rl_status; rl_last_error()
+ *     gives the thread-local message of the last failure;
+ *   - host-pointer entry points are synchronous (results are in the caller's buffer
+ *     on return) and never retain the pointers; *_device entry points take device
+ *     pointers + a hipStream_t (as void*) and only enqueue work;
+ *   - there is NO CPU fallback: without a usable HIP device rl_map_create fails.
+ *   - a handle may be shared by threads (each call locks the handle), as the
+ *     reference's rospy callbacks do (scripts/ros_interface.py:115,142,189).
+ *
+ * Coordinates: occ[r*cols + c], r = row = world y, c = col = world x, row 0 at the
+ * smallest world y (the layout of nav_msgs/OccupancyGrid.data that PyOMap reads).
+ */
+#ifndef SCANLIB_H
+#define SCANLIB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rl_map rl_map;        /* replaces range_libc.PyOMap                */
+typedef struct rl_method rl_method;  /* replaces range_libc.Py<RangeMethod>       */
+
+typedef enum rl_status {
+    RL_OK = 0,
+    RL_ERR_INVALID = -1,     /* bad argument (null pointer, size, kind, ...)      */
+    RL_ERR_NO_DEVICE = -2,   /* no HIP device / device index out of range         */
+    RL_ERR_HIP = -3,         /* a HIP runtime call failed (message has details)   */
+    RL_ERR_UNSUPPORTED = -4, /* e.g. num_rays larger than the kernel's LDS fan    */
+    RL_ERR_NOMEM = -5
+} rl_status;
+
+/* Range methods.  Names follow range_libc's classes. */
+typedef enum rl_kind {
+    RL_BRESENHAM = 0,   /* BresenhamsLine: LDS-tiled bit-packed occupancy march (K2)   */
+    RL_RM = 1,          /* PyRayMarching    scan_simulator.py:72-73  step_coeff 0.999  */
+    RL_RM_GPU = 2,      /* PyRayMarchingGPU scan_simulator.py:74-76  step_coeff 1.0    */
+    RL_CDDT = 3,        /* PyCDDTCast       two_player/scan.py:46                      */
+    RL_GIANT_LUT = 4    /* GiantLUTCast: u16 [row][col][theta] table, fan-contiguous   */
+} rl_kind;
+
+/* ---- library -------------------------------------------------------------- */
+const char *rl_version(void);
+const char *rl_last_error(void);          /* thread-local, never NULL              */
+int rl_device_count(void);                /* 0 when no HIP device is usable        */
+
+/* ---- map: range_libc.PyOMap(map_msg)  scripts/ros_interface.py:210 ----------
+ * occ: rows*cols bytes, nonzero = occupied (the reference feeds {0,255} after its
+ * binarisation, scripts/ros_interface.py:80-86; PyOMap tests data > 10).
+ * res/ox/oy/oyaw: map_msg.info.resolution / origin position / yaw
+ * (scripts/ros_interface.py:212-220).  The exact Euclidean distance transform
+ * (range_libc DistanceTransform) is built on the device at creation.           */
+int rl_map_create(const uint8_t *occ, int rows, int cols, float res, float ox, float oy,
+                  float oyaw, int device, rl_map **out);
+/* replace the occupancy (same shape) and rebuild the distance transform: the
+ * per-scan rebuild of scripts/two_player/rcs_two_player.py:110-121 and the
+ * updateMap stub of scripts/scan_simulator.py:81-86.  Methods created from the
+ * map see the new data (CDDT / GiantLUT tables are rebuilt lazily).            */
+int rl_map_update(rl_map *m, const uint8_t *occ);
+void rl_map_destroy(rl_map *m);
+int rl_map_rows(const rl_map *m);
+int rl_map_cols(const rl_map *m);
+int rl_map_device(const rl_map *m);
+/* test hooks: copy the device-built tables back (float32 rows*cols / u8 rows*cols) */
+int rl_map_get_dt(rl_map *m, float *dt_out);
+int rl_map_get_occ(rl_map *m, uint8_t *occ_out);
+
+/* ---- method: range_libc.PyRayMarching(omap, mrx) etc. -----------------------
+ * max_range_px: scripts/racecar_simulator_v2.py:196 (int(scan_max_range/res));
+ * theta_disc: only for RL_CDDT / RL_GIANT_LUT (two_player/rcs_two_player.py:121). */
+int rl_method_create(rl_map *m, int kind, float max_range_px, int theta_disc, rl_method **out);
+void rl_method_destroy(rl_method *h);
+int rl_method_kind(const rl_method *h);
+
+/* upstream 2-arg calc_range_many(ins, outs): one (x, y, theta) world row per ray.
+ * scripts/two_player/scan.py:69-70.  ins: n*3 floats, outs: n floats (metres).  */
+int rl_calc_range_many(rl_method *h, const float *ins_n3, float *outs_n, int n);
+
+/* the fork's 4-arg calc_range_many(ins, outs, fov, num_rays) exactly as the
+ * reference calls it (scripts/scan_simulator.py:103-106,130-133): ins has n_rows =
+ * n_poses*num_rays rows of 3 floats, pose p lives in row p*num_rays (all other rows
+ * are ignored), beam j of pose p is cast at theta_p - fov/2 + j*fov/num_rays and
+ * written to outs[p*num_rays + j] (layout consumed by racecar/src/racecar.cpp:320).
+ * Only the n_poses live rows cross PCIe.                                         */
+int rl_calc_range_many_fan(rl_method *h, const float *ins_rows3, float *outs, int n_rows,
+                           float fov, int num_rays);
+
+/* dense form of the same call: poses[p*3..] -> outs[p*num_rays + j].
+ * hit_cells (2 ints per ray: col,row or -1,-1) and steps (samples per ray) are
+ * optional diagnostics for RL_RM / RL_RM_GPU / RL_BRESENHAM; pass NULL otherwise. */
+int rl_calc_range_fan(rl_method *h, const float *poses_p3, int n_poses, float fov, int num_rays,
+                      float *outs, int32_t *hit_cells_or_null, uint16_t *steps_or_null);
+
+/* device-resident, asynchronous forms (pointers are device memory on the map's
+ * device, stream is a hipStream_t or NULL for the default stream).               */
+int rl_calc_range_fan_device(rl_method *h, const float *d_poses_p3, int n_poses, float fov,
+                             int num_rays, float *d_outs, int32_t *d_hit_cells_or_null,
+                             uint16_t *d_steps_or_null, void *hip_stream);
+int rl_calc_range_many_device(rl_method *h, const float *d_ins_n3, float *d_outs_n, int n,
+                              void *hip_stream);
+
+/* Gaussian range noise (scripts/scan_simulator.py:33,109; scan_std params.yaml:32):
+ * out += N(0, std) from a counter-based generator keyed by (seed, global ray id +
+ * ray_offset) so a sharded batch reproduces the unsharded one.  std <= 0 disables. */
+int rl_set_noise(rl_method *h, float std, uint64_t seed, uint64_t ray_offset);
+
+/* Fused crash test (Car::isCrashed racecar/src/racecar.cpp:305-328 over the output
+ * of scanMany, scripts/racecar_simulator_v2.py:146-167): scans n_poses poses and
+ * returns in *first_crashed the index of the first pose with any beam j where
+ * (double)range - edge[j] < crash_thresh, else -(n_poses+1).  ranges_or_null gets
+ * the ranges too when non-NULL.  edge: num_rays doubles (setCarEdgeDistances).     */
+int rl_check_collision_many(rl_method *h, const float *poses_p3, int n_poses, float fov,
+                            int num_rays, const double *edge, double crash_thresh,
+                            int *first_crashed, float *ranges_or_null);
+
+/* device time of the last enqueued launch sequence of this handle, from HIP events
+ * recorded on the launch stream (blocks until that work has finished).            */
+int rl_last_kernel_ms(rl_method *h, float *ms_out);
+
+/* tuning / diagnostics: integer options by name ("variant", "grid_mult", ...)     */
+int rl_method_set_option(rl_method *h, const char *name, int value);
+int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCANLIB_H */

@@ -1,0 +1,256 @@
+"""ctypes binding of oracle/librangelib_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED (see rangelib_oracle.h): range_libc is absent from the reference
+mount and the reference has no golden vectors for this path; this oracle is a
+restatement of range_libc's published algorithm anchored on the reference's call
+sites (scripts/scan_simulator.py:72-76,103-106,130-133).
+
+The library is built by ``make -C oracle`` (also done by __graft_entry__.build()).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_u16p = C.POINTER(C.c_uint16)
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_f64p = C.POINTER(C.c_double)
+
+
+class _OrcMap(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("occ", _u8p), ("res", C.c_float),
+                ("ox", C.c_float), ("oy", C.c_float), ("wa_cos", C.c_float),
+                ("wa_sin", C.c_float), ("wa", C.c_float), ("inv_res", C.c_float)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "librangelib_oracle.so")
+    src = os.path.join(_HERE, "rangelib_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "librangelib_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_map_init.argtypes = [C.POINTER(_OrcMap), _u8p, C.c_int, C.c_int, C.c_float,
+                                   C.c_float, C.c_float, C.c_float]
+        L.orc_sincosf.argtypes = [C.c_float, _f32p, _f32p]
+        L.orc_edt.argtypes = [_u8p, C.c_int, C.c_int, _f32p]
+        L.orc_edt_sq.argtypes = [_u8p, C.c_int, C.c_int, _u32p]
+        mp = C.POINTER(_OrcMap)
+        L.orc_rm_fan.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, C.c_float,
+                                 C.c_int, _f32p, _i32p, _u16p, C.c_int]
+        L.orc_rm_rays.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, _f32p, _i32p,
+                                  _u16p, C.c_int]
+        L.orc_rm_rays_libm.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, _f32p]
+        L.orc_bl_fan.argtypes = [mp, C.c_float, _f32p, C.c_int, C.c_float, C.c_int, _f32p, _i32p,
+                                 _u16p, C.c_int]
+        L.orc_bl_rays.argtypes = [mp, C.c_float, _f32p, C.c_int, _f32p, _i32p, _u16p, C.c_int]
+        L.orc_lut_build.argtypes = [mp, _f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                    _u16p, C.c_int]
+        L.orc_lut_fan.argtypes = [mp, _u16p, C.c_int, C.c_float, _f32p, C.c_int, C.c_float,
+                                  C.c_int, _f32p, C.c_int]
+        L.orc_lut_rays.argtypes = [mp, _u16p, C.c_int, C.c_float, _f32p, C.c_int, _f32p, C.c_int]
+        L.orc_cddt_build.argtypes = [mp, C.c_int]
+        L.orc_cddt_build.restype = C.c_void_p
+        L.orc_cddt_free.argtypes = [C.c_void_p]
+        L.orc_cddt_fan.argtypes = [mp, C.c_void_p, C.c_float, _f32p, C.c_int, C.c_float, C.c_int,
+                                   _f32p, C.c_int]
+        L.orc_cddt_rays.argtypes = [mp, C.c_void_p, C.c_float, _f32p, C.c_int, _f32p, C.c_int]
+        L.orc_edge_distances.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, _f64p]
+        L.orc_is_crashed.argtypes = [_f32p, C.c_int, C.c_int, _f64p, C.c_double]
+        L.orc_is_crashed.restype = C.c_int
+        L.orc_max_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def sincosf(x):
+    """Vector wrapper around orc_sincosf -> (sin, cos) float32 arrays."""
+    x = np.atleast_1d(np.asarray(x, dtype=np.float32))
+    s = np.empty_like(x)
+    c = np.empty_like(x)
+    L = lib()
+    sv, cv = C.c_float(), C.c_float()
+    for i, v in enumerate(x):
+        L.orc_sincosf(C.c_float(float(v)), C.byref(sv), C.byref(cv))
+        s[i], c[i] = sv.value, cv.value
+    return s, c
+
+
+def edt(occ):
+    occ = np.ascontiguousarray(occ, dtype=np.uint8)
+    out = np.empty(occ.shape, dtype=np.float32)
+    lib().orc_edt(_p(occ, _u8p), occ.shape[0], occ.shape[1], _p(out, _f32p))
+    return out
+
+
+def edt_sq(occ):
+    occ = np.ascontiguousarray(occ, dtype=np.uint8)
+    out = np.empty(occ.shape, dtype=np.uint32)
+    lib().orc_edt_sq(_p(occ, _u8p), occ.shape[0], occ.shape[1], _p(out, _u32p))
+    return out
+
+
+class OracleMap:
+    """OMap + DistanceTransform + every CPU caster of the oracle on one grid."""
+
+    def __init__(self, occ, resolution, origin, max_range_px):
+        self.occ = np.ascontiguousarray(occ, dtype=np.uint8)
+        self.rows, self.cols = self.occ.shape
+        self.max_range_px = float(max_range_px)
+        self.resolution = float(resolution)
+        self._m = _OrcMap()
+        lib().orc_map_init(C.byref(self._m), _p(self.occ, _u8p), self.rows, self.cols,
+                           float(resolution), float(origin[0]), float(origin[1]), float(origin[2]))
+        self._dt = None
+        self._cddt = {}
+
+    @classmethod
+    def from_gridmap(cls, g, max_range_px):
+        return cls(g.occ, g.resolution, g.origin, max_range_px)
+
+    @property
+    def dt(self):
+        if self._dt is None:
+            self._dt = edt(self.occ)
+        return self._dt
+
+    def __del__(self):
+        for h in getattr(self, "_cddt", {}).values():
+            lib().orc_cddt_free(h)
+
+    # -- RayMarching -------------------------------------------------------
+    def rm_fan(self, poses, fov, num_rays, step_coeff=0.999, nthreads=1, want_hits=True,
+               want_steps=True):
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        n = poses.shape[0] * num_rays
+        ranges = np.empty(n, dtype=np.float32)
+        hits = np.empty((n, 2), dtype=np.int32) if want_hits else None
+        steps = np.empty(n, dtype=np.uint16) if want_steps else None
+        lib().orc_rm_fan(C.byref(self._m), _p(self.dt, _f32p), self.max_range_px, step_coeff,
+                         _p(poses, _f32p), poses.shape[0], fov, num_rays, _p(ranges, _f32p),
+                         _p(hits, _i32p), _p(steps, _u16p), nthreads)
+        return ranges, hits, steps
+
+    def rm_rays(self, ins, step_coeff=0.999, nthreads=1):
+        ins = np.ascontiguousarray(ins, dtype=np.float32).reshape(-1, 3)
+        n = ins.shape[0]
+        ranges = np.empty(n, dtype=np.float32)
+        hits = np.empty((n, 2), dtype=np.int32)
+        steps = np.empty(n, dtype=np.uint16)
+        lib().orc_rm_rays(C.byref(self._m), _p(self.dt, _f32p), self.max_range_px, step_coeff,
+                          _p(ins, _f32p), n, _p(ranges, _f32p), _p(hits, _i32p), _p(steps, _u16p),
+                          nthreads)
+        return ranges, hits, steps
+
+    def rm_rays_libm(self, ins, step_coeff=0.999):
+        ins = np.ascontiguousarray(ins, dtype=np.float32).reshape(-1, 3)
+        ranges = np.empty(ins.shape[0], dtype=np.float32)
+        lib().orc_rm_rays_libm(C.byref(self._m), _p(self.dt, _f32p), self.max_range_px, step_coeff,
+                               _p(ins, _f32p), ins.shape[0], _p(ranges, _f32p))
+        return ranges
+
+    # -- BresenhamsLine ----------------------------------------------------
+    def bl_fan(self, poses, fov, num_rays, nthreads=1):
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        n = poses.shape[0] * num_rays
+        ranges = np.empty(n, dtype=np.float32)
+        hits = np.empty((n, 2), dtype=np.int32)
+        steps = np.empty(n, dtype=np.uint16)
+        lib().orc_bl_fan(C.byref(self._m), self.max_range_px, _p(poses, _f32p), poses.shape[0],
+                         fov, num_rays, _p(ranges, _f32p), _p(hits, _i32p), _p(steps, _u16p),
+                         nthreads)
+        return ranges, hits, steps
+
+    def bl_rays(self, ins, nthreads=1):
+        ins = np.ascontiguousarray(ins, dtype=np.float32).reshape(-1, 3)
+        n = ins.shape[0]
+        ranges = np.empty(n, dtype=np.float32)
+        hits = np.empty((n, 2), dtype=np.int32)
+        steps = np.empty(n, dtype=np.uint16)
+        lib().orc_bl_rays(C.byref(self._m), self.max_range_px, _p(ins, _f32p), n,
+                          _p(ranges, _f32p), _p(hits, _i32p), _p(steps, _u16p), nthreads)
+        return ranges, hits, steps
+
+    # -- GiantLUT ------------------------------------------------------------
+    def lut_build(self, theta_disc, r0=0, r1=None, step_coeff=0.999, nthreads=0):
+        r1 = self.rows if r1 is None else r1
+        lut = np.empty((r1 - r0, self.cols, theta_disc), dtype=np.uint16)
+        lib().orc_lut_build(C.byref(self._m), _p(self.dt, _f32p), self.max_range_px, step_coeff,
+                            theta_disc, r0, r1, _p(lut, _u16p),
+                            nthreads or lib().orc_max_threads())
+        return lut
+
+    def lut_fan(self, lut, poses, fov, num_rays, nthreads=1):
+        """``lut`` must cover every row (r0=0, r1=rows)."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        ranges = np.empty(poses.shape[0] * num_rays, dtype=np.float32)
+        lib().orc_lut_fan(C.byref(self._m), _p(lut, _u16p), lut.shape[2], self.max_range_px,
+                          _p(poses, _f32p), poses.shape[0], fov, num_rays, _p(ranges, _f32p),
+                          nthreads)
+        return ranges
+
+    def lut_rays(self, lut, ins, nthreads=1):
+        ins = np.ascontiguousarray(ins, dtype=np.float32).reshape(-1, 3)
+        ranges = np.empty(ins.shape[0], dtype=np.float32)
+        lib().orc_lut_rays(C.byref(self._m), _p(lut, _u16p), lut.shape[2], self.max_range_px,
+                           _p(ins, _f32p), ins.shape[0], _p(ranges, _f32p), nthreads)
+        return ranges
+
+    # -- CDDT ------------------------------------------------------------------
+    def _cddt_handle(self, theta_disc):
+        if theta_disc not in self._cddt:
+            self._cddt[theta_disc] = lib().orc_cddt_build(C.byref(self._m), theta_disc)
+        return self._cddt[theta_disc]
+
+    def cddt_fan(self, theta_disc, poses, fov, num_rays, nthreads=1):
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        ranges = np.empty(poses.shape[0] * num_rays, dtype=np.float32)
+        lib().orc_cddt_fan(C.byref(self._m), self._cddt_handle(theta_disc), self.max_range_px,
+                           _p(poses, _f32p), poses.shape[0], fov, num_rays, _p(ranges, _f32p),
+                           nthreads)
+        return ranges
+
+    def cddt_rays(self, theta_disc, ins, nthreads=1):
+        ins = np.ascontiguousarray(ins, dtype=np.float32).reshape(-1, 3)
+        ranges = np.empty(ins.shape[0], dtype=np.float32)
+        lib().orc_cddt_rays(C.byref(self._m), self._cddt_handle(theta_disc), self.max_range_px,
+                            _p(ins, _f32p), ins.shape[0], _p(ranges, _f32p), nthreads)
+        return ranges
+
+
+def edge_distances(num_rays, min_ang, inc, scan_dist_to_base, width, wheelbase):
+    out = np.empty(num_rays, dtype=np.float64)
+    lib().orc_edge_distances(num_rays, min_ang, inc, scan_dist_to_base, width, wheelbase,
+                             _p(out, _f64p))
+    return out
+
+
+def is_crashed(rays, num_rays, poses, edge, crash_thresh):
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    edge = np.ascontiguousarray(edge, dtype=np.float64)
+    return int(lib().orc_is_crashed(_p(rays, _f32p), num_rays, poses, _p(edge, _f64p),
+                                    crash_thresh))
+
+
+def max_threads():
+    return int(lib().orc_max_threads())

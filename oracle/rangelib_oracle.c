@@ -1,0 +1,708 @@
+/*
+ * rangelib_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ * See rangelib_oracle.h for scope, the "PARITY UNPINNED" statement and the
+ * list of reference call sites this restatement is anchored on.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile).
+ * Every float32 operation whose result feeds a truncation is written as an
+ * explicit single IEEE operation or an explicit fmaf(), so that a GPU
+ * restatement can be bit-identical.
+ */
+#define _GNU_SOURCE
+#include "rangelib_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------ */
+/* deterministic sin/cos: SURVEY.md Appendix A "dir: canonical form"          */
+/* ------------------------------------------------------------------------ */
+void orc_sincosf(float x, float *s, float *c)
+{
+    /* k = nearest multiple of pi/2 (round-half-even), 3-term Cody-Waite */
+    const float TWO_OVER_PI = 0x1.45f306p-1f;          /* 0.63661975 */
+    const float P1 = 0x1.921fb6p+0f;                   /* float(pi/2)            */
+    const float P2 = -0x1.777a5cp-25f;                 /* float(pi/2 - P1)       */
+    const float P3 = -0x1.ee59dap-50f;                 /* float(pi/2 - P1 - P2)  */
+    float k = rintf(x * TWO_OVER_PI);
+    float r = fmaf(-k, P1, x);
+    r = fmaf(-k, P2, r);
+    r = fmaf(-k, P3, r);
+    float z = r * r;
+    /* sin(r), |r| <= pi/4 */
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(z, ps, -1.6666654611e-1f);
+    float sr = fmaf(r * z, ps, r);
+    /* cos(r) */
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(z, pc, 4.166664568298827e-2f);
+    float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    int q = ((int)k) & 3;
+    float ss = (q & 1) ? cr : sr;
+    float cc = (q & 1) ? sr : cr;
+    if (q == 1 || q == 2) cc = -cc;
+    if (q >= 2) ss = -ss;
+    *s = ss;
+    *c = cc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* OMap + world->grid  (rows a6, a9)                                          */
+/* ------------------------------------------------------------------------ */
+void orc_map_init(orc_map *m, const uint8_t *occ, int rows, int cols,
+                  float res, float ox, float oy, float oyaw)
+{
+    m->rows = rows;
+    m->cols = cols;
+    m->occ = occ;
+    m->res = res;
+    m->ox = ox;
+    m->oy = oy;
+    m->wa = -oyaw;                       /* PyOMap: world_angle = -1.0*yaw */
+    orc_sincosf(m->wa, &m->wa_sin, &m->wa_cos);
+    m->inv_res = (float)(1.0 / (double)res);
+}
+
+/* world pose -> grid position (col,row units) and grid heading */
+static inline void world_to_grid(const orc_map *m, float xw, float yw, float thw,
+                                 float *gx, float *gy, float *thg)
+{
+    float x = (xw - m->ox) * m->inv_res;
+    float y = (yw - m->oy) * m->inv_res;
+    *gx = fmaf(m->wa_cos, x, -(m->wa_sin * y));
+    *gy = fmaf(m->wa_sin, x, m->wa_cos * y);
+    *thg = thw + m->wa;
+}
+
+/* beam j of a fan: alpha_j = -fov/2 + j*(fov/num_rays)
+ * (scripts/ros_interface.py:342-344, scripts/racecar_simulator_v2.py:47-50,
+ *  scripts/two_player/scan.py:57-62) */
+static inline float fan_alpha(float fov, int num_rays, int j)
+{
+    float amin = -0.5f * fov;
+    float inc = fov / (float)num_rays;
+    return fmaf((float)j, inc, amin);
+}
+
+static inline void fan_dir(float ct, float st, float fov, int num_rays, int j,
+                           float *dx, float *dy)
+{
+    float sa, ca;
+    orc_sincosf(fan_alpha(fov, num_rays, j), &sa, &ca);
+    *dx = fmaf(ct, ca, -(st * sa));
+    *dy = fmaf(st, ca, ct * sa);
+}
+
+/* ------------------------------------------------------------------------ */
+/* exact EDT (row a7): column pass + Felzenszwalb lower envelope per row      */
+/* ------------------------------------------------------------------------ */
+#define EDT_INF ((int64_t)1 << 40)
+
+void orc_edt_sq(const uint8_t *occ, int rows, int cols, uint32_t *d2)
+{
+    size_t n = (size_t)rows * (size_t)cols;
+    int64_t *g = (int64_t *)malloc(n * sizeof(int64_t));
+    /* pass 1: per column, squared vertical distance to nearest occupied cell */
+    for (int c = 0; c < cols; ++c) {
+        int64_t last = -EDT_INF;
+        for (int r = 0; r < rows; ++r) {
+            if (occ[(size_t)r * cols + c]) last = r;
+            int64_t d = (last < 0 && last == -EDT_INF) ? EDT_INF : (r - last);
+            g[(size_t)r * cols + c] = d;
+        }
+        last = EDT_INF;
+        for (int r = rows - 1; r >= 0; --r) {
+            if (occ[(size_t)r * cols + c]) last = r;
+            int64_t d = (last == EDT_INF) ? EDT_INF : (last - r);
+            if (d < g[(size_t)r * cols + c]) g[(size_t)r * cols + c] = d;
+        }
+    }
+    /* pass 2: per row, min over c' of (c-c')^2 + g[r][c']^2 by lower envelope */
+    int *v = (int *)malloc((size_t)cols * sizeof(int));
+    double *z = (double *)malloc(((size_t)cols + 1) * sizeof(double));
+    int64_t *f = (int64_t *)malloc((size_t)cols * sizeof(int64_t));
+    for (int r = 0; r < rows; ++r) {
+        int m = 0;
+        for (int c = 0; c < cols; ++c) {
+            int64_t gv = g[(size_t)r * cols + c];
+            if (gv >= EDT_INF) continue;     /* parabola at infinity never wins */
+            f[c] = gv * gv;
+            /* insert parabola rooted at c */
+            while (m > 0) {
+                int p = v[m - 1];
+                /* intersection of parabolas p and c */
+                double s = ((double)(f[c] + (int64_t)c * c) - (double)(f[p] + (int64_t)p * p)) /
+                           (2.0 * (double)(c - p));
+                if (s <= z[m - 1]) { --m; continue; }
+                z[m] = s;
+                break;
+            }
+            if (m == 0) z[0] = -1e300;
+            v[m] = c;
+            ++m;
+        }
+        if (m == 0) {
+            for (int c = 0; c < cols; ++c) d2[(size_t)r * cols + c] = UINT32_MAX;
+            continue;
+        }
+        int k = 0;
+        for (int c = 0; c < cols; ++c) {
+            while (k + 1 < m && z[k + 1] < (double)c) ++k;
+            /* z boundaries are real-valued; check both neighbours to stay exact at ties */
+            int64_t best = (int64_t)(c - v[k]) * (c - v[k]) + f[v[k]];
+            if (k + 1 < m) {
+                int64_t alt = (int64_t)(c - v[k + 1]) * (c - v[k + 1]) + f[v[k + 1]];
+                if (alt < best) best = alt;
+            }
+            if (k > 0) {
+                int64_t alt = (int64_t)(c - v[k - 1]) * (c - v[k - 1]) + f[v[k - 1]];
+                if (alt < best) best = alt;
+            }
+            d2[(size_t)r * cols + c] = best >= (int64_t)UINT32_MAX ? UINT32_MAX - 1 : (uint32_t)best;
+        }
+    }
+    free(f);
+    free(z);
+    free(v);
+    free(g);
+}
+
+void orc_edt(const uint8_t *occ, int rows, int cols, float *dt)
+{
+    size_t n = (size_t)rows * (size_t)cols;
+    uint32_t *d2 = (uint32_t *)malloc(n * sizeof(uint32_t));
+    orc_edt_sq(occ, rows, cols, d2);
+    for (size_t i = 0; i < n; ++i)
+        dt[i] = d2[i] == UINT32_MAX ? 1e10f : sqrtf((float)d2[i]);
+    free(d2);
+}
+
+/* ------------------------------------------------------------------------ */
+/* RayMarching::calc_range (row a8) / cuda_ray_marching (row a11)             */
+/* ------------------------------------------------------------------------ */
+static inline float rm_cast(const orc_map *m, const float *dt, float max_range, float step_coeff,
+                            float gx, float gy, float dx, float dy,
+                            int32_t *hit, uint16_t *steps)
+{
+    const float fcols = (float)m->cols, frows = (float)m->rows;
+    float t = 0.0f;
+    unsigned n = 0;
+    float out = max_range;
+    int hc = -1, hr = -1;
+    while (t < max_range) {
+        float fx = fmaf(dx, t, gx);
+        float fy = fmaf(dy, t, gy);
+        /* same set as (int)fx in [0,cols) && (int)fy in [0,rows) for every
+         * float inside int range (trunc(-0.3)=0 stays in-map, as upstream);
+         * NaN / huge values miss deterministically                             */
+        if (!(fx > -1.0f && fx < fcols && fy > -1.0f && fy < frows)) break;
+        int pc = (int)fx, pr = (int)fy;
+        float d = dt[(size_t)pr * m->cols + pc];
+        ++n;
+        if (d <= 0.0f) {
+            float xd = (float)pc - gx;
+            float yd = (float)pr - gy;
+            out = sqrtf(fmaf(xd, xd, yd * yd));
+            hc = pc;
+            hr = pr;
+            break;
+        }
+        t += fmaxf(d * step_coeff, 1.0f);
+    }
+    if (hit) { hit[0] = hc; hit[1] = hr; }
+    if (steps) *steps = (uint16_t)(n > 65535u ? 65535u : n);
+    return out * m->res;
+}
+
+void orc_rm_fan(const orc_map *m, const float *dt, float max_range_px, float step_coeff,
+                const float *poses, int n_poses, float fov, int num_rays,
+                float *ranges, int32_t *hits, uint16_t *steps, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int p = 0; p < n_poses; ++p) {
+        float gx, gy, thg, st, ct;
+        world_to_grid(m, poses[3 * p], poses[3 * p + 1], poses[3 * p + 2], &gx, &gy, &thg);
+        orc_sincosf(thg, &st, &ct);
+        for (int j = 0; j < num_rays; ++j) {
+            float dx, dy;
+            fan_dir(ct, st, fov, num_rays, j, &dx, &dy);
+            size_t i = (size_t)p * num_rays + j;
+            ranges[i] = rm_cast(m, dt, max_range_px, step_coeff, gx, gy, dx, dy,
+                                hits ? hits + 2 * i : NULL, steps ? steps + i : NULL);
+        }
+    }
+}
+
+void orc_rm_rays(const orc_map *m, const float *dt, float max_range_px, float step_coeff,
+                 const float *ins, int n, float *ranges, int32_t *hits, uint16_t *steps,
+                 int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int i = 0; i < n; ++i) {
+        float gx, gy, thg, dx, dy;
+        world_to_grid(m, ins[3 * i], ins[3 * i + 1], ins[3 * i + 2], &gx, &gy, &thg);
+        orc_sincosf(thg, &dy, &dx);
+        ranges[i] = rm_cast(m, dt, max_range_px, step_coeff, gx, gy, dx, dy,
+                            hits ? hits + 2 * (size_t)i : NULL, steps ? steps + i : NULL);
+    }
+}
+
+/* Upstream-literal form: RangeMethod::numpy_calc_range + RayMarching::calc_range
+ * (rows a8/a9): theta' = -theta_w + (-world_angle - 3pi/2); calc_range(y, x, theta')
+ * marches (first=row, second=col) along (cosf, sinf) of theta' with libm trig and
+ * un-fused multiply-add.  Used only to show the canonical form is the same
+ * geometry (tests compare within one cell).                                    */
+void orc_rm_rays_libm(const orc_map *m, const float *dt, float max_range_px, float step_coeff,
+                      const float *ins, int n, float *ranges)
+{
+    float rotation_const = (float)(-1.0 * (double)m->wa - 3.0 * M_PI / 2.0);
+    float wsin = (float)sin((double)m->wa), wcos = (float)cos((double)m->wa);
+    for (int i = 0; i < n; ++i) {
+        float theta = -ins[3 * i + 2] + rotation_const;
+        float x = (ins[3 * i] - m->ox) * m->inv_res;
+        float y = (ins[3 * i + 1] - m->oy) * m->inv_res;
+        float temp = x;
+        x = wcos * x - wsin * y;
+        y = wsin * temp + wcos * y;
+        /* calc_range(y, x, theta): first coordinate indexes rows */
+        float x0 = y, y0 = x;
+        float rdx = cosf(theta), rdy = sinf(theta);
+        float t = 0.0f, out = max_range_px;
+        while (t < max_range_px) {
+            int px = (int)(x0 + rdx * t);
+            int py = (int)(y0 + rdy * t);
+            if (px >= m->rows || px < 0 || py < 0 || py >= m->cols) break;
+            float d = dt[(size_t)px * m->cols + py];
+            if (d <= 0.0f) {
+                float xd = (float)px - x0, yd = (float)py - y0;
+                out = sqrtf(xd * xd + yd * yd);
+                break;
+            }
+            float st = d * step_coeff;
+            t += st > 1.0f ? st : 1.0f;
+        }
+        ranges[i] = out * m->res;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* BresenhamsLine::calc_range (row a12)                    */
+/* ------------------------------------------------------------------------ */
+static inline float bl_cast(const orc_map *m, float max_range,
+                            float gx, float gy, float dx, float dy,
+                            int32_t *hit, uint16_t *steps)
+{
+    const float fcols = (float)m->cols, frows = (float)m->rows;
+    int hc = -1, hr = -1;
+    unsigned n = 0;
+    float out = max_range;
+    /* start cell occupied -> 0 */
+    if (gx > -1.0f && gx < fcols && gy > -1.0f && gy < frows &&
+        m->occ[(size_t)(int)gy * m->cols + (int)gx]) {
+        out = 0.0f;
+        hc = (int)gx;
+        hr = (int)gy;
+    } else {
+        float x0 = gx, y0 = gy;
+        float x1 = fmaf(max_range, dx, gx);
+        float y1 = fmaf(max_range, dy, gy);
+        int steep = fabsf(y1 - y0) > fabsf(x1 - x0);
+        if (steep) {
+            float tmp = x0; x0 = y0; y0 = tmp;
+            tmp = x1; x1 = y1; y1 = tmp;
+        }
+        /* major axis = x (after the swap); lim_major/minor are the map extents there */
+        const float lim_major = steep ? frows : fcols;
+        const float lim_minor = steep ? fcols : frows;
+        float deltax = fabsf(x1 - x0), deltay = fabsf(y1 - y0);
+        float error = 0.0f;
+        float _x = x0, _y = y0;
+        float xstep = x0 < x1 ? 1.0f : -1.0f;
+        float ystep = y0 < y1 ? 1.0f : -1.0f;
+        int end = (int)(x1 + xstep);
+        int cap = (int)max_range + 3;        /* guard only; never binds for finite inputs */
+        while ((int)_x != end && cap-- > 0) {
+            _x += xstep;
+            error += deltay;
+            if (error * 2.0f >= deltax) {
+                _y += ystep;
+                error -= deltax;
+            }
+            ++n;
+            if (_x >= 0.0f && _x < lim_major && _y >= 0.0f && _y < lim_minor) {
+                int col = steep ? (int)_y : (int)_x;
+                int row = steep ? (int)_x : (int)_y;
+                if (m->occ[(size_t)row * m->cols + col]) {
+                    float xd = _x - x0, yd = _y - y0;
+                    out = sqrtf(fmaf(xd, xd, yd * yd));
+                    hc = col;
+                    hr = row;
+                    break;
+                }
+            }
+        }
+    }
+    if (hit) { hit[0] = hc; hit[1] = hr; }
+    if (steps) *steps = (uint16_t)n;
+    return out * m->res;
+}
+
+void orc_bl_fan(const orc_map *m, float max_range_px,
+                const float *poses, int n_poses, float fov, int num_rays,
+                float *ranges, int32_t *hits, uint16_t *steps, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int p = 0; p < n_poses; ++p) {
+        float gx, gy, thg, st, ct;
+        world_to_grid(m, poses[3 * p], poses[3 * p + 1], poses[3 * p + 2], &gx, &gy, &thg);
+        orc_sincosf(thg, &st, &ct);
+        for (int j = 0; j < num_rays; ++j) {
+            float dx, dy;
+            fan_dir(ct, st, fov, num_rays, j, &dx, &dy);
+            size_t i = (size_t)p * num_rays + j;
+            ranges[i] = bl_cast(m, max_range_px, gx, gy, dx, dy,
+                                hits ? hits + 2 * i : NULL, steps ? steps + i : NULL);
+        }
+    }
+}
+
+void orc_bl_rays(const orc_map *m, float max_range_px,
+                 const float *ins, int n, float *ranges, int32_t *hits, uint16_t *steps,
+                 int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int i = 0; i < n; ++i) {
+        float gx, gy, thg, dx, dy;
+        world_to_grid(m, ins[3 * i], ins[3 * i + 1], ins[3 * i + 2], &gx, &gy, &thg);
+        orc_sincosf(thg, &dy, &dx);
+        ranges[i] = bl_cast(m, max_range_px, gx, gy, dx, dy,
+                            hits ? hits + 2 * (size_t)i : NULL, steps ? steps + i : NULL);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* GiantLUTCast (row a14)                                                     */
+/* ------------------------------------------------------------------------ */
+static inline float lut_bins_per_rad(int theta_disc)
+{
+    return (float)theta_disc * 0.15915494309189535f;   /* theta_disc / 2pi */
+}
+
+static inline int lut_bin(float th, int theta_disc)
+{
+    /* GiantLUTCast::discretize_theta: nearest bin, wrapped into [0,theta_disc) */
+    float u = rintf(th * lut_bins_per_rad(theta_disc));
+    /* |u| stays far inside int range for any sane heading; clamp keeps it defined */
+    if (!(u > -1e9f && u < 1e9f)) u = 0.0f;
+    int b = (int)u % theta_disc;
+    return b < 0 ? b + theta_disc : b;
+}
+
+static inline uint16_t lut_quant(float r_px, float max_range)
+{
+    float q = rintf(fminf(r_px, max_range) * (65535.0f / max_range));
+    return (uint16_t)q;
+}
+
+static inline float lut_dequant(uint16_t q, float max_range)
+{
+    return (float)q * (max_range / 65535.0f);
+}
+
+void orc_lut_build(const orc_map *m, const float *dt, float max_range_px, float step_coeff,
+                   int theta_disc, int r0, int r1, uint16_t *lut, int nthreads)
+{
+    (void)nthreads;
+    orc_map unit = *m;
+    unit.res = 1.0f;                           /* ranges in cells */
+    float bin_w = 6.283185307179586f / (float)theta_disc;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int r = r0; r < r1; ++r) {
+        for (int c = 0; c < m->cols; ++c) {
+            uint16_t *row = lut + ((size_t)(r - r0) * m->cols + c) * theta_disc;
+            for (int b = 0; b < theta_disc; ++b) {
+                float dx, dy;
+                orc_sincosf((float)b * bin_w, &dy, &dx);
+                float rr = rm_cast(&unit, dt, max_range_px, step_coeff, (float)c, (float)r,
+                                   dx, dy, NULL, NULL);
+                row[b] = lut_quant(rr, max_range_px);
+            }
+        }
+    }
+}
+
+static inline float lut_query(const orc_map *m, const uint16_t *lut, int theta_disc,
+                              float max_range, float gx, float gy, float th)
+{
+    const float fcols = (float)m->cols, frows = (float)m->rows;
+    /* GiantLUTCast::calc_range: outside the map -> max_range */
+    if (!(gx >= 0.0f && gx < fcols && gy >= 0.0f && gy < frows)) return max_range * m->res;
+    size_t cell = (size_t)(int)gy * m->cols + (int)gx;
+    return lut_dequant(lut[cell * theta_disc + lut_bin(th, theta_disc)], max_range) * m->res;
+}
+
+void orc_lut_fan(const orc_map *m, const uint16_t *lut, int theta_disc, float max_range_px,
+                 const float *poses, int n_poses, float fov, int num_rays,
+                 float *ranges, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int p = 0; p < n_poses; ++p) {
+        float gx, gy, thg;
+        world_to_grid(m, poses[3 * p], poses[3 * p + 1], poses[3 * p + 2], &gx, &gy, &thg);
+        for (int j = 0; j < num_rays; ++j)
+            ranges[(size_t)p * num_rays + j] =
+                lut_query(m, lut, theta_disc, max_range_px, gx, gy,
+                          thg + fan_alpha(fov, num_rays, j));
+    }
+}
+
+void orc_lut_rays(const orc_map *m, const uint16_t *lut, int theta_disc, float max_range_px,
+                  const float *ins, int n, float *ranges, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int i = 0; i < n; ++i) {
+        float gx, gy, thg;
+        world_to_grid(m, ins[3 * i], ins[3 * i + 1], ins[3 * i + 2], &gx, &gy, &thg);
+        ranges[i] = lut_query(m, lut, theta_disc, max_range_px, gx, gy, thg);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* CDDTCast (row a13)                                                         */
+/* ------------------------------------------------------------------------ */
+#define CDDT_EPS 1e-5f
+
+static int cmp_float(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* per-bin geometry shared by build and query */
+static void cddt_bin_geometry(const orc_map *m, int theta_disc, int a,
+                              float *cosv, float *sinv, int *width, float *translation)
+{
+    float ang = (float)a * (6.283185307179586f / (float)theta_disc);
+    float s, c;
+    orc_sincosf(ang, &s, &c);
+    *cosv = c;
+    *sinv = s;
+    float W = (float)m->cols, H = (float)m->rows;
+    /* height of the rotated map's bounding box = number of buckets */
+    float rotated_height = fabsf(W * s) + fabsf(H * c);
+    *width = (int)ceilf(rotated_height - CDDT_EPS) + 1;
+    /* lowest rotated corner -> translation making every bucket index >= 0 */
+    float lt = H * c, rt = fmaf(W, s, H * c), rb = W * s;
+    float mn = fminf(lt, fminf(rt, rb));
+    *translation = fmaxf(0.0f, -mn - CDDT_EPS);
+}
+
+static inline int is_edge(const orc_map *m, int r, int c)
+{
+    /* OMap::make_edge_map: occupied cell with at least one free 4-neighbour
+     * (cells on the map border count as edges) */
+    if (!m->occ[(size_t)r * m->cols + c]) return 0;
+    if (r == 0 || c == 0 || r == m->rows - 1 || c == m->cols - 1) return 1;
+    return !m->occ[(size_t)(r - 1) * m->cols + c] || !m->occ[(size_t)(r + 1) * m->cols + c] ||
+           !m->occ[(size_t)r * m->cols + c - 1] || !m->occ[(size_t)r * m->cols + c + 1];
+}
+
+/* lut-space projection of a point for bin a */
+static inline void cddt_project(float c, float s, float tr, float x, float y, float *lx, float *ly)
+{
+    *lx = fmaf(x, c, -(y * s));
+    *ly = fmaf(x, s, y * c) + tr;
+}
+
+orc_cddt *orc_cddt_build(const orc_map *m, int theta_disc)
+{
+    orc_cddt *cd = (orc_cddt *)calloc(1, sizeof(orc_cddt));
+    int nb = (theta_disc + 1) / 2;
+    cd->theta_disc = theta_disc;
+    cd->n_bins = nb;
+    cd->lut_width = (int *)malloc(nb * sizeof(int));
+    cd->lut_translation = (float *)malloc(nb * sizeof(float));
+    cd->cosv = (float *)malloc(nb * sizeof(float));
+    cd->sinv = (float *)malloc(nb * sizeof(float));
+    cd->bucket_off = (int64_t *)malloc((nb + 1) * sizeof(int64_t));
+    int64_t nbk = 0;
+    for (int a = 0; a < nb; ++a) {
+        cddt_bin_geometry(m, theta_disc, a, &cd->cosv[a], &cd->sinv[a], &cd->lut_width[a],
+                          &cd->lut_translation[a]);
+        cd->bucket_off[a] = nbk;
+        nbk += cd->lut_width[a];
+    }
+    cd->bucket_off[nb] = nbk;
+    cd->n_buckets = nbk;
+    /* pass 1: count, pass 2: fill, then sort+unique each bucket */
+    int64_t *cnt = (int64_t *)calloc((size_t)nbk + 1, sizeof(int64_t));
+    for (int pass = 0; pass < 2; ++pass) {
+        int64_t *cur = NULL;
+        if (pass == 1) {
+            int64_t acc = 0;
+            for (int64_t b = 0; b <= nbk; ++b) { int64_t t = cnt[b]; cnt[b] = acc; acc += t; }
+            cd->xs = (float *)malloc((size_t)(acc > 0 ? acc : 1) * sizeof(float));
+            cur = (int64_t *)malloc((size_t)nbk * sizeof(int64_t));
+            memcpy(cur, cnt, (size_t)nbk * sizeof(int64_t));
+        }
+        for (int r = 0; r < m->rows; ++r)
+            for (int c = 0; c < m->cols; ++c) {
+                if (!is_edge(m, r, c)) continue;
+                float px = (float)c + 0.5f, py = (float)r + 0.5f;
+                for (int a = 0; a < nb; ++a) {
+                    float cs = cd->cosv[a], sn = cd->sinv[a];
+                    float half = (fabsf(sn) + fabsf(cs)) * 0.5f;
+                    float lx, ly;
+                    cddt_project(cs, sn, cd->lut_translation[a], px, py, &lx, &ly);
+                    int upper = (int)((ly + half) - CDDT_EPS);
+                    int lower = (int)((ly - half) + CDDT_EPS);
+                    if (lower < 0) lower = 0;
+                    if (upper >= cd->lut_width[a]) upper = cd->lut_width[a] - 1;
+                    for (int i = lower; i <= upper; ++i) {
+                        int64_t b = cd->bucket_off[a] + i;
+                        if (pass == 0) cnt[b]++;
+                        else cd->xs[cur[b]++] = lx;
+                    }
+                }
+            }
+        if (pass == 1) free(cur);
+    }
+    /* sort + unique, compact in place */
+    cd->offsets = (int64_t *)malloc(((size_t)nbk + 1) * sizeof(int64_t));
+    int64_t w = 0;
+    for (int64_t b = 0; b < nbk; ++b) {
+        int64_t s = cnt[b], e = cnt[b + 1];
+        qsort(cd->xs + s, (size_t)(e - s), sizeof(float), cmp_float);
+        cd->offsets[b] = w;
+        for (int64_t i = s; i < e; ++i)
+            if (i == s || cd->xs[i] != cd->xs[i - 1]) cd->xs[w++] = cd->xs[i];
+    }
+    cd->offsets[nbk] = w;
+    cd->n_xs = w;
+    free(cnt);
+    return cd;
+}
+
+void orc_cddt_free(orc_cddt *c)
+{
+    if (!c) return;
+    free(c->lut_width); free(c->lut_translation); free(c->cosv); free(c->sinv);
+    free(c->bucket_off); free(c->offsets); free(c->xs); free(c);
+}
+
+static inline float cddt_query(const orc_map *m, const orc_cddt *cd, float max_range,
+                               float gx, float gy, float th)
+{
+    /* CDDTCast::discretize_theta(-heading): nearest bin of -th in [0, theta_disc);
+     * bins >= theta_disc/2 use the bin half a turn away, searching backwards      */
+    int td = cd->theta_disc;
+    int b = lut_bin(-th, td);
+    int flipped = 0;
+    if (b >= cd->n_bins) { b -= td / 2; flipped = 1; }
+    if (b >= cd->n_bins) b = cd->n_bins - 1;           /* odd theta_disc guard */
+    float lx, ly;
+    cddt_project(cd->cosv[b], cd->sinv[b], cd->lut_translation[b], gx, gy, &lx, &ly);
+    float out = max_range;
+    if (ly >= 0.0f && ly < (float)cd->lut_width[b]) {
+        int64_t bk = cd->bucket_off[b] + (int)ly;
+        const float *xs = cd->xs;
+        int64_t lo = cd->offsets[bk], hi = cd->offsets[bk + 1];
+        if (!flipped) {
+            /* ray runs along +x in lut space: first stored x >= lx */
+            int64_t a = lo, z = hi;
+            while (a < z) { int64_t mid = (a + z) >> 1; if (xs[mid] < lx) a = mid + 1; else z = mid; }
+            if (a < hi) out = fminf(xs[a] - lx, max_range);
+        } else {
+            /* ray runs along -x: last stored x <= lx */
+            int64_t a = lo, z = hi;
+            while (a < z) { int64_t mid = (a + z) >> 1; if (xs[mid] <= lx) a = mid + 1; else z = mid; }
+            if (a > lo) out = fminf(lx - xs[a - 1], max_range);
+        }
+    }
+    return out * m->res;
+}
+
+void orc_cddt_fan(const orc_map *m, const orc_cddt *c, float max_range_px,
+                  const float *poses, int n_poses, float fov, int num_rays,
+                  float *ranges, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int p = 0; p < n_poses; ++p) {
+        float gx, gy, thg;
+        world_to_grid(m, poses[3 * p], poses[3 * p + 1], poses[3 * p + 2], &gx, &gy, &thg);
+        for (int j = 0; j < num_rays; ++j)
+            ranges[(size_t)p * num_rays + j] =
+                cddt_query(m, c, max_range_px, gx, gy, thg + fan_alpha(fov, num_rays, j));
+    }
+}
+
+void orc_cddt_rays(const orc_map *m, const orc_cddt *c, float max_range_px,
+                   const float *ins, int n, float *ranges, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int i = 0; i < n; ++i) {
+        float gx, gy, thg;
+        world_to_grid(m, ins[3 * i], ins[3 * i + 1], ins[3 * i + 2], &gx, &gy, &thg);
+        ranges[i] = cddt_query(m, c, max_range_px, gx, gy, thg);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* consumers: racecar/src/racecar.cpp:239-292 and :305-328                    */
+/* ------------------------------------------------------------------------ */
+void orc_edge_distances(int num_rays, double min_ang, double inc, double scan_dist_to_base,
+                        double width, double wheelbase, double *edge)
+{
+    const double PI_REF = 3.145;                 /* racecar/include/racecar.hpp:117 */
+    double side = width / 2.0;
+    double front = wheelbase - scan_dist_to_base;
+    double back = scan_dist_to_base;
+    double ang = min_ang;
+    for (int i = 0; i < num_rays; ++i) {
+        ang += inc;                              /* incremented BEFORE use (:256) */
+        double a, d1, d2;
+        if (ang > 0.0) {
+            if (ang < PI_REF / 2.0) { a = ang; d2 = front / cos(a); }
+            else { a = ang - PI_REF / 2.0; d2 = back / cos(a); }
+        } else {
+            if (ang == 0.0) ang += 0.0001;
+            if (ang > -PI_REF / 2.0) { a = -ang; d2 = front / cos(a); }
+            else { a = -ang - PI_REF / 2.0; d2 = back / cos(a); }
+        }
+        d1 = side / sin(a);
+        edge[i] = d1 < d2 ? d1 : d2;
+    }
+}
+
+int orc_is_crashed(const float *rays, int num_rays, int poses, const double *edge,
+                   double crash_thresh)
+{
+    int i;
+    for (i = 1; i < poses + 1; ++i)
+        for (int j = 0; j < num_rays; ++j)
+            if (((double)rays[(size_t)(i - 1) * num_rays + j] - edge[j]) < crash_thresh)
+                return i - 1;
+    return -i;
+}

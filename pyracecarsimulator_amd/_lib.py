@@ -1,0 +1,101 @@
+"""ctypes loader for libscan_amd.so (C ABI: include/scanlib.h).
+
+The library is the product: hand-written HIP kernels for gfx950 behind a C ABI.
+There is no Python/NumPy fallback — if the shared object is missing or no HIP
+device is usable, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libscan_amd.so")
+_LIB = None
+
+RL_OK = 0
+RL_BRESENHAM, RL_RM, RL_RM_GPU, RL_CDDT, RL_GIANT_LUT = 0, 1, 2, 3, 4
+
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+u16p = C.POINTER(C.c_uint16)
+u8p = C.POINTER(C.c_uint8)
+
+#: every symbol include/scanlib.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "rl_version": (C.c_char_p, []),
+    "rl_last_error": (C.c_char_p, []),
+    "rl_device_count": (C.c_int, []),
+    "rl_map_create": (C.c_int, [u8p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_int, C.POINTER(C.c_void_p)]),
+    "rl_map_update": (C.c_int, [C.c_void_p, u8p]),
+    "rl_map_destroy": (None, [C.c_void_p]),
+    "rl_map_rows": (C.c_int, [C.c_void_p]),
+    "rl_map_cols": (C.c_int, [C.c_void_p]),
+    "rl_map_device": (C.c_int, [C.c_void_p]),
+    "rl_map_get_dt": (C.c_int, [C.c_void_p, f32p]),
+    "rl_map_get_occ": (C.c_int, [C.c_void_p, u8p]),
+    "rl_method_create": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int,
+                                   C.POINTER(C.c_void_p)]),
+    "rl_method_destroy": (None, [C.c_void_p]),
+    "rl_method_kind": (C.c_int, [C.c_void_p]),
+    "rl_calc_range_many": (C.c_int, [C.c_void_p, f32p, f32p, C.c_int]),
+    "rl_calc_range_many_fan": (C.c_int, [C.c_void_p, f32p, f32p, C.c_int, C.c_float, C.c_int]),
+    "rl_calc_range_fan": (C.c_int, [C.c_void_p, f32p, C.c_int, C.c_float, C.c_int, f32p, i32p,
+                                    u16p]),
+    "rl_calc_range_fan_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rl_calc_range_many_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_void_p]),
+    "rl_set_noise": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64, C.c_uint64]),
+    "rl_check_collision_many": (C.c_int, [C.c_void_p, f32p, C.c_int, C.c_float, C.c_int, f64p,
+                                          C.c_double, C.POINTER(C.c_int), f32p]),
+    "rl_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rl_method_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "rl_method_get_info": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
+}
+
+
+class ScanLibError(RuntimeError):
+    """A libscan_amd.so call returned a negative rl_status."""
+
+    def __init__(self, code, msg):
+        super().__init__("libscan_amd: %s (rl_status %d)" % (msg, code))
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile libscan_amd.so for gfx950 with hipcc (in-tree; cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))
+            if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "scanlib.h"))
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO)
+                                             for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "../libscan_amd.so"]
+                              + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    """Load libscan_amd.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise ImportError(
+                "libscan_amd.so is missing: run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or make -C pyracecarsimulator_amd/csrc). There is no CPU fallback.")
+        L = C.CDLL(_SO)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(code: int) -> None:
+    if code != RL_OK:
+        raise ScanLibError(code, lib().rl_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,144 @@
+// scan_device.h — device-side arithmetic of the lidar scan path (gfx950 only).
+//
+// The float32 arithmetic here is the canonical form of SURVEY.md Appendix A:
+// every operation that feeds a float->int truncation is a single IEEE operation
+// or an explicit fma, the translation unit is built with -ffp-contract=off, and
+// no libm/OCML trig is used, so results are bit-identical to the CPU statement
+// the parity tests check against.  Behaviour restated (not ported) from
+// range_libc's RayMarching::calc_range / kernels.cu cuda_ray_marching
+// (SURVEY.md rows a8, a9, a11), reached from the reference at
+// scripts/scan_simulator.py:103-106,130-133.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scan {
+
+struct MapParams {
+    const float *dt;          // exact EDT in cells, row-major [rows][cols]
+    const uint32_t *bits;     // bit-packed occupancy, bits_stride words per row
+    int bits_stride;
+    int rows, cols;
+    float frows, fcols;
+    float res, inv_res;       // world_scale and (float)(1.0/res)
+    float ox, oy;             // world origin
+    float wa, wa_cos, wa_sin; // world_angle = -yaw and its det_sincosf
+};
+
+struct FanParams {
+    int n_poses, num_rays;
+    float amin, inc;          // -fov/2 and fov/num_rays (computed on the host, IEEE)
+    float max_range;          // cells
+    float step_coeff;         // 0.999f (RayMarching) or 1.0f (kernels.cu)
+    float noise_std;          // <= 0: off
+    uint64_t noise_seed, ray_offset;
+};
+
+// ---- deterministic sin/cos: 3-term Cody-Waite by pi/2 + minimax polynomials ----
+__device__ __forceinline__ void det_sincosf(float x, float &s, float &c)
+{
+    const float TWO_OVER_PI = 0x1.45f306p-1f;
+    const float P1 = 0x1.921fb6p+0f, P2 = -0x1.777a5cp-25f, P3 = -0x1.ee59dap-50f;
+    float k = __builtin_rintf(x * TWO_OVER_PI);
+    float r = __builtin_fmaf(-k, P1, x);
+    r = __builtin_fmaf(-k, P2, r);
+    r = __builtin_fmaf(-k, P3, r);
+    float z = r * r;
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+    float sr = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+    float cr = __builtin_fmaf(z * z, pc, __builtin_fmaf(z, -0.5f, 1.0f));
+    int q = ((int)k) & 3;
+    float ss = (q & 1) ? cr : sr;
+    float cc = (q & 1) ? sr : cr;
+    if (q == 1 || q == 2) cc = -cc;
+    if (q >= 2) ss = -ss;
+    s = ss;
+    c = cc;
+}
+
+// world pose -> grid position (col,row units) and grid heading (row a9)
+__device__ __forceinline__ void world_to_grid(const MapParams &m, float xw, float yw, float thw,
+                                              float &gx, float &gy, float &thg)
+{
+    float x = (xw - m.ox) * m.inv_res;
+    float y = (yw - m.oy) * m.inv_res;
+    gx = __builtin_fmaf(m.wa_cos, x, -(m.wa_sin * y));
+    gy = __builtin_fmaf(m.wa_sin, x, m.wa_cos * y);
+    thg = thw + m.wa;
+}
+
+// beam j of the fan: alpha_j = -fov/2 + j*fov/num_rays (scripts/ros_interface.py:342-344)
+__device__ __forceinline__ float fan_alpha(const FanParams &f, int j)
+{
+    return __builtin_fmaf((float)j, f.inc, f.amin);
+}
+
+// ---- counter-based Gaussian noise (row a15): Philox-4x32-10 + Box-Muller ---------
+__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2,
+                                             uint32_t &c3, uint32_t k0, uint32_t k1)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__device__ __forceinline__ float gauss_noise(uint64_t seed, uint64_t ray_id)
+{
+    uint32_t c0 = (uint32_t)ray_id, c1 = (uint32_t)(ray_id >> 32), c2 = 0x6c696461u, c3 = 0x72u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    // two uniforms in (0,1], Box-Muller
+    float u1 = ((float)(c0 >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u2 = (float)(c1 >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+}
+
+// ---- sphere tracing on the float32 distance transform (rows a8 / a11) -------------
+struct RayResult {
+    float range_px;
+    int hit_c, hit_r;
+    unsigned steps;
+};
+
+__device__ __forceinline__ RayResult rm_march(const MapParams &m, float max_range,
+                                              float step_coeff, float gx, float gy, float dx,
+                                              float dy)
+{
+    RayResult res;
+    res.range_px = max_range;
+    res.hit_c = -1;
+    res.hit_r = -1;
+    res.steps = 0;
+    float t = 0.0f;
+    while (t < max_range) {
+        float fx = __builtin_fmaf(dx, t, gx);
+        float fy = __builtin_fmaf(dy, t, gy);
+        // same cell set as (int)fx in [0,cols) && (int)fy in [0,rows); NaN/huge -> miss
+        if (!(fx > -1.0f && fx < m.fcols && fy > -1.0f && fy < m.frows)) break;
+        int pc = (int)fx, pr = (int)fy;
+        float d = m.dt[(size_t)pr * m.cols + pc];
+        ++res.steps;
+        if (d <= 0.0f) {
+            float xd = (float)pc - gx;
+            float yd = (float)pr - gy;
+            res.range_px = __builtin_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+            res.hit_c = pc;
+            res.hit_r = pr;
+            break;
+        }
+        t += __builtin_fmaxf(d * step_coeff, 1.0f);
+    }
+    return res;
+}
+
+}  // namespace scan

@@ -1,0 +1,614 @@
+// scanlib.hip — host side of libscan_amd.so (C ABI declared in include/scanlib.h).
+//
+// Replaces, for the scan path only, range_libc's PyOMap / PyRayMarching /
+// PyRayMarchingGPU / PyCDDTCast objects that the reference builds at
+// scripts/scan_simulator.py:72-76, scripts/ros_interface.py:210 and
+// scripts/two_player/scan.py:45-46.  There is no CPU fallback in this library.
+#include "../../include/scanlib.h"
+#include "scan_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace scan;
+
+// ------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------
+static thread_local std::string g_err = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(RL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+extern "C" const char *rl_last_error(void) { return g_err.c_str(); }
+extern "C" const char *rl_version(void) { return "scanlib-amd 0.1 (gfx950)"; }
+
+extern "C" int rl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------
+struct rl_map {
+    int device = 0;
+    int rows = 0, cols = 0;
+    float res = 0, ox = 0, oy = 0, oyaw = 0;
+    uint8_t *d_occ = nullptr;
+    int *d_g = nullptr;          // EDT pass-1 scratch
+    float *d_dt = nullptr;
+    uint32_t *d_bits = nullptr;
+    int bits_stride = 0;
+    hipStream_t stream = nullptr;
+    uint64_t epoch = 0;          // bumped by rl_map_update; derived tables rebuild lazily
+    MapParams mp{};
+    int n_cu = 256;
+    std::mutex mu;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return RL_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(RL_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want,
+                                         hipGetErrorString(e));
+        cap = want;
+        return RL_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct rl_method {
+    rl_map *map = nullptr;
+    int kind = 0;
+    float max_range = 0;
+    float step_coeff = 0.999f;
+    int theta_disc = 0;
+    float noise_std = 0;
+    uint64_t noise_seed = 0, ray_offset = 0;
+    int variant = 0;
+    int grid_mult = 8;           // workgroups per CU for the persistent launches
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    DevBuf poses, outs, hits, steps, edge, flag;
+    std::vector<float> h_poses;
+    std::mutex mu;
+};
+
+static int set_device(const rl_map *m)
+{
+    HIPCHK(hipSetDevice(m->device));
+    return RL_OK;
+}
+
+// ------------------------------------------------------------------------------
+// map
+// ------------------------------------------------------------------------------
+static void host_sincosf(float x, float &s, float &c)
+{
+    // host twin of scan::det_sincosf (same operations; this TU is built with
+    // -ffp-contract=off and fmaf is a single rounding on the host too)
+    const float TWO_OVER_PI = 0x1.45f306p-1f;
+    const float P1 = 0x1.921fb6p+0f, P2 = -0x1.777a5cp-25f, P3 = -0x1.ee59dap-50f;
+    float k = rintf(x * TWO_OVER_PI);
+    float r = fmaf(-k, P1, x);
+    r = fmaf(-k, P2, r);
+    r = fmaf(-k, P3, r);
+    float z = r * r;
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(z, ps, -1.6666654611e-1f);
+    float sr = fmaf(r * z, ps, r);
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(z, pc, 4.166664568298827e-2f);
+    float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    int q = ((int)k) & 3;
+    float ss = (q & 1) ? cr : sr;
+    float cc = (q & 1) ? sr : cr;
+    if (q == 1 || q == 2) cc = -cc;
+    if (q >= 2) ss = -ss;
+    s = ss;
+    c = cc;
+}
+
+static int map_build_tables(rl_map *m)
+{
+    // K0: exact EDT + bit-packed occupancy, all on the device
+    const int rows = m->rows, cols = m->cols;
+    hipLaunchKernelGGL(edt_cols_kernel, dim3((cols + 255) / 256), dim3(256), 0, m->stream,
+                       m->d_occ, rows, cols, m->d_g);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3(rows), dim3(256), (size_t)cols * sizeof(int),
+                       m->stream, m->d_g, rows, cols, m->d_dt);
+    hipLaunchKernelGGL(pack_bits_kernel, dim3((m->bits_stride + 255) / 256, rows), dim3(256), 0,
+                       m->stream, m->d_occ, rows, cols, m->bits_stride, m->d_bits);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return RL_OK;
+}
+
+extern "C" int rl_map_create(const uint8_t *occ, int rows, int cols, float res, float ox,
+                             float oy, float oyaw, int device, rl_map **out)
+{
+    if (!occ || !out) return fail(RL_ERR_INVALID, "rl_map_create: null pointer");
+    if (rows <= 0 || cols <= 0 || rows > 16384 || cols > 16384)
+        return fail(RL_ERR_INVALID, "rl_map_create: rows/cols must be in [1,16384] (got %dx%d)",
+                    rows, cols);
+    if (!(res > 0.0f)) return fail(RL_ERR_INVALID, "rl_map_create: resolution must be > 0");
+    int ndev = rl_device_count();
+    if (ndev <= 0)
+        return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    rl_map *m = new (std::nothrow) rl_map();
+    if (!m) return fail(RL_ERR_NOMEM, "out of host memory");
+    m->device = device;
+    m->rows = rows;
+    m->cols = cols;
+    m->res = res;
+    m->ox = ox;
+    m->oy = oy;
+    m->oyaw = oyaw;
+    m->bits_stride = (cols + 31) / 32;
+    auto bail = [&](int code) {
+        rl_map_destroy(m);
+        return code;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(fail(RL_ERR_HIP, "hipSetDevice failed"));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_cu = prop.multiProcessorCount;
+    const size_t n = (size_t)rows * cols;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&m->d_occ, n) != hipSuccess ||
+        hipMalloc((void **)&m->d_g, n * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&m->d_dt, n * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&m->d_bits, (size_t)rows * m->bits_stride * sizeof(uint32_t)) !=
+            hipSuccess)
+        return bail(fail(RL_ERR_NOMEM, "device allocation for a %dx%d map failed", rows, cols));
+    if (hipMemcpyAsync(m->d_occ, occ, n, hipMemcpyHostToDevice, m->stream) != hipSuccess)
+        return bail(fail(RL_ERR_HIP, "map upload failed"));
+    int rc = map_build_tables(m);
+    if (rc != RL_OK) return bail(rc);
+
+    MapParams &p = m->mp;
+    p.dt = m->d_dt;
+    p.bits = m->d_bits;
+    p.bits_stride = m->bits_stride;
+    p.rows = rows;
+    p.cols = cols;
+    p.frows = (float)rows;
+    p.fcols = (float)cols;
+    p.res = res;
+    p.inv_res = (float)(1.0 / (double)res);
+    p.ox = ox;
+    p.oy = oy;
+    p.wa = -oyaw;                                   // PyOMap: world_angle = -yaw
+    host_sincosf(p.wa, p.wa_sin, p.wa_cos);
+    *out = m;
+    return RL_OK;
+}
+
+extern "C" int rl_map_update(rl_map *m, const uint8_t *occ)
+{
+    if (!m || !occ) return fail(RL_ERR_INVALID, "rl_map_update: null pointer");
+    std::lock_guard<std::mutex> lk(m->mu);
+    int rc = set_device(m);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(m->d_occ, occ, (size_t)m->rows * m->cols, hipMemcpyHostToDevice,
+                          m->stream));
+    rc = map_build_tables(m);
+    if (rc) return rc;
+    m->epoch++;
+    return RL_OK;
+}
+
+extern "C" void rl_map_destroy(rl_map *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->d_occ) (void)hipFree(m->d_occ);
+    if (m->d_g) (void)hipFree(m->d_g);
+    if (m->d_dt) (void)hipFree(m->d_dt);
+    if (m->d_bits) (void)hipFree(m->d_bits);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int rl_map_rows(const rl_map *m) { return m ? m->rows : 0; }
+extern "C" int rl_map_cols(const rl_map *m) { return m ? m->cols : 0; }
+extern "C" int rl_map_device(const rl_map *m) { return m ? m->device : -1; }
+
+extern "C" int rl_map_get_dt(rl_map *m, float *dt_out)
+{
+    if (!m || !dt_out) return fail(RL_ERR_INVALID, "rl_map_get_dt: null pointer");
+    std::lock_guard<std::mutex> lk(m->mu);
+    int rc = set_device(m);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(dt_out, m->d_dt, (size_t)m->rows * m->cols * sizeof(float),
+                     hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+extern "C" int rl_map_get_occ(rl_map *m, uint8_t *occ_out)
+{
+    if (!m || !occ_out) return fail(RL_ERR_INVALID, "rl_map_get_occ: null pointer");
+    std::lock_guard<std::mutex> lk(m->mu);
+    int rc = set_device(m);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(occ_out, m->d_occ, (size_t)m->rows * m->cols, hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+// ------------------------------------------------------------------------------
+// method
+// ------------------------------------------------------------------------------
+extern "C" int rl_method_create(rl_map *m, int kind, float max_range_px, int theta_disc,
+                                rl_method **out)
+{
+    if (!m || !out) return fail(RL_ERR_INVALID, "rl_method_create: null pointer");
+    if (!(max_range_px > 0.0f)) return fail(RL_ERR_INVALID, "max_range_px must be > 0");
+    if (kind != RL_RM && kind != RL_RM_GPU)
+        return fail(RL_ERR_UNSUPPORTED, "range method kind %d is not available in this build",
+                    kind);
+    rl_method *h = new (std::nothrow) rl_method();
+    if (!h) return fail(RL_ERR_NOMEM, "out of host memory");
+    h->map = m;
+    h->kind = kind;
+    h->max_range = max_range_px;
+    h->theta_disc = theta_disc;
+    h->step_coeff = kind == RL_RM ? 0.999f : 1.0f;   // RayMarching vs kernels.cu STEP_COEFF
+    if (hipSetDevice(m->device) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        rl_method_destroy(h);
+        return fail(RL_ERR_HIP, "stream/event creation failed");
+    }
+    *out = h;
+    return RL_OK;
+}
+
+extern "C" void rl_method_destroy(rl_method *h)
+{
+    if (!h) return;
+    if (h->map) (void)hipSetDevice(h->map->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->poses.release();
+    h->outs.release();
+    h->hits.release();
+    h->steps.release();
+    h->edge.release();
+    h->flag.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int rl_method_kind(const rl_method *h) { return h ? h->kind : -1; }
+
+extern "C" int rl_set_noise(rl_method *h, float std, uint64_t seed, uint64_t ray_offset)
+{
+    if (!h) return fail(RL_ERR_INVALID, "rl_set_noise: null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->noise_std = std;
+    h->noise_seed = seed;
+    h->ray_offset = ray_offset;
+    return RL_OK;
+}
+
+extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
+{
+    if (!h || !name) return fail(RL_ERR_INVALID, "rl_method_set_option: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!strcmp(name, "variant")) h->variant = value;
+    else if (!strcmp(name, "grid_mult")) h->grid_mult = value < 1 ? 1 : value;
+    else return fail(RL_ERR_INVALID, "unknown option '%s'", name);
+    return RL_OK;
+}
+
+extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out)
+{
+    if (!h || !name || !value_out) return fail(RL_ERR_INVALID, "rl_method_get_info: null pointer");
+    if (!strcmp(name, "n_cu")) *value_out = h->map->n_cu;
+    else if (!strcmp(name, "variant")) *value_out = h->variant;
+    else if (!strcmp(name, "grid_mult")) *value_out = h->grid_mult;
+    else if (!strcmp(name, "map_epoch")) *value_out = (int64_t)h->map->epoch;
+    else return fail(RL_ERR_INVALID, "unknown info '%s'", name);
+    return RL_OK;
+}
+
+// ------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------
+static FanParams make_fan(const rl_method *h, int n_poses, float fov, int num_rays)
+{
+    FanParams f{};
+    f.n_poses = n_poses;
+    f.num_rays = num_rays;
+    f.amin = -0.5f * fov;
+    f.inc = fov / (float)num_rays;
+    f.max_range = h->max_range;
+    f.step_coeff = h->step_coeff;
+    f.noise_std = h->noise_std;
+    f.noise_seed = h->noise_seed;
+    f.ray_offset = h->ray_offset;
+    return f;
+}
+
+static int check_fan_args(const rl_method *h, int n_poses, float fov, int num_rays)
+{
+    if (!h) return fail(RL_ERR_INVALID, "null method handle");
+    if (n_poses < 0) return fail(RL_ERR_INVALID, "n_poses must be >= 0");
+    if (num_rays <= 0) return fail(RL_ERR_INVALID, "num_rays must be > 0");
+    if (num_rays > 16384)
+        return fail(RL_ERR_UNSUPPORTED, "num_rays %d exceeds the LDS fan table (16384)", num_rays);
+    if (!(fov == fov)) return fail(RL_ERR_INVALID, "fov is NaN");
+    return RL_OK;
+}
+
+// enqueue the fan kernel on `stream`; all pointers are device pointers
+static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov, int num_rays,
+                      float *d_out, int32_t *d_hits, uint16_t *d_steps, const CrashParams *crash,
+                      hipStream_t stream)
+{
+    if (n_poses == 0) return RL_OK;
+    const rl_map *m = h->map;
+    FanParams f = make_fan(h, n_poses, fov, num_rays);
+    const long cpp = (num_rays + 63) / 64;
+    const long n_chunks = (long)n_poses * cpp;
+    long want = (n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    long cap = (long)m->n_cu * h->grid_mult;
+    int grid = (int)std::max(1L, std::min(want, cap));
+    size_t lds = (size_t)num_rays * sizeof(float2);
+    CrashParams cp{nullptr, 0.0, nullptr};
+    if (crash) cp = *crash;
+    const bool aux = d_hits || d_steps;
+    HIPCHK(hipEventRecord(h->ev0, stream));
+    if (crash) {
+        if (aux)
+            hipLaunchKernelGGL((rm_fan_kernel<true, true>), dim3(grid), dim3(WG), lds, stream,
+                               m->mp, f, d_poses, d_out, d_hits, d_steps, cp);
+        else
+            hipLaunchKernelGGL((rm_fan_kernel<false, true>), dim3(grid), dim3(WG), lds, stream,
+                               m->mp, f, d_poses, d_out, d_hits, d_steps, cp);
+    } else {
+        if (aux)
+            hipLaunchKernelGGL((rm_fan_kernel<true, false>), dim3(grid), dim3(WG), lds, stream,
+                               m->mp, f, d_poses, d_out, d_hits, d_steps, cp);
+        else
+            hipLaunchKernelGGL((rm_fan_kernel<false, false>), dim3(grid), dim3(WG), lds, stream,
+                               m->mp, f, d_poses, d_out, d_hits, d_steps, cp);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, stream));
+    h->timed = true;
+    return RL_OK;
+}
+
+static int launch_rays(rl_method *h, const float *d_ins, long n, float *d_out, int32_t *d_hits,
+                       uint16_t *d_steps, hipStream_t stream)
+{
+    if (n == 0) return RL_OK;
+    const rl_map *m = h->map;
+    FanParams f = make_fan(h, 0, 0.0f, 1);
+    long want = (n + WG - 1) / WG;
+    long cap = (long)m->n_cu * h->grid_mult;
+    int grid = (int)std::max(1L, std::min(want, cap));
+    HIPCHK(hipEventRecord(h->ev0, stream));
+    hipLaunchKernelGGL(rm_rays_kernel, dim3(grid), dim3(WG), 0, stream, m->mp, f, d_ins, n, d_out,
+                       d_hits, d_steps);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, stream));
+    h->timed = true;
+    return RL_OK;
+}
+
+extern "C" int rl_calc_range_fan_device(rl_method *h, const float *d_poses, int n_poses, float fov,
+                                        int num_rays, float *d_outs, int32_t *d_hits,
+                                        uint16_t *d_steps, void *hip_stream)
+{
+    int rc = check_fan_args(h, n_poses, fov, num_rays);
+    if (rc) return rc;
+    if (n_poses > 0 && (!d_poses || !d_outs))
+        return fail(RL_ERR_INVALID, "rl_calc_range_fan_device: null device pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    rc = set_device(h->map);
+    if (rc) return rc;
+    return launch_fan(h, d_poses, n_poses, fov, num_rays, d_outs, d_hits, d_steps, nullptr,
+                      (hipStream_t)hip_stream);
+}
+
+extern "C" int rl_calc_range_many_device(rl_method *h, const float *d_ins, float *d_outs, int n,
+                                         void *hip_stream)
+{
+    if (!h) return fail(RL_ERR_INVALID, "null method handle");
+    if (n < 0) return fail(RL_ERR_INVALID, "n must be >= 0");
+    if (n > 0 && (!d_ins || !d_outs))
+        return fail(RL_ERR_INVALID, "rl_calc_range_many_device: null device pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = set_device(h->map);
+    if (rc) return rc;
+    return launch_rays(h, d_ins, n, d_outs, nullptr, nullptr, (hipStream_t)hip_stream);
+}
+
+// host-pointer forms ---------------------------------------------------------------
+static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, int num_rays,
+                    float *outs, int32_t *hits, uint16_t *steps, const double *edge,
+                    double crash_thresh, int *first_crashed)
+{
+    const size_t n_rays = (size_t)n_poses * num_rays;
+    int rc = set_device(h->map);
+    if (rc) return rc;
+    if (n_poses == 0) {
+        if (first_crashed) *first_crashed = -1;
+        return RL_OK;
+    }
+    if ((rc = h->poses.ensure((size_t)n_poses * 3 * sizeof(float)))) return rc;
+    if (outs || !first_crashed)
+        if ((rc = h->outs.ensure(n_rays * sizeof(float)))) return rc;
+    if (hits && (rc = h->hits.ensure(n_rays * 2 * sizeof(int32_t)))) return rc;
+    if (steps && (rc = h->steps.ensure(n_rays * sizeof(uint16_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(h->poses.p, poses, (size_t)n_poses * 3 * sizeof(float),
+                          hipMemcpyHostToDevice, h->stream));
+    CrashParams cp{nullptr, 0.0, nullptr};
+    if (first_crashed) {
+        if ((rc = h->edge.ensure((size_t)num_rays * sizeof(double)))) return rc;
+        if ((rc = h->flag.ensure(sizeof(int)))) return rc;
+        HIPCHK(hipMemcpyAsync(h->edge.p, edge, (size_t)num_rays * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+        const int init = INT_MAX;
+        HIPCHK(hipMemcpyAsync(h->flag.p, &init, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        cp.edge = (const double *)h->edge.p;
+        cp.thresh = crash_thresh;
+        cp.first_crashed = (int *)h->flag.p;
+    }
+    float *d_out = (outs || !first_crashed) ? (float *)h->outs.p : nullptr;
+    rc = launch_fan(h, (const float *)h->poses.p, n_poses, fov, num_rays, d_out,
+                    hits ? (int32_t *)h->hits.p : nullptr, steps ? (uint16_t *)h->steps.p : nullptr,
+                    first_crashed ? &cp : nullptr, h->stream);
+    if (rc) return rc;
+    if (outs)
+        HIPCHK(hipMemcpyAsync(outs, h->outs.p, n_rays * sizeof(float), hipMemcpyDeviceToHost,
+                              h->stream));
+    if (hits)
+        HIPCHK(hipMemcpyAsync(hits, h->hits.p, n_rays * 2 * sizeof(int32_t), hipMemcpyDeviceToHost,
+                              h->stream));
+    if (steps)
+        HIPCHK(hipMemcpyAsync(steps, h->steps.p, n_rays * sizeof(uint16_t), hipMemcpyDeviceToHost,
+                              h->stream));
+    int flag = INT_MAX;
+    if (first_crashed)
+        HIPCHK(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (first_crashed) *first_crashed = flag == INT_MAX ? -(n_poses + 1) : flag;
+    return RL_OK;
+}
+
+extern "C" int rl_calc_range_fan(rl_method *h, const float *poses, int n_poses, float fov,
+                                 int num_rays, float *outs, int32_t *hits, uint16_t *steps)
+{
+    int rc = check_fan_args(h, n_poses, fov, num_rays);
+    if (rc) return rc;
+    if (n_poses > 0 && (!poses || !outs))
+        return fail(RL_ERR_INVALID, "rl_calc_range_fan: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return fan_host(h, poses, n_poses, fov, num_rays, outs, hits, steps, nullptr, 0.0, nullptr);
+}
+
+extern "C" int rl_calc_range_many_fan(rl_method *h, const float *ins_rows3, float *outs, int n_rows,
+                                      float fov, int num_rays)
+{
+    if (!h) return fail(RL_ERR_INVALID, "null method handle");
+    if (num_rays <= 0) return fail(RL_ERR_INVALID, "num_rays must be > 0");
+    if (n_rows < 0) return fail(RL_ERR_INVALID, "n_rows must be >= 0");
+    // n_poses = ins.shape[0] / num_rays; trailing rows that do
+    // not make a whole fan are left untouched
+    const int n_poses = n_rows / num_rays;
+    int rc = check_fan_args(h, n_poses, fov, num_rays);
+    if (rc) return rc;
+    if (n_poses > 0 && (!ins_rows3 || !outs))
+        return fail(RL_ERR_INVALID, "rl_calc_range_many_fan: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    // gather the live row of every pose (row p*num_rays): 12 B per pose cross PCIe,
+    // not the reference's 12 B per ray (scripts/scan_simulator.py:39-40)
+    h->h_poses.resize((size_t)n_poses * 3);
+    for (int p = 0; p < n_poses; ++p) {
+        const float *row = ins_rows3 + (size_t)p * num_rays * 3;
+        h->h_poses[3 * (size_t)p] = row[0];
+        h->h_poses[3 * (size_t)p + 1] = row[1];
+        h->h_poses[3 * (size_t)p + 2] = row[2];
+    }
+    return fan_host(h, h->h_poses.data(), n_poses, fov, num_rays, outs, nullptr, nullptr, nullptr,
+                    0.0, nullptr);
+}
+
+extern "C" int rl_calc_range_many(rl_method *h, const float *ins, float *outs, int n)
+{
+    if (!h) return fail(RL_ERR_INVALID, "null method handle");
+    if (n < 0) return fail(RL_ERR_INVALID, "n must be >= 0");
+    if (n == 0) return RL_OK;
+    if (!ins || !outs) return fail(RL_ERR_INVALID, "rl_calc_range_many: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = set_device(h->map);
+    if (rc) return rc;
+    if ((rc = h->poses.ensure((size_t)n * 3 * sizeof(float)))) return rc;
+    if ((rc = h->outs.ensure((size_t)n * sizeof(float)))) return rc;
+    HIPCHK(hipMemcpyAsync(h->poses.p, ins, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice,
+                          h->stream));
+    rc = launch_rays(h, (const float *)h->poses.p, n, (float *)h->outs.p, nullptr, nullptr,
+                     h->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(outs, h->outs.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RL_OK;
+}
+
+extern "C" int rl_check_collision_many(rl_method *h, const float *poses, int n_poses, float fov,
+                                       int num_rays, const double *edge, double crash_thresh,
+                                       int *first_crashed, float *ranges_or_null)
+{
+    int rc = check_fan_args(h, n_poses, fov, num_rays);
+    if (rc) return rc;
+    if (!first_crashed || !edge || (n_poses > 0 && !poses))
+        return fail(RL_ERR_INVALID, "rl_check_collision_many: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (n_poses == 0) {
+        *first_crashed = -1;
+        return RL_OK;
+    }
+    return fan_host(h, poses, n_poses, fov, num_rays, ranges_or_null, nullptr, nullptr, edge,
+                    crash_thresh, first_crashed);
+}
+
+extern "C" int rl_last_kernel_ms(rl_method *h, float *ms_out)
+{
+    if (!h || !ms_out) return fail(RL_ERR_INVALID, "rl_last_kernel_ms: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->timed) return fail(RL_ERR_INVALID, "no launch has been timed on this handle yet");
+    int rc = set_device(h->map);
+    if (rc) return rc;
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(ms_out, h->ev0, h->ev1));
+    return RL_OK;
+}

@@ -1,0 +1,107 @@
+"""Pose-batch sharding of the scan path over the GPUs of one node.
+
+One process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo"
+in the CPU tests).  Rays are independent, so the only exchanges are the two BASELINE.json's
+north_star names:
+
+* once per map: broadcast of the occupancy bytes from rank 0 (each rank then builds its own
+  distance transform / tables on its GPU);
+* per batch: all-gather of the ranges, issued per CHUNK of the local pose block so that the
+  gather of chunk k runs on RCCL's stream while the march kernel of chunk k+1 runs on the
+  compute stream (xGMI is point-to-point: a ring all-gather is per-link bound, and for
+  4 B/ray it costs more than the kernel, so overlap is what matters).
+
+The reference has no collective anywhere (single process, single GPU: SURVEY §2.1).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .workloads import shard_range
+
+
+def broadcast_map(gmap_or_none, src=0, device=None):
+    """Rank ``src`` passes a ``maps.GridMap``; every rank returns an equal GridMap.
+    Metadata travels as a small float64 tensor, the grid as uint8."""
+    import torch
+    import torch.distributed as dist
+    from .maps import GridMap
+
+    rank = dist.get_rank()
+    dev = device if device is not None else "cpu"
+    meta = torch.zeros(6, dtype=torch.float64, device=dev)
+    if rank == src:
+        g = gmap_or_none
+        meta = torch.tensor([g.rows, g.cols, g.resolution, *g.origin], dtype=torch.float64,
+                            device=dev)
+    dist.broadcast(meta, src)
+    rows, cols = int(meta[0].item()), int(meta[1].item())
+    if rank == src:
+        occ = torch.from_numpy(np.ascontiguousarray(gmap_or_none.occ, dtype=np.uint8)).to(dev)
+    else:
+        occ = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+    dist.broadcast(occ, src)
+    name = gmap_or_none.name if rank == src else "map"
+    return GridMap(occ.cpu().numpy(), float(meta[2].item()),
+                   (float(meta[3].item()), float(meta[4].item()), float(meta[5].item())), name)
+
+
+def chunk_bounds(n_local: int, n_chunks: int):
+    """Split a local block of ``n_local`` poses into <= n_chunks equal chunks (the last rank-
+    uniform size is required by all_gather_into_tensor, so n_local must divide evenly or the
+    chunk count is reduced until it does)."""
+    c = max(1, min(n_chunks, n_local))
+    while n_local % c:
+        c -= 1
+    step = n_local // c
+    return [(i * step, (i + 1) * step) for i in range(c)]
+
+
+class ShardedScan:
+    """Scan a global pose batch with every rank taking a contiguous block.
+
+    ``compute(lo, hi, out_view)`` must enqueue the scan of local poses [lo, hi) into
+    ``out_view`` (a (hi-lo)*num_rays float32 tensor) on the current stream — on the GPU that
+    is ``method.calc_range_fan_device``; the CPU tests pass a NumPy stand-in.
+    """
+
+    def __init__(self, n_local: int, num_rays: int, device, n_chunks: int = 4, gather=True):
+        import torch
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.n_local, self.num_rays = n_local, num_rays
+        self.gather = gather and self.world > 1
+        self.chunks = chunk_bounds(n_local, n_chunks if self.gather else 1)
+        self.local = torch.empty(n_local * num_rays, dtype=torch.float32, device=device)
+        # chunk-major gather buffer: [chunk][rank][poses_in_chunk * num_rays]
+        self.gathered = (torch.empty(self.world * n_local * num_rays, dtype=torch.float32,
+                                     device=device) if self.gather else None)
+
+    def step(self, compute):
+        B = self.num_rays
+        handles = []
+        for ci, (lo, hi) in enumerate(self.chunks):
+            view = self.local[lo * B:hi * B]
+            compute(lo, hi, view)
+            if self.gather:
+                per = (hi - lo) * B
+                dst = self.gathered[ci * self.world * per:(ci + 1) * self.world * per]
+                handles.append(self.dist.all_gather_into_tensor(dst, view, async_op=True))
+        for h in handles:
+            h.wait()
+        return self.gathered if self.gather else self.local
+
+    def global_order(self):
+        """Gathered ranges re-ordered to global pose order: rank-major blocks, i.e. exactly what
+        one GPU scanning the whole batch writes.  Returns a (world*n_local*num_rays,) tensor."""
+        if not self.gather:
+            return self.local
+        B, W = self.num_rays, self.world
+        per = (self.chunks[0][1] - self.chunks[0][0]) * B
+        g = self.gathered.view(len(self.chunks), W, per)
+        return g.permute(1, 0, 2).reshape(-1)
+
+
+__all__ = ["broadcast_map", "chunk_bounds", "ShardedScan", "shard_range"]

@@ -1,0 +1,281 @@
+"""``range_libc``-compatible surface for the scan path, backed by libscan_amd.so.
+
+Mirrors the objects the reference builds and calls (same names, argument meaning
+and in-place/None-returning behaviour):
+
+* ``PyOMap(map_msg)``                      scripts/ros_interface.py:210, scripts/mcts_driver.py:278
+* ``PyRayMarching(omap, max_range_px)``    scripts/scan_simulator.py:72-73
+* ``PyRayMarchingGPU(omap, max_range_px)`` scripts/scan_simulator.py:74-76
+* ``PyCDDTCast(omap, max_range_px, theta_disc)``   scripts/two_player/scan.py:46
+* ``obj.calc_range_many(ins, outs, fov, num_rays)`` scripts/scan_simulator.py:103-106,130-133
+* ``obj.calc_range_many(ins, outs)``                scripts/two_player/scan.py:69-70
+
+plus range_libc's remaining casters (``PyBresenhamsLine``, ``PyGiantLUTCast``).
+Array contract: ``ins`` float32 C-contiguous (n,3), ``outs`` float32
+C-contiguous (n,); anything else raises ``ValueError`` like the Cython
+``np.ndarray[float, ndim=2, mode="c"]`` signature does.
+
+Usage as a drop-in: ``from pyracecarsimulator_amd import range_libc`` (or put
+``sys.modules["range_libc"] = pyracecarsimulator_amd.range_libc`` before importing
+the reference's scan_simulator).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import f32p, f64p, i32p, u16p, u8p
+
+__all__ = ["PyOMap", "PyRayMarching", "PyRayMarchingGPU", "PyCDDTCast", "PyBresenhamsLine",
+           "PyGiantLUTCast", "USE_CUDA", "SHOULD_USE_CUDA"]
+
+#: range_libc exports these flags; the AMD build always has its device path.
+USE_CUDA = True
+SHOULD_USE_CUDA = True
+
+
+def _yaw_from_quaternion(q) -> float:
+    """yaw of tf.transformations.euler_from_quaternion (scripts/ros_interface.py:212-216)."""
+    x, y, z, w = (float(q.x), float(q.y), float(q.z), float(q.w))
+    return math.atan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (y * y + z * z))
+
+
+class PyOMap:
+    """Occupancy grid + world transform, resident on one MI355X.
+
+    Accepts what the reference passes — a ``nav_msgs/OccupancyGrid``-like object with
+    ``.info.{width,height,resolution,origin}`` and row-major ``.data`` (occupied where
+    ``data > 10``) — or, since ROS messages do not exist on the GPU
+    box, a NumPy ``(H, W)`` array (nonzero = occupied) with ``resolution`` and
+    ``origin=(x, y, yaw)``, or a ``maps.GridMap``.
+    """
+
+    def __init__(self, arg1, arg2=None, resolution=None, origin=None, device=0):
+        occ, res, org = self._ingest(arg1, arg2, resolution, origin)
+        self.occ = np.ascontiguousarray(occ, dtype=np.uint8)
+        if self.occ.ndim != 2:
+            raise ValueError("PyOMap: occupancy must be a 2-D array")
+        self.height, self.width = (int(v) for v in self.occ.shape)
+        self.resolution = float(res)
+        self.origin = tuple(float(v) for v in org)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().rl_map_create(
+            self.occ.ctypes.data_as(u8p), self.height, self.width, self.resolution,
+            self.origin[0], self.origin[1], self.origin[2], self.device, C.byref(self._h)))
+
+    @staticmethod
+    def _ingest(arg1, arg2, resolution, origin):
+        if hasattr(arg1, "info") and hasattr(arg1, "data"):          # OccupancyGrid duck type
+            info = arg1.info
+            w, h = int(info.width), int(info.height)
+            data = np.asarray(arg1.data).reshape(h, w)
+            pos, ori = info.origin.position, info.origin.orientation
+            return (data > 10), float(info.resolution), (pos.x, pos.y, _yaw_from_quaternion(ori))
+        if hasattr(arg1, "occ") and hasattr(arg1, "resolution"):     # maps.GridMap
+            return arg1.occ != 0, arg1.resolution, arg1.origin
+        arr = np.asarray(arg1)
+        if arr.ndim == 2:
+            if resolution is None and arg2 is not None and not isinstance(arg2, (tuple, list)):
+                resolution = arg2
+            return arr != 0, (1.0 if resolution is None else resolution), \
+                ((0.0, 0.0, 0.0) if origin is None else origin)
+        raise TypeError("PyOMap: expected an OccupancyGrid-like message, a GridMap or a 2-D array")
+
+    # -- range_libc.PyOMap helpers ------------------------------------------
+    def isOccupied(self, x, y):
+        return bool(self.occ[int(x), int(y)])
+
+    def update(self, occ):
+        """Replace the grid (same shape) and rebuild the device tables — the per-scan
+        rebuild of scripts/two_player/rcs_two_player.py:110-121."""
+        occ = np.ascontiguousarray(np.asarray(occ) != 0, dtype=np.uint8)
+        if occ.shape != self.occ.shape:
+            raise ValueError("PyOMap.update: shape mismatch")
+        self.occ = occ
+        _lib.check(_lib.lib().rl_map_update(self._h, occ.ctypes.data_as(u8p)))
+
+    def distance_transform(self):
+        """float32 (H, W) exact EDT in cells as built on the device (test hook)."""
+        out = np.empty((self.height, self.width), dtype=np.float32)
+        _lib.check(_lib.lib().rl_map_get_dt(self._h, out.ctypes.data_as(f32p)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().rl_map_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _check_ins_outs(ins, outs):
+    if not isinstance(ins, np.ndarray) or not isinstance(outs, np.ndarray):
+        raise TypeError("calc_range_many: ins/outs must be numpy arrays")
+    if ins.dtype != np.float32 or outs.dtype != np.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float'")
+    if ins.ndim != 2 or outs.ndim != 1:
+        raise ValueError("Buffer has wrong number of dimensions (expected 2 and 1)")
+    if not ins.flags.c_contiguous or not outs.flags.c_contiguous:
+        raise ValueError("ndarray is not C-contiguous")
+    if ins.shape[1] != 3:
+        raise ValueError("ins must have shape (n, 3)")
+    if outs.shape[0] < ins.shape[0]:
+        raise ValueError("outs is shorter than ins")
+
+
+class _RangeMethod:
+    KIND = None
+
+    def __init__(self, omap, max_range_px, theta_disc=0):
+        if not isinstance(omap, PyOMap):
+            raise TypeError("expected a PyOMap")
+        self.omap = omap                         # keep the map alive
+        self.max_range_px = float(max_range_px)
+        self.theta_disc = int(theta_disc)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().rl_method_create(omap._h, self.KIND, self.max_range_px,
+                                               self.theta_disc, C.byref(self._h)))
+
+    # -- the reference's entry point ----------------------------------------
+    def calc_range_many(self, ins, outs, fov=None, num_rays=None):
+        """In-place, returns None.  2 args: one (x, y, theta) row per ray
+        (scripts/two_player/scan.py:69-70).  4 args: the fork's fan form — pose p in row
+        ``p*num_rays``, result ``outs[p*num_rays + j]`` (scripts/scan_simulator.py:103-106,
+        130-133)."""
+        _check_ins_outs(ins, outs)
+        L = _lib.lib()
+        if fov is None and num_rays is None:
+            _lib.check(L.rl_calc_range_many(self._h, ins.ctypes.data_as(f32p),
+                                            outs.ctypes.data_as(f32p), ins.shape[0]))
+        elif fov is None or num_rays is None:
+            raise TypeError("calc_range_many takes (ins, outs) or (ins, outs, fov, num_rays)")
+        else:
+            _lib.check(L.rl_calc_range_many_fan(self._h, ins.ctypes.data_as(f32p),
+                                                outs.ctypes.data_as(f32p), ins.shape[0],
+                                                float(fov), int(num_rays)))
+        return None
+
+    def calc_range(self, x, y, heading):
+        """Scalar query in world coordinates (upstream's RayMarchingGPU does not support
+        this and returns -1; here it is one 1-ray launch)."""
+        ins = np.array([[x, y, heading]], dtype=np.float32)
+        outs = np.zeros(1, dtype=np.float32)
+        self.calc_range_many(ins, outs)
+        return float(outs[0])
+
+    # -- dense fast paths -------------------------------------
+    def calc_range_fan(self, poses, outs, fov, num_rays, hit_cells=None, steps=None):
+        """poses float32 (P,3) -> outs float32 (P*num_rays,), optional diagnostics."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        n = poses.shape[0] * int(num_rays)
+        if outs.dtype != np.float32 or not outs.flags.c_contiguous or outs.size < n:
+            raise ValueError("outs must be C-contiguous float32 with P*num_rays elements")
+        if hit_cells is not None and (hit_cells.dtype != np.int32 or hit_cells.size < 2 * n
+                                      or not hit_cells.flags.c_contiguous):
+            raise ValueError("hit_cells must be C-contiguous int32 (P*num_rays, 2)")
+        if steps is not None and (steps.dtype != np.uint16 or steps.size < n
+                                  or not steps.flags.c_contiguous):
+            raise ValueError("steps must be C-contiguous uint16 (P*num_rays,)")
+        _lib.check(_lib.lib().rl_calc_range_fan(
+            self._h, poses.ctypes.data_as(f32p), poses.shape[0], float(fov), int(num_rays),
+            outs.ctypes.data_as(f32p),
+            hit_cells.ctypes.data_as(i32p) if hit_cells is not None else None,
+            steps.ctypes.data_as(u16p) if steps is not None else None))
+        return None
+
+    def calc_range_fan_device(self, d_poses_ptr, n_poses, fov, num_rays, d_outs_ptr,
+                              d_hits_ptr=0, d_steps_ptr=0, stream=0):
+        """Asynchronous launch on device pointers (ints), e.g. torch ``tensor.data_ptr()``."""
+        _lib.check(_lib.lib().rl_calc_range_fan_device(
+            self._h, C.c_void_p(d_poses_ptr), int(n_poses), float(fov), int(num_rays),
+            C.c_void_p(d_outs_ptr), C.c_void_p(d_hits_ptr or None),
+            C.c_void_p(d_steps_ptr or None), C.c_void_p(stream or None)))
+
+    def calc_range_many_device(self, d_ins_ptr, d_outs_ptr, n, stream=0):
+        _lib.check(_lib.lib().rl_calc_range_many_device(
+            self._h, C.c_void_p(d_ins_ptr), C.c_void_p(d_outs_ptr), int(n),
+            C.c_void_p(stream or None)))
+
+    def check_collision_many(self, poses, fov, num_rays, edge_distances, crash_thresh,
+                             ranges=None):
+        """Scan + Car::isCrashed fused (racecar/src/racecar.cpp:305-328): index of the first
+        crashed pose, else ``-(n_poses+1)``."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        edge = np.ascontiguousarray(edge_distances, dtype=np.float64)
+        if edge.size < num_rays:
+            raise ValueError("edge_distances needs num_rays entries")
+        first = C.c_int(0)
+        _lib.check(_lib.lib().rl_check_collision_many(
+            self._h, poses.ctypes.data_as(f32p), poses.shape[0], float(fov), int(num_rays),
+            edge.ctypes.data_as(f64p), float(crash_thresh), C.byref(first),
+            ranges.ctypes.data_as(f32p) if ranges is not None else None))
+        return int(first.value)
+
+    def set_noise(self, std, seed=0, ray_offset=0):
+        _lib.check(_lib.lib().rl_set_noise(self._h, float(std), int(seed), int(ray_offset)))
+
+    def set_option(self, name, value):
+        _lib.check(_lib.lib().rl_method_set_option(self._h, name.encode(), int(value)))
+
+    def get_info(self, name):
+        v = C.c_int64(0)
+        _lib.check(_lib.lib().rl_method_get_info(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _lib.check(_lib.lib().rl_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().rl_method_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PyRayMarching(_RangeMethod):
+    """range_libc.PyRayMarching(omap, mrx) — step coefficient 0.999 (CPU RayMarching)."""
+    KIND = _lib.RL_RM
+
+
+class PyRayMarchingGPU(_RangeMethod):
+    """range_libc.PyRayMarchingGPU(omap, mrx) — step coefficient 1.0 (kernels.cu)."""
+    KIND = _lib.RL_RM_GPU
+
+
+class PyBresenhamsLine(_RangeMethod):
+    """range_libc.PyBresenhamsLine(omap, mrx)."""
+    KIND = _lib.RL_BRESENHAM
+
+
+class PyCDDTCast(_RangeMethod):
+    """range_libc.PyCDDTCast(omap, mrx, theta_disc) (scripts/two_player/scan.py:46)."""
+    KIND = _lib.RL_CDDT
+
+    def __init__(self, omap, max_range_px, theta_disc):
+        super().__init__(omap, max_range_px, theta_disc)
+
+    def prune(self, max_range=None):   # upstream API; pruning is a no-op for exactness
+        return None
+
+
+class PyGiantLUTCast(_RangeMethod):
+    """range_libc.PyGiantLUTCast(omap, mrx, theta_disc)."""
+    KIND = _lib.RL_GIANT_LUT
+
+    def __init__(self, omap, max_range_px, theta_disc):
+        super().__init__(omap, max_range_px, theta_disc)

@@ -1,0 +1,81 @@
+"""world_size-2 gloo tests of the pose-batch sharding on CPU: map broadcast,
+contiguous pose blocks, chunk-overlapped all-gather and its global ordering.  The march itself
+is stood in by a NumPy function of the pose (the GPU kernel is covered by the -m gpu tests)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from pyracecarsimulator_amd import maps
+from pyracecarsimulator_amd.distributed import ShardedScan, broadcast_map, chunk_bounds, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_ranges(poses, B):
+    j = np.arange(B, dtype=np.float32)[None, :]
+    return (poses[:, 0:1] * 1000 + poses[:, 1:2] * 10 + poses[:, 2:3] + j * 1e-3).astype(np.float32).ravel()
+
+
+def _worker(rank, world, port, n_total, B, chunks, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g0 = maps.make_maze(64, cell=16, wall=2, seed=3, origin=(1.0, -2.0, 0.25)) if rank == 0 else None
+        g = broadcast_map(g0, 0)
+        poses_all = maps.sample_free_poses(g, n_total, 5)
+        lo, hi = shard_range(n_total, rank, world)
+        mine = poses_all[lo:hi]
+        scan = ShardedScan(hi - lo, B, "cpu", n_chunks=chunks)
+
+        def compute(clo, chi, view):
+            view.copy_(torch.from_numpy(_fake_ranges(mine[clo:chi], B)))
+
+        scan.step(compute)
+        got = scan.global_order().numpy().copy()
+        q.put((rank, g.occ.sum(), g.origin, g.resolution, got, len(scan.chunks)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunks", [1, 4])
+def test_sharded_scan_world2_matches_single_process(chunks):
+    world, n_total, B = 2, 24, 37
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, B, chunks, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = maps.make_maze(64, cell=16, wall=2, seed=3, origin=(1.0, -2.0, 0.25))
+    want = _fake_ranges(maps.sample_free_poses(g, n_total, 5), B)
+    for rank, occ_sum, origin, res_, got, n_chunks in res:
+        assert occ_sum == g.occ.sum() and origin == g.origin and res_ == g.resolution
+        assert n_chunks == chunks
+        assert np.array_equal(got, want), "rank %d: gathered ranges are not in global pose order" % rank
+
+
+def test_chunk_bounds_and_shards():
+    assert chunk_bounds(4096, 4) == [(0, 1024), (1024, 2048), (2048, 3072), (3072, 4096)]
+    assert chunk_bounds(10, 4) == [(0, 5), (5, 10)]          # reduced until it divides
+    assert chunk_bounds(7, 4) == [(0, 7)]
+    assert chunk_bounds(3, 8) == [(0, 1), (1, 2), (2, 3)]
+    assert [shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]

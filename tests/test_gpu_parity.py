@@ -1,0 +1,273 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).  Every test calls the HIP kernels
+through the C ABI (libscan_amd.so) and compares with the CPU oracle on the same seeded inputs,
+with the committed golden vectors, or — at BASELINE.json's full sizes — through
+size-independent properties.  Bar: bit-exact ranges / hit cells / step counts for ray marching."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from pyracecarsimulator_amd import ScanSimulator2D, maps, range_libc, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu(need_gpu):
+    yield
+
+
+def _fan(method, poses, fov, B):
+    n = len(poses) * B
+    out = np.empty(n, np.float32)
+    hits = np.empty((n, 2), np.int32)
+    steps = np.empty(n, np.uint16)
+    method.calc_range_fan(poses, out, fov, B, hit_cells=hits, steps=steps)
+    return out, hits, steps
+
+
+# ---------------------------------------------------------------- K0: EDT
+@pytest.mark.parametrize("case", ["colombia", "maze", "random", "single", "empty", "wide"])
+def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
+    rng = np.random.default_rng(1)
+    occ = {"colombia": lambda: maps.load_colombia().occ,
+           "maze": lambda: maps.make_maze(300, cell=30, wall=2, seed=2).occ,
+           "random": lambda: (rng.random((211, 173)) < 0.01).astype(np.uint8),
+           "single": lambda: np.pad(np.ones((1, 1), np.uint8), ((40, 9), (3, 77))),
+           "empty": lambda: np.zeros((33, 65), np.uint8),
+           "wide": lambda: (rng.random((5, 3000)) < 0.002).astype(np.uint8)}[case]()
+    omap = range_libc.PyOMap(occ, 0.05)
+    assert np.array_equal(omap.distance_transform(), oracle_mod.edt(occ))
+
+
+# ---------------------------------------------------------------- K1 vs golden vectors
+@pytest.mark.parametrize("name", ["rm_colombia", "rm_maze256", "rm_maze192_yaw"])
+def test_rm_fan_reproduces_golden_vectors(name):
+    g, z = load_golden(name)
+    omap = range_libc.PyOMap(g)
+    fov, B, mrx = float(z["fov"]), int(z["num_rays"]), int(z["max_range_px"])
+    for tag, cls in (("cpu", range_libc.PyRayMarching), ("gpu", range_libc.PyRayMarchingGPU)):
+        r, h, s = _fan(cls(omap, mrx), z["poses"], fov, B)
+        assert np.array_equal(r, z["ranges_" + tag]), tag
+        assert np.array_equal(h, z["hits_" + tag].astype(np.int32)), tag
+        assert np.array_equal(s, z["steps_" + tag]), tag
+
+
+# ---------------------------------------------------------------- K1 vs oracle, seeded sweeps
+@pytest.mark.parametrize("B,fov", [(1, 4.71), (63, 1.0), (64, 6.283), (65, 4.71), (1081, 4.71),
+                                   (1080, 4.71), (720, 3.14), (2500, 6.0)])
+def test_rm_fan_vs_oracle_beam_counts(oracle_mod, B, fov):
+    g = maps.make_maze(320, cell=32, wall=3, p=0.5, seed=B, resolution=0.05,
+                       origin=(-3.0, 4.0, 0.1 * (B % 7)))
+    mrx = 150
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    poses = maps.sample_free_poses(g, 37, B + 1, dt=om.dt)
+    for sc, cls in ((0.999, range_libc.PyRayMarching), (1.0, range_libc.PyRayMarchingGPU)):
+        r, h, s = _fan(cls(omap, mrx), poses, fov, B)
+        r0, h0, s0 = oracle_mod.OracleMap.rm_fan(om, poses, fov, B, step_coeff=sc)
+        assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0)
+
+
+def test_edge_cases(oracle_mod):
+    g = maps.make_room(128, wall=2)
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyRayMarching(omap, 300)
+    poses = np.array([
+        [3.0, 3.0, 0.0], [3.0, 3.0, 1e-30], [3.0, 3.0, -1e-38], [3.0, 3.0, 1e-42],   # tiny / denormal
+        [0.01, 0.01, 0.7],                      # inside the wall
+        [-0.3 * 0.05, 1.0, 0.0],                # -1 < gx < 0: in-map by truncation
+        [-5.0, -5.0, 0.3], [100.0, 3.0, 3.0],   # outside the map
+        [np.nan, 1.0, 0.0], [1.0, np.inf, 0.0], [1.0, 1.0, np.nan], [1e30, -1e30, 5.0],
+        [3.0, 3.0, 1e4], [3.0, 3.0, -777.0],    # large headings
+    ], np.float32)
+    r, h, s = _fan(m, poses, 4.71, 129)
+    r0, h0, s0 = om.rm_fan(poses, 4.71, 129)
+    assert np.array_equal(r, r0, equal_nan=True) and np.array_equal(h, h0) and np.array_equal(s, s0)
+    # empty batch: nothing happens, nothing raises
+    out = np.empty(0, np.float32)
+    m.calc_range_fan(np.zeros((0, 3), np.float32), out, 4.71, 129)
+    m.calc_range_many(np.zeros((0, 3), np.float32), out)
+    # map without any obstacle: every ray is a miss at max range
+    omap2 = range_libc.PyOMap(np.zeros((50, 60), np.uint8), 0.1)
+    r, h, s = _fan(range_libc.PyRayMarchingGPU(omap2, 40), np.array([[3.0, 2.5, 0.2]], np.float32), 6.0, 100)
+    assert np.all(r == np.float32(40) * np.float32(0.1)) and np.all(h == -1)
+
+
+def test_two_arg_rays_api_and_four_arg_sparse_api(oracle_mod):
+    g, z = load_golden("rm_maze192_yaw")
+    mrx, B, fov = int(z["max_range_px"]), int(z["num_rays"]), float(z["fov"])
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyRayMarching(omap, mrx)
+    # upstream 2-arg form: one (x,y,theta) row per ray (scripts/two_player/scan.py:57-70)
+    rng = np.random.default_rng(3)
+    ins = z["poses"][rng.integers(0, len(z["poses"]), 5000)].copy()
+    ins[:, 2] = rng.uniform(-7, 7, len(ins)).astype(np.float32)
+    outs = np.zeros(len(ins), np.float32)
+    assert m.calc_range_many(ins, outs) is None
+    r0, _, _ = om.rm_rays(ins)
+    assert np.array_equal(outs, r0)
+    assert m.calc_range(*ins[7]) == float(r0[7])
+    # the fork's 4-arg form exactly as ScanSimulator2D calls it: sparse ins, pose p at row p*B
+    P = 5
+    sparse = np.zeros((P * B, 3), np.float32)
+    sparse[::B] = z["poses"][:P]
+    outs = np.full(P * B, -1, np.float32)
+    assert m.calc_range_many(sparse, outs, fov, B) is None
+    assert np.array_equal(outs, z["ranges_cpu"][:P * B])
+    with pytest.raises(ValueError):
+        m.calc_range_many(sparse.astype(np.float64), outs, fov, B)
+    with pytest.raises(TypeError):
+        m.calc_range_many(sparse, outs, fov)
+
+
+def test_scan_simulator_end_to_end(oracle_mod):
+    g = maps.load_colombia()
+    mrx = int(15.0 / g.resolution)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    poses = maps.sample_free_poses(g, 10, 77, dt=om.dt)
+    for method, sc in (("RM", 0.999), ("RMGPU", 1.0)):
+        sim = ScanSimulator2D(1081, 4.71, 0.01, batch_size=8)
+        sim.setMap(omap, mrx, g.resolution, g.origin)
+        sim.setRaytracingMethod(method)
+        want, _, _ = om.rm_fan(poses[:8], 4.71, 1081, step_coeff=sc)
+        many = sim.scanMany(poses)                  # 10 given, batch_size 8 scanned
+        assert many is sim.output_vector_many and np.array_equal(many, want)
+        one = sim.scan(float(poses[2, 0]), float(poses[2, 1]), float(poses[2, 2]))
+        assert one is sim.output_vector and np.array_equal(one, want[2 * 1081:3 * 1081])
+        first = one.copy()
+        sim.scan(*[float(v) for v in poses[3]])     # alias: the earlier result is overwritten
+        assert not np.array_equal(one, first)
+
+
+def test_noise_statistics_and_shard_invariance(oracle_mod):
+    g, z = load_golden("rm_maze256")
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyRayMarchingGPU(omap, 300)
+    poses, B = z["poses"], 1081
+    clean = np.empty(len(poses) * B, np.float32)
+    m.calc_range_fan(poses, clean, 4.71, B)
+    assert np.array_equal(clean, z["ranges_gpu"])
+    m.set_noise(0.01, seed=6)
+    noisy = np.empty_like(clean)
+    m.calc_range_fan(poses, noisy, 4.71, B)
+    d = (noisy - clean).astype(np.float64)
+    assert abs(d.mean()) < 3e-4 and abs(d.std() - 0.01) < 3e-4
+    k = (d / 0.01)
+    assert abs((k ** 3).mean()) < 0.05 and abs((k ** 4).mean() - 3.0) < 0.15      # gaussian moments
+    again = np.empty_like(clean)
+    m.calc_range_fan(poses, again, 4.71, B)
+    assert np.array_equal(noisy, again)                                           # counter-based
+    # sharding: second half scanned alone with ray_offset reproduces the unsharded noise
+    half = len(poses) // 2
+    m.set_noise(0.01, seed=6, ray_offset=half * B)
+    part = np.empty((len(poses) - half) * B, np.float32)
+    m.calc_range_fan(poses[half:], part, 4.71, B)
+    assert np.array_equal(part, noisy[half * B:])
+    m.set_noise(0.0)
+    m.calc_range_fan(poses, again, 4.71, B)
+    assert np.array_equal(again, clean)
+
+
+def test_fused_crash_test_matches_is_crashed(oracle_mod):
+    g = maps.load_colombia()
+    mrx, B, fov = 300, 1081, 4.71
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyRayMarchingGPU(omap, mrx)
+    edge = oracle_mod.edge_distances(B, -fov / 2, fov / B, 0.275, 0.2032, 0.3302)
+    rng = np.random.default_rng(8)
+    seen = set()
+    for trial in range(12):
+        clear = 2.0 if trial % 2 == 0 else 8.0
+        rr, cc = np.nonzero(om.dt >= clear)
+        k = rng.integers(0, rr.size, 40)
+        poses = np.stack([cc[k] * 0.05 + g.origin[0] + 0.02, rr[k] * 0.05 + g.origin[1] + 0.02,
+                          rng.uniform(-3, 3, 40)], 1).astype(np.float32)
+        ranges = np.empty(40 * B, np.float32)
+        code = m.check_collision_many(poses, fov, B, edge, 0.001, ranges=ranges)
+        want_r, _, _ = om.rm_fan(poses, fov, B, step_coeff=1.0)
+        assert np.array_equal(ranges, want_r)
+        assert code == oracle_mod.is_crashed(want_r, B, 40, edge, 0.001)
+        assert m.check_collision_many(poses, fov, B, edge, 0.001) == code     # ranges not requested
+        seen.add(code >= 0)
+    assert seen == {True, False}
+    assert m.check_collision_many(np.zeros((0, 3), np.float32), fov, B, edge, 0.001) == -1
+
+
+def test_map_update_rebuilds_tables(oracle_mod):
+    g = maps.make_maze(200, cell=25, wall=2, seed=5)
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyRayMarching(omap, 120)
+    poses = maps.sample_free_poses(g, 6, 1)
+    occ2 = g.occ.copy()
+    occ2[90:110, 90:110] = 1                         # stamp an obstacle (two-player car outline)
+    omap.update(occ2)
+    om2 = oracle_mod.OracleMap(occ2, g.resolution, g.origin, 120)
+    assert np.array_equal(omap.distance_transform(), om2.dt)
+    r, h, s = _fan(m, poses, 4.71, 360)
+    r0, h0, s0 = om2.rm_fan(poses, 4.71, 360)
+    assert np.array_equal(r, r0) and np.array_equal(h, h0)
+
+
+def test_device_resident_api_with_torch_streams(oracle_mod):
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    g, z = load_golden("rm_colombia")
+    omap = range_libc.PyOMap(g, device=0)
+    m = range_libc.PyRayMarchingGPU(omap, 300)
+    B = 1081
+    d_poses = torch.from_numpy(z["poses"]).cuda()
+    d_out = torch.zeros(len(z["poses"]) * B, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        m.calc_range_fan_device(d_poses.data_ptr(), len(z["poses"]), 4.71, B, d_out.data_ptr(),
+                                stream=side.cuda_stream)
+    side.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), z["ranges_gpu"])
+    assert m.last_kernel_ms() > 0.0
+
+
+# ---------------------------------------------------------------- full BASELINE size: properties
+def test_cfg2_full_size_properties(oracle_mod):
+    """configs[1]: 2049^2 map, 4096 poses x 1081 beams (4.4 M rays) — checked through properties
+    that do not need the oracle on every ray, plus an oracle spot check on a pose subsample."""
+    w = workloads.cfg2()
+    g, B, mrx = w.gmap, w.num_rays, w.max_range_px
+    omap = range_libc.PyOMap(g)
+    dt = omap.distance_transform()
+    assert np.array_equal(dt == 0, g.occ != 0)
+    poses = workloads.make_poses(w, dt=dt)
+    m = range_libc.PyRayMarchingGPU(omap, mrx)
+    r, h, s = _fan(m, poses, w.fov, B)
+    hit = h[:, 0] >= 0
+    # (a) every reported hit cell is an occupied cell inside the map
+    assert np.all(g.occ[h[hit, 1], h[hit, 0]] == 1)
+    # (b) range == |origin - hit cell corner| * res in float32, recomputed independently
+    inv = np.float32(1.0 / float(np.float32(g.resolution)))
+    gx = np.repeat(((poses[:, 0] - np.float32(g.origin[0])) * inv).astype(np.float32), B)
+    gy = np.repeat(((poses[:, 1] - np.float32(g.origin[1])) * inv).astype(np.float32), B)
+    xd = (h[hit, 0].astype(np.float32) - gx[hit]).astype(np.float64)
+    yd = (h[hit, 1].astype(np.float32) - gy[hit]).astype(np.float64)
+    want = (np.sqrt((xd * xd + yd * yd).astype(np.float32)).astype(np.float32) * np.float32(g.resolution))
+    assert np.abs(r[hit] - want).max() <= 2e-6
+    # (c) misses report exactly max range; all ranges bounded; step counts sane
+    assert np.all(r[~hit] == np.float32(mrx) * np.float32(g.resolution))
+    assert r.min() >= 0 and r.max() <= (mrx + 1.5) * g.resolution and s.min() >= 1
+    # (d) determinism + batch-split invariance
+    r2 = np.empty_like(r)
+    m.calc_range_fan(poses, r2, w.fov, B)
+    assert np.array_equal(r, r2)
+    cut = 1357
+    ra, rb = np.empty(cut * B, np.float32), np.empty((len(poses) - cut) * B, np.float32)
+    m.calc_range_fan(poses[:cut], ra, w.fov, B)
+    m.calc_range_fan(poses[cut:], rb, w.fov, B)
+    assert np.array_equal(np.concatenate([ra, rb]), r)
+    # (e) oracle spot check: every 64th pose, bit-exact
+    sub = np.arange(0, len(poses), 64)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    r0, h0, s0 = om.rm_fan(poses[sub], w.fov, B, step_coeff=1.0, nthreads=4)
+    pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
+    assert np.array_equal(r[pick], r0) and np.array_equal(h[pick], h0) and np.array_equal(s[pick], s0)

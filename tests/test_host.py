@@ -1,0 +1,167 @@
+"""CPU tests of the host side: map ingestion, workload generators, the ScanSimulator2D call
+protocol (GOLD-C, captured from the reference's own scan_simulator.py) and the C-ABI surface."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+from pyracecarsimulator_amd import _lib, maps, range_libc, workloads
+from pyracecarsimulator_amd.scan_simulator import ScanSimulator2D
+
+
+# ---------------------------------------------------------------- maps
+def test_pgm_p2_and_p5_roundtrip(tmp_path):
+    img = (np.arange(12 * 7).reshape(7, 12) * 3 % 256).astype(np.uint8)
+    p5 = tmp_path / "a.pgm"
+    p5.write_bytes(b"P5\n# c\n12 7\n255\n" + img.tobytes())
+    p2 = tmp_path / "b.pgm"
+    p2.write_text("P2\n# 8-bit pgm gray\n12 7\n255\n" +
+                  "\n".join(" ".join("%3d" % v for v in row) for row in img) + "\n")
+    assert np.array_equal(maps.read_pgm(str(p5)), img)
+    assert np.array_equal(maps.read_pgm(str(p2)), img)
+    with pytest.raises(ValueError):
+        (tmp_path / "c.pgm").write_text("P3\n1 1\n255\n0 0 0\n")
+        maps.read_pgm(str(tmp_path / "c.pgm"))
+
+
+def test_map_server_thresholds_flip_and_reference_binarisation(tmp_path):
+    img = np.array([[0, 254, 205], [100, 255, 30]], np.uint8)      # row 0 = TOP of the map
+    data = maps.occupancy_from_image(img, 0, 0.65, 0.196)
+    # (255-p)/255: 0->1.0 occ, 254->0.004 free, 205->0.196.. unknown, 100->0.61 unknown, 255 free, 30->0.88 occ
+    assert data.tolist() == [[-1, 0, 100], [100, 0, -1]]           # flipped vertically
+    occ = maps.binarise_reference(data)                            # unknown(-1) -> free
+    assert occ.tolist() == [[0, 0, 1], [1, 0, 0]]
+    (tmp_path / "m").mkdir()
+    (tmp_path / "m" / "map.pgm").write_bytes(b"P5\n3 2\n255\n" + img.tobytes())
+    (tmp_path / "m" / "map.yaml").write_text(
+        "image: map.pgm\nresolution: 0.05\norigin: [-1.0, -2.0, 0.0]\nnegate: 0\n"
+        "occupied_thresh: 0.65\nfree_thresh: 0.196\n")
+    g = maps.load_map_server_map(str(tmp_path / "m" / "map.yaml"))
+    assert g.occ.tolist() == occ.tolist() and g.resolution == 0.05 and g.origin == (-1.0, -2.0, 0.0)
+
+
+def test_colombia_fixture():
+    g = maps.load_colombia()
+    assert (g.rows, g.cols) == (350, 435) and abs(g.occ.mean() - 0.7173) < 1e-3
+    assert g.resolution == 0.05 and g.origin == (-5.70654, -2.020793, 0.0)
+
+
+def test_generators_are_deterministic():
+    a, b = maps.make_maze(200, seed=3), maps.make_maze(200, seed=3)
+    assert np.array_equal(a.occ, b.occ) and not np.array_equal(a.occ, maps.make_maze(200, seed=4).occ)
+    assert a.occ[0].all() and a.occ[:, -1].all()
+    p1, p2 = maps.sample_free_poses(a, 50, 9), maps.sample_free_poses(a, 50, 9)
+    assert np.array_equal(p1, p2) and p1.dtype == np.float32 and p1.shape == (50, 3)
+    col = np.floor((p1[:, 0] - a.origin[0]) / a.resolution).astype(int)
+    row = np.floor((p1[:, 1] - a.origin[1]) / a.resolution).astype(int)
+    assert np.all(a.occ[row, col] == 0)
+
+
+def test_workload_configs_match_baseline_json():
+    w2 = workloads.cfg2()
+    assert (w2.gmap.rows, w2.n_poses, w2.num_rays, w2.method) == (2049, 4096, 1081, "RMGPU")
+    assert w2.max_range_px == 300 and w2.fov == 4.71
+    assert workloads.cfg5().num_rays == 720 and workloads.cfg5().noise_std == 0.01
+    assert workloads.cfg4().gmap.name == "colombia" and workloads.cfg4().n_poses == 1 << 20
+    for n, world in [(10, 3), (4096, 8), (7, 8)]:
+        spans = [workloads.shard_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+# ---------------------------------------------------------------- ScanSimulator2D protocol (GOLD-C)
+class _RecordingMethod:
+    def __init__(self):
+        self.calls = []
+
+    def set_noise(self, *a):
+        pass
+
+    def calc_range_many(self, ins, outs, fov=None, num_rays=None):
+        self.calls.append(("many", ins.copy(), outs.shape, outs.dtype, fov, num_rays))
+        outs[:] = np.arange(outs.size, dtype=np.float32)
+
+    def calc_range_fan(self, poses, outs, fov, num_rays, hit_cells=None, steps=None):
+        self.calls.append(("fan", poses.copy(), outs.shape, outs.dtype, fov, num_rays))
+        outs[:] = np.arange(outs.size, dtype=np.float32)
+
+
+def test_scan_simulator_reproduces_reference_call_protocol():
+    proto = json.load(open(os.path.join(GOLD, "protocol.json")))
+    c = proto["ctor"]
+    sim = ScanSimulator2D(c["num_rays"], c["fov"], c["scan_std"], batch_size=c["batch_size"])
+    sim.setMap("omap", 300, 0.05, (0.0, 0.0, 0.0))
+    sim.scan_method = rec = _RecordingMethod()
+    # every public attribute of the reference object exists here too
+    assert set(proto["attributes"]) <= set(vars(sim))
+    out = sim.scan(1.0, 2.0, 0.5)
+    kind, ins, oshape, odt, fov, nr = rec.calls[0]
+    ref = proto["scan_call"]
+    assert kind == "many" and list(ins.shape) == ref["ins_shape"] and str(ins.dtype) == ref["ins_dtype"]
+    assert np.nonzero(ins.any(axis=1))[0].tolist() == ref["nonzero_rows"]
+    assert list(oshape) == ref["outs_shape"] and [fov, nr] == ref["extra_args"]
+    assert (out is sim.output_vector) == proto["scan_returns_cached_buffer"]
+    poses = np.array([[1, 2, 0.1], [3, 4, 0.2], [5, 6, 0.3], [7, 8, 0.4], [9, 9, 9]], np.float32)
+    out = sim.scanMany(poses)            # 5 poses given, batch_size 4 used (scan_simulator.py:119)
+    kind, p, oshape, odt, fov, nr = rec.calls[1]
+    refm = proto["scanMany_call"]
+    assert p.shape == (proto["scanMany_pose_rows_used"], 3) and np.array_equal(p, poses[:4])
+    assert list(oshape) == refm["outs_shape"] and [fov, nr] == refm["extra_args"]
+    assert list(sim.input_vector_many.shape) == refm["ins_shape"]
+    assert np.nonzero(sim.input_vector_many.any(axis=1))[0].tolist() == refm["nonzero_rows"]
+    assert (out is sim.output_vector_many) == proto["scanMany_returns_cached_buffer"]
+    assert sim.scanMany(poses, copy=True) is not sim.output_vector_many
+
+
+def test_set_raytracing_method_error_behaviour(capsys):
+    sim = ScanSimulator2D(16, 4.71, 0.01, batch_size=2)
+    sim.setRaytracingMethod("RM")                      # no map: prints and returns (:67-69)
+    assert "setMap first" in capsys.readouterr().out and sim.scan_method is None
+    sim.setMap("omap", 300, 0.05, (0, 0, 0))
+    with pytest.raises(SystemExit):                    # unknown method: print + sys.exit() (:77-79)
+        sim.setRaytracingMethod("CDDT")
+
+
+def test_calc_range_many_array_contract():
+    chk = range_libc._check_ins_outs
+    ins, outs = np.zeros((8, 3), np.float32), np.zeros(8, np.float32)
+    chk(ins, outs)
+    for bad_ins, bad_outs in [(ins.astype(np.float64), outs), (ins, outs.astype(np.float64)),
+                              (np.zeros((8, 2), np.float32), outs), (ins[::2], outs),
+                              (ins, np.zeros(4, np.float32)), (np.zeros(24, np.float32), outs)]:
+        with pytest.raises(ValueError):
+            chk(bad_ins, bad_outs)
+    with pytest.raises(TypeError):
+        chk([[0, 0, 0]], outs)
+
+
+# ---------------------------------------------------------------- C ABI surface
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "scanlib.h")).read()
+    declared = set(re.findall(r"\b(rl_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = _lib.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert b"gfx950" in L.rl_version()
+
+
+def test_no_cpu_fallback_fails_loudly_without_device():
+    L = _lib.lib()
+    if L.rl_device_count() > 0:
+        pytest.skip("a HIP device is visible here")
+    with pytest.raises(_lib.ScanLibError) as e:
+        range_libc.PyOMap(np.zeros((8, 8), np.uint8), 0.05)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pyracecarsimulator_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in src.replace("SURVEY", ""), os.path.join(dirpath, f)

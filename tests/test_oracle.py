@@ -1,0 +1,259 @@
+"""CPU tests of the oracle itself: known answers, the independent NumPy statement, and the
+committed golden vectors.  PARITY UNPINNED upstream (range_libc absent) — these
+pins are the build's own."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT, load_golden
+from oracle import np_statement as N
+from pyracecarsimulator_amd import maps
+
+
+# ---------------------------------------------------------------- trig / EDT
+def test_det_sincos_matches_numpy_statement_and_libm(oracle_mod):
+    x = np.concatenate([np.random.default_rng(0).uniform(-50, 50, 4000),
+                        [0.0, -0.0, 1e-30, -1e-30, math.pi / 2, math.pi, -math.pi, 2 * math.pi,
+                         0.7853981633974483, 1e-8, 100.0, -1000.0]]).astype(np.float32)
+    s, c = oracle_mod.sincosf(x)
+    s2, c2 = N.sincosf(x)
+    assert np.array_equal(s, s2) and np.array_equal(c, c2)
+    assert np.abs(s - np.sin(x.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(c - np.cos(x.astype(np.float64))).max() < 2.5e-7
+    s0, c0 = oracle_mod.sincosf(np.float32(0.0))
+    assert s0[0] == 0.0 and c0[0] == 1.0
+
+
+def test_edt_closed_forms(oracle_mod):
+    # KAT-5: single pixel and two pixels
+    occ = np.zeros((17, 23), np.uint8)
+    occ[5, 7] = 1
+    d = oracle_mod.edt(occ)
+    rr, cc = np.mgrid[0:17, 0:23]
+    want = np.sqrt(((rr - 5) ** 2 + (cc - 7) ** 2).astype(np.float32))
+    assert np.array_equal(d, want)
+    occ[12, 20] = 1
+    d = oracle_mod.edt(occ)
+    want2 = np.minimum(want, np.sqrt(((rr - 12) ** 2 + (cc - 20) ** 2).astype(np.float32)))
+    assert np.array_equal(d, want2)
+    # empty map: Felzenszwalb INF -> 1e10
+    assert np.all(oracle_mod.edt(np.zeros((4, 5), np.uint8)) == np.float32(1e10))
+
+
+@pytest.mark.parametrize("seed,shape", [(1, (64, 64)), (2, (97, 131)), (3, (200, 50))])
+def test_edt_vs_scipy(oracle_mod, seed, shape):
+    rng = np.random.default_rng(seed)
+    occ = (rng.random(shape) < 0.03).astype(np.uint8)
+    assert np.array_equal(oracle_mod.edt(occ), N.edt(occ))
+    d2 = oracle_mod.edt_sq(occ)
+    assert np.array_equal(np.sqrt(d2.astype(np.float32)), oracle_mod.edt(occ))
+
+
+def test_edt_colombia_vs_scipy(oracle_mod):
+    g = maps.load_colombia()
+    assert g.occ.shape == (350, 435)
+    assert np.array_equal(oracle_mod.edt(g.occ), N.edt(g.occ))
+
+
+# ---------------------------------------------------------------- known answers
+def _room(oracle_mod, n=64, res=0.05, mrx=300):
+    g = maps.make_room(n, wall=1, resolution=res)
+    return g, oracle_mod.OracleMap.from_gridmap(g, mrx)
+
+
+def test_kat1_axis_aligned_room(oracle_mod):
+    g, om = _room(oracle_mod)
+    # pose at a cell centre (col 20.5, row 30.5); 4 beams at 0, pi/2, pi, 3pi/2 via rays API
+    xw, yw = 20.5 * 0.05, 30.5 * 0.05
+    ins = np.array([[xw, yw, 0.0], [xw, yw, math.pi / 2], [xw, yw, math.pi],
+                    [xw, yw, -math.pi / 2]], np.float32)
+    r, h, s = om.rm_rays(ins, step_coeff=0.999)
+    # +x: wall column 63: the march lands in cell (63,30); range = distance to its corner
+    gx, gy = np.float32(xw) * np.float32(20.0), np.float32(yw) * np.float32(20.0)
+    assert h[0].tolist() == [63, 30]
+    assert r[0] == np.float32(np.sqrt(np.float32((63 - gx) ** 2 + (30 - gy) ** 2)) * np.float32(0.05))
+    assert h[1].tolist()[1] == 63          # +y: top wall row
+    assert h[2].tolist()[0] == 0           # -x: left wall col
+    assert h[3].tolist()[1] == 0           # -y: bottom wall row
+    assert np.all(s >= 2)
+
+
+def test_kat2_pose_inside_occupied_cell(oracle_mod):
+    g, om = _room(oracle_mod)
+    ins = np.array([[0.3 * 0.05, 10.6 * 0.05, 0.4]], np.float32)   # inside the left wall
+    r, h, s = om.rm_rays(ins)
+    gx, gy = ins[0, 0] * np.float32(20.0), ins[0, 1] * np.float32(20.0)
+    fx, fy = gx - np.float32(0), gy - np.float32(10)
+    want = np.sqrt(np.float32(fx * fx + fy * fy)) * np.float32(0.05)
+    assert h[0].tolist() == [0, 10] and s[0] == 1
+    assert abs(float(r[0]) - float(want)) < 1e-7 and r[0] > 0      # RM: NOT zero
+    rb, hb, sb = om.bl_rays(ins)
+    assert rb[0] == 0.0 and hb[0].tolist() == [0, 10]             # Bresenham: zero
+
+
+def test_kat3_ray_leaving_the_map_and_kat4_open_field(oracle_mod):
+    occ = np.zeros((700, 700), np.uint8)
+    occ[0, 0] = 1                                    # one far obstacle so the EDT is finite
+    om = oracle_mod.OracleMap(occ, 0.05, (0.0, 0.0, 0.0), 300)
+    # KAT-3: pose near the right edge looking out -> leaves the map -> max range
+    r, h, s = om.rm_rays(np.array([[699.5 * 0.05, 350 * 0.05, 0.0]], np.float32))
+    assert r[0] == np.float32(300.0) * np.float32(0.05) and h[0].tolist() == [-1, -1]
+    # KAT-4: open field > 300 px in every direction -> t >= max_range
+    r, h, s = om.rm_fan(np.array([[350 * 0.05, 350 * 0.05, 0.3]], np.float32), 6.28, 90)
+    assert np.all(r == np.float32(15.0)) and np.all(h == -1)
+    # outside the map entirely / NaN pose: deterministic miss
+    r, h, s = om.rm_rays(np.array([[-5.0, -5.0, 0.0], [np.nan, 1.0, 0.0], [1e30, 0, 0]], np.float32))
+    assert np.all(r == np.float32(15.0)) and np.all(s == 0)
+
+
+def test_negative_coordinate_caveat_kept(oracle_mod):
+    # trunc(-0.3) = 0: a pose at -1 < g < 0 is treated as in-map
+    g, om = _room(oracle_mod)
+    r, h, s = om.rm_rays(np.array([[-0.3 * 0.05, 5.5 * 0.05, 0.0]], np.float32))
+    assert h[0].tolist() == [0, 5] and s[0] == 1
+
+
+# ---------------------------------------------------------------- independent statement + golden
+@pytest.mark.parametrize("seed", [11, 12])
+def test_rm_c_oracle_equals_numpy_statement(oracle_mod, seed):
+    g = maps.make_maze(160, cell=20, wall=2, p=0.5, seed=seed, resolution=0.1,
+                       origin=(1.5, -2.0, 0.3 * (seed - 11)))
+    om = oracle_mod.OracleMap.from_gridmap(g, 90)
+    poses = maps.sample_free_poses(g, 12, seed, dt=om.dt)
+    for sc in (0.999, 1.0):
+        r, h, s = om.rm_fan(poses, 4.71, 271, step_coeff=sc)
+        r2, h2, s2 = N.rm_fan(g.occ, g.resolution, g.origin, 90, poses, 4.71, 271, sc)
+        assert np.array_equal(r, r2) and np.array_equal(h, h2) and np.array_equal(s, s2)
+
+
+@pytest.mark.parametrize("name", ["rm_colombia", "rm_maze256", "rm_maze192_yaw"])
+def test_oracle_reproduces_golden_vectors(oracle_mod, name):
+    g, z = load_golden(name)
+    om = oracle_mod.OracleMap.from_gridmap(g, int(z["max_range_px"]))
+    fov, B = float(z["fov"]), int(z["num_rays"])
+    for tag, sc in (("cpu", 0.999), ("gpu", 1.0)):
+        r, h, s = om.rm_fan(z["poses"], fov, B, step_coeff=sc, nthreads=2)
+        assert np.array_equal(r, z["ranges_" + tag])
+        assert np.array_equal(h, z["hits_" + tag].astype(np.int32))
+        assert np.array_equal(s, z["steps_" + tag])
+    rb, hb, _ = om.bl_fan(z["poses"], fov, B)
+    assert np.array_equal(rb, z["ranges_bl"]) and np.array_equal(hb, z["hits_bl"].astype(np.int32))
+
+
+def test_fan_equals_per_ray_rows_up_to_trig_form(oracle_mod):
+    """4-arg fan vs the 2-arg per-ray form (scripts/two_player/scan.py:57-66): same geometry, the
+    direction comes from angle addition vs one sincos of the summed angle -> <= 1 cell apart on
+    all but grazing rays."""
+    g, z = load_golden("rm_maze256")
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    poses, B, fov = z["poses"][:6], 1081, 4.71
+    r_fan, _, _ = om.rm_fan(poses, fov, B)
+    th = (poses[:, 2:3] + (np.float32(-fov / 2) + np.arange(B, dtype=np.float32) *
+                           np.float32(fov / B))[None, :]).astype(np.float32)
+    ins = np.stack([np.repeat(poses[:, 0], B), np.repeat(poses[:, 1], B), th.ravel()], 1)
+    r_rays, _, _ = om.rm_rays(ins)
+    close = np.abs(r_fan - r_rays) <= g.resolution * 1.0001
+    assert close.mean() > 0.995
+
+
+def test_canonical_form_vs_upstream_literal_libm(oracle_mod):
+    """The canonical (deterministic-trig, fused) march and the upstream-literal statement
+    (libm cosf/sinf of -theta+rot_const, calc_range(y,x,.), unfused) trace the same geometry."""
+    for name in ("rm_colombia", "rm_maze192_yaw"):
+        g, z = load_golden(name)
+        om = oracle_mod.OracleMap.from_gridmap(g, int(z["max_range_px"]))
+        rng = np.random.default_rng(5)
+        base = z["poses"][rng.integers(0, len(z["poses"]), 4000)]
+        ins = base.copy()
+        ins[:, 2] = rng.uniform(-np.pi, np.pi, len(ins)).astype(np.float32)
+        a, _, _ = om.rm_rays(ins)
+        b = om.rm_rays_libm(ins)
+        # measured here: identical hit cells on every ray; ranges differ only by the rounding of
+        # the fused vs unfused origin arithmetic (<= 4e-5 cell)
+        assert (np.abs(a - b) <= g.resolution * 1.0001).mean() > 0.99
+        assert np.median(np.abs(a - b)) == 0.0 and (a == b).mean() > 0.6
+
+
+def test_bresenham_close_to_ray_marching(oracle_mod):
+    g, z = load_golden("rm_maze256")
+    diff = np.abs(z["ranges_bl"] - z["ranges_cpu"])
+    assert (diff <= 2.0 * g.resolution).mean() > 0.97
+
+
+# ---------------------------------------------------------------- LUT / CDDT restatements
+def test_giant_lut_matches_ray_marching_from_cell_corner(oracle_mod):
+    g = maps.make_maze(96, cell=16, wall=2, p=0.5, seed=4)
+    om = oracle_mod.OracleMap.from_gridmap(g, 80)
+    td = 180
+    lut = om.lut_build(td, nthreads=4)
+    assert lut.shape == (96, 96, td)
+    # a LUT query equals (quantised) RM from the cell corner at the bin angle
+    rng = np.random.default_rng(0)
+    rr, cc = np.nonzero(g.occ == 0)
+    k = rng.integers(0, rr.size, 500)
+    b = rng.integers(0, td, 500)
+    ins = np.stack([cc[k] * g.resolution + g.origin[0] + 1e-4, rr[k] * g.resolution + g.origin[1] + 1e-4,
+                    b * (2 * np.pi / td)], 1).astype(np.float32)
+    q = om.lut_rays(lut, ins)
+    exact, _, _ = om.rm_rays(np.stack([ins[:, 0] - 1e-4, ins[:, 1] - 1e-4, ins[:, 2]], 1))
+    assert np.abs(q - np.minimum(exact, 80 * g.resolution)).max() < 0.01 * g.resolution + 2e-3
+    # fan form == per-ray form on the same headings
+    poses = maps.sample_free_poses(g, 5, 1)
+    fan = om.lut_fan(lut, poses, 4.71, 271)
+    assert fan.shape == (5 * 271,) and np.all(fan >= 0) and np.all(fan <= 80 * g.resolution + 1e-6)
+
+
+def test_cddt_tracks_ray_marching(oracle_mod):
+    g, z = load_golden("rm_maze256")
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    poses = z["poses"][:8]
+    r_rm, _, _ = om.rm_fan(poses, 4.71, 1081)
+    r_cd = om.cddt_fan(720, poses, 4.71, 1081)
+    err = np.abs(r_cd - r_rm) / g.resolution
+    assert np.median(err) < 1.0 and (err < 3.0).mean() > 0.9
+
+
+# ---------------------------------------------------------------- consumers: Car (racecar.cpp)
+def test_edge_distances_and_is_crashed_vs_reference_build(oracle_mod):
+    """GOLD-D: codes produced by the reference's own compiled Car::isCrashed
+    (racecar/src/racecar.cpp:305-328 via oracle/_ref) on seeded scans."""
+    z = np.load(os.path.join(GOLD, "car_ref.npz"))
+    car = dict(zip([str(k) for k in z["car_keys"]], z["car"]))
+    for i in range(len(z["codes"])):
+        B, fov, P = int(z["num_rays"][i]), float(z["fov"][i]), int(z["poses"][i])
+        edge = oracle_mod.edge_distances(B, -fov / 2.0, fov / B, 0.275, car["width"], car["wb"])
+        code = oracle_mod.is_crashed(z["rays_%d" % i], B, P, edge, car["ttc_thresh"])
+        assert code == int(z["codes"][i]), i
+    # semantics pinned by the survey probe: no crash -> -(poses+1); crash in pose k -> k
+    edge = oracle_mod.edge_distances(8, -1.0, 0.25, 0.275, 0.2032, 0.3302)
+    far = np.full(24, 10.0, np.float32)
+    assert oracle_mod.is_crashed(far, 8, 3, edge, 0.001) == -4
+    assert oracle_mod.is_crashed(far[:8], 8, 1, edge, 0.001) == -2
+    far[8 + 2] = 0.0   # (beam 3 sits at angle 0: the reference's -1016 m edge quirk, racecar.cpp:277-278)
+    assert oracle_mod.is_crashed(far, 8, 3, edge, 0.001) == 1
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle/_ref/libracecar_ref.so")),
+                    reason="oracle/_ref not built")
+def test_oracle_edge_table_equals_live_reference_build(oracle_mod):
+    L = C.CDLL(os.path.join(ROOT, "oracle/_ref/libracecar_ref.so"))
+    L.ref_car_create.restype = C.c_void_p
+    L.ref_car_create.argtypes = [C.POINTER(C.c_double)]
+    L.ref_car_set_edge_distances.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+    L.ref_car_is_crashed.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]
+    z = np.load(os.path.join(GOLD, "car_ref.npz"))
+    car = L.ref_car_create((C.c_double * 17)(*z["car"]))
+    B, fov = 1081, 4.71
+    L.ref_car_set_edge_distances(car, B, -fov / 2, fov / B, 0.275)
+    edge = oracle_mod.edge_distances(B, -fov / 2, fov / B, 0.275, float(z["car"][10]), float(z["car"][0]))
+    # probe the private table through isCrashed: a ray just under / over edge+thresh per beam
+    thresh = float(z["car"][9])
+    for j in range(0, B, 37):
+        rays = np.full(B, 100.0, np.float32)
+        rays[j] = np.float32(edge[j] + thresh) - np.float32(1e-3)
+        assert L.ref_car_is_crashed(car, rays.ctypes.data_as(C.POINTER(C.c_float)), B, 1) == 0
+        rays[j] = np.float32(edge[j] + thresh) + np.float32(1e-3)
+        assert L.ref_car_is_crashed(car, rays.ctypes.data_as(C.POINTER(C.c_float)), B, 1) == -2

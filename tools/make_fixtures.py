@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ and pyracecarsimulator_amd/data/.
+
+Run in the build container only (reads /root/reference; the GPU box never does):
+
+* data/colombia_map.npz   the one map the reference mount holds (maps/colombia/map.pgm +
+                          map.yaml values), re-encoded — a data file, not source.
+* golden/protocol.json    GOLD-C: call protocol of the reference's own ScanSimulator2D
+                          (scripts/scan_simulator.py run through lib2to3 on a /tmp copy, with a
+                          recording stub in place of range_libc): shapes, dtypes, live rows,
+                          fov/num_rays arguments, buffer aliasing.
+* golden/car_ref.npz      GOLD-D: outputs of the reference's compiled Car (oracle/_ref):
+                          setCarEdgeDistances-driven isCrashed codes on seeded scans.
+* golden/rm_*.npz         GOLD-A/B: ranges, hit cells, step counts of the C oracle on seeded
+                          poses (cross-checked here against the independent NumPy statement
+                          before being written).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from pyracecarsimulator_amd import maps  # noqa: E402
+from oracle import oracle as O, np_statement as N  # noqa: E402
+
+CAR = dict(wb=0.3302, fc=0.523, h_cg=0.074, l_f=0.15875, l_r=0.17145, cs_f=4.718, cs_r=5.4562,
+           mass=3.47, I_z=0.04712, ttc_thresh=0.001, width=0.2032, length=0.5,
+           max_steer_vel=3.2, max_steer_ang=0.4189, max_speed=7.0, max_accel=7.51,
+           max_decel=8.26)
+
+
+def colombia():
+    img = maps.read_pgm(os.path.join(REF, "maps/colombia/map.pgm"))
+    meta = maps.read_map_yaml(os.path.join(REF, "maps/colombia/map.yaml"))
+    np.savez_compressed(os.path.join(ROOT, "pyracecarsimulator_amd/data/colombia_map.npz"),
+                        image=img, resolution=meta["resolution"], origin=np.array(meta["origin"]),
+                        negate=meta["negate"], occupied_thresh=meta["occupied_thresh"],
+                        free_thresh=meta["free_thresh"])
+
+
+def protocol():
+    tmp = tempfile.mkdtemp(prefix="scanproto")
+    shutil.copy(os.path.join(REF, "scripts/scan_simulator.py"), tmp)
+    subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", tmp],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    calls = []
+
+    class _Rec:
+        def __init__(self, *a):
+            self.args = a
+
+        def calc_range_many(self, ins, outs, *rest):
+            calls.append({"ins_shape": list(ins.shape), "ins_dtype": str(ins.dtype),
+                          "ins_c_contiguous": bool(ins.flags.c_contiguous),
+                          "outs_shape": list(outs.shape), "outs_dtype": str(outs.dtype),
+                          "nonzero_rows": np.nonzero(ins.any(axis=1))[0].tolist(),
+                          "extra_args": [float(rest[0]), int(rest[1])] if rest else []})
+            outs[:] = np.arange(outs.size, dtype=np.float32)
+
+    stub = types.ModuleType("range_libc")
+    stub.PyRayMarching = type("PyRayMarching", (_Rec,), {})
+    stub.PyRayMarchingGPU = type("PyRayMarchingGPU", (_Rec,), {})
+    sys.modules["range_libc"] = stub
+    sys.path.insert(0, tmp)
+    import scan_simulator as ref
+    sim = ref.ScanSimulator2D(1081, 4.71, 0.01, batch_size=4)
+    sim.setMap("omap", 300, 0.05, (0.0, 0.0, 0.0))
+    sim.setRaytracingMethod("RMGPU")
+    method_cls = type(sim.scan_method).__name__
+    method_args = [str(a) for a in sim.scan_method.args]
+    out1 = sim.scan(1.0, 2.0, 0.5)
+    alias1 = out1 is sim.output_vector
+    poses = np.array([[1, 2, 0.1], [3, 4, 0.2], [5, 6, 0.3], [7, 8, 0.4], [9, 9, 9]], np.float32)
+    out2 = sim.scanMany(poses)
+    alias2 = out2 is sim.output_vector_many
+    proto = {"source": "scripts/scan_simulator.py (lib2to3 copy, recording range_libc stub)",
+             "ctor": {"num_rays": 1081, "fov": 4.71, "scan_std": 0.01, "batch_size": 4},
+             "attributes": sorted(k for k in vars(sim) if not k.startswith("_")),
+             "method_class_for_RMGPU": method_cls, "method_ctor_args": method_args,
+             "scan_call": calls[0], "scan_returns_cached_buffer": alias1,
+             "scanMany_call": calls[1], "scanMany_returns_cached_buffer": alias2,
+             "scanMany_pose_rows_used": 4, "scanMany_poses_given": 5}
+    sys.path.remove(tmp)
+    del sys.modules["range_libc"], sys.modules["scan_simulator"]
+    with open(os.path.join(GOLD, "protocol.json"), "w") as f:
+        json.dump(proto, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp)
+
+
+def car_ref():
+    so = os.path.join(ROOT, "oracle/_ref/libracecar_ref.so")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"],
+                          stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    L.ref_car_create.restype = C.c_void_p
+    L.ref_car_create.argtypes = [C.POINTER(C.c_double)]
+    L.ref_car_set_edge_distances.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+    L.ref_car_is_crashed.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]
+    L.ref_car_is_crashed.restype = C.c_int
+    order = ["wb", "fc", "h_cg", "l_f", "l_r", "cs_f", "cs_r", "mass", "I_z", "ttc_thresh",
+             "width", "length", "max_steer_vel", "max_steer_ang", "max_speed", "max_accel",
+             "max_decel"]
+    args = (C.c_double * 17)(*[CAR[k] for k in order])
+    car = L.ref_car_create(args)
+    cases = []
+    rng = np.random.default_rng(42)
+    for num_rays, fov, poses in [(1081, 4.71, 1), (1081, 4.71, 6), (1080, 4.71, 5), (720, 3.14, 4),
+                                 (64, 6.2, 3)]:
+        L.ref_car_set_edge_distances(car, num_rays, -fov / 2.0, fov / num_rays, 0.275)
+        edge = O.edge_distances(num_rays, -fov / 2.0, fov / num_rays, 0.275, CAR["width"], CAR["wb"])
+        for trial in range(6):
+            rays = rng.uniform(0.3, 15.0, size=poses * num_rays).astype(np.float32)
+            if trial % 3 == 1:      # plant a crash in a random pose/beam
+                p, j = rng.integers(0, poses), rng.integers(0, num_rays)
+                rays[p * num_rays + j] = np.float32(max(edge[j], 0.0) * 0.5)
+            if trial % 3 == 2:      # borderline: exactly at edge + thresh
+                p, j = rng.integers(0, poses), rng.integers(0, num_rays)
+                rays[p * num_rays + j] = np.float32(edge[j] + CAR["ttc_thresh"])
+            code = L.ref_car_is_crashed(car, rays.ctypes.data_as(C.POINTER(C.c_float)), num_rays,
+                                        poses)
+            cases.append((num_rays, fov, poses, rays, code))
+    np.savez_compressed(
+        os.path.join(GOLD, "car_ref.npz"),
+        car=np.array([CAR[k] for k in order]), car_keys=np.array(order),
+        num_rays=np.array([c[0] for c in cases]), fov=np.array([c[1] for c in cases]),
+        poses=np.array([c[2] for c in cases]), codes=np.array([c[4] for c in cases]),
+        **{"rays_%d" % i: c[3] for i, c in enumerate(cases)})
+
+
+def rm_golden(name, g, n_poses, seed, mrx=300, fov=4.71, num_rays=1081):
+    om = O.OracleMap.from_gridmap(g, mrx)
+    assert np.array_equal(om.dt, N.edt(g.occ)), "EDT: C oracle vs scipy statement"
+    poses = maps.sample_free_poses(g, n_poses, seed, dt=om.dt)
+    out = {"poses": poses, "fov": fov, "num_rays": num_rays, "max_range_px": mrx,
+           "occ_packed": np.packbits(g.occ, axis=1), "shape": np.array(g.occ.shape),
+           "resolution": g.resolution, "origin": np.array(g.origin)}
+    for tag, sc in (("cpu", 0.999), ("gpu", 1.0)):
+        r, h, s = om.rm_fan(poses, fov, num_rays, step_coeff=sc)
+        r2, h2, s2 = N.rm_fan(g.occ, g.resolution, g.origin, mrx, poses, fov, num_rays, sc)
+        assert np.array_equal(r, r2) and np.array_equal(h, h2) and np.array_equal(s, s2), \
+            "C oracle vs NumPy statement disagree on " + name
+        out["ranges_" + tag] = r
+        out["hits_" + tag] = h.astype(np.int16)
+        out["steps_" + tag] = s
+    rb, hb, sb = om.bl_fan(poses, fov, num_rays)
+    out["ranges_bl"] = rb
+    out["hits_bl"] = hb.astype(np.int16)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "poses", n_poses, "mean steps", out["steps_cpu"].mean(),
+          os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024, "KiB")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    colombia()
+    protocol()
+    car_ref()
+    rm_golden("rm_colombia", maps.load_colombia(), 24, 101)
+    rm_golden("rm_maze256", maps.make_maze(256, cell=32, wall=2, p=0.45, seed=7), 24, 102)
+    g = maps.make_maze(192, cell=24, wall=2, p=0.5, seed=9, resolution=0.1,
+                       origin=(-3.0, 2.5, 0.6))           # rotated origin (yaw != 0)
+    rm_golden("rm_maze192_yaw", g, 16, 103, mrx=120, fov=6.0, num_rays=360)
+
+
+if __name__ == "__main__":
+    main()
