@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
+    ap.add_argument("--opt", action="append", default=[], help="kernel option name=int (tuning)")
     return ap.parse_args()
 
 
@@ -151,6 +152,9 @@ def main():
     meth = make_method(range_libc, omap, w, method)
     if a.variant >= 0:
         meth.set_option("variant", a.variant)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        meth.set_option(k, int(v))
     if w.noise_std > 0:
         meth.set_noise(w.noise_std, w.noise_seed, rank * w.n_poses * B)
 

@@ -107,12 +107,22 @@ struct rl_method {
     int theta_disc = 0;
     float noise_std = 0;
     uint64_t noise_seed = 0, ray_offset = 0;
-    int variant = 0;
-    int grid_mult = 8;           // workgroups per CU for the persistent launches
+    int variant = 1;             // 0: chunk kernel (K1); 1: binned + banded + lane-refill stream kernel (K1b)
+    int grid_mult = 8;           // workgroups per CU for the persistent launches (8 resident: <= 80 SGPRs, <= 64 VGPRs)
+    int low_water = 24;          // queue kernel: refill when <= this many lanes still march
+    int sort_poses = 1;          // queue kernel: order poses by map tile
+    int xcd_bands = 8;           // queue kernel: bands of the sorted list, one per XCD
+    int drain_prio = 0;
+    int wg_threads = 1024;       // stream kernel: workgroup size (256/512/1024) sharing one ray stream
+    DevBuf pdt;                  // EDT with a border of `pad` cells of -1 (stream kernel)
+    int pad = 0, pstride = 0;
+    uint64_t pdt_epoch = ~0ull;  // map epoch the padded copy was built from
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf poses, outs, hits, steps, edge, flag;
+    DevBuf poses, outs, hits, steps, edge, flag, rec, rec_sorted, order, keys, dbg;
+    int debug_stamps = 0;        // diagnostics: per-wave start/end stamps of the stream kernel
+    int last_grid = 0;
     std::vector<float> h_poses;
     std::mutex mu;
 };
@@ -318,6 +328,12 @@ extern "C" void rl_method_destroy(rl_method *h)
     h->steps.release();
     h->edge.release();
     h->flag.release();
+    h->rec.release();
+    h->rec_sorted.release();
+    h->order.release();
+    h->keys.release();
+    h->dbg.release();
+    h->pdt.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -342,6 +358,12 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     std::lock_guard<std::mutex> lk(h->mu);
     if (!strcmp(name, "variant")) h->variant = value;
     else if (!strcmp(name, "grid_mult")) h->grid_mult = value < 1 ? 1 : value;
+    else if (!strcmp(name, "low_water")) h->low_water = value < 0 ? 0 : (value > 63 ? 63 : value);
+    else if (!strcmp(name, "sort_poses")) h->sort_poses = value != 0;
+    else if (!strcmp(name, "debug_stamps")) h->debug_stamps = value != 0;
+    else if (!strcmp(name, "drain_prio")) h->drain_prio = value != 0;
+    else if (!strcmp(name, "wg_threads")) h->wg_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256);
+    else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
     else return fail(RL_ERR_INVALID, "unknown option '%s'", name);
     return RL_OK;
 }
@@ -352,6 +374,13 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     if (!strcmp(name, "n_cu")) *value_out = h->map->n_cu;
     else if (!strcmp(name, "variant")) *value_out = h->variant;
     else if (!strcmp(name, "grid_mult")) *value_out = h->grid_mult;
+    else if (!strcmp(name, "low_water")) *value_out = h->low_water;
+    else if (!strcmp(name, "sort_poses")) *value_out = h->sort_poses;
+    else if (!strcmp(name, "debug_stamps")) *value_out = h->debug_stamps;
+    else if (!strcmp(name, "drain_prio")) *value_out = h->drain_prio;
+    else if (!strcmp(name, "wg_threads")) *value_out = h->wg_threads;
+    else if (!strcmp(name, "last_grid")) *value_out = h->last_grid;
+    else if (!strcmp(name, "xcd_bands")) *value_out = h->xcd_bands;
     else if (!strcmp(name, "map_epoch")) *value_out = (int64_t)h->map->epoch;
     else return fail(RL_ERR_INVALID, "unknown info '%s'", name);
     return RL_OK;
@@ -386,7 +415,19 @@ static int check_fan_args(const rl_method *h, int n_poses, float fov, int num_ra
     return RL_OK;
 }
 
-// enqueue the fan kernel on `stream`; all pointers are device pointers
+static FastDiv make_fastdiv(uint32_t d)
+{
+    FastDiv f{};
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    f.d = d;
+    return f;
+}
+
+// enqueue the fan kernels on `stream`; all pointers are device pointers
 static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov, int num_rays,
                       float *d_out, int32_t *d_hits, uint16_t *d_steps, const CrashParams *crash,
                       hipStream_t stream)
@@ -403,21 +444,91 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
     CrashParams cp{nullptr, 0.0, nullptr};
     if (crash) cp = *crash;
     const bool aux = d_hits || d_steps;
+    const bool stream_ok = (long)n_poses * num_rays < (1L << 31);
     HIPCHK(hipEventRecord(h->ev0, stream));
-    if (crash) {
-        if (aux)
-            hipLaunchKernelGGL((rm_fan_kernel<true, true>), dim3(grid), dim3(WG), lds, stream,
-                               m->mp, f, d_poses, d_out, d_hits, d_steps, cp);
-        else
-            hipLaunchKernelGGL((rm_fan_kernel<false, true>), dim3(grid), dim3(WG), lds, stream,
-                               m->mp, f, d_poses, d_out, d_hits, d_steps, cp);
+    if (h->variant >= 1 && stream_ok) {
+        // (1) per-pose records + tile-ordered permutation, (2) banded lane-refill march
+        int rc;
+        if ((rc = h->rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
+        if ((rc = h->order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
+        if ((rc = h->keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
+        // padded EDT of this method (border = -1), rebuilt when the map changed
+        if (h->pdt_epoch != m->epoch || !h->pdt.p) {
+            h->pad = (int)std::ceil(h->max_range) + 2;
+            h->pstride = (m->cols + 2 * h->pad + 31) & ~31;
+            const int prow = m->rows + 2 * h->pad;
+            if ((rc = h->pdt.ensure((size_t)prow * h->pstride * sizeof(float)))) return rc;
+            hipLaunchKernelGGL(pad_dt_kernel, dim3((h->pstride + 255) / 256, prow), dim3(256), 0,
+                               stream, m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad,
+                               h->pstride);
+            h->pdt_epoch = m->epoch;
+        }
+        if ((rc = h->rec_sorted.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
+        const int bands = n_poses >= 64 ? h->xcd_bands : 1;
+        const int do_sort = (h->sort_poses && n_poses >= 64) ? 1 : 0;
+        int shift = 6;
+        while ((long)((m->cols >> shift) + 1) * ((m->rows >> shift) + 1) > 8192) ++shift;
+        const int tiles_x = (m->cols >> shift) + 1;
+        const int n_tiles = tiles_x * ((m->rows >> shift) + 1);
+        hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
+                           (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
+                           n_poses, (PoseRec *)h->rec.p, (PoseRec *)h->rec_sorted.p,
+                           (uint32_t *)h->order.p, (uint32_t *)h->keys.p, shift, tiles_x, n_tiles,
+                           do_sort);
+        PadMap pm{};
+        pm.pdt = (const float *)h->pdt.p;
+        pm.stride = h->pstride;
+        pm.pad = h->pad;
+        pm.k4 = (uint32_t)(((size_t)h->pad * h->pstride + h->pad) * 4);
+        pm.div_stride = make_fastdiv((uint32_t)h->pstride);
+        pm.res = m->res;
+        StreamParams sp{};
+        sp.rec = (const PoseRec *)h->rec_sorted.p;
+        sp.order = (const uint32_t *)h->order.p;
+        sp.cpp = (int)cpp;
+        sp.div_cpp = make_fastdiv((uint32_t)cpp);
+        sp.low_water = h->low_water;
+        sp.n_bands = bands;
+        sp.drain_prio = h->drain_prio;
+        sp.dbg = nullptr;
+        // persistent grid: grid_mult x 256 threads per CU, whatever the workgroup size
+        const int nt = h->wg_threads;
+        const int waves_per_wg = nt / 64;
+        long want_q = (n_chunks + waves_per_wg - 1) / waves_per_wg;
+        long cap_q = (long)m->n_cu * h->grid_mult * WG / nt;
+        grid = (int)std::max((long)bands, std::min(want_q, std::max(cap_q, 1L)));
+        if (h->debug_stamps) {
+            if ((rc = h->dbg.ensure((size_t)grid * waves_per_wg * 4 * sizeof(uint64_t)))) return rc;
+            sp.dbg = (unsigned long long *)h->dbg.p;
+        }
+        h->last_grid = grid * waves_per_wg / WAVES_PER_WG;
+        const size_t lds_q = lds + 2 * sizeof(float);
+        const bool unit = h->step_coeff == 1.0f;
+#define LAUNCH_S(A, C, U, N)                                                                      \
+    hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, U, N>), dim3(grid), dim3(N), lds_q, stream,    \
+                       pm, f, sp, d_out, d_hits, d_steps, cp)
+#define LAUNCH_S_N(A, C, U)                                    \
+    do {                                                       \
+        if (nt == 1024) LAUNCH_S(A, C, U, 1024);               \
+        else if (nt == 512) LAUNCH_S(A, C, U, 512);            \
+        else LAUNCH_S(A, C, U, 256);                           \
+    } while (0)
+        if (unit) {
+            if (crash) { if (aux) LAUNCH_S_N(true, true, true); else LAUNCH_S_N(false, true, true); }
+            else       { if (aux) LAUNCH_S_N(true, false, true); else LAUNCH_S_N(false, false, true); }
+        } else {
+            if (crash) { if (aux) LAUNCH_S_N(true, true, false); else LAUNCH_S_N(false, true, false); }
+            else       { if (aux) LAUNCH_S_N(true, false, false); else LAUNCH_S_N(false, false, false); }
+        }
+#undef LAUNCH_S_N
+#undef LAUNCH_S
     } else {
-        if (aux)
-            hipLaunchKernelGGL((rm_fan_kernel<true, false>), dim3(grid), dim3(WG), lds, stream,
-                               m->mp, f, d_poses, d_out, d_hits, d_steps, cp);
-        else
-            hipLaunchKernelGGL((rm_fan_kernel<false, false>), dim3(grid), dim3(WG), lds, stream,
-                               m->mp, f, d_poses, d_out, d_hits, d_steps, cp);
+#define LAUNCH_CHUNK(A, C)                                                                  \
+    hipLaunchKernelGGL((rm_fan_kernel<A, C>), dim3(grid), dim3(WG), lds, stream, m->mp, f,  \
+                       d_poses, d_out, d_hits, d_steps, cp)
+        if (crash) { if (aux) LAUNCH_CHUNK(true, true); else LAUNCH_CHUNK(false, true); }
+        else       { if (aux) LAUNCH_CHUNK(true, false); else LAUNCH_CHUNK(false, false); }
+#undef LAUNCH_CHUNK
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, stream));
@@ -599,6 +710,20 @@ extern "C" int rl_check_collision_many(rl_method *h, const float *poses, int n_p
     }
     return fan_host(h, poses, n_poses, fov, num_rays, ranges_or_null, nullptr, nullptr, edge,
                     crash_thresh, first_crashed);
+}
+
+extern "C" int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words)
+{
+    if (!h || !out) return fail(RL_ERR_INVALID, "rl_debug_read_stamps: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = set_device(h->map);
+    if (rc) return rc;
+    size_t words = (size_t)h->last_grid * WAVES_PER_WG * 4;
+    if (!h->dbg.p || words == 0) return fail(RL_ERR_INVALID, "no stamps recorded (set debug_stamps=1)");
+    if ((size_t)max_words < words) words = (size_t)max_words;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, h->dbg.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return (int)words;
 }
 
 extern "C" int rl_last_kernel_ms(rl_method *h, float *ms_out)

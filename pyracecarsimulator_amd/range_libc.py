@@ -230,6 +230,15 @@ class _RangeMethod:
         _lib.check(_lib.lib().rl_method_get_info(self._h, name.encode(), C.byref(v)))
         return int(v.value)
 
+    def debug_stamps(self):
+        """(n_waves, 4) uint64 diagnostics of the last stream-kernel launch (option debug_stamps)."""
+        n = self.get_info("last_grid") * 4 * 4
+        buf = np.zeros(max(n, 4), dtype=np.uint64)
+        got = _lib.lib().rl_debug_read_stamps(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        if got < 0:
+            _lib.check(got)
+        return buf[:got].reshape(-1, 4)
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         _lib.check(_lib.lib().rl_last_kernel_ms(self._h, C.byref(ms)))

@@ -39,6 +39,42 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     assert np.array_equal(omap.distance_transform(), oracle_mod.edt(occ))
 
 
+# ---------------------------------------------------------------- schedules of K1 are result-neutral
+@pytest.mark.parametrize("opts", [
+    {"variant": 0},                                             # chunk kernel (K1)
+    {"variant": 1},                                             # stream kernel (K1b), defaults
+    {"variant": 1, "low_water": 0, "wg_threads": 256},          # no refill until all lanes done
+    {"variant": 1, "low_water": 63, "wg_threads": 512},         # refill after every step
+    {"variant": 1, "sort_poses": 0, "xcd_bands": 1},            # unsorted, one band
+    {"variant": 1, "xcd_bands": 3, "grid_mult": 1},             # odd band count, small grid
+    {"variant": 1, "grid_mult": 16, "wg_threads": 256},
+])
+def test_every_kernel_schedule_is_bit_identical(oracle_mod, opts):
+    g = maps.make_maze(400, cell=40, wall=3, p=0.45, seed=21, origin=(-7.0, 3.0, -0.4))
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    omap = range_libc.PyOMap(g)
+    poses = maps.sample_free_poses(g, 333, 4, dt=om.dt)
+    poses[17] = [np.nan, 0, 0]
+    poses[200] = [1e6, 1e6, 1.0]
+    poses[201] = [g.origin[0] - 0.3 * g.resolution, g.origin[1] + 1.0, 0.2]   # -1 < gx < 0
+    for cls, sc in ((range_libc.PyRayMarchingGPU, 1.0), (range_libc.PyRayMarching, 0.999)):
+        m = cls(omap, 300)
+        for k, v in opts.items():
+            m.set_option(k, v)
+            assert m.get_info(k) == v
+        r, h, s = _fan(m, poses, 4.71, 1081)
+        r0, h0, s0 = om.rm_fan(poses, 4.71, 1081, step_coeff=sc, nthreads=4)
+        assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0)
+        # ranges-only launch (no diagnostics) takes the non-AUX template
+        r1 = np.empty_like(r)
+        m.calc_range_fan(poses, r1, 4.71, 1081)
+        assert np.array_equal(r1, r0)
+        # small batches take the unsorted single-band path
+        r, h, s = _fan(m, poses[:5], 4.71, 70)
+        r0, h0, s0 = om.rm_fan(poses[:5], 4.71, 70, step_coeff=sc)
+        assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0)
+
+
 # ---------------------------------------------------------------- K1 vs golden vectors
 @pytest.mark.parametrize("name", ["rm_colombia", "rm_maze256", "rm_maze192_yaw"])
 def test_rm_fan_reproduces_golden_vectors(name):

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Tuning sweep on the GPU box: kernel time of the cfg2 workload (or --workload) for a grid of
+kernel options.  Prints one line per configuration (ms from HIP events, Mrays/s)."""
+import argparse
+import itertools
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+from pyracecarsimulator_amd import range_libc, workloads  # noqa: E402
+
+
+def time_cfg(meth, d_poses, n, fov, B, d_out, reps=20, warm=3):
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(warm):
+        meth.calc_range_fan_device(d_poses.data_ptr(), n, fov, B, d_out.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        meth.calc_range_fan_device(d_poses.data_ptr(), n, fov, B, d_out.data_ptr(), stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--poses", type=int, default=0)
+    ap.add_argument("--grid", default="full")
+    a = ap.parse_args()
+    w = workloads.CONFIGS[a.workload]()
+    if a.poses:
+        w.n_poses = a.poses
+    omap = range_libc.PyOMap(w.gmap)
+    dt = omap.distance_transform()
+    poses = workloads.make_poses(w, dt=dt)
+    n, B = len(poses), w.num_rays
+    d_poses = torch.from_numpy(poses).cuda()
+    d_out = torch.empty(n * B, dtype=torch.float32, device="cuda")
+    meth = range_libc.PyRayMarchingGPU(omap, w.max_range_px)
+    ref = None
+    rows = []
+    if a.grid == "full":
+        combos = [dict(variant=0, grid_mult=8)]
+        combos += [dict(variant=1, low_water=lw, wg_threads=nt, grid_mult=8)
+                   for nt, lw in itertools.product((256, 512, 1024), (0, 16, 24, 32, 40, 48))]
+        combos += [dict(variant=1, low_water=32, wg_threads=1024, grid_mult=gm) for gm in (4, 6, 7, 16)]
+        combos += [dict(variant=1, low_water=32, wg_threads=1024, grid_mult=8, sort_poses=0),
+                   dict(variant=1, low_water=32, wg_threads=1024, grid_mult=8, sort_poses=1, xcd_bands=1),
+                   dict(variant=1, low_water=32, wg_threads=1024, grid_mult=8, xcd_bands=16),
+                   dict(variant=1, low_water=32, wg_threads=1024, grid_mult=8, xcd_bands=8)]
+    elif a.grid == "prio":
+        combos = [dict(variant=1, low_water=lw, wg_threads=1024, grid_mult=8, drain_prio=dp)
+                  for lw, dp in itertools.product((16, 24), (0, 1, 0, 1))]
+    elif a.grid == "small":
+        combos = [dict(variant=0, grid_mult=8)]
+        combos += [dict(variant=1, low_water=lw, wg_threads=nt, grid_mult=8)
+                   for nt, lw in itertools.product((256, 1024), (16, 32))]
+    else:
+        combos = [json.loads(a.grid)]
+    for c in combos:
+        for k, v in c.items():
+            meth.set_option(k, v)
+        med, mn = time_cfg(meth, d_poses, n, w.fov, B, d_out)
+        got = d_out.cpu().numpy()
+        if ref is None:
+            ref = got.copy()
+        same = bool(np.array_equal(ref, got))
+        rows.append((med, c))
+        print("%8.4f ms (min %8.4f)  %9.1f Mrays/s  same=%s  %s" %
+              (med, mn, n * B / med / 1e3, same, json.dumps(c)), flush=True)
+    best = min(rows, key=lambda r: r[0])
+    print("BEST %.4f ms %s" % (best[0], json.dumps(best[1])))
+
+
+if __name__ == "__main__":
+    main()
