@@ -135,6 +135,9 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
 /* tuning / diagnostics: integer options by name ("variant", "grid_mult", ...)     */
 int rl_method_set_option(rl_method *h, const char *name, int value);
 int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
+/* test hook (RL_GIANT_LUT): builds the table if needed and copies rows [row0,row1) of
+ * uint16 lut[row][col][theta_bin] (entry = rint(min(range_px,max_range)*65535/max_range)). */
+int rl_method_read_lut(rl_method *h, int row0, int row1, uint16_t *out);
 /* diagnostics: after a launch with option "debug_stamps"=1, copies 4 words per wave of the
  * stream kernel (start, end in 100 MHz ticks; services<<32|iterations; chunks<<32|band);
  * returns the number of words copied (>= 0) or a negative rl_status.                       */

@@ -312,8 +312,13 @@ static inline float bl_cast(const orc_map *m, float max_range,
     int hc = -1, hr = -1;
     unsigned n = 0;
     float out = max_range;
+    /* poses that cannot index the grid (non-finite, absurdly far) miss without walking:
+     * upstream's (int) conversions are undefined there */
+    const int sane = fabsf(gx) < 1e9f && fabsf(gy) < 1e9f && (dx - dx) + (dy - dy) == 0.0f;
     /* start cell occupied -> 0 */
-    if (gx > -1.0f && gx < fcols && gy > -1.0f && gy < frows &&
+    if (!sane) {
+        /* miss, no steps */
+    } else if (gx > -1.0f && gx < fcols && gy > -1.0f && gy < frows &&
         m->occ[(size_t)(int)gy * m->cols + (int)gx]) {
         out = 0.0f;
         hc = (int)gx;

@@ -55,6 +55,7 @@ SYMBOLS = {
     "rl_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rl_method_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "rl_method_get_info": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
+    "rl_method_read_lut": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u16p]),
     "rl_debug_read_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
 }
 

@@ -518,3 +518,408 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
 }
 
 }  // namespace scan
+
+// ==============================================================================
+// K3: GiantLUTCast — the bandwidth-bound variant.
+// Table: uint16 lut[row][col][theta_bin], so the fan of one pose is ONE contiguous
+// run of ~num_rays entries (bin spacing ~ beam spacing when theta_disc ~ 2pi*B/fov):
+// a query streams ~2 B/ray in and 4 B/ray out, nothing else.  2000^2 x 1442 bins =
+// 11.5 GB of the 288 GB HBM.  Built on the device with the K1 march from every cell
+// corner (range_libc seeds its table with RayMarching the same way).
+// ==============================================================================
+namespace scan {
+
+struct LutParams {
+    uint16_t *lut;
+    int theta_disc;
+    float bins_per_rad;      // theta_disc / 2pi (float)
+    float bin_width;         // 2pi / theta_disc
+    float quant, dequant;    // 65535/max_range, max_range/65535
+};
+
+__device__ __forceinline__ int lut_bin(float th, const LutParams &lp)
+{
+    float u = __builtin_rintf(th * lp.bins_per_rad);
+    if (!(u > -1e9f && u < 1e9f)) u = 0.0f;
+    int b = (int)u % lp.theta_disc;
+    return b < 0 ? b + lp.theta_disc : b;
+}
+
+// one workgroup per (row, 4-column group); lane = theta bin
+__global__ __launch_bounds__(256) void lut_build_kernel(MapParams m, LutParams lp, float max_range,
+                                                        float step_coeff, int row0, int row1)
+{
+    const long cells = (long)(row1 - row0) * m.cols;
+    for (long cell = blockIdx.x; cell < cells; cell += gridDim.x) {
+        const int r = row0 + (int)(cell / m.cols), c = (int)(cell % m.cols);
+        uint16_t *dst = lp.lut + ((size_t)r * m.cols + c) * lp.theta_disc;
+        for (int b = threadIdx.x; b < lp.theta_disc; b += blockDim.x) {
+            float dx, dy;
+            det_sincosf((float)b * lp.bin_width, dy, dx);
+            RayResult rr = rm_march(m, max_range, step_coeff, (float)c, (float)r, dx, dy);
+            float q = __builtin_rintf(__builtin_fminf(rr.range_px, max_range) * lp.quant);
+            dst[b] = (uint16_t)q;
+        }
+    }
+}
+
+// fan query: workgroup-stride over poses, lane = beam.  out[pose*num_rays + j] metres.
+__global__ __launch_bounds__(256) void lut_fan_kernel(MapParams m, FanParams f, LutParams lp,
+                                                      const float *__restrict__ poses,
+                                                      float *__restrict__ out)
+{
+    const float miss = f.max_range * m.res;
+    for (int pose = blockIdx.x; pose < f.n_poses; pose += gridDim.x) {
+        float gx, gy, thg;
+        world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
+                      poses[3 * (size_t)pose + 2], gx, gy, thg);
+        const bool inb = gx >= 0.0f && gx < m.fcols && gy >= 0.0f && gy < m.frows;
+        const uint16_t *row = lp.lut + (inb ? ((size_t)(int)gy * m.cols + (int)gx) * lp.theta_disc : 0);
+        for (int j = threadIdx.x; j < f.num_rays; j += blockDim.x) {
+            float r = miss;
+            if (inb) r = (float)row[lut_bin(thg + fan_alpha(f, j), lp)] * lp.dequant * m.res;
+            const size_t i = (size_t)pose * f.num_rays + j;
+            if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + i);
+            out[i] = r;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lut_rays_kernel(MapParams m, FanParams f, LutParams lp,
+                                                       const float *__restrict__ ins, long n,
+                                                       float *__restrict__ out)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gx, gy, thg;
+        world_to_grid(m, ins[3 * i], ins[3 * i + 1], ins[3 * i + 2], gx, gy, thg);
+        float r = f.max_range * m.res;
+        if (gx >= 0.0f && gx < m.fcols && gy >= 0.0f && gy < m.frows)
+            r = (float)lp.lut[((size_t)(int)gy * m.cols + (int)gx) * lp.theta_disc + lut_bin(thg, lp)] *
+                lp.dequant * m.res;
+        if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + i);
+        out[i] = r;
+    }
+}
+
+}  // namespace scan
+
+// ==============================================================================
+// K2: BresenhamsLine on an LDS-resident occupancy tile.
+// One workgroup per pose.  The (2R+1)^2 window of the BIT-PACKED occupancy around the
+// pose (R = max_range + 3; 607 rows x 21 words = 51 KB for 300 px) is staged into LDS
+// with coalesced row loads — that is all the map traffic of the pose: 47 B per ray —
+// together with the per-beam (cos, sin) fan.  Each lane then walks one beam cell by
+// cell entirely in LDS; a wave leaves the walk as soon as all of its lanes have hit
+// or run out (EXEC-mask early termination).  Bit-exact to the CPU statement.
+// ==============================================================================
+namespace scan {
+
+struct BlParams {
+    int R;            // window radius in cells
+    int ww;           // window row stride in 32-bit words (odd)
+    int use_lds;      // 0: window too large for LDS -> read the global bit map directly
+};
+
+template <bool AUX>
+__global__ __launch_bounds__(256) void bl_fan_kernel(MapParams m, FanParams f, BlParams bp,
+                                                     const float *__restrict__ poses,
+                                                     float *__restrict__ out,
+                                                     int32_t *__restrict__ hits,
+                                                     uint16_t *__restrict__ steps)
+{
+    extern __shared__ uint32_t lds_u[];
+    float2 *fan_cs = reinterpret_cast<float2 *>(lds_u);                  // num_rays float2
+    uint32_t *win = lds_u + 2 * (size_t)f.num_rays;                      // (2R+1) * ww words
+    for (int j = threadIdx.x; j < f.num_rays; j += blockDim.x) {
+        float s, c;
+        det_sincosf(fan_alpha(f, j), s, c);
+        fan_cs[j] = make_float2(c, s);
+    }
+    const int WH = 2 * bp.R + 1;
+    const float miss = f.max_range;
+
+    for (int pose = blockIdx.x; pose < f.n_poses; pose += gridDim.x) {
+        float gx, gy, thg, st, ct;
+        world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
+                      poses[3 * (size_t)pose + 2], gx, gy, thg);
+        det_sincosf(thg, st, ct);
+        // poses that cannot index the grid (non-finite / absurdly far) miss without walking
+        const bool sane = fabsf(gx) < 1e9f && fabsf(gy) < 1e9f && (ct - ct) + (st - st) == 0.0f;
+        // window origin: word-aligned column, row; may lie outside the map (zeros there)
+        const int cx = sane ? (int)gx : 0, cy = sane ? (int)gy : 0;
+        const int wx0 = ((cx - bp.R) >> 5) << 5;        // arithmetic shift: floor to a word
+        const int wy0 = cy - bp.R;
+        __syncthreads();                                // previous pose's walkers are done
+        if (bp.use_lds) {
+            for (int i = threadIdx.x; i < WH * bp.ww; i += blockDim.x) {
+                const int wr = i / bp.ww, wc = i - wr * bp.ww;
+                const int r = wy0 + wr, w = (wx0 >> 5) + wc;
+                uint32_t v = 0;
+                if (r >= 0 && r < m.rows && w >= 0 && w < m.bits_stride)
+                    v = m.bits[(size_t)r * m.bits_stride + w];
+                win[i] = v;
+            }
+        }
+        __syncthreads();
+        auto occupied = [&](int col, int row) -> bool {
+            if (bp.use_lds) {
+                const int x = col - wx0, y = row - wy0;
+                return (win[y * bp.ww + (x >> 5)] >> (x & 31)) & 1u;
+            }
+            return (m.bits[(size_t)row * m.bits_stride + (col >> 5)] >> (col & 31)) & 1u;
+        };
+        for (int j = threadIdx.x; j < f.num_rays; j += blockDim.x) {
+            const float2 cs = fan_cs[j];
+            const float dx = __builtin_fmaf(ct, cs.x, -(st * cs.y));
+            const float dy = __builtin_fmaf(st, cs.x, ct * cs.y);
+            float range = miss;
+            int hc = -1, hr = -1;
+            unsigned n = 0;
+            if (sane) {
+                if (gx > -1.0f && gx < m.fcols && gy > -1.0f && gy < m.frows &&
+                    occupied((int)gx, (int)gy)) {
+                    range = 0.0f;                       // start cell occupied
+                    hc = (int)gx;
+                    hr = (int)gy;
+                } else {
+                    float x0 = gx, y0 = gy;
+                    float x1 = __builtin_fmaf(f.max_range, dx, gx);
+                    float y1 = __builtin_fmaf(f.max_range, dy, gy);
+                    const bool steep = fabsf(y1 - y0) > fabsf(x1 - x0);
+                    if (steep) {
+                        float tmp = x0; x0 = y0; y0 = tmp;
+                        tmp = x1; x1 = y1; y1 = tmp;
+                    }
+                    const float lim_major = steep ? m.frows : m.fcols;
+                    const float lim_minor = steep ? m.fcols : m.frows;
+                    const float deltax = fabsf(x1 - x0), deltay = fabsf(y1 - y0);
+                    float error = 0.0f, _x = x0, _y = y0;
+                    const float xstep = x0 < x1 ? 1.0f : -1.0f;
+                    const float ystep = y0 < y1 ? 1.0f : -1.0f;
+                    const int end = (int)(x1 + xstep);
+                    int cap = (int)f.max_range + 3;
+                    while ((int)_x != end && cap-- > 0) {
+                        _x += xstep;
+                        error += deltay;
+                        if (error * 2.0f >= deltax) {
+                            _y += ystep;
+                            error -= deltax;
+                        }
+                        ++n;
+                        if (_x >= 0.0f && _x < lim_major && _y >= 0.0f && _y < lim_minor) {
+                            const int col = steep ? (int)_y : (int)_x;
+                            const int row = steep ? (int)_x : (int)_y;
+                            if (occupied(col, row)) {
+                                const float xd = _x - x0, yd = _y - y0;
+                                range = __builtin_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+                                hc = col;
+                                hr = row;
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
+            const size_t i = (size_t)pose * f.num_rays + j;
+            float r = range * m.res;
+            if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + i);
+            out[i] = r;
+            if (AUX) {
+                if (hits) { hits[2 * i] = hc; hits[2 * i + 1] = hr; }
+                if (steps) steps[i] = (uint16_t)n;
+            }
+        }
+    }
+}
+
+// one world (x, y, theta) row per ray, straight from the global bit map
+__global__ __launch_bounds__(256) void bl_rays_kernel(MapParams m, FanParams f,
+                                                      const float *__restrict__ ins, long n_rays,
+                                                      float *__restrict__ out)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rays; i += stride) {
+        float gx, gy, thg, dx, dy;
+        world_to_grid(m, ins[3 * i], ins[3 * i + 1], ins[3 * i + 2], gx, gy, thg);
+        det_sincosf(thg, dy, dx);
+        auto occupied = [&](int col, int row) -> bool {
+            return (m.bits[(size_t)row * m.bits_stride + (col >> 5)] >> (col & 31)) & 1u;
+        };
+        float range = f.max_range;
+        const bool sane = fabsf(gx) < 1e9f && fabsf(gy) < 1e9f && (dx - dx) + (dy - dy) == 0.0f;
+        if (sane) {
+            if (gx > -1.0f && gx < m.fcols && gy > -1.0f && gy < m.frows && occupied((int)gx, (int)gy)) {
+                range = 0.0f;
+            } else {
+                float x0 = gx, y0 = gy;
+                float x1 = __builtin_fmaf(f.max_range, dx, gx);
+                float y1 = __builtin_fmaf(f.max_range, dy, gy);
+                const bool steep = fabsf(y1 - y0) > fabsf(x1 - x0);
+                if (steep) {
+                    float tmp = x0; x0 = y0; y0 = tmp;
+                    tmp = x1; x1 = y1; y1 = tmp;
+                }
+                const float lim_major = steep ? m.frows : m.fcols;
+                const float lim_minor = steep ? m.fcols : m.frows;
+                const float deltax = fabsf(x1 - x0), deltay = fabsf(y1 - y0);
+                float error = 0.0f, _x = x0, _y = y0;
+                const float xstep = x0 < x1 ? 1.0f : -1.0f;
+                const float ystep = y0 < y1 ? 1.0f : -1.0f;
+                const int end = (int)(x1 + xstep);
+                int cap = (int)f.max_range + 3;
+                while ((int)_x != end && cap-- > 0) {
+                    _x += xstep;
+                    error += deltay;
+                    if (error * 2.0f >= deltax) {
+                        _y += ystep;
+                        error -= deltax;
+                    }
+                    if (_x >= 0.0f && _x < lim_major && _y >= 0.0f && _y < lim_minor) {
+                        const int col = steep ? (int)_y : (int)_x;
+                        const int row = steep ? (int)_x : (int)_y;
+                        if (occupied(col, row)) {
+                            const float xd = _x - x0, yd = _y - y0;
+                            range = __builtin_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        float r = range * m.res;
+        if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + i);
+        out[i] = r;
+    }
+}
+
+}  // namespace scan
+
+// ==============================================================================
+// K3b: CDDTCast (scripts/two_player/scan.py:46).
+// Table: for every theta bin in [0, pi) the edge cells of the map are projected into
+// the bin's rotated frame and bucketed by their rotated row; each bucket holds the
+// sorted rotated x of the cells it covers (CSR: offsets[] + xs[]).  A query rotates
+// the ray origin into the frame of the bin nearest to -heading and binary-searches
+// ONE bucket for the next stored x ahead of (or, for the flipped half turn, behind)
+// the origin.  Built entirely on the device: edge list -> count -> scan -> fill ->
+// segmented sort.
+// ==============================================================================
+namespace scan {
+
+constexpr float CDDT_EPS = 1e-5f;
+
+struct CddtParams {
+    int theta_disc, n_bins;
+    const float *cosv, *sinv, *trans;   // per bin
+    const int *width;                   // per bin: buckets
+    const uint32_t *bucket_off;         // per bin: first bucket (n_bins + 1)
+    uint32_t *offsets;                  // per bucket: [start, end) in xs (n_buckets + 1)
+    float *xs;
+    float bins_per_rad;
+};
+
+__global__ __launch_bounds__(256) void cddt_edges_kernel(const uint8_t *__restrict__ occ, int rows,
+                                                         int cols, uint32_t *__restrict__ n_edges,
+                                                         uint32_t *__restrict__ edges /* r<<16|c */)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    if (!occ[(size_t)r * cols + c]) return;
+    // occupied cell with a free 4-neighbour; border cells count as edges
+    bool edge = r == 0 || c == 0 || r == rows - 1 || c == cols - 1;
+    if (!edge)
+        edge = !occ[(size_t)(r - 1) * cols + c] || !occ[(size_t)(r + 1) * cols + c] ||
+               !occ[(size_t)r * cols + c - 1] || !occ[(size_t)r * cols + c + 1];
+    if (edge) edges[atomicAdd(n_edges, 1u)] = ((uint32_t)r << 16) | (uint32_t)c;
+}
+
+// FILL = false: count bucket sizes into offsets[]; FILL = true: write xs at the cursors
+template <bool FILL>
+__global__ __launch_bounds__(256) void cddt_project_kernel(CddtParams cp, const uint32_t *__restrict__ edges,
+                                                           const uint32_t *__restrict__ n_edges,
+                                                           uint32_t *__restrict__ cursor)
+{
+    const long total = (long)(*n_edges) * cp.n_bins;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint32_t e = edges[i / cp.n_bins];
+        const int a = (int)(i % cp.n_bins);
+        const float px = (float)(e & 0xFFFFu) + 0.5f, py = (float)(e >> 16) + 0.5f;
+        const float cs = cp.cosv[a], sn = cp.sinv[a];
+        const float half = (fabsf(sn) + fabsf(cs)) * 0.5f;
+        const float lx = __builtin_fmaf(px, cs, -(py * sn));
+        const float ly = __builtin_fmaf(px, sn, py * cs) + cp.trans[a];
+        int upper = (int)((ly + half) - CDDT_EPS);
+        int lower = (int)((ly - half) + CDDT_EPS);
+        if (lower < 0) lower = 0;
+        if (upper >= cp.width[a]) upper = cp.width[a] - 1;
+        for (int k = lower; k <= upper; ++k) {
+            const uint32_t b = cp.bucket_off[a] + (uint32_t)k;
+            if (FILL) cp.xs[atomicAdd(&cursor[b], 1u)] = lx;
+            else atomicAdd(&cursor[b], 1u);
+        }
+    }
+}
+
+__device__ __forceinline__ float cddt_query(const MapParams &m, const CddtParams &cp, float max_range,
+                                            float gx, float gy, float th)
+{
+    LutParams lp{};
+    lp.theta_disc = cp.theta_disc;
+    lp.bins_per_rad = cp.bins_per_rad;
+    int b = lut_bin(-th, lp);                 // nearest bin of -heading in [0, theta_disc)
+    bool flipped = false;
+    if (b >= cp.n_bins) { b -= cp.theta_disc / 2; flipped = true; }
+    if (b >= cp.n_bins) b = cp.n_bins - 1;
+    const float cs = cp.cosv[b], sn = cp.sinv[b];
+    const float lx = __builtin_fmaf(gx, cs, -(gy * sn));
+    const float ly = __builtin_fmaf(gx, sn, gy * cs) + cp.trans[b];
+    float out = max_range;
+    if (ly >= 0.0f && ly < (float)cp.width[b]) {
+        const uint32_t bk = cp.bucket_off[b] + (uint32_t)(int)ly;
+        const uint32_t lo = cp.offsets[bk], hi = cp.offsets[bk + 1];
+        uint32_t a = lo, z = hi;
+        if (!flipped) {                        // first stored x >= lx
+            while (a < z) { const uint32_t mid = (a + z) >> 1; if (cp.xs[mid] < lx) a = mid + 1; else z = mid; }
+            if (a < hi) out = __builtin_fminf(cp.xs[a] - lx, max_range);
+        } else {                               // last stored x <= lx
+            while (a < z) { const uint32_t mid = (a + z) >> 1; if (cp.xs[mid] <= lx) a = mid + 1; else z = mid; }
+            if (a > lo) out = __builtin_fminf(lx - cp.xs[a - 1], max_range);
+        }
+    }
+    return out * m.res;
+}
+
+__global__ __launch_bounds__(256) void cddt_fan_kernel(MapParams m, FanParams f, CddtParams cp,
+                                                       const float *__restrict__ poses,
+                                                       float *__restrict__ out)
+{
+    for (int pose = blockIdx.x; pose < f.n_poses; pose += gridDim.x) {
+        float gx, gy, thg;
+        world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
+                      poses[3 * (size_t)pose + 2], gx, gy, thg);
+        for (int j = threadIdx.x; j < f.num_rays; j += blockDim.x) {
+            const size_t i = (size_t)pose * f.num_rays + j;
+            float r = cddt_query(m, cp, f.max_range, gx, gy, thg + fan_alpha(f, j));
+            if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + i);
+            out[i] = r;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cddt_rays_kernel(MapParams m, FanParams f, CddtParams cp,
+                                                        const float *__restrict__ ins, long n,
+                                                        float *__restrict__ out)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gx, gy, thg;
+        world_to_grid(m, ins[3 * i], ins[3 * i + 1], ins[3 * i + 2], gx, gy, thg);
+        float r = cddt_query(m, cp, f.max_range, gx, gy, thg);
+        if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + i);
+        out[i] = r;
+    }
+}
+
+}  // namespace scan

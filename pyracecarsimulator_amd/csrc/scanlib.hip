@@ -8,6 +8,7 @@
 #include "scan_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <climits>
@@ -114,6 +115,16 @@ struct rl_method {
     int xcd_bands = 8;           // queue kernel: bands of the sorted list, one per XCD
     int drain_prio = 0;
     int wg_threads = 1024;       // stream kernel: workgroup size (256/512/1024) sharing one ray stream
+    // GiantLUT (K3)
+    DevBuf lut;
+    uint64_t lut_epoch = ~0ull;
+    LutParams lp{};
+    // CDDT (K3b)
+    DevBuf cd_cos, cd_sin, cd_trans, cd_width, cd_boff, cd_offsets, cd_xs, cd_xs2, cd_edges, cd_cnt,
+        cd_cursor, cd_tmp;
+    uint64_t cddt_epoch = ~0ull;
+    CddtParams cdp{};
+    uint32_t cd_buckets = 0;
     DevBuf pdt;                  // EDT with a border of `pad` cells of -1 (stream kernel)
     int pad = 0, pstride = 0;
     uint64_t pdt_epoch = ~0ull;  // map epoch the padded copy was built from
@@ -297,16 +308,18 @@ extern "C" int rl_method_create(rl_map *m, int kind, float max_range_px, int the
 {
     if (!m || !out) return fail(RL_ERR_INVALID, "rl_method_create: null pointer");
     if (!(max_range_px > 0.0f)) return fail(RL_ERR_INVALID, "max_range_px must be > 0");
-    if (kind != RL_RM && kind != RL_RM_GPU)
-        return fail(RL_ERR_UNSUPPORTED, "range method kind %d is not available in this build",
-                    kind);
+    if (kind < RL_BRESENHAM || kind > RL_GIANT_LUT)
+        return fail(RL_ERR_INVALID, "unknown range method kind %d", kind);
+    if ((kind == RL_CDDT || kind == RL_GIANT_LUT) && (theta_disc < 2 || theta_disc > 65536))
+        return fail(RL_ERR_INVALID, "theta_disc must be in [2, 65536] for CDDT / GiantLUT (got %d)",
+                    theta_disc);
     rl_method *h = new (std::nothrow) rl_method();
     if (!h) return fail(RL_ERR_NOMEM, "out of host memory");
     h->map = m;
     h->kind = kind;
     h->max_range = max_range_px;
     h->theta_disc = theta_disc;
-    h->step_coeff = kind == RL_RM ? 0.999f : 1.0f;   // RayMarching vs kernels.cu STEP_COEFF
+    h->step_coeff = kind == RL_RM_GPU ? 1.0f : 0.999f;   // kernels.cu STEP_COEFF vs RayMarching (also seeds the LUT)
     if (hipSetDevice(m->device) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -334,6 +347,10 @@ extern "C" void rl_method_destroy(rl_method *h)
     h->keys.release();
     h->dbg.release();
     h->pdt.release();
+    h->lut.release();
+    for (DevBuf *b : {&h->cd_cos, &h->cd_sin, &h->cd_trans, &h->cd_width, &h->cd_boff, &h->cd_offsets,
+                      &h->cd_xs, &h->cd_xs2, &h->cd_edges, &h->cd_cnt, &h->cd_cursor, &h->cd_tmp})
+        b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -415,6 +432,137 @@ static int check_fan_args(const rl_method *h, int n_poses, float fov, int num_ra
     return RL_OK;
 }
 
+// ------------------------------------------------------------------------------
+// derived tables (built lazily on the launch stream, rebuilt when the map changed)
+// ------------------------------------------------------------------------------
+static int ensure_lut(rl_method *h, hipStream_t stream)
+{
+    rl_map *m = h->map;
+    if (h->lut_epoch == m->epoch && h->lut.p) return RL_OK;
+    const size_t n = (size_t)m->rows * m->cols * h->theta_disc;
+    int rc = h->lut.ensure(n * sizeof(uint16_t));
+    if (rc) return rc;
+    LutParams &lp = h->lp;
+    lp.lut = (uint16_t *)h->lut.p;
+    lp.theta_disc = h->theta_disc;
+    lp.bins_per_rad = (float)h->theta_disc * 0.15915494309189535f;
+    lp.bin_width = 6.283185307179586f / (float)h->theta_disc;
+    lp.quant = 65535.0f / h->max_range;
+    lp.dequant = h->max_range / 65535.0f;
+    const long cells = (long)m->rows * m->cols;
+    const int grid = (int)std::min(cells, (long)m->n_cu * 16);
+    hipLaunchKernelGGL(lut_build_kernel, dim3(grid), dim3(256), 0, stream, m->mp, lp, h->max_range,
+                       h->step_coeff, 0, m->rows);
+    HIPCHK(hipGetLastError());
+    h->lut_epoch = m->epoch;
+    return RL_OK;
+}
+
+static int ensure_cddt(rl_method *h, hipStream_t stream)
+{
+    rl_map *m = h->map;
+    if (h->cddt_epoch == m->epoch && h->cd_xs.p) return RL_OK;
+    const int td = h->theta_disc, nb = (td + 1) / 2;
+    std::vector<float> cosv(nb), sinv(nb), trans(nb);
+    std::vector<int> width(nb);
+    std::vector<uint32_t> boff(nb + 1);
+    uint32_t nbk = 0;
+    const float W = (float)m->cols, H = (float)m->rows;
+    for (int a = 0; a < nb; ++a) {
+        float s, c;
+        host_sincosf((float)a * (6.283185307179586f / (float)td), s, c);
+        cosv[a] = c;
+        sinv[a] = s;
+        // buckets = height of the rotated map's bounding box; translation lifts the lowest
+        // rotated corner to bucket 0
+        width[a] = (int)ceilf((fabsf(W * s) + fabsf(H * c)) - CDDT_EPS) + 1;
+        const float lt = H * c, rt = fmaf(W, s, H * c), rb = W * s;
+        trans[a] = fmaxf(0.0f, -fminf(lt, fminf(rt, rb)) - CDDT_EPS);
+        boff[a] = nbk;
+        nbk += (uint32_t)width[a];
+    }
+    boff[nb] = nbk;
+    h->cd_buckets = nbk;
+    int rc;
+    if ((rc = h->cd_cos.ensure(nb * 4)) || (rc = h->cd_sin.ensure(nb * 4)) ||
+        (rc = h->cd_trans.ensure(nb * 4)) || (rc = h->cd_width.ensure(nb * 4)) ||
+        (rc = h->cd_boff.ensure((nb + 1) * 4)) || (rc = h->cd_offsets.ensure(((size_t)nbk + 1) * 4)) ||
+        (rc = h->cd_cursor.ensure(((size_t)nbk + 1) * 4)) || (rc = h->cd_cnt.ensure(256)) ||
+        (rc = h->cd_edges.ensure((size_t)m->rows * m->cols * 4)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(h->cd_cos.p, cosv.data(), nb * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->cd_sin.p, sinv.data(), nb * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->cd_trans.p, trans.data(), nb * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->cd_width.p, width.data(), nb * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(h->cd_boff.p, boff.data(), (nb + 1) * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemsetAsync(h->cd_cnt.p, 0, 256, stream));
+    HIPCHK(hipMemsetAsync(h->cd_cursor.p, 0, ((size_t)nbk + 1) * 4, stream));
+    HIPCHK(hipStreamSynchronize(stream));   // host vectors go out of scope below
+    CddtParams &cp = h->cdp;
+    cp.theta_disc = td;
+    cp.n_bins = nb;
+    cp.cosv = (const float *)h->cd_cos.p;
+    cp.sinv = (const float *)h->cd_sin.p;
+    cp.trans = (const float *)h->cd_trans.p;
+    cp.width = (const int *)h->cd_width.p;
+    cp.bucket_off = (const uint32_t *)h->cd_boff.p;
+    cp.offsets = (uint32_t *)h->cd_offsets.p;
+    cp.xs = nullptr;
+    cp.bins_per_rad = (float)td * 0.15915494309189535f;
+    uint32_t *n_edges = (uint32_t *)h->cd_cnt.p;
+    hipLaunchKernelGGL(cddt_edges_kernel, dim3((m->cols + 255) / 256, m->rows), dim3(256), 0, stream,
+                       m->d_occ, m->rows, m->cols, n_edges, (uint32_t *)h->cd_edges.p);
+    const int pgrid = m->n_cu * 16;
+    hipLaunchKernelGGL(cddt_project_kernel<false>, dim3(pgrid), dim3(256), 0, stream, cp,
+                       (const uint32_t *)h->cd_edges.p, n_edges, (uint32_t *)h->cd_cursor.p);
+    // exclusive scan of the bucket sizes -> CSR offsets
+    size_t tmp_bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (uint32_t *)h->cd_cursor.p,
+                                            (uint32_t *)h->cd_offsets.p, (int)nbk + 1, stream));
+    if ((rc = h->cd_tmp.ensure(tmp_bytes))) return rc;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->cd_tmp.p, tmp_bytes, (uint32_t *)h->cd_cursor.p,
+                                            (uint32_t *)h->cd_offsets.p, (int)nbk + 1, stream));
+    uint32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, (uint32_t *)h->cd_offsets.p + nbk, 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if ((rc = h->cd_xs.ensure(std::max<size_t>(total, 1) * 4)) ||
+        (rc = h->cd_xs2.ensure(std::max<size_t>(total, 1) * 4)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(h->cd_cursor.p, h->cd_offsets.p, ((size_t)nbk + 1) * 4,
+                          hipMemcpyDeviceToDevice, stream));
+    cp.xs = (float *)h->cd_xs2.p;
+    hipLaunchKernelGGL(cddt_project_kernel<true>, dim3(pgrid), dim3(256), 0, stream, cp,
+                       (const uint32_t *)h->cd_edges.p, n_edges, (uint32_t *)h->cd_cursor.p);
+    // sort every bucket
+    if (total > 0) {
+        tmp_bytes = 0;
+        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(
+            nullptr, tmp_bytes, (const float *)h->cd_xs2.p, (float *)h->cd_xs.p, (int)total, (int)nbk,
+            (const uint32_t *)h->cd_offsets.p, (const uint32_t *)h->cd_offsets.p + 1, 0, 32, stream));
+        if ((rc = h->cd_tmp.ensure(tmp_bytes))) return rc;
+        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(
+            h->cd_tmp.p, tmp_bytes, (const float *)h->cd_xs2.p, (float *)h->cd_xs.p, (int)total,
+            (int)nbk, (const uint32_t *)h->cd_offsets.p, (const uint32_t *)h->cd_offsets.p + 1, 0, 32,
+            stream));
+    }
+    cp.xs = (float *)h->cd_xs.p;
+    HIPCHK(hipGetLastError());
+    h->cddt_epoch = m->epoch;
+    return RL_OK;
+}
+
+static BlParams make_bl(const rl_method *h, int num_rays, size_t &lds_bytes)
+{
+    BlParams bp{};
+    bp.R = (int)std::ceil(h->max_range) + 3;
+    bp.ww = ((2 * bp.R + 32 + 31) / 32) | 1;
+    const size_t win = (size_t)(2 * bp.R + 1) * bp.ww * sizeof(uint32_t);
+    const size_t fan = (size_t)num_rays * sizeof(float2);
+    bp.use_lds = (win + fan) <= 150 * 1024;
+    lds_bytes = fan + (bp.use_lds ? win : 0);
+    return bp;
+}
+
 static FastDiv make_fastdiv(uint32_t d)
 {
     FastDiv f{};
@@ -435,6 +583,43 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
     if (n_poses == 0) return RL_OK;
     const rl_map *m = h->map;
     FanParams f = make_fan(h, n_poses, fov, num_rays);
+    if (h->kind != RL_RM && h->kind != RL_RM_GPU) {
+        if (crash) return fail(RL_ERR_UNSUPPORTED, "fused crash test needs a ray-marching method");
+        if ((d_hits || d_steps) && h->kind != RL_BRESENHAM)
+            return fail(RL_ERR_UNSUPPORTED, "hit cells / step counts exist only for RM and Bresenham");
+        int rc;
+        const int pgrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * h->grid_mult));
+        HIPCHK(hipEventRecord(h->ev0, stream));
+        if (h->kind == RL_GIANT_LUT) {
+            if ((rc = ensure_lut(h, stream))) return rc;
+            hipLaunchKernelGGL(lut_fan_kernel, dim3(pgrid), dim3(256), 0, stream, m->mp, f, h->lp,
+                               d_poses, d_out);
+        } else if (h->kind == RL_CDDT) {
+            if ((rc = ensure_cddt(h, stream))) return rc;
+            hipLaunchKernelGGL(cddt_fan_kernel, dim3(pgrid), dim3(256), 0, stream, m->mp, f, h->cdp,
+                               d_poses, d_out);
+        } else {
+            size_t lds_bl = 0;
+            BlParams bp = make_bl(h, num_rays, lds_bl);
+            if (lds_bl > 48 * 1024) {          // more dynamic LDS than the default cap: opt in
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl_fan_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl_fan_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
+            }
+            const int bgrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * 2));
+            if (d_hits || d_steps)
+                hipLaunchKernelGGL((bl_fan_kernel<true>), dim3(bgrid), dim3(256), lds_bl, stream,
+                                   m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+            else
+                hipLaunchKernelGGL((bl_fan_kernel<false>), dim3(bgrid), dim3(256), lds_bl, stream,
+                                   m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(h->ev1, stream));
+        h->timed = true;
+        return RL_OK;
+    }
     const long cpp = (num_rays + 63) / 64;
     const long n_chunks = (long)n_poses * cpp;
     long want = (n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG;
@@ -546,8 +731,22 @@ static int launch_rays(rl_method *h, const float *d_ins, long n, float *d_out, i
     long cap = (long)m->n_cu * h->grid_mult;
     int grid = (int)std::max(1L, std::min(want, cap));
     HIPCHK(hipEventRecord(h->ev0, stream));
-    hipLaunchKernelGGL(rm_rays_kernel, dim3(grid), dim3(WG), 0, stream, m->mp, f, d_ins, n, d_out,
-                       d_hits, d_steps);
+    int rc;
+    if (h->kind == RL_GIANT_LUT) {
+        if ((rc = ensure_lut(h, stream))) return rc;
+        hipLaunchKernelGGL(lut_rays_kernel, dim3(grid), dim3(256), 0, stream, m->mp, f, h->lp, d_ins,
+                           n, d_out);
+    } else if (h->kind == RL_CDDT) {
+        if ((rc = ensure_cddt(h, stream))) return rc;
+        hipLaunchKernelGGL(cddt_rays_kernel, dim3(grid), dim3(256), 0, stream, m->mp, f, h->cdp,
+                           d_ins, n, d_out);
+    } else if (h->kind == RL_BRESENHAM) {
+        hipLaunchKernelGGL(bl_rays_kernel, dim3(grid), dim3(256), 0, stream, m->mp, f, d_ins, n,
+                           d_out);
+    } else {
+        hipLaunchKernelGGL(rm_rays_kernel, dim3(grid), dim3(WG), 0, stream, m->mp, f, d_ins, n,
+                           d_out, d_hits, d_steps);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, stream));
     h->timed = true;
@@ -710,6 +909,24 @@ extern "C" int rl_check_collision_many(rl_method *h, const float *poses, int n_p
     }
     return fan_host(h, poses, n_poses, fov, num_rays, ranges_or_null, nullptr, nullptr, edge,
                     crash_thresh, first_crashed);
+}
+
+extern "C" int rl_method_read_lut(rl_method *h, int row0, int row1, uint16_t *out)
+{
+    if (!h || !out) return fail(RL_ERR_INVALID, "rl_method_read_lut: null pointer");
+    if (h->kind != RL_GIANT_LUT) return fail(RL_ERR_INVALID, "not a GiantLUT method");
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = set_device(h->map);
+    if (rc) return rc;
+    if (row0 < 0 || row1 > h->map->rows || row0 > row1)
+        return fail(RL_ERR_INVALID, "row range [%d,%d) outside the map", row0, row1);
+    if ((rc = ensure_lut(h, h->stream))) return rc;
+    const size_t per_row = (size_t)h->map->cols * h->theta_disc;
+    HIPCHK(hipMemcpyAsync(out, (const uint16_t *)h->lut.p + (size_t)row0 * per_row,
+                          (size_t)(row1 - row0) * per_row * sizeof(uint16_t), hipMemcpyDeviceToHost,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RL_OK;
 }
 
 extern "C" int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words)

@@ -283,8 +283,16 @@ class PyCDDTCast(_RangeMethod):
 
 
 class PyGiantLUTCast(_RangeMethod):
-    """range_libc.PyGiantLUTCast(omap, mrx, theta_disc)."""
+    """range_libc.PyGiantLUTCast(omap, mrx, theta_disc): uint16 table [row][col][theta_bin] built
+    on the device at first use (rows*cols*theta_disc*2 bytes of HBM)."""
     KIND = _lib.RL_GIANT_LUT
 
     def __init__(self, omap, max_range_px, theta_disc):
         super().__init__(omap, max_range_px, theta_disc)
+
+    def table(self, row0=0, row1=None):
+        """(row1-row0, cols, theta_disc) uint16 slab of the device table (test hook)."""
+        row1 = self.omap.height if row1 is None else row1
+        out = np.empty((row1 - row0, self.omap.width, self.theta_disc), dtype=np.uint16)
+        _lib.check(_lib.lib().rl_method_read_lut(self._h, row0, row1, out.ctypes.data_as(u16p)))
+        return out

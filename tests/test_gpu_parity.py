@@ -307,3 +307,126 @@ def test_cfg2_full_size_properties(oracle_mod):
     r0, h0, s0 = om.rm_fan(poses[sub], w.fov, B, step_coeff=1.0, nthreads=4)
     pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
     assert np.array_equal(r[pick], r0) and np.array_equal(h[pick], h0) and np.array_equal(s[pick], s0)
+
+
+# ---------------------------------------------------------------- K2: BresenhamsLine (LDS tile)
+@pytest.mark.parametrize("name", ["rm_colombia", "rm_maze256", "rm_maze192_yaw"])
+def test_bresenham_fan_reproduces_golden_vectors(oracle_mod, name):
+    g, z = load_golden(name)
+    omap = range_libc.PyOMap(g)
+    fov, B, mrx = float(z["fov"]), int(z["num_rays"]), int(z["max_range_px"])
+    m = range_libc.PyBresenhamsLine(omap, mrx)
+    r, h, s = _fan(m, z["poses"], fov, B)
+    assert np.array_equal(r, z["ranges_bl"]) and np.array_equal(h, z["hits_bl"].astype(np.int32))
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    r0, h0, s0 = om.bl_fan(z["poses"], fov, B)
+    assert np.array_equal(s, s0)
+    r1 = np.empty_like(r)
+    m.calc_range_fan(z["poses"], r1, fov, B)                  # non-AUX template
+    assert np.array_equal(r1, r0)
+
+
+@pytest.mark.parametrize("mrx", [40, 300, 700])               # 700: window > LDS -> global bit map
+def test_bresenham_vs_oracle_edge_cases_and_rays(oracle_mod, mrx):
+    g = maps.make_maze(300, cell=30, wall=2, p=0.5, seed=mrx, origin=(2.0, -1.0, 0.35))
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyBresenhamsLine(omap, mrx)
+    poses = maps.sample_free_poses(g, 40, 3)
+    poses[3] = [np.nan, 0, 0]
+    poses[4] = [1e20, 1.0, 0.5]
+    poses[5] = [g.origin[0] - 0.01, g.origin[1] - 0.01, 0.8]          # just outside the map
+    poses[6] = [g.origin[0] + 0.001, g.origin[1] + 0.001, 0.8]        # inside the border wall
+    poses[7, 2] = 1e-30
+    r, h, s = _fan(m, poses, 4.71, 257)
+    r0, h0, s0 = om.bl_fan(poses, 4.71, 257)
+    assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0)
+    rng = np.random.default_rng(2)
+    ins = poses[rng.integers(0, 40, 3000)].copy()
+    ins[:, 2] = rng.uniform(-8, 8, 3000).astype(np.float32)
+    outs = np.empty(3000, np.float32)
+    m.calc_range_many(ins, outs)
+    r0, _, _ = om.bl_rays(ins)
+    assert np.array_equal(outs, r0)
+
+
+# ---------------------------------------------------------------- K3: GiantLUT
+def test_giant_lut_table_and_queries_bit_equal_to_oracle(oracle_mod):
+    g = maps.make_maze(96, cell=16, wall=2, p=0.5, seed=4, origin=(-1.0, 0.5, 0.2))
+    mrx, td = 80, 180
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyGiantLUTCast(omap, mrx, td)
+    lut0 = om.lut_build(td, nthreads=4)
+    assert np.array_equal(m.table(), lut0)
+    assert np.array_equal(m.table(10, 13), lut0[10:13])
+    poses = maps.sample_free_poses(g, 50, 1)
+    poses[0] = [-50.0, 0.0, 0.0]                       # outside: max range
+    poses[1] = [np.nan, 0.0, 0.0]
+    out = np.empty(50 * 271, np.float32)
+    m.calc_range_fan(poses, out, 4.71, 271)
+    assert np.array_equal(out, om.lut_fan(lut0, poses, 4.71, 271))
+    rng = np.random.default_rng(5)
+    ins = poses[rng.integers(0, 50, 4000)].copy()
+    ins[:, 2] = rng.uniform(-20, 20, 4000).astype(np.float32)
+    outs = np.empty(4000, np.float32)
+    m.calc_range_many(ins, outs)
+    assert np.array_equal(outs, om.lut_rays(lut0, ins))
+    # LUT answers track exact ray marching (cell-corner origin + angular rounding)
+    rm, _, _ = om.rm_rays(ins[2:])
+    err = np.abs(outs[2:] - np.minimum(rm, mrx * g.resolution)) / g.resolution
+    assert np.median(err) < 1.5
+    with pytest.raises(Exception):
+        m.calc_range_fan(poses, out, 4.71, 271, hit_cells=np.empty((50 * 271, 2), np.int32))
+
+
+# ---------------------------------------------------------------- K3b: CDDT
+@pytest.mark.parametrize("td", [112, 720, 113])        # 112: scripts/two_player/rcs_two_player.py:121
+def test_cddt_queries_bit_equal_to_oracle(oracle_mod, td):
+    g, z = load_golden("rm_maze256")
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyCDDTCast(omap, 300, td)
+    poses = z["poses"][:12]
+    out = np.empty(12 * 1081, np.float32)
+    m.calc_range_fan(poses, out, 4.71, 1081)
+    assert np.array_equal(out, om.cddt_fan(td, poses, 4.71, 1081))
+    rng = np.random.default_rng(6)
+    ins = z["poses"][rng.integers(0, len(z["poses"]), 5000)].copy()
+    ins[:, 2] = rng.uniform(-10, 10, 5000).astype(np.float32)
+    outs = np.empty(5000, np.float32)
+    m.calc_range_many(ins, outs)                       # the reference's 2-arg CDDT call
+    assert np.array_equal(outs, om.cddt_rays(td, ins))
+    # rebuilt after a map change (two-player: car outline stamped every scan)
+    occ2 = g.occ.copy()
+    occ2[100:120, 100:140] = 1
+    omap.update(occ2)
+    om2 = oracle_mod.OracleMap(occ2, g.resolution, g.origin, 300)
+    m.calc_range_many(ins, outs)
+    assert np.array_equal(outs, om2.cddt_rays(td, ins))
+
+
+def test_cfg3_giant_lut_full_size(oracle_mod):
+    """configs[2]: 2000^2 maze, theta_disc 1442 (11.5 GB table), 65536 poses x 1081 beams."""
+    w = workloads.cfg3()
+    g, B, mrx, td = w.gmap, w.num_rays, w.max_range_px, w.theta_disc
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyGiantLUTCast(omap, mrx, td)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    om._dt = omap.distance_transform()
+    # table slab vs the oracle (2 rows = 5.8 M entries), bit-exact
+    slab = om.lut_build(td, 1000, 1002, nthreads=oracle_mod.max_threads())
+    assert np.array_equal(m.table(1000, 1002), slab)
+    poses = workloads.make_poses(w, dt=om.dt)
+    out = np.empty(len(poses) * B, np.float32)
+    m.calc_range_fan(poses, out, w.fov, B)
+    assert out.min() >= 0 and out.max() <= mrx * g.resolution + 1e-5
+    again = np.empty_like(out)
+    m.calc_range_fan(poses, again, w.fov, B)
+    assert np.array_equal(out, again)
+    # against exact ray marching on a pose subsample: within 2 cells for nearly all beams
+    sub = np.arange(0, len(poses), 1024)
+    rm, _, _ = om.rm_fan(poses[sub], w.fov, B, nthreads=oracle_mod.max_threads())
+    pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
+    err = np.abs(out[pick] - np.minimum(rm, mrx * g.resolution)) / g.resolution
+    assert np.median(err) < 1.0 and (err < 2.0).mean() > 0.9
