@@ -237,7 +237,9 @@ def main():
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                            "traffic": _pmc_traffic(a.workload, method),
                            "bytes_per_ray": round(bpr, 3),
-                           "kernel": "rm_fan_kernel" if method in ("RM", "RMGPU") else method}
+                           "kernel": {"RM": "rm_fan_stream_kernel", "RMGPU": "rm_fan_stream_kernel",
+                                      "BL": "bl_fan_kernel", "GLT": "lut_fan_kernel",
+                                      "CDDT": "cddt_fan_kernel"}[method]}
         if rank == 0 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, gmap, poses_all, method, a.cpu_seconds)
     if rank == 0:

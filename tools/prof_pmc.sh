@@ -11,19 +11,16 @@ PASSES=(
  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM"
  "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"
  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_PENDING_STALL_CYCLES_sum"
- "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum"
- "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"
- "TA_BUSY_avr TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum"
- "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum"
- "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum"
- "TCC_EA0_RDREQ_sum TCC_BUSY_avr TCC_READ_sum GRBM_GUI_ACTIVE"
+ "TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
+ "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
+ "GRBM_GUI_ACTIVE"
  "FETCH_SIZE"
  "WRITE_SIZE"
 )
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d "$OUT/p$i" -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OUT/p$i.json" 2> "$OUT/p$i.err" || echo "pass $i failed: $P"
+  timeout 150 rocprofv3 --pmc $P --output-format csv -d "$OUT/p$i" -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OUT/p$i.json" 2> "$OUT/p$i.err" || echo "pass $i failed: $P"
 done
 python3 tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json"
 rm -rf "$OUT"/p[0-9]* 
