@@ -535,6 +535,7 @@ struct LutParams {
     float bins_per_rad;      // theta_disc / 2pi (float)
     float bin_width;         // 2pi / theta_disc
     float quant, dequant;    // 65535/max_range, max_range/65535
+    int debug;               // diagnostics only: bit0 skip table loads, bit1 skip range stores
 };
 
 __device__ __forceinline__ int lut_bin(float th, const LutParams &lp)
@@ -563,25 +564,153 @@ __global__ __launch_bounds__(256) void lut_build_kernel(MapParams m, LutParams l
     }
 }
 
-// fan query: workgroup-stride over poses, lane = beam.  out[pose*num_rays + j] metres.
+// nearest-bin index without an integer division: u is an integer-valued float; for
+// |u| < 2^23 the float wrap below is exact and equals ((int)u % td + td) % td
+__device__ __forceinline__ int lut_bin_fast(float th, const LutParams &lp, float td_f, float inv_td)
+{
+    const float u = __builtin_rintf(th * lp.bins_per_rad);
+    if (!(__builtin_fabsf(u) < 8388608.0f)) return lut_bin(th, lp);   // huge headings: integer path
+    const float q = __builtin_floorf(u * inv_td);
+    float b = __builtin_fmaf(-q, td_f, u);
+    b = b < 0.0f ? b + td_f : b;
+    b = b >= td_f ? b - td_f : b;
+    return (int)b;
+}
+
+// fan query: ONE WAVE PER POSE, lane = beam within a 64-beam chunk.  The kernel is a pure
+// stream (2 B/ray in, 4 B/ray out), so what matters is bytes in flight: all CH chunks of a pose
+// (CH independent 2-byte loads per lane, ~2 KiB per wave) are issued before the first use, and
+// the loop is software-pipelined across poses — the loads of pose n+1 are issued BEFORE the
+// stores of pose n, because gfx950's vmcnt retires loads and stores in issue order and a load
+// issued behind 17 stores would wait for their write acknowledgements.
+// out[pose*num_rays + j] metres.
+template <int CH>
 __global__ __launch_bounds__(256) void lut_fan_kernel(MapParams m, FanParams f, LutParams lp,
                                                       const float *__restrict__ poses,
                                                       float *__restrict__ out)
 {
     const float miss = f.max_range * m.res;
-    for (int pose = blockIdx.x; pose < f.n_poses; pose += gridDim.x) {
+    const float td_f = (float)lp.theta_disc, inv_td = 1.0f / (float)lp.theta_disc;
+    const float scale = lp.dequant;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int cpp = (f.num_rays + 63) >> 6;
+
+    auto issue = [&](int pose, uint16_t (&q)[CH], bool &inb, int k_lo) {
         float gx, gy, thg;
         world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
                       poses[3 * (size_t)pose + 2], gx, gy, thg);
-        const bool inb = gx >= 0.0f && gx < m.fcols && gy >= 0.0f && gy < m.frows;
+        inb = gx >= 0.0f && gx < m.fcols && gy >= 0.0f && gy < m.frows;
         const uint16_t *row = lp.lut + (inb ? ((size_t)(int)gy * m.cols + (int)gx) * lp.theta_disc : 0);
-        for (int j = threadIdx.x; j < f.num_rays; j += blockDim.x) {
-            float r = miss;
-            if (inb) r = (float)row[lut_bin(thg + fan_alpha(f, j), lp)] * lp.dequant * m.res;
-            const size_t i = (size_t)pose * f.num_rays + j;
-            if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + i);
-            out[i] = r;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int j = ((k_lo + k) << 6) + lane;
+            q[k] = 0;
+            if (inb && j < f.num_rays && !(lp.debug & 1)) q[k] = row[lut_bin_fast(thg + fan_alpha(f, j), lp, td_f, inv_td)];
         }
+    };
+    auto retire = [&](int pose, const uint16_t (&q)[CH], bool inb, int k_lo) {
+        float *dst = out + (size_t)pose * f.num_rays;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int j = ((k_lo + k) << 6) + lane;
+            if (j < f.num_rays) {
+                float r = inb ? (float)q[k] * scale * m.res : miss;
+                if (f.noise_std > 0.0f)
+                    r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (size_t)pose * f.num_rays + j);
+                if (!(lp.debug & 2) || r < 0.0f) dst[j] = r;
+            }
+        }
+    };
+
+    // work items: (pose, group of CH chunks); rounds per pose = ceil(cpp / CH)
+    const int rpp = (cpp + CH - 1) / CH;
+    const long n_items = (long)f.n_poses * rpp;
+    long it = wave;
+    if (it >= n_items) return;
+    uint16_t qa[CH], qb[CH];
+    bool ia, ib;
+    int pa = (int)(it / rpp), ka = (int)(it % rpp) * CH;
+    issue(pa, qa, ia, ka);
+    for (it += n_waves; it < n_items; it += n_waves) {
+        const int pb = (int)(it / rpp), kb = (int)(it % rpp) * CH;
+        issue(pb, qb, ib, kb);            // next item's loads first ...
+        retire(pa, qa, ia, ka);           // ... then this item's stores
+#pragma unroll
+        for (int k = 0; k < CH; ++k) qa[k] = qb[k];
+        ia = ib;
+        pa = pb;
+        ka = kb;
+    }
+    retire(pa, qa, ia, ka);
+}
+
+// The production fan query.  Measured on MI355X: with one 2-byte load per beam the table read
+// ran at only ~2 TB/s even when the poses' rows fit the Infinity Cache — the limit is requests in
+// flight, not bytes (a wave-load covered just 128 B).  So the wave fetches the pose's WHOLE theta
+// row (theta_disc*2 B, e.g. 2884 B) with NL 16-byte-per-lane loads (1 KiB per wave-instruction),
+// parks it in LDS, and the beams gather their bins from LDS.  Rows are read 1.33x wider than the
+// fan needs (fov/2pi of the row), which costs less than narrow requests do.  Software-pipelined:
+// the next pose's row is in flight while the current one is gathered and stored.
+template <int NL, int CH>
+__global__ __launch_bounds__(256) void lut_fan_lds_kernel(MapParams m, FanParams f, LutParams lp,
+                                                          const float *__restrict__ poses,
+                                                          float *__restrict__ out)
+{
+    extern __shared__ uint32_t lds_rows[];                   // per wave: NL*256 dwords
+    uint32_t *my = lds_rows + (threadIdx.x >> 6) * (NL * 256);
+    const uint16_t *my16 = reinterpret_cast<const uint16_t *>(my);
+    const float miss = f.max_range * m.res;
+    const float td_f = (float)lp.theta_disc, inv_td = 1.0f / (float)lp.theta_disc;
+    const float scale = lp.dequant;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int D = lp.theta_disc >> 1;                        // dwords per row (theta_disc even)
+
+    uint4 regs[NL];
+    auto issue = [&](int pose, float &thg, bool &inb) {
+        float gx, gy;
+        world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
+                      poses[3 * (size_t)pose + 2], gx, gy, thg);
+        inb = gx >= 0.0f && gx < m.fcols && gy >= 0.0f && gy < m.frows;
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(
+            lp.lut + (inb ? ((size_t)(int)gy * m.cols + (int)gx) * lp.theta_disc : 0));
+#pragma unroll
+        for (int n = 0; n < NL; ++n) {
+            const int idx = (n * 64 + lane) * 4;
+            regs[n] = make_uint4(0, 0, 0, 0);
+            if (inb && idx < D) regs[n] = *reinterpret_cast<const uint4 *>(row + idx);
+        }
+    };
+
+    int pose = wave;
+    if (pose >= f.n_poses) return;
+    float thg, thg_n = 0.0f;
+    bool inb, inb_n = false;
+    issue(pose, thg, inb);
+    for (;;) {
+#pragma unroll
+        for (int n = 0; n < NL; ++n) *reinterpret_cast<uint4 *>(my + (n * 64 + lane) * 4) = regs[n];
+        const int next = pose + n_waves;
+        if (next < f.n_poses) issue(next, thg_n, inb_n);      // in flight during the gather
+        float *dst = out + (size_t)pose * f.num_rays;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int j = (k << 6) + lane;
+            if (j < f.num_rays) {
+                float r = miss;
+                if (inb) r = (float)my16[lut_bin_fast(thg + fan_alpha(f, j), lp, td_f, inv_td)] * scale * m.res;
+                if (f.noise_std > 0.0f)
+                    r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (size_t)pose * f.num_rays + j);
+                if (!(lp.debug & 2) || r < 0.0f) dst[j] = r;
+            }
+        }
+        if (next >= f.n_poses) break;
+        pose = next;
+        thg = thg_n;
+        inb = inb_n;
     }
 }
 

@@ -113,6 +113,7 @@ struct rl_method {
     int low_water = 24;          // queue kernel: refill when <= this many lanes still march
     int sort_poses = 1;          // queue kernel: order poses by map tile
     int xcd_bands = 8;           // queue kernel: bands of the sorted list, one per XCD
+    int lut_debug = 0;
     int drain_prio = 0;
     int wg_threads = 1024;       // stream kernel: workgroup size (256/512/1024) sharing one ray stream
     // GiantLUT (K3)
@@ -379,6 +380,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "sort_poses")) h->sort_poses = value != 0;
     else if (!strcmp(name, "debug_stamps")) h->debug_stamps = value != 0;
     else if (!strcmp(name, "drain_prio")) h->drain_prio = value != 0;
+    else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
     else if (!strcmp(name, "wg_threads")) h->wg_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256);
     else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
     else return fail(RL_ERR_INVALID, "unknown option '%s'", name);
@@ -440,7 +442,7 @@ static int ensure_lut(rl_method *h, hipStream_t stream)
     rl_map *m = h->map;
     if (h->lut_epoch == m->epoch && h->lut.p) return RL_OK;
     const size_t n = (size_t)m->rows * m->cols * h->theta_disc;
-    int rc = h->lut.ensure(n * sizeof(uint16_t));
+    int rc = h->lut.ensure(n * sizeof(uint16_t) + 64);      // + slack: rows are read in 16-B pieces
     if (rc) return rc;
     LutParams &lp = h->lp;
     lp.lut = (uint16_t *)h->lut.p;
@@ -449,6 +451,7 @@ static int ensure_lut(rl_method *h, hipStream_t stream)
     lp.bin_width = 6.283185307179586f / (float)h->theta_disc;
     lp.quant = 65535.0f / h->max_range;
     lp.dequant = h->max_range / 65535.0f;
+    lp.debug = h->lut_debug;
     const long cells = (long)m->rows * m->cols;
     const int grid = (int)std::min(cells, (long)m->n_cu * 16);
     hipLaunchKernelGGL(lut_build_kernel, dim3(grid), dim3(256), 0, stream, m->mp, lp, h->max_range,
@@ -592,8 +595,25 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         HIPCHK(hipEventRecord(h->ev0, stream));
         if (h->kind == RL_GIANT_LUT) {
             if ((rc = ensure_lut(h, stream))) return rc;
-            hipLaunchKernelGGL(lut_fan_kernel, dim3(pgrid), dim3(256), 0, stream, m->mp, f, h->lp,
-                               d_poses, d_out);
+            const int lgrid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4,
+                                                         (long)m->n_cu * h->grid_mult));
+            const int td = h->theta_disc;
+            const int nl = (td / 2 + 255) / 256;                 // 16-B loads per lane for one row
+            const bool lds_ok = (td % 2 == 0) && nl <= 3 && num_rays <= 17 * 64 && !(h->lut_debug & 4);
+            if (lds_ok) {
+                const size_t lds_b = (size_t)4 * nl * 256 * sizeof(uint32_t);
+#define LAUNCH_LL(N, C)                                                                           \
+    hipLaunchKernelGGL((lut_fan_lds_kernel<N, C>), dim3(lgrid), dim3(256), lds_b, stream, m->mp, f, \
+                       h->lp, d_poses, d_out)
+                if (num_rays <= 12 * 64) { if (nl == 1) LAUNCH_LL(1, 12); else if (nl == 2) LAUNCH_LL(2, 12); else LAUNCH_LL(3, 12); }
+                else                     { if (nl == 1) LAUNCH_LL(1, 17); else if (nl == 2) LAUNCH_LL(2, 17); else LAUNCH_LL(3, 17); }
+#undef LAUNCH_LL
+            } else if (num_rays <= 12 * 64)
+                hipLaunchKernelGGL((lut_fan_kernel<12>), dim3(lgrid), dim3(256), 0, stream, m->mp, f,
+                                   h->lp, d_poses, d_out);
+            else
+                hipLaunchKernelGGL((lut_fan_kernel<17>), dim3(lgrid), dim3(256), 0, stream, m->mp, f,
+                                   h->lp, d_poses, d_out);
         } else if (h->kind == RL_CDDT) {
             if ((rc = ensure_cddt(h, stream))) return rc;
             hipLaunchKernelGGL(cddt_fan_kernel, dim3(pgrid), dim3(256), 0, stream, m->mp, f, h->cdp,
