@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
     ap.add_argument("--opt", action="append", default=[], help="kernel option name=int (tuning)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="dry run of the N>1 code path on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     return ap.parse_args()
 
 
@@ -132,11 +135,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     w = workloads.CONFIGS[a.workload]()
     if a.poses:

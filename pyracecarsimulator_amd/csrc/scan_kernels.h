@@ -307,6 +307,112 @@ __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float
     }
 }
 
+// Large batches: the same binning as three grid-wide kernels (one lane per pose, tile histogram
+// and cursors in global memory), because one workgroup walking 10^5..10^6 poses would serialise
+// hundreds of microseconds in front of the march.
+__device__ __forceinline__ uint32_t pose_record(const MapParams &m, const float *__restrict__ poses,
+                                                int p, int tile_shift, int tiles_x, int n_tiles,
+                                                PoseRec &r)
+{
+    float thg;
+    world_to_grid(m, poses[3 * (size_t)p], poses[3 * (size_t)p + 1], poses[3 * (size_t)p + 2], r.gx,
+                  r.gy, thg);
+    det_sincosf(thg, r.st, r.ct);
+    const bool fin = (r.ct - r.ct) + (r.st - r.st) == 0.0f;
+    const bool inb = r.gx > -1.0f && r.gx < m.fcols && r.gy > -1.0f && r.gy < m.frows;
+    if (!(fin && inb)) {
+        r.gx = 0.0f; r.gy = 0.0f; r.ct = 1.0f; r.st = 0.0f;
+        return ((uint32_t)n_tiles - 1) | POSE_INVALID;
+    }
+    return (uint32_t)(((int)r.gy >> tile_shift) * tiles_x + ((int)r.gx >> tile_shift));
+}
+
+// Workgroup w owns poses [w*POSES_PER_WG, ...): per-workgroup tile histograms in LDS (no contended
+// global atomics — clustered roll-out poses would serialise on a few words), written tile-major
+// as hist_all[tile * n_wg + w]; one scan over that array then gives every (tile, workgroup) pair
+// its base slot, and the scatter pass hands out slots from LDS cursors.
+constexpr int POSES_PER_WG = 2048;
+
+__global__ __launch_bounds__(256) void pose_prep_kernel(MapParams m, const float *__restrict__ poses,
+                                                        int n, PoseRec *__restrict__ rec,
+                                                        uint32_t *__restrict__ keys,
+                                                        uint32_t *__restrict__ hist_all, int n_wg,
+                                                        int tile_shift, int tiles_x, int n_tiles,
+                                                        uint32_t *__restrict__ order_if_unsorted)
+{
+    extern __shared__ uint32_t lhist[];            // n_tiles
+    const int w = blockIdx.x;
+    if (!order_if_unsorted) {
+        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) lhist[i] = 0;
+        __syncthreads();
+    }
+    const int p_end = min(n, (w + 1) * POSES_PER_WG);
+    for (int p = w * POSES_PER_WG + threadIdx.x; p < p_end; p += blockDim.x) {
+        PoseRec r;
+        const uint32_t kf = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r);
+        rec[p] = r;
+        if (order_if_unsorted) {                   // keep the caller's pose order
+            order_if_unsorted[p] = (uint32_t)p | (kf & POSE_INVALID);
+        } else {
+            keys[p] = kf;
+            atomicAdd(&lhist[kf & ~POSE_INVALID], 1u);
+        }
+    }
+    if (order_if_unsorted) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) hist_all[(size_t)i * n_wg + w] = lhist[i];
+}
+
+// in-place exclusive scan of n counters by one workgroup
+__global__ __launch_bounds__(1024) void tile_scan_kernel(uint32_t *__restrict__ hist, int n)
+{
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const int E = (n + 1023) / 1024;
+    uint32_t local = 0;
+    for (int e = 0; e < E; ++e) {
+        int i = tid * E + e;
+        if (i < n) local += hist[i];
+    }
+    part[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t base = part[tid] - local;
+    for (int e = 0; e < E; ++e) {
+        int i = tid * E + e;
+        if (i < n) {
+            uint32_t c = hist[i];
+            hist[i] = base;
+            base += c;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pose_scatter_kernel(int n, const PoseRec *__restrict__ rec,
+                                                           const uint32_t *__restrict__ keys,
+                                                           const uint32_t *__restrict__ base_all,
+                                                           int n_wg, int n_tiles,
+                                                           PoseRec *__restrict__ rec_sorted,
+                                                           uint32_t *__restrict__ order)
+{
+    extern __shared__ uint32_t cursor[];           // n_tiles
+    const int w = blockIdx.x;
+    for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) cursor[i] = base_all[(size_t)i * n_wg + w];
+    __syncthreads();
+    const int p_end = min(n, (w + 1) * POSES_PER_WG);
+    for (int p = w * POSES_PER_WG + threadIdx.x; p < p_end; p += blockDim.x) {
+        const uint32_t kf = keys[p];
+        const uint32_t slot = atomicAdd(&cursor[kf & ~POSE_INVALID], 1u);
+        order[slot] = (uint32_t)p | (kf & POSE_INVALID);
+        rec_sorted[slot] = rec[p];
+    }
+}
+
 // unsigned division by a launch-time constant (round-up method, any 32-bit dividend)
 struct FastDiv {
     uint32_t mul, sh1, sh2, d;

@@ -132,7 +132,8 @@ struct rl_method {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf poses, outs, hits, steps, edge, flag, rec, rec_sorted, order, keys, dbg;
+    DevBuf poses, outs, hits, steps, edge, flag, rec, rec_sorted, order, keys, dbg, hist;
+    int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
     int debug_stamps = 0;        // diagnostics: per-wave start/end stamps of the stream kernel
     int last_grid = 0;
     std::vector<float> h_poses;
@@ -344,6 +345,7 @@ extern "C" void rl_method_destroy(rl_method *h)
     h->flag.release();
     h->rec.release();
     h->rec_sorted.release();
+    h->hist.release();
     h->order.release();
     h->keys.release();
     h->dbg.release();
@@ -380,6 +382,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "sort_poses")) h->sort_poses = value != 0;
     else if (!strcmp(name, "debug_stamps")) h->debug_stamps = value != 0;
     else if (!strcmp(name, "drain_prio")) h->drain_prio = value != 0;
+    else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
     else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
     else if (!strcmp(name, "wg_threads")) h->wg_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256);
     else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
@@ -397,6 +400,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "sort_poses")) *value_out = h->sort_poses;
     else if (!strcmp(name, "debug_stamps")) *value_out = h->debug_stamps;
     else if (!strcmp(name, "drain_prio")) *value_out = h->drain_prio;
+    else if (!strcmp(name, "bin_multi_min")) *value_out = h->bin_multi_min;
     else if (!strcmp(name, "wg_threads")) *value_out = h->wg_threads;
     else if (!strcmp(name, "last_grid")) *value_out = h->last_grid;
     else if (!strcmp(name, "xcd_bands")) *value_out = h->xcd_bands;
@@ -675,11 +679,41 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         while ((long)((m->cols >> shift) + 1) * ((m->rows >> shift) + 1) > 8192) ++shift;
         const int tiles_x = (m->cols >> shift) + 1;
         const int n_tiles = tiles_x * ((m->rows >> shift) + 1);
-        hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
-                           (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
-                           n_poses, (PoseRec *)h->rec.p, (PoseRec *)h->rec_sorted.p,
-                           (uint32_t *)h->order.p, (uint32_t *)h->keys.p, shift, tiles_x, n_tiles,
-                           do_sort);
+        if (n_poses >= h->bin_multi_min) {
+            const int n_wg = (n_poses + POSES_PER_WG - 1) / POSES_PER_WG;
+            if (do_sort) {
+                // grid-wide binning on coarse tiles (<= 1024): per-workgroup LDS histograms ->
+                // one scan over (tile, workgroup) -> scatter from LDS cursors
+                int cshift = shift;
+                while ((long)((m->cols >> cshift) + 1) * ((m->rows >> cshift) + 1) > 1024) ++cshift;
+                const int ctx = (m->cols >> cshift) + 1;
+                const int cnt = ctx * ((m->rows >> cshift) + 1);
+                const size_t n_ctr = (size_t)cnt * n_wg;
+                if ((rc = h->hist.ensure(n_ctr * sizeof(uint32_t)))) return rc;
+                hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
+                                   m->mp, d_poses, n_poses, (PoseRec *)h->rec.p,
+                                   (uint32_t *)h->keys.p, (uint32_t *)h->hist.p, n_wg, cshift, ctx,
+                                   cnt, (uint32_t *)nullptr);
+                hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream,
+                                   (uint32_t *)h->hist.p, (int)n_ctr);
+                hipLaunchKernelGGL(pose_scatter_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
+                                   n_poses, (const PoseRec *)h->rec.p, (const uint32_t *)h->keys.p,
+                                   (const uint32_t *)h->hist.p, n_wg, cnt, (PoseRec *)h->rec_sorted.p,
+                                   (uint32_t *)h->order.p);
+            } else {
+                // caller's order kept: one fully parallel pass, records land in place
+                hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), 0, stream, m->mp, d_poses,
+                                   n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)nullptr,
+                                   (uint32_t *)nullptr, n_wg, shift, tiles_x, n_tiles,
+                                   (uint32_t *)h->order.p);
+            }
+        } else {
+            hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
+                               (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
+                               n_poses, (PoseRec *)h->rec.p, (PoseRec *)h->rec_sorted.p,
+                               (uint32_t *)h->order.p, (uint32_t *)h->keys.p, shift, tiles_x,
+                               n_tiles, do_sort);
+        }
         PadMap pm{};
         pm.pdt = (const float *)h->pdt.p;
         pm.stride = h->pstride;

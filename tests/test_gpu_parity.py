@@ -48,6 +48,8 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "sort_poses": 0, "xcd_bands": 1},            # unsorted, one band
     {"variant": 1, "xcd_bands": 3, "grid_mult": 1},             # odd band count, small grid
     {"variant": 1, "grid_mult": 16, "wg_threads": 256},
+    {"variant": 1, "bin_multi_min": 64},                        # grid-wide binning kernels
+    {"variant": 1, "bin_multi_min": 1 << 30},                   # single-workgroup binning
 ])
 def test_every_kernel_schedule_is_bit_identical(oracle_mod, opts):
     g = maps.make_maze(400, cell=40, wall=3, p=0.45, seed=21, origin=(-7.0, 3.0, -0.4))
