@@ -179,7 +179,7 @@ static int map_build_tables(rl_map *m)
 {
     // K0: exact EDT + bit-packed occupancy, all on the device
     const int rows = m->rows, cols = m->cols;
-    hipLaunchKernelGGL(edt_cols_kernel, dim3((cols + 255) / 256), dim3(256), 0, m->stream,
+    hipLaunchKernelGGL(edt_cols_kernel, dim3((cols + 63) / 64), dim3(1024), 0, m->stream,
                        m->d_occ, rows, cols, m->d_g);
     hipLaunchKernelGGL(edt_rows_kernel, dim3(rows), dim3(256), (size_t)cols * sizeof(int),
                        m->stream, m->d_g, rows, cols, m->d_dt);
