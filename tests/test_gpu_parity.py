@@ -432,3 +432,75 @@ def test_cfg3_giant_lut_full_size(oracle_mod):
     pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
     err = np.abs(out[pick] - np.minimum(rm, mrx * g.resolution)) / g.resolution
     assert np.median(err) < 1.0 and (err < 2.0).mean() > 0.9
+
+
+# ---------------------------------------------------------------- configs 4 and 5: one GPU's shard
+def _free_poses(g, dt, n, seed):
+    return maps.sample_free_poses(g, n, seed, 2.0, dt)
+
+
+def test_cfg4_colombia_rollout_shard_properties(oracle_mod):
+    """configs[3]: maps/colombia, 2^20 poses sharded 8 ways -> this is ONE rank's block
+    (131072 poses x 1081 beams = 141.7 M rays), checked through properties + an oracle subsample,
+    and the sharding contract: scanning a block in two halves == scanning it whole."""
+    w = workloads.cfg4()
+    g, B, mrx = w.gmap, w.num_rays, w.max_range_px
+    omap = range_libc.PyOMap(g)
+    dt = omap.distance_transform()
+    lo, hi = workloads.shard_range(1 << 20, 3, 8)              # rank 3 of 8
+    assert hi - lo == 131072
+    poses = _free_poses(g, dt, hi - lo, 1000 + 3)
+    m = range_libc.PyRayMarchingGPU(omap, mrx)
+    out = np.empty(len(poses) * B, np.float32)
+    m.calc_range_fan(poses, out, w.fov, B)
+    assert out.min() >= 0.0 and out.max() <= (mrx + 1.5) * g.resolution
+    # oracle on every 512th pose, bit-exact
+    sub = np.arange(0, len(poses), 512)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    r0, _, _ = om.rm_fan(poses[sub], w.fov, B, step_coeff=1.0, nthreads=8)
+    pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
+    assert np.array_equal(out[pick], r0)
+    # two half-blocks reproduce the block (what all-gather of shards relies on)
+    half = len(poses) // 2
+    a, b = np.empty(half * B, np.float32), np.empty((len(poses) - half) * B, np.float32)
+    m.calc_range_fan(poses[:half], a, w.fov, B)
+    m.calc_range_fan(poses[half:], b, w.fov, B)
+    assert np.array_equal(out[:half * B], a) and np.array_equal(out[half * B:], b)
+    # fused crash test over the whole block == isCrashed over the ranges
+    edge = oracle_mod.edge_distances(B, -w.fov / 2, w.fov / B, 0.275, 0.2032, 0.3302)
+    code = m.check_collision_many(poses, w.fov, B, edge, 0.001)
+    assert code == oracle_mod.is_crashed(out, B, len(poses), edge, 0.001)
+
+
+def test_cfg5_noise_shard_reproduces_unsharded(oracle_mod):
+    """configs[4]: 4096^2 maze, 720 beams + Gaussian noise, pose batch sharded.  A rank that scans
+    its block with ray_offset = first global ray id must reproduce the unsharded noisy scan bit for
+    bit; noise-free ranges match the oracle on a subsample; noise has the configured sigma."""
+    w = workloads.cfg5()
+    g, B, mrx = w.gmap, w.num_rays, w.max_range_px
+    omap = range_libc.PyOMap(g)
+    dt = omap.distance_transform()
+    n = 16384                                                   # 2 "ranks" of 8192 poses
+    poses = _free_poses(g, dt, n, 55)
+    m = range_libc.PyRayMarchingGPU(omap, mrx)
+    clean = np.empty(n * B, np.float32)
+    m.calc_range_fan(poses, clean, w.fov, B)
+    sub = np.arange(0, n, 256)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    om._dt = dt
+    r0, _, _ = om.rm_fan(poses[sub], w.fov, B, step_coeff=1.0, nthreads=8)
+    pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
+    assert np.array_equal(clean[pick], r0)
+    m.set_noise(w.noise_std, w.noise_seed, 0)
+    whole = np.empty(n * B, np.float32)
+    m.calc_range_fan(poses, whole, w.fov, B)
+    d = (whole - clean).astype(np.float64)
+    assert abs(d.mean()) < 1e-4 and abs(d.std() - w.noise_std) < 1e-4
+    parts = []
+    for r in range(2):
+        lo, hi = workloads.shard_range(n, r, 2)
+        m.set_noise(w.noise_std, w.noise_seed, lo * B)
+        part = np.empty((hi - lo) * B, np.float32)
+        m.calc_range_fan(poses[lo:hi], part, w.fov, B)
+        parts.append(part)
+    assert np.array_equal(np.concatenate(parts), whole)
