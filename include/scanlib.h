@@ -128,6 +128,36 @@ int rl_check_collision_many(rl_method *h, const float *poses_p3, int n_poses, fl
                             int num_rays, const double *edge, double crash_thresh,
                             int *first_crashed, float *ranges_or_null);
 
+/* The same test per roll-out of a batch: poses holds n_groups roll-outs of `group` consecutive
+ * poses (scripts/mcts.py:228-231 stores 200 per roll-out); first_crashed[g] = index inside
+ * roll-out g of its first crashed pose, else -(group+1).  Works for every range method.       */
+int rl_check_collision_groups(rl_method *h, const float *poses_p3, int n_groups, int group,
+                              float fov, int num_rays, const double *edge, double crash_thresh,
+                              int *first_crashed, float *ranges_or_null);
+
+/* ---- roll-out pose generator ---------------------------------------
+ * The step in front of scanMany in MCTS.rollout (scripts/mcts.py:214-231): 200 x
+ * {Car::control, Car::updatePosition(dt)} (racecar/src/racecar.cpp:53-98,118-237,294-303) per
+ * roll-out, one GPU lane per roll-out in float64.
+ * car_params: the 17 constructor arguments of Car in order (racecar/include/racecar.hpp:32-36).
+ * states: 11 doubles per roll-out in Car::getState layout (racecar.cpp:355-376).
+ * actions: (speed, steer) pairs, ceil(n_steps/action_every) per roll-out.                      */
+typedef struct rl_car rl_car;
+int rl_car_create(int device, const double *car_params17, rl_car **out);
+void rl_car_destroy(rl_car *c);
+/* poses_out: n_rollouts*n_steps*3 float32 (x, y, theta of the car after each step);
+ * states_out (optional): final states; velocities_out (optional): state[3] after each step.   */
+int rl_car_rollout(rl_car *c, const double *states_in, const double *actions, int n_rollouts,
+                   int n_steps, int action_every, double dt, float *poses_out,
+                   double *states_out_or_null, double *velocities_out_or_null);
+/* roll-outs -> poses -> scan -> per-roll-out crash index without the poses or the ranges ever
+ * leaving the device: what MCTS.rollout + checkCollisionMany compute (scripts/mcts.py:202-245,
+ * scripts/racecar_simulator_v2.py:146-167), for n_rollouts roll-outs in one call.              */
+int rl_car_rollout_check(rl_car *c, rl_method *h, const double *states_in, const double *actions,
+                         int n_rollouts, int n_steps, int action_every, double dt, float fov,
+                         int num_rays, const double *edge, double crash_thresh, int *first_crashed,
+                         double *states_out_or_null, double *velocities_out_or_null);
+
 /* device time of the last enqueued launch sequence of this handle, from HIP events
  * recorded on the launch stream (blocks until that work has finished).            */
 int rl_last_kernel_ms(rl_method *h, float *ms_out);

@@ -52,6 +52,15 @@ SYMBOLS = {
     "rl_set_noise": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64, C.c_uint64]),
     "rl_check_collision_many": (C.c_int, [C.c_void_p, f32p, C.c_int, C.c_float, C.c_int, f64p,
                                           C.c_double, C.POINTER(C.c_int), f32p]),
+    "rl_check_collision_groups": (C.c_int, [C.c_void_p, f32p, C.c_int, C.c_int, C.c_float, C.c_int, f64p,
+                                            C.c_double, C.POINTER(C.c_int), f32p]),
+    "rl_car_create": (C.c_int, [C.c_int, f64p, C.POINTER(C.c_void_p)]),
+    "rl_car_destroy": (None, [C.c_void_p]),
+    "rl_car_rollout": (C.c_int, [C.c_void_p, f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_double, f32p,
+                                 f64p, f64p]),
+    "rl_car_rollout_check": (C.c_int, [C.c_void_p, C.c_void_p, f64p, f64p, C.c_int, C.c_int, C.c_int,
+                                       C.c_double, C.c_float, C.c_int, f64p, C.c_double,
+                                       C.POINTER(C.c_int), f64p, f64p]),
     "rl_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rl_method_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "rl_method_get_info": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),

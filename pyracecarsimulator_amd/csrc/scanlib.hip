@@ -6,6 +6,7 @@
 // scripts/two_player/scan.py:45-46.  There is no CPU fallback in this library.
 #include "../../include/scanlib.h"
 #include "scan_kernels.h"
+#include "car_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -956,11 +957,14 @@ extern "C" int rl_check_collision_many(rl_method *h, const float *poses, int n_p
     if (rc) return rc;
     if (!first_crashed || !edge || (n_poses > 0 && !poses))
         return fail(RL_ERR_INVALID, "rl_check_collision_many: null pointer");
-    std::lock_guard<std::mutex> lk(h->mu);
     if (n_poses == 0) {
         *first_crashed = -1;
         return RL_OK;
     }
+    if (h->kind != RL_RM && h->kind != RL_RM_GPU)      // generic: scan, then one crash pass
+        return rl_check_collision_groups(h, poses, 1, n_poses, fov, num_rays, edge, crash_thresh,
+                                         first_crashed, ranges_or_null);
+    std::lock_guard<std::mutex> lk(h->mu);
     return fan_host(h, poses, n_poses, fov, num_rays, ranges_or_null, nullptr, nullptr, edge,
                     crash_thresh, first_crashed);
 }
@@ -995,6 +999,163 @@ extern "C" int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words)
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, h->dbg.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return (int)words;
+}
+
+// ------------------------------------------------------------------------------
+// grouped crash test and the roll-out generator ("next" rows)
+// ------------------------------------------------------------------------------
+static int crash_groups_device(rl_method *h, const float *d_poses, int n_groups, int group, float fov,
+                               int num_rays, const double *d_edge, double thresh, int *d_first,
+                               float *d_ranges, hipStream_t stream)
+{
+    const int n_poses = n_groups * group;
+    int rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_ranges, nullptr, nullptr, nullptr, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fill_int_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, stream, d_first,
+                       n_groups, INT_MAX);
+    const int grid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4, (long)h->map->n_cu * 8));
+    hipLaunchKernelGGL(crash_groups_kernel, dim3(grid), dim3(256), 0, stream, d_ranges, d_edge, thresh,
+                       n_poses, num_rays, group, d_first);
+    hipLaunchKernelGGL(crash_finalize_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, stream,
+                       d_first, n_groups, group);
+    HIPCHK(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_check_collision_groups(rl_method *h, const float *poses, int n_groups, int group,
+                                         float fov, int num_rays, const double *edge,
+                                         double crash_thresh, int *first_crashed, float *ranges_or_null)
+{
+    if (n_groups < 0 || group <= 0) return fail(RL_ERR_INVALID, "n_groups >= 0 and group > 0 required");
+    const long n_poses_l = (long)n_groups * group;
+    if (n_poses_l > INT_MAX) return fail(RL_ERR_INVALID, "too many poses");
+    const int n_poses = (int)n_poses_l;
+    int rc = check_fan_args(h, n_poses, fov, num_rays);
+    if (rc) return rc;
+    if (n_groups == 0) return RL_OK;
+    if (!poses || !edge || !first_crashed) return fail(RL_ERR_INVALID, "rl_check_collision_groups: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if ((rc = set_device(h->map))) return rc;
+    const size_t n_rays = (size_t)n_poses * num_rays;
+    if ((rc = h->poses.ensure((size_t)n_poses * 12)) || (rc = h->outs.ensure(n_rays * 4)) ||
+        (rc = h->edge.ensure((size_t)num_rays * 8)) || (rc = h->flag.ensure((size_t)n_groups * 4)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(h->poses.p, poses, (size_t)n_poses * 12, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->edge.p, edge, (size_t)num_rays * 8, hipMemcpyHostToDevice, h->stream));
+    rc = crash_groups_device(h, (const float *)h->poses.p, n_groups, group, fov, num_rays,
+                             (const double *)h->edge.p, crash_thresh, (int *)h->flag.p,
+                             (float *)h->outs.p, h->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(first_crashed, h->flag.p, (size_t)n_groups * 4, hipMemcpyDeviceToHost, h->stream));
+    if (ranges_or_null)
+        HIPCHK(hipMemcpyAsync(ranges_or_null, h->outs.p, n_rays * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RL_OK;
+}
+
+struct rl_car {
+    int device = 0;
+    CarParams P{};
+    hipStream_t stream = nullptr;
+    DevBuf states, actions, poses, states_out, vel, ranges, edge, first;
+    std::mutex mu;
+};
+
+extern "C" int rl_car_create(int device, const double *p, rl_car **out)
+{
+    if (!p || !out) return fail(RL_ERR_INVALID, "rl_car_create: null pointer");
+    int ndev = rl_device_count();
+    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    rl_car *c = new (std::nothrow) rl_car();
+    if (!c) return fail(RL_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->P = CarParams{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12],
+                     p[13], p[14], p[15], p[16]};
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(RL_ERR_HIP, "stream creation failed");
+    }
+    *out = c;
+    return RL_OK;
+}
+
+extern "C" void rl_car_destroy(rl_car *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->states, &c->actions, &c->poses, &c->states_out, &c->vel, &c->ranges, &c->edge, &c->first})
+        b->release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int car_rollout_device(rl_car *c, const double *states_in, const double *actions, int R,
+                              int n_steps, int every, double dt, bool want_states, bool want_vel)
+{
+    if (R < 0 || n_steps <= 0 || every <= 0) return fail(RL_ERR_INVALID, "n_rollouts >= 0, n_steps > 0, action_every > 0 required");
+    if ((long)R * n_steps > INT_MAX / 4) return fail(RL_ERR_INVALID, "too many roll-out poses");
+    HIPCHK(hipSetDevice(c->device));
+    if (R == 0) return RL_OK;
+    const int n_act = (n_steps + every - 1) / every;
+    int rc;
+    if ((rc = c->states.ensure((size_t)R * 11 * 8)) || (rc = c->actions.ensure((size_t)R * n_act * 16)) ||
+        (rc = c->poses.ensure((size_t)R * n_steps * 12)) || (rc = c->states_out.ensure((size_t)R * 11 * 8)) ||
+        (rc = c->vel.ensure((size_t)R * n_steps * 8)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(c->states.p, states_in, (size_t)R * 11 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->actions.p, actions, (size_t)R * n_act * 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(rollout_kernel, dim3((R + 63) / 64), dim3(64), 0, c->stream, c->P,
+                       (const double *)c->states.p, (const double *)c->actions.p, R, n_steps, every, dt,
+                       (float *)c->poses.p, want_states ? (double *)c->states_out.p : nullptr,
+                       want_vel ? (double *)c->vel.p : nullptr);
+    HIPCHK(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_car_rollout(rl_car *c, const double *states_in, const double *actions, int R,
+                              int n_steps, int every, double dt, float *poses_out, double *states_out,
+                              double *vel_out)
+{
+    if (!c || (R > 0 && (!states_in || !actions || !poses_out))) return fail(RL_ERR_INVALID, "rl_car_rollout: null pointer");
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = car_rollout_device(c, states_in, actions, R, n_steps, every, dt, states_out != nullptr, vel_out != nullptr);
+    if (rc || R == 0) return rc;
+    HIPCHK(hipMemcpyAsync(poses_out, c->poses.p, (size_t)R * n_steps * 12, hipMemcpyDeviceToHost, c->stream));
+    if (states_out) HIPCHK(hipMemcpyAsync(states_out, c->states_out.p, (size_t)R * 11 * 8, hipMemcpyDeviceToHost, c->stream));
+    if (vel_out) HIPCHK(hipMemcpyAsync(vel_out, c->vel.p, (size_t)R * n_steps * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return RL_OK;
+}
+
+extern "C" int rl_car_rollout_check(rl_car *c, rl_method *h, const double *states_in, const double *actions,
+                                    int R, int n_steps, int every, double dt, float fov, int num_rays,
+                                    const double *edge, double crash_thresh, int *first_crashed,
+                                    double *states_out, double *vel_out)
+{
+    if (!c || !h || (R > 0 && (!states_in || !actions || !edge || !first_crashed)))
+        return fail(RL_ERR_INVALID, "rl_car_rollout_check: null pointer");
+    if (c->device != h->map->device) return fail(RL_ERR_INVALID, "car and range method live on different devices");
+    std::scoped_lock lk(c->mu, h->mu);
+    int rc = car_rollout_device(c, states_in, actions, R, n_steps, every, dt, states_out != nullptr, vel_out != nullptr);
+    if (rc || R == 0) return rc;
+    if ((rc = check_fan_args(h, R * n_steps, fov, num_rays))) return rc;
+    const size_t n_rays = (size_t)R * n_steps * num_rays;
+    if ((rc = c->ranges.ensure(n_rays * 4)) || (rc = c->edge.ensure((size_t)num_rays * 8)) ||
+        (rc = c->first.ensure((size_t)R * 4)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(c->edge.p, edge, (size_t)num_rays * 8, hipMemcpyHostToDevice, c->stream));
+    rc = crash_groups_device(h, (const float *)c->poses.p, R, n_steps, fov, num_rays,
+                             (const double *)c->edge.p, crash_thresh, (int *)c->first.p,
+                             (float *)c->ranges.p, c->stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(first_crashed, c->first.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
+    if (states_out) HIPCHK(hipMemcpyAsync(states_out, c->states_out.p, (size_t)R * 11 * 8, hipMemcpyDeviceToHost, c->stream));
+    if (vel_out) HIPCHK(hipMemcpyAsync(vel_out, c->vel.p, (size_t)R * n_steps * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return RL_OK;
 }
 
 extern "C" int rl_last_kernel_ms(rl_method *h, float *ms_out)

@@ -219,6 +219,23 @@ class _RangeMethod:
             ranges.ctypes.data_as(f32p) if ranges is not None else None))
         return int(first.value)
 
+    def check_collision_groups(self, poses, group, fov, num_rays, edge_distances, crash_thresh,
+                               ranges=None):
+        """isCrashed per roll-out of a batch: ``poses`` holds consecutive roll-outs of ``group``
+        poses; returns int32[n_groups] (first crashed pose inside each roll-out, else -(group+1))."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        if poses.shape[0] % group:
+            raise ValueError("number of poses is not a multiple of the group size")
+        n_groups = poses.shape[0] // group
+        edge = np.ascontiguousarray(edge_distances, dtype=np.float64)
+        first = np.zeros(n_groups, dtype=np.int32)
+        _lib.check(_lib.lib().rl_check_collision_groups(
+            self._h, poses.ctypes.data_as(f32p), n_groups, int(group), float(fov), int(num_rays),
+            edge.ctypes.data_as(f64p), float(crash_thresh),
+            first.ctypes.data_as(C.POINTER(C.c_int)),
+            ranges.ctypes.data_as(f32p) if ranges is not None else None))
+        return first
+
     def set_noise(self, std, seed=0, ray_offset=0):
         _lib.check(_lib.lib().rl_set_noise(self._h, float(std), int(seed), int(ray_offset)))
 

@@ -504,3 +504,63 @@ def test_cfg5_noise_shard_reproduces_unsharded(oracle_mod):
         m.calc_range_fan(poses[lo:hi], part, w.fov, B)
         parts.append(part)
     assert np.array_equal(np.concatenate(parts), whole)
+
+
+# ---------------------------------------------------------------- "next" rows: roll-outs + crash
+def test_rollout_generator_matches_reference_car():
+    """GOLD-D2: 48 roll-outs x 200 steps integrated by the reference's compiled Car (oracle/_ref)."""
+    import os
+    from conftest import GOLD
+    from pyracecarsimulator_amd import racecar as RC
+    z = np.load(os.path.join(GOLD, "car_rollouts_ref.npz"))
+    cars = RC.CarBatch(dict(zip(RC.CAR_PARAM_ORDER, z["params"])))
+    poses, final, vel = cars.rollout(z["states"], z["actions"], int(z["n_steps"]),
+                                     int(z["action_every"]), float(z["dt"]))
+    # float64 ODE, libm vs OCML trig: <= 1e-9 relative (SURVEY §8f), not bitwise
+    assert np.allclose(final, z["final"], rtol=1e-9, atol=1e-9)
+    assert np.allclose(vel, z["velocities"], rtol=1e-9, atol=1e-9)
+    assert np.abs(poses.astype(np.float64) - z["poses"].astype(np.float64)).max() < 2e-6
+    assert (poses == z["poses"]).mean() > 0.99
+    # the survey's probe: 200 x control(2.0, 0.1) from rest
+    p, f, _ = cars.rollout(np.zeros((1, 11)), np.tile([2.0, 0.1], (1, 20, 1)))
+    assert np.allclose(f[0, :4], [2.080581685, 0.773390818, 0.665095230, 1.675438380], atol=2e-9)
+    assert f[0, 10] == 200 and f[0, 7] == 1.0
+
+
+def test_rollout_check_chain_equals_staged_oracle(oracle_mod):
+    """roll-outs -> poses -> scan -> per-roll-out crash index in ONE call == the same stages done
+    separately with the oracle scanning the generated poses."""
+    from pyracecarsimulator_amd import racecar as RC
+    g = maps.load_colombia()
+    mrx, B, fov = 300, 1081, 4.71
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyRayMarchingGPU(omap, mrx)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    rng = np.random.default_rng(9)
+    R, n_steps = 24, 200
+    start = maps.sample_free_poses(g, R, 5, 6.0, om.dt)
+    states = np.zeros((R, 11))
+    states[:, :3] = start
+    states[:, 3] = rng.uniform(0, 3, R)
+    actions = np.stack([rng.uniform(0, 7, (R, 20)), rng.uniform(-0.4189, 0.4189, (R, 20))], -1)
+    cars = RC.CarBatch()
+    edge = RC.edge_distances(B, -fov / 2, fov / B, 0.275, RC.DEFAULT_CAR["width"], RC.DEFAULT_CAR["wb"])
+    first, final, vel = cars.rollout_check(m, states, actions, fov, B, edge, 0.001)
+    poses, final2, vel2 = cars.rollout(states, actions)
+    assert np.array_equal(final, final2) and np.array_equal(vel, vel2)
+    want_r, _, _ = om.rm_fan(poses.reshape(-1, 3), fov, B, step_coeff=1.0, nthreads=8)
+    want = [oracle_mod.is_crashed(want_r[r * n_steps * B:(r + 1) * n_steps * B], B, n_steps, edge, 0.001)
+            for r in range(R)]
+    assert first.tolist() == want
+    assert any(w >= 0 for w in want) and any(w < 0 for w in want)
+    # the grouped test on its own, for a method without a fused path (CDDT) and for Bresenham
+    for cls, args, ofun in ((range_libc.PyCDDTCast, (112,), lambda p: om.cddt_fan(112, p, fov, B)),
+                            (range_libc.PyBresenhamsLine, (), lambda p: om.bl_fan(p, fov, B)[0])):
+        mm = cls(omap, mrx, *args)
+        sub = poses[:6].reshape(-1, 3)
+        got = mm.check_collision_groups(sub, n_steps, fov, B, edge, 0.001)
+        rr = ofun(sub)
+        want = [oracle_mod.is_crashed(rr[r * n_steps * B:(r + 1) * n_steps * B], B, n_steps, edge, 0.001)
+                for r in range(6)]
+        assert got.tolist() == want
+        assert mm.check_collision_many(sub[:n_steps], fov, B, edge, 0.001) == want[0]

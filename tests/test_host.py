@@ -165,3 +165,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.replace("SURVEY", ""), os.path.join(dirpath, f)
+
+
+# ---------------------------------------------------------------- racecar host table
+def test_edge_distances_host_table_equals_reference_behaviour(oracle_mod):
+    from pyracecarsimulator_amd import racecar as RC
+    z = np.load(os.path.join(GOLD, "car_ref.npz"))
+    car = dict(zip([str(k) for k in z["car_keys"]], z["car"]))
+    for B, fov in [(1081, 4.71), (1080, 4.71), (720, 3.14), (64, 6.2), (8, 2.0)]:
+        mine = RC.edge_distances(B, -fov / 2.0, fov / B, 0.275, car["width"], car["wb"])
+        ref = oracle_mod.edge_distances(B, -fov / 2.0, fov / B, 0.275, car["width"], car["wb"])
+        assert np.array_equal(mine, ref)
+    # and through the reference binary's isCrashed codes (GOLD-D)
+    for i in range(0, len(z["codes"]), 5):
+        B, fov, P = int(z["num_rays"][i]), float(z["fov"][i]), int(z["poses"][i])
+        edge = RC.edge_distances(B, -fov / 2.0, fov / B, 0.275, car["width"], car["wb"])
+        assert oracle_mod.is_crashed(z["rays_%d" % i], B, P, edge, car["ttc_thresh"]) == int(z["codes"][i])
+    assert tuple(RC.CAR_PARAM_ORDER) == tuple(str(k) for k in z["car_keys"])

@@ -140,6 +140,49 @@ def car_ref():
         **{"rays_%d" % i: c[3] for i, c in enumerate(cases)})
 
 
+def car_rollouts():
+    """GOLD-D2: roll-outs integrated by the reference's compiled Car (control + updatePosition,
+    racecar.cpp:53-98,294-303) with the action schedule of scripts/mcts.py:214-231."""
+    from pyracecarsimulator_amd import racecar as RC
+    L = C.CDLL(os.path.join(ROOT, "oracle/_ref/libracecar_ref.so"))
+    L.ref_car_create.restype = C.c_void_p
+    L.ref_car_create.argtypes = [C.POINTER(C.c_double)]
+    L.ref_car_control.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.ref_car_update_position.argtypes = [C.c_void_p, C.c_double]
+    L.ref_car_get_state.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.ref_car_set_state.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    params = np.array([RC.DEFAULT_CAR[k] for k in RC.CAR_PARAM_ORDER])
+    car = L.ref_car_create((C.c_double * 17)(*params))
+    rng = np.random.default_rng(123)
+    R, n_steps, every = 48, 200, 10
+    states = np.zeros((R, 11))
+    states[:, 0] = rng.uniform(-5, 5, R)
+    states[:, 1] = rng.uniform(-5, 5, R)
+    states[:, 2] = rng.uniform(-3.1, 3.1, R)
+    states[:, 3] = rng.uniform(0, 6, R) * (rng.random(R) < 0.8)
+    states[:, 4] = rng.uniform(-0.4, 0.4, R)
+    states[R // 2:, 5] = rng.uniform(-1, 1, R - R // 2)
+    states[R // 2:, 6] = rng.uniform(-0.1, 0.1, R - R // 2)
+    states[R // 2:, 7] = 1.0
+    actions = np.stack([rng.uniform(0, 7, (R, 20)), rng.uniform(-0.4189, 0.4189, (R, 20))], -1)
+    poses = np.zeros((R, n_steps, 3), np.float32)
+    vel = np.zeros((R, n_steps))
+    out = np.zeros((R, 11))
+    for r in range(R):
+        st = (C.c_double * 11)(*states[r])
+        L.ref_car_set_state(car, st)
+        for i in range(n_steps):
+            L.ref_car_control(car, actions[r, i // every, 0], actions[r, i // every, 1])
+            L.ref_car_update_position(car, 0.01)
+            L.ref_car_get_state(car, st)
+            poses[r, i] = (st[0], st[1], st[2])
+            vel[r, i] = st[3]
+        out[r] = list(st)
+    np.savez_compressed(os.path.join(GOLD, "car_rollouts_ref.npz"), params=params, states=states,
+                        actions=actions, poses=poses, velocities=vel, final=out, n_steps=n_steps,
+                        action_every=every, dt=0.01)
+
+
 def rm_golden(name, g, n_poses, seed, mrx=300, fov=4.71, num_rays=1081):
     om = O.OracleMap.from_gridmap(g, mrx)
     assert np.array_equal(om.dt, N.edt(g.occ)), "EDT: C oracle vs scipy statement"
@@ -168,6 +211,7 @@ def main():
     colombia()
     protocol()
     car_ref()
+    car_rollouts()
     rm_golden("rm_colombia", maps.load_colombia(), 24, 101)
     rm_golden("rm_maze256", maps.make_maze(256, cell=32, wall=2, p=0.45, seed=7), 24, 102)
     g = maps.make_maze(192, cell=24, wall=2, p=0.5, seed=9, resolution=0.1,
