@@ -528,11 +528,14 @@ struct StreamParams {
     int cpp;
     int low_water;           // refill when <= low_water lanes are still marching
     int n_bands;
+    const float *raw_poses;  // INLINE only: world poses (x, y, theta); every workgroup derives the
+    const MapParams *map;    //   records of the chunks it owns itself (device copy of the map params)
+    int k_max;               // INLINE only: LDS capacity in chunk records
     int drain_prio;          // raise wave priority once the workgroup's stream is exhausted
     unsigned long long *dbg; // diagnostics (nullptr in production): 4 words per wave
 };
 
-template <bool AUX, bool CRASH, bool UNIT, int NT>
+template <bool AUX, bool CRASH, bool UNIT, int NT, bool INLINE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
 void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__restrict__ out,
                           int32_t *__restrict__ hits, uint16_t *__restrict__ steps, CrashParams cp)
@@ -540,13 +543,15 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     extern __shared__ float lds_f[];
     uint32_t *q_next = reinterpret_cast<uint32_t *>(lds_f);     // shared slot counter
     float2 *fan_cs = reinterpret_cast<float2 *>(lds_f + 2);     // num_rays float2
+    // INLINE: per owned chunk {gx, gy, cos, sin} and pose id | invalid flag, filled below
+    PoseRec *lrec = reinterpret_cast<PoseRec *>(lds_f + ((2 + 2 * (size_t)f.num_rays + 3) & ~(size_t)3));   // 16-B aligned
+    uint32_t *lord = reinterpret_cast<uint32_t *>(lrec + (INLINE ? sp.k_max : 0));
     if (threadIdx.x == 0) *q_next = 0;
     for (int j = threadIdx.x; j < f.num_rays; j += NT) {
         float s, c;
         det_sincosf(fan_alpha(f, j), s, c);
         fan_cs[j] = make_float2(c, s);
     }
-    __syncthreads();
 
     // ---- which band of the sorted pose list, and which workgroups share it
     const int nb = sp.n_bands;
@@ -560,6 +565,19 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     const uint32_t K = g < seg_chunks ? (seg_chunks - g + G - 1) / G : 0;
     const uint32_t total = K << 6;
     const unsigned lane = threadIdx.x & 63;
+    if (INLINE) {
+        // small batches: no binning launch in front of the march — each workgroup turns the poses
+        // of its own chunks into records (a few hundred, one per lane) and keeps them in LDS
+        const MapParams mp = *sp.map;
+        for (uint32_t k = threadIdx.x; k < K; k += NT) {
+            const uint32_t spose = seg_lo + fast_div(g + k * G, sp.div_cpp);
+            PoseRec r;
+            const uint32_t kf = pose_record(mp, sp.raw_poses, (int)spose, 0, 1, 1, r);
+            lrec[k] = r;
+            lord[k] = spose | (kf & POSE_INVALID);
+        }
+    }
+    __syncthreads();
     const float INF = __builtin_inff();
 
     unsigned long long t_start = 0;
@@ -617,8 +635,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                     const uint32_t spose = fast_div(chunk, sp.div_cpp);
                     const int j = (int)((chunk - spose * (uint32_t)sp.cpp) << 6) + (int)(q & 63);
                     if (j < f.num_rays) {
-                        const uint32_t po = sp.order[seg_lo + spose];
-                        const PoseRec pr_ = sp.rec[seg_lo + spose];
+                        const uint32_t po = INLINE ? lord[q >> 6] : sp.order[seg_lo + spose];
+                        const PoseRec pr_ = INLINE ? lrec[q >> 6] : sp.rec[seg_lo + spose];
                         const float2 cs = fan_cs[j];
                         pose = po & ~POSE_INVALID;
                         gx = pr_.gx;

@@ -73,6 +73,7 @@ struct rl_map {
     hipStream_t stream = nullptr;
     uint64_t epoch = 0;          // bumped by rl_map_update; derived tables rebuild lazily
     MapParams mp{};
+    MapParams *d_mp = nullptr;   // device copy (kernels that take the map by pointer)
     int n_cu = 256;
     std::mutex mu;
 };
@@ -135,6 +136,8 @@ struct rl_method {
     bool timed = false;
     DevBuf poses, outs, hits, steps, edge, flag, rec, rec_sorted, order, keys, dbg, hist;
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
+    int inline_prep = 1;         // tiny batches: no binning launch, workgroups derive their own records
+    int inline_max = 512;        //   ... below this many poses (measured: wins below ~512, loses above)
     int debug_stamps = 0;        // diagnostics: per-wave start/end stamps of the stream kernel
     int last_grid = 0;
     std::vector<float> h_poses;
@@ -248,6 +251,9 @@ extern "C" int rl_map_create(const uint8_t *occ, int rows, int cols, float res, 
     p.oy = oy;
     p.wa = -oyaw;                                   // PyOMap: world_angle = -yaw
     host_sincosf(p.wa, p.wa_sin, p.wa_cos);
+    if (hipMalloc((void **)&m->d_mp, sizeof(MapParams)) != hipSuccess ||
+        hipMemcpy(m->d_mp, &m->mp, sizeof(MapParams), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(RL_ERR_NOMEM, "map parameter upload failed"));
     *out = m;
     return RL_OK;
 }
@@ -274,6 +280,7 @@ extern "C" void rl_map_destroy(rl_map *m)
     if (m->d_g) (void)hipFree(m->d_g);
     if (m->d_dt) (void)hipFree(m->d_dt);
     if (m->d_bits) (void)hipFree(m->d_bits);
+    if (m->d_mp) (void)hipFree(m->d_mp);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -384,6 +391,8 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "debug_stamps")) h->debug_stamps = value != 0;
     else if (!strcmp(name, "drain_prio")) h->drain_prio = value != 0;
     else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
+    else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
+    else if (!strcmp(name, "inline_max")) h->inline_max = value;
     else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
     else if (!strcmp(name, "wg_threads")) h->wg_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256);
     else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
@@ -402,6 +411,8 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "debug_stamps")) *value_out = h->debug_stamps;
     else if (!strcmp(name, "drain_prio")) *value_out = h->drain_prio;
     else if (!strcmp(name, "bin_multi_min")) *value_out = h->bin_multi_min;
+    else if (!strcmp(name, "inline_prep")) *value_out = h->inline_prep;
+    else if (!strcmp(name, "inline_max")) *value_out = h->inline_max;
     else if (!strcmp(name, "wg_threads")) *value_out = h->wg_threads;
     else if (!strcmp(name, "last_grid")) *value_out = h->last_grid;
     else if (!strcmp(name, "xcd_bands")) *value_out = h->xcd_bands;
@@ -673,47 +684,62 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
                                h->pstride);
             h->pdt_epoch = m->epoch;
         }
-        if ((rc = h->rec_sorted.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
         const int bands = n_poses >= 64 ? h->xcd_bands : 1;
-        const int do_sort = (h->sort_poses && n_poses >= 64) ? 1 : 0;
-        int shift = 6;
-        while ((long)((m->cols >> shift) + 1) * ((m->rows >> shift) + 1) > 8192) ++shift;
-        const int tiles_x = (m->cols >> shift) + 1;
-        const int n_tiles = tiles_x * ((m->rows >> shift) + 1);
-        if (n_poses >= h->bin_multi_min) {
-            const int n_wg = (n_poses + POSES_PER_WG - 1) / POSES_PER_WG;
-            if (do_sort) {
-                // grid-wide binning on coarse tiles (<= 1024): per-workgroup LDS histograms ->
-                // one scan over (tile, workgroup) -> scatter from LDS cursors
-                int cshift = shift;
-                while ((long)((m->cols >> cshift) + 1) * ((m->rows >> cshift) + 1) > 1024) ++cshift;
-                const int ctx = (m->cols >> cshift) + 1;
-                const int cnt = ctx * ((m->rows >> cshift) + 1);
-                const size_t n_ctr = (size_t)cnt * n_wg;
-                if ((rc = h->hist.ensure(n_ctr * sizeof(uint32_t)))) return rc;
-                hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
-                                   m->mp, d_poses, n_poses, (PoseRec *)h->rec.p,
-                                   (uint32_t *)h->keys.p, (uint32_t *)h->hist.p, n_wg, cshift, ctx,
-                                   cnt, (uint32_t *)nullptr);
-                hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream,
-                                   (uint32_t *)h->hist.p, (int)n_ctr);
-                hipLaunchKernelGGL(pose_scatter_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
-                                   n_poses, (const PoseRec *)h->rec.p, (const uint32_t *)h->keys.p,
-                                   (const uint32_t *)h->hist.p, n_wg, cnt, (PoseRec *)h->rec_sorted.p,
-                                   (uint32_t *)h->order.p);
+        // persistent grid: grid_mult x 256 threads per CU, whatever the workgroup size
+        int nt = h->wg_threads;
+        // small batches: skip the binning launch, workgroups derive the records of their own chunks
+        bool inl = h->inline_prep && n_poses < h->inline_max && n_poses < h->bin_multi_min;
+        int k_max = 0;
+        if (inl) {
+            nt = 1024;
+            const long g_min = std::max(1L, std::min((n_chunks + 15) / 16, (long)m->n_cu * h->grid_mult * WG / nt) / bands);
+            const long seg_chunks_max = (((long)n_poses + bands - 1) / bands) * cpp;
+            k_max = (int)((seg_chunks_max + g_min - 1) / g_min) + 1;
+            if ((size_t)k_max * 20 + lds + 32 > 56 * 1024) inl = false;
+        }
+        if (!inl) {
+            nt = h->wg_threads;
+            if ((rc = h->rec_sorted.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
+            const int do_sort = (h->sort_poses && n_poses >= 64) ? 1 : 0;
+            int shift = 6;
+            while ((long)((m->cols >> shift) + 1) * ((m->rows >> shift) + 1) > 8192) ++shift;
+            const int tiles_x = (m->cols >> shift) + 1;
+            const int n_tiles = tiles_x * ((m->rows >> shift) + 1);
+            if (n_poses >= h->bin_multi_min) {
+                const int n_wg = (n_poses + POSES_PER_WG - 1) / POSES_PER_WG;
+                if (do_sort) {
+                    // grid-wide binning on coarse tiles (<= 1024): per-workgroup LDS histograms ->
+                    // one scan over (tile, workgroup) -> scatter from LDS cursors
+                    int cshift = shift;
+                    while ((long)((m->cols >> cshift) + 1) * ((m->rows >> cshift) + 1) > 1024) ++cshift;
+                    const int ctx = (m->cols >> cshift) + 1;
+                    const int cnt = ctx * ((m->rows >> cshift) + 1);
+                    const size_t n_ctr = (size_t)cnt * n_wg;
+                    if ((rc = h->hist.ensure(n_ctr * sizeof(uint32_t)))) return rc;
+                    hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
+                                       m->mp, d_poses, n_poses, (PoseRec *)h->rec.p,
+                                       (uint32_t *)h->keys.p, (uint32_t *)h->hist.p, n_wg, cshift, ctx,
+                                       cnt, (uint32_t *)nullptr);
+                    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream,
+                                       (uint32_t *)h->hist.p, (int)n_ctr);
+                    hipLaunchKernelGGL(pose_scatter_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
+                                       n_poses, (const PoseRec *)h->rec.p, (const uint32_t *)h->keys.p,
+                                       (const uint32_t *)h->hist.p, n_wg, cnt, (PoseRec *)h->rec_sorted.p,
+                                       (uint32_t *)h->order.p);
+                } else {
+                    // caller's order kept: one fully parallel pass, records land in place
+                    hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), 0, stream, m->mp, d_poses,
+                                       n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)nullptr,
+                                       (uint32_t *)nullptr, n_wg, shift, tiles_x, n_tiles,
+                                       (uint32_t *)h->order.p);
+                }
             } else {
-                // caller's order kept: one fully parallel pass, records land in place
-                hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), 0, stream, m->mp, d_poses,
-                                   n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)nullptr,
-                                   (uint32_t *)nullptr, n_wg, shift, tiles_x, n_tiles,
-                                   (uint32_t *)h->order.p);
+                hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
+                                   (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
+                                   n_poses, (PoseRec *)h->rec.p, (PoseRec *)h->rec_sorted.p,
+                                   (uint32_t *)h->order.p, (uint32_t *)h->keys.p, shift, tiles_x,
+                                   n_tiles, do_sort);
             }
-        } else {
-            hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
-                               (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
-                               n_poses, (PoseRec *)h->rec.p, (PoseRec *)h->rec_sorted.p,
-                               (uint32_t *)h->order.p, (uint32_t *)h->keys.p, shift, tiles_x,
-                               n_tiles, do_sort);
         }
         PadMap pm{};
         pm.pdt = (const float *)h->pdt.p;
@@ -729,10 +755,11 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.div_cpp = make_fastdiv((uint32_t)cpp);
         sp.low_water = h->low_water;
         sp.n_bands = bands;
+        sp.raw_poses = d_poses;
+        sp.map = m->d_mp;
+        sp.k_max = k_max;
         sp.drain_prio = h->drain_prio;
         sp.dbg = nullptr;
-        // persistent grid: grid_mult x 256 threads per CU, whatever the workgroup size
-        const int nt = h->wg_threads;
         const int waves_per_wg = nt / 64;
         long want_q = (n_chunks + waves_per_wg - 1) / waves_per_wg;
         long cap_q = (long)m->n_cu * h->grid_mult * WG / nt;
@@ -742,16 +769,18 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             sp.dbg = (unsigned long long *)h->dbg.p;
         }
         h->last_grid = grid * waves_per_wg / WAVES_PER_WG;
-        const size_t lds_q = lds + 2 * sizeof(float);
+        const size_t lds_q = inl ? (((2 + 2 * (size_t)num_rays + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 20)
+                                 : lds + 2 * sizeof(float);
         const bool unit = h->step_coeff == 1.0f;
-#define LAUNCH_S(A, C, U, N)                                                                      \
-    hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, U, N>), dim3(grid), dim3(N), lds_q, stream,    \
+#define LAUNCH_S(A, C, U, N, I)                                                                   \
+    hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, U, N, I>), dim3(grid), dim3(N), lds_q, stream, \
                        pm, f, sp, d_out, d_hits, d_steps, cp)
 #define LAUNCH_S_N(A, C, U)                                    \
     do {                                                       \
-        if (nt == 1024) LAUNCH_S(A, C, U, 1024);               \
-        else if (nt == 512) LAUNCH_S(A, C, U, 512);            \
-        else LAUNCH_S(A, C, U, 256);                           \
+        if (inl) LAUNCH_S(A, C, U, 1024, true);                \
+        else if (nt == 1024) LAUNCH_S(A, C, U, 1024, false);   \
+        else if (nt == 512) LAUNCH_S(A, C, U, 512, false);     \
+        else LAUNCH_S(A, C, U, 256, false);                    \
     } while (0)
         if (unit) {
             if (crash) { if (aux) LAUNCH_S_N(true, true, true); else LAUNCH_S_N(false, true, true); }

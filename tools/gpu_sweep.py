@@ -59,6 +59,9 @@ def main():
                    dict(variant=1, low_water=32, wg_threads=1024, grid_mult=8, sort_poses=1, xcd_bands=1),
                    dict(variant=1, low_water=32, wg_threads=1024, grid_mult=8, xcd_bands=16),
                    dict(variant=1, low_water=32, wg_threads=1024, grid_mult=8, xcd_bands=8)]
+    elif a.grid == "inline":
+        combos = [dict(variant=1, inline_prep=i, low_water=lw, xcd_bands=b)
+                  for i, lw, b in itertools.product((0, 1), (16, 24, 32), (8, 1))]
     elif a.grid == "prio":
         combos = [dict(variant=1, low_water=lw, wg_threads=1024, grid_mult=8, drain_prio=dp)
                   for lw, dp in itertools.product((16, 24), (0, 1, 0, 1))]
