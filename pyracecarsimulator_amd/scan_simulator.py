@@ -101,10 +101,14 @@ class ScanSimulator2D:
     def scanMany(self, poses, copy=False):
         n, b = self.num_rays, self.batch_size
         p = self._poses_many
-        for i in range(b):                       # scan_simulator.py:119-127
-            p[i, 0] = poses[i][0]
-            p[i, 1] = poses[i][1]
-            p[i, 2] = poses[i][2]
+        if isinstance(poses, np.ndarray) and poses.ndim == 2 and poses.shape[0] >= b \
+                and poses.shape[1] >= 3:
+            p[:, :] = poses[:b, :3]              # same rows as the loop below, one copy
+        else:
+            for i in range(b):                   # scan_simulator.py:119-127
+                p[i, 0] = poses[i][0]
+                p[i, 1] = poses[i][1]
+                p[i, 2] = poses[i][2]
         self.input_vector_many[::n, :] = p       # reference-visible sparse layout
         self.scan_method.calc_range_fan(p, self.output_vector_many, self.fov, n)
         return self.output_vector_many.copy() if copy else self.output_vector_many
