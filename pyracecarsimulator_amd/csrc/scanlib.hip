@@ -115,6 +115,7 @@ struct rl_method {
     int low_water = 24;          // queue kernel: refill when <= this many lanes still march
     int sort_poses = 1;          // queue kernel: order poses by map tile
     int xcd_bands = 8;           // queue kernel: bands of the sorted list, one per XCD
+    int timing = 0;              // record HIP events around every launch (rl_last_kernel_ms)
     int lut_debug = 0;
     int drain_prio = 0;
     int wg_threads = 1024;       // stream kernel: workgroup size (256/512/1024) sharing one ray stream
@@ -390,6 +391,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "sort_poses")) h->sort_poses = value != 0;
     else if (!strcmp(name, "debug_stamps")) h->debug_stamps = value != 0;
     else if (!strcmp(name, "drain_prio")) h->drain_prio = value != 0;
+    else if (!strcmp(name, "timing")) h->timing = value != 0;
     else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
     else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
     else if (!strcmp(name, "inline_max")) h->inline_max = value;
@@ -410,6 +412,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "sort_poses")) *value_out = h->sort_poses;
     else if (!strcmp(name, "debug_stamps")) *value_out = h->debug_stamps;
     else if (!strcmp(name, "drain_prio")) *value_out = h->drain_prio;
+    else if (!strcmp(name, "timing")) *value_out = h->timing;
     else if (!strcmp(name, "bin_multi_min")) *value_out = h->bin_multi_min;
     else if (!strcmp(name, "inline_prep")) *value_out = h->inline_prep;
     else if (!strcmp(name, "inline_max")) *value_out = h->inline_max;
@@ -608,7 +611,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             return fail(RL_ERR_UNSUPPORTED, "hit cells / step counts exist only for RM and Bresenham");
         int rc;
         const int pgrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * h->grid_mult));
-        HIPCHK(hipEventRecord(h->ev0, stream));
+        if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
         if (h->kind == RL_GIANT_LUT) {
             if ((rc = ensure_lut(h, stream))) return rc;
             const int lgrid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4,
@@ -652,8 +655,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
                                    m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(h->ev1, stream));
-        h->timed = true;
+        if (h->timing) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
         return RL_OK;
     }
     const long cpp = (num_rays + 63) / 64;
@@ -666,7 +668,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
     if (crash) cp = *crash;
     const bool aux = d_hits || d_steps;
     const bool stream_ok = (long)n_poses * num_rays < (1L << 31);
-    HIPCHK(hipEventRecord(h->ev0, stream));
+    if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
     if (h->variant >= 1 && stream_ok) {
         // (1) per-pose records + tile-ordered permutation, (2) banded lane-refill march
         int rc;
@@ -800,8 +802,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
 #undef LAUNCH_CHUNK
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(h->ev1, stream));
-    h->timed = true;
+    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
     return RL_OK;
 }
 
@@ -814,7 +815,7 @@ static int launch_rays(rl_method *h, const float *d_ins, long n, float *d_out, i
     long want = (n + WG - 1) / WG;
     long cap = (long)m->n_cu * h->grid_mult;
     int grid = (int)std::max(1L, std::min(want, cap));
-    HIPCHK(hipEventRecord(h->ev0, stream));
+    if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
     int rc;
     if (h->kind == RL_GIANT_LUT) {
         if ((rc = ensure_lut(h, stream))) return rc;
@@ -832,8 +833,7 @@ static int launch_rays(rl_method *h, const float *d_ins, long n, float *d_out, i
                            d_out, d_hits, d_steps);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(h->ev1, stream));
-    h->timed = true;
+    if (h->timing) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
     return RL_OK;
 }
 
@@ -1191,7 +1191,7 @@ extern "C" int rl_last_kernel_ms(rl_method *h, float *ms_out)
 {
     if (!h || !ms_out) return fail(RL_ERR_INVALID, "rl_last_kernel_ms: null pointer");
     std::lock_guard<std::mutex> lk(h->mu);
-    if (!h->timed) return fail(RL_ERR_INVALID, "no launch has been timed on this handle yet");
+    if (!h->timed) return fail(RL_ERR_INVALID, "no launch has been timed on this handle (set option \"timing\"=1 first)");
     int rc = set_device(h->map);
     if (rc) return rc;
     HIPCHK(hipEventSynchronize(h->ev1));

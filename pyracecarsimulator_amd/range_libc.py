@@ -257,6 +257,7 @@ class _RangeMethod:
         return buf[:got].reshape(-1, 4)
 
     def last_kernel_ms(self):
+        """Device time of the last launch; needs ``set_option("timing", 1)`` before that launch."""
         ms = C.c_float(0)
         _lib.check(_lib.lib().rl_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)

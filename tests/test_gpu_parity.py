@@ -259,6 +259,9 @@ def test_device_resident_api_with_torch_streams(oracle_mod):
     g, z = load_golden("rm_colombia")
     omap = range_libc.PyOMap(g, device=0)
     m = range_libc.PyRayMarchingGPU(omap, 300)
+    with pytest.raises(Exception):
+        m.last_kernel_ms()                       # timing events are opt-in
+    m.set_option("timing", 1)
     B = 1081
     d_poses = torch.from_numpy(z["poses"]).cuda()
     d_out = torch.zeros(len(z["poses"]) * B, dtype=torch.float32, device="cuda")
