@@ -269,6 +269,23 @@ __global__ __launch_bounds__(256) void pad_dt_kernel(const float *__restrict__ d
     }
 }
 
+__device__ __forceinline__ uint32_t pose_record(const MapParams &m, const float *__restrict__ poses,
+                                                int p, int tile_shift, int tiles_x, int n_tiles,
+                                                PoseRec &r)
+{
+    float thg;
+    world_to_grid(m, poses[3 * (size_t)p], poses[3 * (size_t)p + 1], poses[3 * (size_t)p + 2], r.gx,
+                  r.gy, thg);
+    det_sincosf(thg, r.st, r.ct);
+    const bool fin = (r.ct - r.ct) + (r.st - r.st) == 0.0f;
+    const bool inb = r.gx > -1.0f && r.gx < m.fcols && r.gy > -1.0f && r.gy < m.frows;
+    if (!(fin && inb)) {
+        r.gx = 0.0f; r.gy = 0.0f; r.ct = 1.0f; r.st = 0.0f;
+        return ((uint32_t)n_tiles - 1) | POSE_INVALID;
+    }
+    return (uint32_t)(((int)r.gy >> tile_shift) * tiles_x + ((int)r.gx >> tile_shift));
+}
+
 __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float *__restrict__ poses,
                                                         int n, PoseRec *__restrict__ rec,
                                                         PoseRec *__restrict__ rec_sorted,
@@ -340,26 +357,69 @@ __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float
     }
 }
 
+// Up to 8192 poses: the same binning with every lane keeping its (up to 8) pose records in
+// registers between the histogram and the scatter pass — no scratch round trip through memory,
+// and the 8 pose loads of a lane are in flight together.
+__global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const float *__restrict__ poses,
+                                                              int n, PoseRec *__restrict__ rec_sorted,
+                                                              uint32_t *__restrict__ order,
+                                                              int tile_shift, int tiles_x, int n_tiles)
+{
+    extern __shared__ uint32_t hist[];          // n_tiles counters, then 1024 scan partials
+    uint32_t *part = hist + n_tiles;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_tiles; i += 1024) hist[i] = 0;
+    __syncthreads();
+    PoseRec r[8];
+    uint32_t kf[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int p = tid + u * 1024;
+        kf[u] = 0;
+        if (p < n) {
+            kf[u] = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r[u]);
+            atomicAdd(&hist[kf[u] & ~POSE_INVALID], 1u);
+        }
+    }
+    __syncthreads();
+    const int E = (n_tiles + 1023) / 1024;
+    uint32_t local = 0;
+    for (int e = 0; e < E; ++e) {
+        int i = tid * E + e;
+        if (i < n_tiles) local += hist[i];
+    }
+    part[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t base = part[tid] - local;
+    for (int e = 0; e < E; ++e) {
+        int i = tid * E + e;
+        if (i < n_tiles) {
+            uint32_t c = hist[i];
+            hist[i] = base;
+            base += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int p = tid + u * 1024;
+        if (p < n) {
+            const uint32_t slot = atomicAdd(&hist[kf[u] & ~POSE_INVALID], 1u);
+            order[slot] = (uint32_t)p | (kf[u] & POSE_INVALID);
+            rec_sorted[slot] = r[u];
+        }
+    }
+}
+
 // Large batches: the same binning as three grid-wide kernels (one lane per pose, tile histogram
 // and cursors in global memory), because one workgroup walking 10^5..10^6 poses would serialise
 // hundreds of microseconds in front of the march.
-__device__ __forceinline__ uint32_t pose_record(const MapParams &m, const float *__restrict__ poses,
-                                                int p, int tile_shift, int tiles_x, int n_tiles,
-                                                PoseRec &r)
-{
-    float thg;
-    world_to_grid(m, poses[3 * (size_t)p], poses[3 * (size_t)p + 1], poses[3 * (size_t)p + 2], r.gx,
-                  r.gy, thg);
-    det_sincosf(thg, r.st, r.ct);
-    const bool fin = (r.ct - r.ct) + (r.st - r.st) == 0.0f;
-    const bool inb = r.gx > -1.0f && r.gx < m.fcols && r.gy > -1.0f && r.gy < m.frows;
-    if (!(fin && inb)) {
-        r.gx = 0.0f; r.gy = 0.0f; r.ct = 1.0f; r.st = 0.0f;
-        return ((uint32_t)n_tiles - 1) | POSE_INVALID;
-    }
-    return (uint32_t)(((int)r.gy >> tile_shift) * tiles_x + ((int)r.gx >> tile_shift));
-}
-
 // Workgroup w owns poses [w*POSES_PER_WG, ...): per-workgroup tile histograms in LDS (no contended
 // global atomics — clustered roll-out poses would serialise on a few words), written tile-major
 // as hist_all[tile * n_wg + w]; one scan over that array then gives every (tile, workgroup) pair

@@ -137,6 +137,7 @@ struct rl_method {
     bool timed = false;
     DevBuf poses, outs, hits, steps, edge, flag, rec, rec_sorted, order, keys, dbg, hist;
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
+    int bin_generic = 0;         // diagnostics: force the generic single-workgroup binning kernel
     int inline_prep = 1;         // tiny batches: no binning launch, workgroups derive their own records
     int inline_max = 512;        //   ... below this many poses (measured: wins below ~512, loses above)
     int debug_stamps = 0;        // diagnostics: per-wave start/end stamps of the stream kernel
@@ -394,6 +395,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "timing")) h->timing = value != 0;
     else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
     else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
+    else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
     else if (!strcmp(name, "inline_max")) h->inline_max = value;
     else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
     else if (!strcmp(name, "wg_threads")) h->wg_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256);
@@ -415,6 +417,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "timing")) *value_out = h->timing;
     else if (!strcmp(name, "bin_multi_min")) *value_out = h->bin_multi_min;
     else if (!strcmp(name, "inline_prep")) *value_out = h->inline_prep;
+    else if (!strcmp(name, "bin_generic")) *value_out = h->bin_generic;
     else if (!strcmp(name, "inline_max")) *value_out = h->inline_max;
     else if (!strcmp(name, "wg_threads")) *value_out = h->wg_threads;
     else if (!strcmp(name, "last_grid")) *value_out = h->last_grid;
@@ -735,6 +738,11 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
                                        (uint32_t *)nullptr, n_wg, shift, tiles_x, n_tiles,
                                        (uint32_t *)h->order.p);
                 }
+            } else if (do_sort && n_poses <= 8192 && !h->bin_generic) {
+                hipLaunchKernelGGL(pose_bin_small_kernel, dim3(1), dim3(1024),
+                                   (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
+                                   n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)h->order.p, shift,
+                                   tiles_x, n_tiles);
             } else {
                 hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
                                    (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,

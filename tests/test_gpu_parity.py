@@ -49,6 +49,7 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "xcd_bands": 3, "grid_mult": 1},             # odd band count, small grid
     {"variant": 1, "grid_mult": 16, "wg_threads": 256},
     {"variant": 1, "inline_prep": 0},                           # single-workgroup binning launch
+    {"variant": 1, "inline_prep": 0, "bin_generic": 1},         # ... its generic (any size) form
     {"variant": 1, "inline_prep": 0, "bin_multi_min": 64},      # grid-wide binning kernels
     {"variant": 1, "inline_prep": 1, "inline_max": 100000, "xcd_bands": 5},   # workgroups derive their own pose records
     {"variant": 1, "bin_multi_min": 64},                        # grid-wide binning kernels
