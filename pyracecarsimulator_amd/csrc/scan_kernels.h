@@ -256,6 +256,11 @@ struct PoseRec {
 
 constexpr uint32_t POSE_INVALID = 0x80000000u;   // order[] flag: origin outside the map / non-finite
 
+// Stop codes stored in the padded EDT instead of 0 / "outside": adding them to t ends the march
+// through the ordinary `t < max_range` test, so the loop needs no separate hit test.
+#define PDT_HIT __builtin_inff()        /* occupied cell (EDT 0)          */
+#define PDT_OUTSIDE 3.0e38f             /* border: the ray left the map   */
+
 __global__ __launch_bounds__(256) void pad_dt_kernel(const float *__restrict__ dt, int rows, int cols,
                                                      float *__restrict__ pdt, int pad, int stride)
 {
@@ -263,8 +268,11 @@ __global__ __launch_bounds__(256) void pad_dt_kernel(const float *__restrict__ d
     const int r = pr - pad;
     for (int pc = blockIdx.x * blockDim.x + threadIdx.x; pc < stride; pc += gridDim.x * blockDim.x) {
         const int c = pc - pad;
-        float v = -1.0f;
-        if (r >= 0 && r < rows && c >= 0 && c < cols) v = dt[(size_t)r * cols + c];
+        float v = PDT_OUTSIDE;
+        if (r >= 0 && r < rows && c >= 0 && c < cols) {
+            v = dt[(size_t)r * cols + c];
+            if (v <= 0.0f) v = PDT_HIT;
+        }
         pdt[(size_t)pr * stride + pc] = v;
     }
 }
@@ -521,10 +529,10 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f)
 // (v_cmpx drops a lane the moment its t reaches max_range, hits, or leaves the map),
 // so finished lanes cost nothing but their slot and keep (c, r, d) of their last
 // sample; the loop leaves when at most `low` lanes are still live.
-// Per sample: 12 VALU + 1 global load + 4 SALU (unit step coefficient).
+// Per sample: 10 VALU + 1 global load + 4 SALU (unit step coefficient).
 //   fx = fma(dx,t,gx); fy = fma(dy,t,gy); c = (int)fx; r = (int)fy      (Appendix A "march")
-//   d  = pdt[(r*stride + c)*4 + k4]          border cells read -1 => stop (left the map)
-//   t  = d > 0 ? t + max(d*coeff, 1) : +inf   (d == 0: hit)
+//   d  = pdt[(r*stride + c)*4 + k4]     occupied cells read +inf, border cells 3e38
+//   t += max(d*coeff, 1)                 => a hit / leaving the map pushes t past max_range
 // ------------------------------------------------------------------------------
 template <bool UNIT, bool AUX>
 __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float gy, float &t, int &c,
@@ -535,7 +543,6 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
     float a, b;
     unsigned long long save;
     uint32_t n;
-    const float inf = __builtin_inff();
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
         "v_cmpx_gt_f32_e32 %[mx], %[t]\n"
@@ -557,9 +564,7 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
         "v_mul_f32_e32 %[a], %[co], %[d]\n\t"
         "v_max_f32_e32 %[a], 1.0, %[a]\n\t"
         ".endif\n\t"
-        "v_add_f32_e32 %[a], %[t], %[a]\n\t"
-        "v_cmp_lt_f32_e32 vcc, 0, %[d]\n\t"
-        "v_cndmask_b32_e32 %[t], %[inf], %[a], vcc\n\t"
+        "v_add_f32_e32 %[t], %[t], %[a]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], %[t]\n\t"
         "s_bcnt1_i32_b64 %[n], exec\n\t"
         "s_cmp_gt_u32 %[n], %[low]\n\t"
@@ -567,7 +572,7 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
         "s_mov_b64 exec, %[save]\n\t"
         : [t] "+v"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [ns] "+v"(nstep), [a] "=&v"(a),
           [b] "=&v"(b), [save] "=&s"(save), [n] "=&s"(n)
-        : [dx] "v"(dx), [dy] "v"(dy), [gx] "v"(gx), [gy] "v"(gy), [inf] "v"(inf),
+        : [dx] "v"(dx), [dy] "v"(dy), [gx] "v"(gx), [gy] "v"(gy),
           [mx] "s"(max_range), [stride] "s"(stride), [k4] "s"(k4), [base] "s"(pdt),
           [co] "s"(coeff), [low] "s"(low), [unit] "n"(UNIT ? 1 : 0), [aux] "n"(AUX ? 1 : 0)
         : "vcc", "scc", "memory");
@@ -648,7 +653,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     bool has_ray = false;
     float gx = 0, gy = 0, dx = 0, dy = 0;
     float t = INF;                 // t < max_range  <=>  the lane is marching
-    float d_last = 1.0f;           // last sample: 0 = hit, -1 = left the map, > 0 = free
+    float d_last = 1.0f;           // last sample: PDT_HIT, PDT_OUTSIDE, or the free cell's distance
     int pc = 0, pr = 0;            // cell of the last sample
     uint32_t oidx = 0, nstep = 0, pose = 0;
     int jbeam = 0;
@@ -664,7 +669,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             if (mine && has_ray) {
                 float r = f.max_range;
                 int hc = -1, hr = -1;
-                if (d_last == 0.0f) {
+                if (d_last == PDT_HIT) {
                     hc = pc;
                     hr = pr;
                     const float xd = (float)hc - gx, yd = (float)hr - gy;
