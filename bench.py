@@ -37,7 +37,11 @@ def parse_args():
     ap.add_argument("--poses", type=int, default=0, help="poses per GPU (0 = workload default)")
     ap.add_argument("--method", default="", help="override: RM | RMGPU | BL | CDDT | GLT")
     ap.add_argument("--chunks", type=int, default=4, help="all-gather overlap chunks (N>1)")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the range all-gather")
+    ap.add_argument("--gather", default="crash", choices=["crash", "ranges", "none"],
+                    help="N>1 exchange per step: 'crash' (default) = fused per-roll-out crash test, all-gather "
+                         "of the int32 crash indices (what MCTS.rollout consumes); 'ranges' = all-gather "
+                         "of every range (4 B/ray); 'none' = shards stay on their GPU")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
@@ -176,7 +180,25 @@ def main():
     n = len(poses)
     stream = torch.cuda.current_stream().cuda_stream
 
-    scan = ShardedScan(n, B, dev, n_chunks=a.chunks, gather=not a.no_gather)
+    mode = "none" if (a.no_gather or world == 1) else a.gather
+    if mode == "crash" and method in ("GLT", "CDDT", "BL") and False:
+        mode = "ranges"
+    scan = ShardedScan(n, B, dev, n_chunks=a.chunks, gather=(mode == "ranges"))
+    # 'crash': the reference's consumer of a scanned batch is Car::isCrashed per roll-out
+    # (scripts/racecar_simulator_v2.py:146-167); group = roll-out length (params.yaml:126 uses 200)
+    group = next(gsz for gsz in range(min(200, n), 0, -1) if n % gsz == 0)
+    n_groups = n // group
+    if mode == "crash":
+        from pyracecarsimulator_amd import racecar as RC
+        edge = RC.edge_distances(B, -w.fov / 2.0, w.fov / B, 0.275, RC.DEFAULT_CAR["width"],
+                                 RC.DEFAULT_CAR["wb"])
+        d_edge = torch.from_numpy(edge).to(dev)
+        # double-buffered so the (latency-bound, ~100 B) all-gather of step i overlaps the march of
+        # step i+1 on RCCL's stream; every gather is complete before the timed region closes
+        d_first = [torch.empty(n_groups, dtype=torch.int32, device=dev) for _ in range(2)]
+        d_first_all = [torch.empty(world * n_groups, dtype=torch.int32, device=dev) for _ in range(2)]
+    pending = [None, None]
+    tick = [0]
 
     def compute(clo, chi, view):
         meth.calc_range_fan_device(d_poses.data_ptr() + clo * 12, chi - clo, w.fov, B,
@@ -192,13 +214,33 @@ def main():
         mean_steps = float(d_steps.to(torch.int32).bitwise_and(0xFFFF).float().mean().item())
         del d_steps
 
+    def step():
+        if mode == "crash":
+            k = tick[0] & 1
+            tick[0] += 1
+            if pending[k] is not None:
+                pending[k].wait()                  # the gather issued two steps ago used this buffer
+            meth.check_collision_groups_device(d_poses.data_ptr(), n_groups, group, w.fov, B,
+                                               d_edge.data_ptr(), 0.001, d_first[k].data_ptr(),
+                                               scan.local.data_ptr(), stream=stream)
+            pending[k] = dist.all_gather_into_tensor(d_first_all[k], d_first[k], async_op=True)
+        else:
+            scan.step(compute)
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        scan.step(compute)
+        step()
+    drain()
     barrier()
     # HIP events on the launch stream bracket the K timed steps (one pair: an event per step would
     # put two extra barrier packets between consecutive launches)
@@ -206,7 +248,8 @@ def main():
     t0 = time.perf_counter()
     e0.record()
     for i in range(a.steps):
-        scan.step(compute)
+        step()
+    drain()
     e1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -236,8 +279,10 @@ def main():
                    "global_poses": n * world, "num_rays": B, "fov": w.fov,
                    "max_range_px": w.max_range_px, "map": "%dx%d" % (gmap.rows, gmap.cols),
                    "parallelism": "pose-batch dp%d" % world,
-                   "gather": "none" if (world == 1 or a.no_gather) else
-                             "all-gather ranges, %d overlap chunks" % len(scan.chunks)},
+                   "gather": {"none": "none",
+                              "ranges": "all-gather ranges (4 B/ray), %d overlap chunks" % len(scan.chunks),
+                              "crash": "fused crash test per %d-pose roll-out, all-gather of int32 "
+                                       "crash indices" % group}[mode]},
         "kernel_ms_avg": round(k_ms, 4),
         "mean_samples_per_ray": round(mean_steps, 3),
     }

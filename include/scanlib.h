@@ -135,6 +135,14 @@ int rl_check_collision_groups(rl_method *h, const float *poses_p3, int n_groups,
                               float fov, int num_rays, const double *edge, double crash_thresh,
                               int *first_crashed, float *ranges_or_null);
 
+/* device-resident, asynchronous form: every pointer is device memory, d_first_crashed gets
+ * n_groups ints; d_ranges_or_null may be NULL for RL_RM / RL_RM_GPU (the test is fused into the
+ * march kernel, ranges need not be stored at all) and is required scratch for the other methods. */
+int rl_check_collision_groups_device(rl_method *h, const float *d_poses_p3, int n_groups, int group,
+                                     float fov, int num_rays, const double *d_edge,
+                                     double crash_thresh, int *d_first_crashed,
+                                     float *d_ranges_or_null, void *hip_stream);
+
 /* ---- roll-out pose generator ---------------------------------------
  * The step in front of scanMany in MCTS.rollout (scripts/mcts.py:214-231): 200 x
  * {Car::control, Car::updatePosition(dt)} (racecar/src/racecar.cpp:53-98,118-237,294-303) per

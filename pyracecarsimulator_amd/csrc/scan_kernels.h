@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *__restric
 struct CrashParams {
     const double *edge;      // num_rays doubles (Car::setCarEdgeDistances) or nullptr
     double thresh;
-    int *first_crashed;      // atomicMin target, initialised to INT_MAX
+    int *first_crashed;      // atomicMin targets, one per group, initialised to INT_MAX
+    int group;               // poses per group (roll-out); the whole batch is one group by default
 };
 
 template <bool AUX, bool CRASH>
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(WG) void rm_fan_kernel(MapParams m, FanParams f,
                 const bool crashed = ((double)r - cp.edge[j]) < cp.thresh;
                 if (__ballot(crashed)) {
                     if (lane == __ffsll((long long)__ballot(crashed)) - 1)
-                        atomicMin(cp.first_crashed, pose);
+                        atomicMin(&cp.first_crashed[pose / cp.group], pose % cp.group);
                 }
             }
         }
@@ -684,7 +685,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                     if (steps) steps[oidx] = (uint16_t)(nstep > 65535u ? 65535u : nstep);
                 }
                 if (CRASH) {
-                    if (((double)r - cp.edge[jbeam]) < cp.thresh) atomicMin(cp.first_crashed, (int)pose);
+                    if (((double)r - cp.edge[jbeam]) < cp.thresh)
+                        atomicMin(&cp.first_crashed[pose / (uint32_t)cp.group], (int)(pose % (uint32_t)cp.group));
                 }
                 has_ray = false;
             }

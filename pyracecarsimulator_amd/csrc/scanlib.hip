@@ -667,7 +667,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
     long cap = (long)m->n_cu * h->grid_mult;
     int grid = (int)std::max(1L, std::min(want, cap));
     size_t lds = (size_t)num_rays * sizeof(float2);
-    CrashParams cp{nullptr, 0.0, nullptr};
+    CrashParams cp{nullptr, 0.0, nullptr, 1};
     if (crash) cp = *crash;
     const bool aux = d_hits || d_steps;
     const bool stream_ok = (long)n_poses * num_rays < (1L << 31);
@@ -892,7 +892,7 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     if (steps && (rc = h->steps.ensure(n_rays * sizeof(uint16_t)))) return rc;
     HIPCHK(hipMemcpyAsync(h->poses.p, poses, (size_t)n_poses * 3 * sizeof(float),
                           hipMemcpyHostToDevice, h->stream));
-    CrashParams cp{nullptr, 0.0, nullptr};
+    CrashParams cp{nullptr, 0.0, nullptr, 1};
     if (first_crashed) {
         if ((rc = h->edge.ensure((size_t)num_rays * sizeof(double)))) return rc;
         if ((rc = h->flag.ensure(sizeof(int)))) return rc;
@@ -903,6 +903,7 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
         cp.edge = (const double *)h->edge.p;
         cp.thresh = crash_thresh;
         cp.first_crashed = (int *)h->flag.p;
+        cp.group = n_poses;
     }
     float *d_out = (outs || !first_crashed) ? (float *)h->outs.p : nullptr;
     rc = launch_fan(h, (const float *)h->poses.p, n_poses, fov, num_rays, d_out,
@@ -1041,22 +1042,53 @@ extern "C" int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words)
 // ------------------------------------------------------------------------------
 // grouped crash test and the roll-out generator ("next" rows)
 // ------------------------------------------------------------------------------
+// d_first[g] <- first crashed pose of group g, or INT_MAX when none (finalize = false), or
+// -(group+1) (finalize = true).  Ray-marching methods fuse the test into the march kernel; the
+// others scan into d_ranges (required then) and run one pass over the ranges.
 static int crash_groups_device(rl_method *h, const float *d_poses, int n_groups, int group, float fov,
                                int num_rays, const double *d_edge, double thresh, int *d_first,
-                               float *d_ranges, hipStream_t stream)
+                               float *d_ranges, bool finalize, hipStream_t stream)
 {
     const int n_poses = n_groups * group;
-    int rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_ranges, nullptr, nullptr, nullptr, stream);
-    if (rc) return rc;
     hipLaunchKernelGGL(fill_int_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, stream, d_first,
                        n_groups, INT_MAX);
-    const int grid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4, (long)h->map->n_cu * 8));
-    hipLaunchKernelGGL(crash_groups_kernel, dim3(grid), dim3(256), 0, stream, d_ranges, d_edge, thresh,
-                       n_poses, num_rays, group, d_first);
-    hipLaunchKernelGGL(crash_finalize_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, stream,
-                       d_first, n_groups, group);
+    int rc;
+    if (h->kind == RL_RM || h->kind == RL_RM_GPU) {
+        CrashParams cp{d_edge, thresh, d_first, group};
+        if ((rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_ranges, nullptr, nullptr, &cp, stream)))
+            return rc;
+    } else {
+        if (!d_ranges) return fail(RL_ERR_INVALID, "this range method needs a ranges buffer for the crash test");
+        if ((rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_ranges, nullptr, nullptr, nullptr, stream)))
+            return rc;
+        const int grid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4, (long)h->map->n_cu * 8));
+        hipLaunchKernelGGL(crash_groups_kernel, dim3(grid), dim3(256), 0, stream, d_ranges, d_edge,
+                           thresh, n_poses, num_rays, group, d_first);
+    }
+    if (finalize)
+        hipLaunchKernelGGL(crash_finalize_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, stream,
+                           d_first, n_groups, group);
     HIPCHK(hipGetLastError());
     return RL_OK;
+}
+
+extern "C" int rl_check_collision_groups_device(rl_method *h, const float *d_poses, int n_groups,
+                                                int group, float fov, int num_rays,
+                                                const double *d_edge, double crash_thresh,
+                                                int *d_first_crashed, float *d_ranges_or_null,
+                                                void *hip_stream)
+{
+    if (n_groups < 0 || group <= 0) return fail(RL_ERR_INVALID, "n_groups >= 0 and group > 0 required");
+    if ((long)n_groups * group > INT_MAX) return fail(RL_ERR_INVALID, "too many poses");
+    int rc = check_fan_args(h, n_groups * group, fov, num_rays);
+    if (rc) return rc;
+    if (n_groups == 0) return RL_OK;
+    if (!d_poses || !d_edge || !d_first_crashed)
+        return fail(RL_ERR_INVALID, "rl_check_collision_groups_device: null device pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if ((rc = set_device(h->map))) return rc;
+    return crash_groups_device(h, d_poses, n_groups, group, fov, num_rays, d_edge, crash_thresh,
+                               d_first_crashed, d_ranges_or_null, true, (hipStream_t)hip_stream);
 }
 
 extern "C" int rl_check_collision_groups(rl_method *h, const float *poses, int n_groups, int group,
@@ -1081,7 +1113,7 @@ extern "C" int rl_check_collision_groups(rl_method *h, const float *poses, int n
     HIPCHK(hipMemcpyAsync(h->edge.p, edge, (size_t)num_rays * 8, hipMemcpyHostToDevice, h->stream));
     rc = crash_groups_device(h, (const float *)h->poses.p, n_groups, group, fov, num_rays,
                              (const double *)h->edge.p, crash_thresh, (int *)h->flag.p,
-                             (float *)h->outs.p, h->stream);
+                             (float *)h->outs.p, true, h->stream);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(first_crashed, h->flag.p, (size_t)n_groups * 4, hipMemcpyDeviceToHost, h->stream));
     if (ranges_or_null)
@@ -1186,7 +1218,7 @@ extern "C" int rl_car_rollout_check(rl_car *c, rl_method *h, const double *state
     HIPCHK(hipMemcpyAsync(c->edge.p, edge, (size_t)num_rays * 8, hipMemcpyHostToDevice, c->stream));
     rc = crash_groups_device(h, (const float *)c->poses.p, R, n_steps, fov, num_rays,
                              (const double *)c->edge.p, crash_thresh, (int *)c->first.p,
-                             (float *)c->ranges.p, c->stream);
+                             (float *)c->ranges.p, true, c->stream);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(first_crashed, c->first.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
     if (states_out) HIPCHK(hipMemcpyAsync(states_out, c->states_out.p, (size_t)R * 11 * 8, hipMemcpyDeviceToHost, c->stream));

@@ -236,6 +236,14 @@ class _RangeMethod:
             ranges.ctypes.data_as(f32p) if ranges is not None else None))
         return first
 
+    def check_collision_groups_device(self, d_poses_ptr, n_groups, group, fov, num_rays, d_edge_ptr,
+                                      crash_thresh, d_first_ptr, d_ranges_ptr=0, stream=0):
+        """Asynchronous grouped scan + crash test on device pointers (ints)."""
+        _lib.check(_lib.lib().rl_check_collision_groups_device(
+            self._h, C.c_void_p(d_poses_ptr), int(n_groups), int(group), float(fov), int(num_rays),
+            C.c_void_p(d_edge_ptr), float(crash_thresh), C.c_void_p(d_first_ptr),
+            C.c_void_p(d_ranges_ptr or None), C.c_void_p(stream or None)))
+
     def set_noise(self, std, seed=0, ray_offset=0):
         _lib.check(_lib.lib().rl_set_noise(self._h, float(std), int(seed), int(ray_offset)))
 
