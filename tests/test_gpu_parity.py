@@ -571,3 +571,33 @@ def test_rollout_check_chain_equals_staged_oracle(oracle_mod):
                 for r in range(6)]
         assert got.tolist() == want
         assert mm.check_collision_many(sub[:n_steps], fov, B, edge, 0.001) == want[0]
+
+
+def test_grouped_crash_device_api_fused_and_generic(oracle_mod):
+    torch = pytest.importorskip("torch")
+    from pyracecarsimulator_amd import racecar as RC
+    g = maps.load_colombia()
+    mrx, B, fov, group = 300, 1081, 4.71, 50
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    poses = np.concatenate([maps.sample_free_poses(g, 200, 12, 9.0, om.dt),      # far from walls
+                            maps.sample_free_poses(g, 200, 13, 2.0, om.dt)])     # some too close
+    edge = RC.edge_distances(B, -fov / 2, fov / B, 0.275, 0.2032, 0.3302)
+    want_r, _, _ = om.rm_fan(poses, fov, B, step_coeff=1.0, nthreads=8)
+    want = [oracle_mod.is_crashed(want_r[k * group * B:(k + 1) * group * B], B, group, edge, 0.001)
+            for k in range(8)]
+    d_poses = torch.from_numpy(poses).cuda()
+    d_edge = torch.from_numpy(edge).cuda()
+    d_first = torch.zeros(8, dtype=torch.int32, device="cuda")
+    d_ranges = torch.zeros(400 * B, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    m = range_libc.PyRayMarchingGPU(omap, mrx)
+    for ranges_ptr in (d_ranges.data_ptr(), 0):              # with and without storing the ranges
+        d_first.zero_()
+        m.check_collision_groups_device(d_poses.data_ptr(), 8, group, fov, B, d_edge.data_ptr(), 0.001,
+                                        d_first.data_ptr(), ranges_ptr, stream=st)
+        torch.cuda.synchronize()
+        assert d_first.cpu().tolist() == want
+    assert np.array_equal(d_ranges.cpu().numpy(), want_r)
+    assert any(w >= 0 for w in want) and any(w < 0 for w in want)
+    assert m.check_collision_groups(poses, group, fov, B, edge, 0.001).tolist() == want
