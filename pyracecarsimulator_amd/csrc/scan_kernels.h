@@ -590,8 +590,7 @@ struct PadMap {
 struct StreamParams {
     const PoseRec *rec;      // sorted order
     const uint32_t *order;   // sorted slot -> pose index | POSE_INVALID
-    FastDiv div_cpp;         // chunks per pose
-    int cpp;
+    FastDiv div_B;           // division by num_rays
     int low_water;           // refill when <= low_water lanes are still marching
     int n_bands;
     const float *raw_poses;  // INLINE only: world poses (x, y, theta); every workgroup derives the
@@ -626,8 +625,10 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     const uint32_t G = ((uint32_t)gridDim.x - (uint32_t)band + (uint32_t)nb - 1) / (uint32_t)nb;
     const uint32_t seg_lo = (uint32_t)(((long)f.n_poses * band) / nb);
     const uint32_t seg_hi = (uint32_t)(((long)f.n_poses * (band + 1)) / nb);
-    const uint32_t seg_chunks = (seg_hi - seg_lo) * (uint32_t)sp.cpp;
-    // this workgroup owns chunks g, g+G, ... of the band: K chunks, 64*K ray slots
+    // the band's rays (pose-major, beam-minor) in blocks of 64: this workgroup owns blocks
+    // g, g+G, ... — K blocks, 64*K ray slots (any num_rays, no padding lanes)
+    const uint32_t seg_rays = (seg_hi - seg_lo) * (uint32_t)f.num_rays;
+    const uint32_t seg_chunks = (seg_rays + 63u) >> 6;
     const uint32_t K = g < seg_chunks ? (seg_chunks - g + G - 1) / G : 0;
     const uint32_t total = K << 6;
     const unsigned lane = threadIdx.x & 63;
@@ -635,12 +636,15 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         // small batches: no binning launch in front of the march — each workgroup turns the poses
         // of its own chunks into records (a few hundred, one per lane) and keeps them in LDS
         const MapParams mp = *sp.map;
-        for (uint32_t k = threadIdx.x; k < K; k += NT) {
-            const uint32_t spose = seg_lo + fast_div(g + k * G, sp.div_cpp);
-            PoseRec r;
-            const uint32_t kf = pose_record(mp, sp.raw_poses, (int)spose, 0, 1, 1, r);
-            lrec[k] = r;
-            lord[k] = spose | (kf & POSE_INVALID);
+        // (num_rays >= 64 here, so a block of 64 rays touches at most two poses: slots 2k, 2k+1)
+        for (uint32_t k2 = threadIdx.x; k2 < 2 * K; k2 += NT) {
+            const uint32_t p0 = fast_div((g + (k2 >> 1) * G) << 6, sp.div_B) + (k2 & 1);
+            if (seg_lo + p0 < seg_hi) {
+                PoseRec r;
+                const uint32_t kf = pose_record(mp, sp.raw_poses, (int)(seg_lo + p0), 0, 1, 1, r);
+                lrec[k2] = r;
+                lord[k2] = (seg_lo + p0) | (kf & POSE_INVALID);
+            }
         }
     }
     __syncthreads();
@@ -698,12 +702,15 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 exhausted = qb + cnt >= total;
                 const uint32_t q = qb + rank;
                 if (mine && q < total) {
-                    const uint32_t chunk = g + (q >> 6) * G;
-                    const uint32_t spose = fast_div(chunk, sp.div_cpp);
-                    const int j = (int)((chunk - spose * (uint32_t)sp.cpp) << 6) + (int)(q & 63);
-                    if (j < f.num_rays) {
-                        const uint32_t po = INLINE ? lord[q >> 6] : sp.order[seg_lo + spose];
-                        const PoseRec pr_ = INLINE ? lrec[q >> 6] : sp.rec[seg_lo + spose];
+                    const uint32_t blk = (g + (q >> 6) * G) << 6;
+                    const uint32_t ray = blk + (q & 63);
+                    if (ray < seg_rays) {
+                        const uint32_t spose = fast_div(ray, sp.div_B);
+                        const int j = (int)(ray - spose * (uint32_t)f.num_rays);
+                        uint32_t li = 0;
+                        if (INLINE) li = 2 * (q >> 6) + (spose - fast_div(blk, sp.div_B));
+                        const uint32_t po = INLINE ? lord[li] : sp.order[seg_lo + spose];
+                        const PoseRec pr_ = INLINE ? lrec[li] : sp.rec[seg_lo + spose];
                         const float2 cs = fan_cs[j];
                         pose = po & ~POSE_INVALID;
                         gx = pr_.gx;

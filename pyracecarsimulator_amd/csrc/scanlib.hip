@@ -662,7 +662,8 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         return RL_OK;
     }
     const long cpp = (num_rays + 63) / 64;
-    const long n_chunks = (long)n_poses * cpp;
+    const long n_chunks = (h->variant >= 1) ? ((long)n_poses * num_rays + 63) / 64   // 64-ray blocks
+                                            : (long)n_poses * cpp;                   // K1: chunks
     long want = (n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG;
     long cap = (long)m->n_cu * h->grid_mult;
     int grid = (int)std::max(1L, std::min(want, cap));
@@ -693,13 +694,14 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         // persistent grid: grid_mult x 256 threads per CU, whatever the workgroup size
         int nt = h->wg_threads;
         // small batches: skip the binning launch, workgroups derive the records of their own chunks
-        bool inl = h->inline_prep && n_poses < h->inline_max && n_poses < h->bin_multi_min;
+        bool inl = h->inline_prep && n_poses < h->inline_max && n_poses < h->bin_multi_min &&
+                   num_rays >= 64;
         int k_max = 0;
         if (inl) {
             nt = 1024;
             const long g_min = std::max(1L, std::min((n_chunks + 15) / 16, (long)m->n_cu * h->grid_mult * WG / nt) / bands);
-            const long seg_chunks_max = (((long)n_poses + bands - 1) / bands) * cpp;
-            k_max = (int)((seg_chunks_max + g_min - 1) / g_min) + 1;
+            const long seg_chunks_max = ((((long)n_poses + bands - 1) / bands) * num_rays + 63) / 64;
+            k_max = 2 * ((int)((seg_chunks_max + g_min - 1) / g_min) + 1);   // two records per block
             if ((size_t)k_max * 20 + lds + 32 > 56 * 1024) inl = false;
         }
         if (!inl) {
@@ -761,8 +763,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         StreamParams sp{};
         sp.rec = (const PoseRec *)h->rec_sorted.p;
         sp.order = (const uint32_t *)h->order.p;
-        sp.cpp = (int)cpp;
-        sp.div_cpp = make_fastdiv((uint32_t)cpp);
+        sp.div_B = make_fastdiv((uint32_t)num_rays);
         sp.low_water = h->low_water;
         sp.n_bands = bands;
         sp.raw_poses = d_poses;
@@ -836,6 +837,10 @@ static int launch_rays(rl_method *h, const float *d_ins, long n, float *d_out, i
     } else if (h->kind == RL_BRESENHAM) {
         hipLaunchKernelGGL(bl_rays_kernel, dim3(grid), dim3(256), 0, stream, m->mp, f, d_ins, n,
                            d_out);
+    } else if (h->variant >= 1 && n <= INT_MAX) {
+        // a ray is a pose with one beam at alpha = 0: fan(num_rays = 1, fov = 0) gives exactly
+        // (cos, sin) of the heading as direction, and the stream kernel packs 64 rays per block
+        return launch_fan(h, d_ins, (int)n, 0.0f, 1, d_out, d_hits, d_steps, nullptr, stream);
     } else {
         hipLaunchKernelGGL(rm_rays_kernel, dim3(grid), dim3(WG), 0, stream, m->mp, f, d_ins, n,
                            d_out, d_hits, d_steps);
