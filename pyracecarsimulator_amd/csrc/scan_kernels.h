@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void pad_dt_kernel(const float *__restrict__ d
 
 __device__ __forceinline__ uint32_t pose_record(const MapParams &m, const float *__restrict__ poses,
                                                 int p, int tile_shift, int tiles_x, int n_tiles,
-                                                PoseRec &r)
+                                                PoseRec &r, bool walk_outside = false)
 {
     float thg;
     world_to_grid(m, poses[3 * (size_t)p], poses[3 * (size_t)p + 1], poses[3 * (size_t)p + 2], r.gx,
@@ -288,7 +288,16 @@ __device__ __forceinline__ uint32_t pose_record(const MapParams &m, const float 
     det_sincosf(thg, r.st, r.ct);
     const bool fin = (r.ct - r.ct) + (r.st - r.st) == 0.0f;
     const bool inb = r.gx > -1.0f && r.gx < m.fcols && r.gy > -1.0f && r.gy < m.frows;
-    if (!(fin && inb)) {
+    if (walk_outside) {
+        // Bresenham keeps walking from an origin outside the map (cells out there are free); only
+        // poses that cannot index the grid at all are dropped
+        const bool sane = fin && __builtin_fabsf(r.gx) < 1e9f && __builtin_fabsf(r.gy) < 1e9f;
+        if (!sane) {
+            r.gx = 0.0f; r.gy = 0.0f; r.ct = 1.0f; r.st = 0.0f;
+            return ((uint32_t)n_tiles - 1) | POSE_INVALID;
+        }
+        if (!inb) return (uint32_t)n_tiles - 1;
+    } else if (!(fin && inb)) {
         r.gx = 0.0f; r.gy = 0.0f; r.ct = 1.0f; r.st = 0.0f;
         return ((uint32_t)n_tiles - 1) | POSE_INVALID;
     }
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float
                                                         PoseRec *__restrict__ rec_sorted,
                                                         uint32_t *__restrict__ order,
                                                         uint32_t *__restrict__ keys, int tile_shift,
-                                                        int tiles_x, int n_tiles, int do_sort)
+                                                        int tiles_x, int n_tiles, int do_sort, int walk_outside)
 {
     extern __shared__ uint32_t hist[];          // n_tiles counters, then 1024 scan partials
     uint32_t *part = hist + n_tiles;
@@ -309,19 +318,8 @@ __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float
     __syncthreads();
     for (int p = tid; p < n; p += 1024) {
         PoseRec r;
-        float thg;
-        world_to_grid(m, poses[3 * (size_t)p], poses[3 * (size_t)p + 1], poses[3 * (size_t)p + 2],
-                      r.gx, r.gy, thg);
-        det_sincosf(thg, r.st, r.ct);
-        // the t = 0 sample of every beam is the origin: outside the map (or non-finite) means
-        // every beam of the pose misses without sampling
-        const bool fin = (r.ct - r.ct) + (r.st - r.st) == 0.0f;
-        const bool inb = r.gx > -1.0f && r.gx < m.fcols && r.gy > -1.0f && r.gy < m.frows;
-        const uint32_t flag = (fin && inb) ? 0u : POSE_INVALID;
-        if (!(fin && inb)) { r.gx = 0.0f; r.gy = 0.0f; r.ct = 1.0f; r.st = 0.0f; }
-        uint32_t key = (uint32_t)n_tiles - 1;       // invalid poses go last; they cost nothing
-        if (!flag)
-            key = (uint32_t)(((int)r.gy >> tile_shift) * tiles_x + ((int)r.gx >> tile_shift));
+        const uint32_t kf = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r, walk_outside != 0);
+        const uint32_t flag = kf & POSE_INVALID, key = kf & ~POSE_INVALID;
         if (do_sort) {
             rec[p] = r;
             keys[p] = key | flag;
@@ -372,7 +370,8 @@ __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float
 __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const float *__restrict__ poses,
                                                               int n, PoseRec *__restrict__ rec_sorted,
                                                               uint32_t *__restrict__ order,
-                                                              int tile_shift, int tiles_x, int n_tiles)
+                                                              int tile_shift, int tiles_x, int n_tiles,
+                                                              int walk_outside)
 {
     extern __shared__ uint32_t hist[];          // n_tiles counters, then 1024 scan partials
     uint32_t *part = hist + n_tiles;
@@ -386,7 +385,7 @@ __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const
         const int p = tid + u * 1024;
         kf[u] = 0;
         if (p < n) {
-            kf[u] = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r[u]);
+            kf[u] = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r[u], walk_outside != 0);
             atomicAdd(&hist[kf[u] & ~POSE_INVALID], 1u);
         }
     }
@@ -440,7 +439,8 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(MapParams m, const float
                                                         uint32_t *__restrict__ keys,
                                                         uint32_t *__restrict__ hist_all, int n_wg,
                                                         int tile_shift, int tiles_x, int n_tiles,
-                                                        uint32_t *__restrict__ order_if_unsorted)
+                                                        uint32_t *__restrict__ order_if_unsorted,
+                                                        int walk_outside)
 {
     extern __shared__ uint32_t lhist[];            // n_tiles
     const int w = blockIdx.x;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(MapParams m, const float
     const int p_end = min(n, (w + 1) * POSES_PER_WG);
     for (int p = w * POSES_PER_WG + threadIdx.x; p < p_end; p += blockDim.x) {
         PoseRec r;
-        const uint32_t kf = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r);
+        const uint32_t kf = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r, walk_outside != 0);
         rec[p] = r;
         if (order_if_unsorted) {                   // keep the caller's pose order
             order_if_unsorted[p] = (uint32_t)p | (kf & POSE_INVALID);
@@ -1090,6 +1090,156 @@ __global__ __launch_bounds__(256) void bl_fan_kernel(MapParams m, FanParams f, B
                 if (steps) steps[i] = (uint16_t)n;
             }
         }
+    }
+}
+
+// K2b: the same walk on the K1b schedule (tile-ordered poses, XCD bands, a workgroup's waves
+// sharing one ray stream with lane refill), reading the bit-packed map straight through L1/L2
+// (2049^2 cells = 0.5 MB: the whole map is cache resident).  Staging a per-pose LDS window
+// (bl_fan_kernel above) ties 1081 rays to one workgroup and makes every pose end with its
+// slowest ray (up to 303 steps against a mean of 46); the stream form has no such join.
+template <bool AUX, int NT>
+__global__ __launch_bounds__(NT) void bl_fan_stream_kernel(MapParams m, FanParams f, StreamParams sp,
+                                                          float *__restrict__ out,
+                                                          int32_t *__restrict__ hits,
+                                                          uint16_t *__restrict__ steps)
+{
+    extern __shared__ float lds_f[];
+    uint32_t *q_next = reinterpret_cast<uint32_t *>(lds_f);
+    float2 *fan_cs = reinterpret_cast<float2 *>(lds_f + 2);
+    if (threadIdx.x == 0) *q_next = 0;
+    for (int j = threadIdx.x; j < f.num_rays; j += NT) {
+        float s, c;
+        det_sincosf(fan_alpha(f, j), s, c);
+        fan_cs[j] = make_float2(c, s);
+    }
+    __syncthreads();
+    const int nb = sp.n_bands;
+    const int band = (int)(blockIdx.x % (unsigned)nb);
+    const uint32_t g = blockIdx.x / (unsigned)nb;
+    const uint32_t G = ((uint32_t)gridDim.x - (uint32_t)band + (uint32_t)nb - 1) / (uint32_t)nb;
+    const uint32_t seg_lo = (uint32_t)(((long)f.n_poses * band) / nb);
+    const uint32_t seg_hi = (uint32_t)(((long)f.n_poses * (band + 1)) / nb);
+    const uint32_t seg_rays = (seg_hi - seg_lo) * (uint32_t)f.num_rays;
+    const uint32_t seg_chunks = (seg_rays + 63u) >> 6;
+    const uint32_t K = g < seg_chunks ? (seg_chunks - g + G - 1) / G : 0;
+    const uint32_t total = K << 6;
+    const unsigned lane = threadIdx.x & 63;
+    auto occupied = [&](int col, int row) -> bool {
+        return (m.bits[(size_t)row * m.bits_stride + (col >> 5)] >> (col & 31)) & 1u;
+    };
+
+    bool exhausted = total == 0;
+    bool has_ray = false, active = false, steep = false;
+    float x0 = 0, y0 = 0, _x = 0, _y = 0, error = 0, deltax = 0, deltay = 0, xstep = 0, ystep = 0;
+    float range = 0;
+    int end = 0, cap = 0, hc = -1, hr = -1;
+    uint32_t oidx = 0, nstep = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (idle) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (!active && has_ray) {
+                float r = range * m.res;
+                if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + oidx);
+                out[oidx] = r;
+                if (AUX) {
+                    if (hits) { hits[2 * (size_t)oidx] = hc; hits[2 * (size_t)oidx + 1] = hr; }
+                    if (steps) steps[oidx] = (uint16_t)nstep;
+                }
+                has_ray = false;
+            }
+            if (!exhausted) {
+                const uint32_t cnt = (uint32_t)__popcll(idle);
+                uint32_t qb = 0;
+                if (lane == 0) qb = atomicAdd(q_next, cnt);
+                qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+                exhausted = qb + cnt >= total;
+                const uint32_t q = qb + rank;
+                const uint32_t ray = ((g + (q >> 6) * G) << 6) + (q & 63);
+                if (!active && q < total && ray < seg_rays) {
+                    const uint32_t spose = fast_div(ray, sp.div_B);
+                    const int j = (int)(ray - spose * (uint32_t)f.num_rays);
+                    const uint32_t po = sp.order[seg_lo + spose];
+                    const PoseRec pr_ = sp.rec[seg_lo + spose];
+                    const float2 cs = fan_cs[j];
+                    const float gx = pr_.gx, gy = pr_.gy;
+                    const float dx = __builtin_fmaf(pr_.ct, cs.x, -(pr_.st * cs.y));
+                    const float dy = __builtin_fmaf(pr_.st, cs.x, pr_.ct * cs.y);
+                    oidx = (po & ~POSE_INVALID) * (uint32_t)f.num_rays + (uint32_t)j;
+                    has_ray = true;
+                    nstep = 0;
+                    range = f.max_range;
+                    hc = -1;
+                    hr = -1;
+                    if (!(po & POSE_INVALID)) {
+                        if (gx > -1.0f && gx < m.fcols && gy > -1.0f && gy < m.frows &&
+                            occupied((int)gx, (int)gy)) {
+                            range = 0.0f;                       // start cell occupied
+                            hc = (int)gx;
+                            hr = (int)gy;
+                        } else {
+                            x0 = gx;
+                            y0 = gy;
+                            float x1 = __builtin_fmaf(f.max_range, dx, gx);
+                            float y1 = __builtin_fmaf(f.max_range, dy, gy);
+                            steep = fabsf(y1 - y0) > fabsf(x1 - x0);
+                            if (steep) {
+                                float tmp = x0; x0 = y0; y0 = tmp;
+                                tmp = x1; x1 = y1; y1 = tmp;
+                            }
+                            deltax = fabsf(x1 - x0);
+                            deltay = fabsf(y1 - y0);
+                            error = 0.0f;
+                            _x = x0;
+                            _y = y0;
+                            xstep = x0 < x1 ? 1.0f : -1.0f;
+                            ystep = y0 < y1 ? 1.0f : -1.0f;
+                            end = (int)(x1 + xstep);
+                            cap = (int)f.max_range + 3;
+                            active = true;
+                        }
+                    }
+                }
+            }
+        }
+        unsigned long long act = __ballot(active);
+        if (!act) {
+            if (exhausted && !__ballot(has_ray)) break;
+            continue;
+        }
+        const int low = exhausted ? 0 : sp.low_water;
+        do {
+            if (active) {
+                if ((int)_x != end && cap-- > 0) {
+                    _x += xstep;
+                    error += deltay;
+                    if (error * 2.0f >= deltax) {
+                        _y += ystep;
+                        error -= deltax;
+                    }
+                    ++nstep;
+                    const float lim_major = steep ? m.frows : m.fcols;
+                    const float lim_minor = steep ? m.fcols : m.frows;
+                    if (_x >= 0.0f && _x < lim_major && _y >= 0.0f && _y < lim_minor) {
+                        const int col = steep ? (int)_y : (int)_x;
+                        const int row = steep ? (int)_x : (int)_y;
+                        if (occupied(col, row)) {
+                            const float xd = _x - x0, yd = _y - y0;
+                            range = __builtin_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+                            hc = col;
+                            hr = row;
+                            active = false;
+                        }
+                    }
+                } else {
+                    active = false;
+                }
+            }
+            act = __ballot(active);
+        } while (__popcll(act) > low);
     }
 }
 

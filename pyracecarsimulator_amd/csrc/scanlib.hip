@@ -588,6 +588,65 @@ static BlParams make_bl(const rl_method *h, int num_rays, size_t &lds_bytes)
     return bp;
 }
 
+// pose records in map-tile order (rec_sorted / order), by the binning kernel set that fits the
+// batch size; walk_outside = Bresenham semantics (origins outside the map still walk)
+static int bin_poses(rl_method *h, const float *d_poses, int n_poses, int walk_outside,
+                     hipStream_t stream)
+{
+    const rl_map *m = h->map;
+    int rc;
+    if ((rc = h->rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
+    if ((rc = h->order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
+    if ((rc = h->keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
+    if ((rc = h->rec_sorted.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
+    const int do_sort = (h->sort_poses && n_poses >= 64) ? 1 : 0;
+    int shift = 6;
+    while ((long)((m->cols >> shift) + 1) * ((m->rows >> shift) + 1) > 8192) ++shift;
+    const int tiles_x = (m->cols >> shift) + 1;
+    const int n_tiles = tiles_x * ((m->rows >> shift) + 1);
+    if (n_poses >= h->bin_multi_min) {
+        const int n_wg = (n_poses + POSES_PER_WG - 1) / POSES_PER_WG;
+        if (do_sort) {
+            // grid-wide binning on coarse tiles (<= 1024): per-workgroup LDS histograms ->
+            // one scan over (tile, workgroup) -> scatter from LDS cursors
+            int cshift = shift;
+            while ((long)((m->cols >> cshift) + 1) * ((m->rows >> cshift) + 1) > 1024) ++cshift;
+            const int ctx = (m->cols >> cshift) + 1;
+            const int cnt = ctx * ((m->rows >> cshift) + 1);
+            const size_t n_ctr = (size_t)cnt * n_wg;
+            if ((rc = h->hist.ensure(n_ctr * sizeof(uint32_t)))) return rc;
+            hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
+                               m->mp, d_poses, n_poses, (PoseRec *)h->rec.p,
+                               (uint32_t *)h->keys.p, (uint32_t *)h->hist.p, n_wg, cshift, ctx,
+                               cnt, (uint32_t *)nullptr, walk_outside);
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream,
+                               (uint32_t *)h->hist.p, (int)n_ctr);
+            hipLaunchKernelGGL(pose_scatter_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
+                               n_poses, (const PoseRec *)h->rec.p, (const uint32_t *)h->keys.p,
+                               (const uint32_t *)h->hist.p, n_wg, cnt, (PoseRec *)h->rec_sorted.p,
+                               (uint32_t *)h->order.p);
+        } else {
+            // caller's order kept: one fully parallel pass, records land in place
+            hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), 0, stream, m->mp, d_poses,
+                               n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)nullptr,
+                               (uint32_t *)nullptr, n_wg, shift, tiles_x, n_tiles,
+                               (uint32_t *)h->order.p, walk_outside);
+        }
+    } else if (do_sort && n_poses <= 8192 && !h->bin_generic) {
+        hipLaunchKernelGGL(pose_bin_small_kernel, dim3(1), dim3(1024),
+                           (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
+                           n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)h->order.p, shift,
+                           tiles_x, n_tiles, walk_outside);
+    } else {
+        hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
+                           (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
+                           n_poses, (PoseRec *)h->rec.p, (PoseRec *)h->rec_sorted.p,
+                           (uint32_t *)h->order.p, (uint32_t *)h->keys.p, shift, tiles_x,
+                           n_tiles, do_sort, walk_outside);
+    }
+    return RL_OK;
+}
+
 static FastDiv make_fastdiv(uint32_t d)
 {
     FastDiv f{};
@@ -641,22 +700,43 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             hipLaunchKernelGGL(cddt_fan_kernel, dim3(pgrid), dim3(256), 0, stream, m->mp, f, h->cdp,
                                d_poses, d_out);
         } else {
-            size_t lds_bl = 0;
-            BlParams bp = make_bl(h, num_rays, lds_bl);
-            if (lds_bl > 48 * 1024) {          // more dynamic LDS than the default cap: opt in
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl_fan_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl_fan_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
+            if (h->variant >= 1 && (long)n_poses * num_rays < (1L << 31)) {
+                // K2b: stream schedule on the cache-resident bit map
+                if ((rc = bin_poses(h, d_poses, n_poses, 1, stream))) return rc;
+                StreamParams sp{};
+                sp.rec = (const PoseRec *)h->rec_sorted.p;
+                sp.order = (const uint32_t *)h->order.p;
+                sp.div_B = make_fastdiv((uint32_t)num_rays);
+                sp.low_water = h->low_water;
+                sp.n_bands = n_poses >= 64 ? h->xcd_bands : 1;
+                const long n_blocks = ((long)n_poses * num_rays + 63) / 64;
+                const int bg = (int)std::max((long)sp.n_bands,
+                                             std::min((n_blocks + 15) / 16, (long)m->n_cu * h->grid_mult / 4));
+                const size_t lds_s = (size_t)num_rays * sizeof(float2) + 2 * sizeof(float);
+                if (d_hits || d_steps)
+                    hipLaunchKernelGGL((bl_fan_stream_kernel<true, 1024>), dim3(bg), dim3(1024), lds_s,
+                                       stream, m->mp, f, sp, d_out, d_hits, d_steps);
+                else
+                    hipLaunchKernelGGL((bl_fan_stream_kernel<false, 1024>), dim3(bg), dim3(1024), lds_s,
+                                       stream, m->mp, f, sp, d_out, d_hits, d_steps);
+            } else {
+                size_t lds_bl = 0;
+                BlParams bp = make_bl(h, num_rays, lds_bl);
+                if (lds_bl > 48 * 1024) {          // more dynamic LDS than the default cap: opt in
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl_fan_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl_fan_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
+                }
+                const int bgrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * 2));
+                if (d_hits || d_steps)
+                    hipLaunchKernelGGL((bl_fan_kernel<true>), dim3(bgrid), dim3(256), lds_bl, stream,
+                                       m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+                else
+                    hipLaunchKernelGGL((bl_fan_kernel<false>), dim3(bgrid), dim3(256), lds_bl, stream,
+                                       m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
             }
-            const int bgrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * 2));
-            if (d_hits || d_steps)
-                hipLaunchKernelGGL((bl_fan_kernel<true>), dim3(bgrid), dim3(256), lds_bl, stream,
-                                   m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
-            else
-                hipLaunchKernelGGL((bl_fan_kernel<false>), dim3(bgrid), dim3(256), lds_bl, stream,
-                                   m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
-        }
+            }
         HIPCHK(hipGetLastError());
         if (h->timing) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
         return RL_OK;
@@ -706,52 +786,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         }
         if (!inl) {
             nt = h->wg_threads;
-            if ((rc = h->rec_sorted.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
-            const int do_sort = (h->sort_poses && n_poses >= 64) ? 1 : 0;
-            int shift = 6;
-            while ((long)((m->cols >> shift) + 1) * ((m->rows >> shift) + 1) > 8192) ++shift;
-            const int tiles_x = (m->cols >> shift) + 1;
-            const int n_tiles = tiles_x * ((m->rows >> shift) + 1);
-            if (n_poses >= h->bin_multi_min) {
-                const int n_wg = (n_poses + POSES_PER_WG - 1) / POSES_PER_WG;
-                if (do_sort) {
-                    // grid-wide binning on coarse tiles (<= 1024): per-workgroup LDS histograms ->
-                    // one scan over (tile, workgroup) -> scatter from LDS cursors
-                    int cshift = shift;
-                    while ((long)((m->cols >> cshift) + 1) * ((m->rows >> cshift) + 1) > 1024) ++cshift;
-                    const int ctx = (m->cols >> cshift) + 1;
-                    const int cnt = ctx * ((m->rows >> cshift) + 1);
-                    const size_t n_ctr = (size_t)cnt * n_wg;
-                    if ((rc = h->hist.ensure(n_ctr * sizeof(uint32_t)))) return rc;
-                    hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
-                                       m->mp, d_poses, n_poses, (PoseRec *)h->rec.p,
-                                       (uint32_t *)h->keys.p, (uint32_t *)h->hist.p, n_wg, cshift, ctx,
-                                       cnt, (uint32_t *)nullptr);
-                    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream,
-                                       (uint32_t *)h->hist.p, (int)n_ctr);
-                    hipLaunchKernelGGL(pose_scatter_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
-                                       n_poses, (const PoseRec *)h->rec.p, (const uint32_t *)h->keys.p,
-                                       (const uint32_t *)h->hist.p, n_wg, cnt, (PoseRec *)h->rec_sorted.p,
-                                       (uint32_t *)h->order.p);
-                } else {
-                    // caller's order kept: one fully parallel pass, records land in place
-                    hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), 0, stream, m->mp, d_poses,
-                                       n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)nullptr,
-                                       (uint32_t *)nullptr, n_wg, shift, tiles_x, n_tiles,
-                                       (uint32_t *)h->order.p);
-                }
-            } else if (do_sort && n_poses <= 8192 && !h->bin_generic) {
-                hipLaunchKernelGGL(pose_bin_small_kernel, dim3(1), dim3(1024),
-                                   (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
-                                   n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)h->order.p, shift,
-                                   tiles_x, n_tiles);
-            } else {
-                hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
-                                   (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
-                                   n_poses, (PoseRec *)h->rec.p, (PoseRec *)h->rec_sorted.p,
-                                   (uint32_t *)h->order.p, (uint32_t *)h->keys.p, shift, tiles_x,
-                                   n_tiles, do_sort);
-            }
+            if ((rc = bin_poses(h, d_poses, n_poses, 0, stream))) return rc;
         }
         PadMap pm{};
         pm.pdt = (const float *)h->pdt.p;

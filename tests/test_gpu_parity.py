@@ -319,12 +319,14 @@ def test_cfg2_full_size_properties(oracle_mod):
 
 
 # ---------------------------------------------------------------- K2: BresenhamsLine (LDS tile)
+@pytest.mark.parametrize("variant", [0, 1])        # 0: LDS-window kernel (K2), 1: stream kernel (K2b)
 @pytest.mark.parametrize("name", ["rm_colombia", "rm_maze256", "rm_maze192_yaw"])
-def test_bresenham_fan_reproduces_golden_vectors(oracle_mod, name):
+def test_bresenham_fan_reproduces_golden_vectors(oracle_mod, name, variant):
     g, z = load_golden(name)
     omap = range_libc.PyOMap(g)
     fov, B, mrx = float(z["fov"]), int(z["num_rays"]), int(z["max_range_px"])
     m = range_libc.PyBresenhamsLine(omap, mrx)
+    m.set_option("variant", variant)
     r, h, s = _fan(m, z["poses"], fov, B)
     assert np.array_equal(r, z["ranges_bl"]) and np.array_equal(h, z["hits_bl"].astype(np.int32))
     om = oracle_mod.OracleMap.from_gridmap(g, mrx)
@@ -335,12 +337,14 @@ def test_bresenham_fan_reproduces_golden_vectors(oracle_mod, name):
     assert np.array_equal(r1, r0)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("mrx", [40, 300, 700])               # 700: window > LDS -> global bit map
-def test_bresenham_vs_oracle_edge_cases_and_rays(oracle_mod, mrx):
+def test_bresenham_vs_oracle_edge_cases_and_rays(oracle_mod, mrx, variant):
     g = maps.make_maze(300, cell=30, wall=2, p=0.5, seed=mrx, origin=(2.0, -1.0, 0.35))
     om = oracle_mod.OracleMap.from_gridmap(g, mrx)
     omap = range_libc.PyOMap(g)
     m = range_libc.PyBresenhamsLine(omap, mrx)
+    m.set_option("variant", variant)
     poses = maps.sample_free_poses(g, 40, 3)
     poses[3] = [np.nan, 0, 0]
     poses[4] = [1e20, 1.0, 0.5]
