@@ -224,10 +224,10 @@ __global__ __launch_bounds__(WG) void rm_rays_kernel(MapParams m, FanParams f,
 // K1b: the MI355X-shaped ray-marching path (variant 1, default).
 //
 //  (0) pad_dt_kernel — per method: the float32 EDT copied into an array with a border of
-//      ceil(max_range)+2 cells holding -1 ("outside the map").  A ray whose origin is
-//      inside the map stays within max_range of it while it is live, so the march loop
-//      needs no bounds test and no address clamp: leaving the map reads -1 and stops
-//      like a hit does.  (Origins outside the map are misses before the first sample —
+//      ceil(max_range)+2 cells holding 3e38 ("outside the map"), occupied cells +inf.  A
+//      ray whose origin is inside the map stays within max_range of it while it is live, so
+//      the march loop needs no bounds test, no address clamp and no hit test: leaving the
+//      map or hitting adds a huge step and t leaves the [0, max_range) window.  (Origins outside the map are misses before the first sample —
 //      decided once per pose.)
 //  (1) pose_bin_kernel — one 1024-lane workgroup turns the pose list into per-pose
 //      records (gx, gy, cos th, sin th) ordered by the map tile the pose stands in
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(WG) void rm_rays_kernel(MapParams m, FanParams f,
 //      ~130 cycles, ~60 VALU+SALU per sample in the first version), so the march loop is
 //      written predicated — every lane executes every instruction, a finished lane has
 //      t = +inf and re-reads its origin cell — with no EXEC-mask traffic:
-//      14 VALU + 1 load + ~5 SALU per sample.
+//      10 VALU + 1 load + 4 SALU per sample (march_loop below).
 // Results are bit-identical to K1 (same arithmetic; only the schedule differs).
 // ==============================================================================
 struct PoseRec {
