@@ -686,6 +686,9 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 if (out) out[oidx] = r;
                 if (AUX) {
                     if (hits) { hits[2 * (size_t)oidx] = hc; hits[2 * (size_t)oidx + 1] = hr; }
+                    // the read that found the border is not a map sample (the CPU statement
+                    // leaves the loop before reading)
+                    if (d_last == PDT_OUTSIDE) --nstep;
                     if (steps) steps[oidx] = (uint16_t)(nstep > 65535u ? 65535u : nstep);
                 }
                 if (CRASH) {

@@ -736,7 +736,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
                     hipLaunchKernelGGL((bl_fan_kernel<false>), dim3(bgrid), dim3(256), lds_bl, stream,
                                        m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
             }
-            }
+        }
         HIPCHK(hipGetLastError());
         if (h->timing) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
         return RL_OK;

@@ -605,3 +605,22 @@ def test_grouped_crash_device_api_fused_and_generic(oracle_mod):
     assert np.array_equal(d_ranges.cpu().numpy(), want_r)
     assert any(w >= 0 for w in want) and any(w < 0 for w in want)
     assert m.check_collision_groups(poses, group, fov, B, edge, 0.001).tolist() == want
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_rays_leaving_an_open_map_count_no_border_sample(oracle_mod, variant):
+    """Map without border walls (found by tools/gpu_fuzz.py, seed 35492827): beams that leave the
+    map must report the oracle's sample count — the border read of the padded EDT is not a sample."""
+    g = maps.GridMap(maps.make_maze(212, cell=20, wall=2, p=0.5, seed=3).occ[:, :155].copy()[5:-5, 5:],
+                     0.05, (31.0, 17.0, 0.0), "open")
+    om = oracle_mod.OracleMap.from_gridmap(g, 120)
+    omap = range_libc.PyOMap(g)
+    poses = maps.sample_free_poses(g, 64, 1)
+    for cls, sc in ((range_libc.PyRayMarching, 0.999), (range_libc.PyRayMarchingGPU, 1.0)):
+        m = cls(omap, 120)
+        m.set_option("variant", variant)
+        for B, fov in ((2, -2.0), (1081, 4.71)):
+            r, h, s = _fan(m, poses, fov, B)
+            r0, h0, s0 = om.rm_fan(poses, fov, B, step_coeff=sc)
+            assert (h0[:, 0] < 0).any()                          # some beams do leave the map
+            assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0)
