@@ -624,3 +624,16 @@ def test_rays_leaving_an_open_map_count_no_border_sample(oracle_mod, variant):
             r0, h0, s0 = om.rm_fan(poses, fov, B, step_coeff=sc)
             assert (h0[:, 0] < 0).any()                          # some beams do leave the map
             assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0)
+
+
+def test_randomised_parity_fuzz_short():
+    """A few seconds of tools/gpu_fuzz.py (random map shapes, origins, yaw, ranges, fans, batch sizes,
+    every method and kernel variant, crash tests, map updates) — all bit-identical to the oracle.
+    Longer runs: ``python tools/gpu_fuzz.py --seconds 300 --seed N`` (4000+ cases clean in round 1)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("gpu_fuzz", os.path.join(ROOT, "tools", "gpu_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.run(8.0, 2026) > 10
