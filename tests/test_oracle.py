@@ -257,3 +257,29 @@ def test_oracle_edge_table_equals_live_reference_build(oracle_mod):
         assert L.ref_car_is_crashed(car, rays.ctypes.data_as(C.POINTER(C.c_float)), B, 1) == 0
         rays[j] = np.float32(edge[j] + thresh) + np.float32(1e-3)
         assert L.ref_car_is_crashed(car, rays.ctypes.data_as(C.POINTER(C.c_float)), B, 1) == -2
+
+
+def test_random_maps_c_oracle_vs_numpy_statement(oracle_mod):
+    """Randomised cross-check of the two CPU statements (C restatement vs NumPy/SciPy): shapes,
+    origins, yaw, ranges, fans — bit-identical EDT, ranges, hit cells and sample counts."""
+    rng = np.random.default_rng(77)
+    for case in range(25):
+        rows, cols = int(rng.integers(1, 120)), int(rng.integers(1, 120))
+        dens = float(rng.choice([0.0, 0.01, 0.05, 0.3]))
+        occ = (rng.random((rows, cols)) < dens).astype(np.uint8)
+        res = float(rng.choice([0.05, 0.1, 1.0]))
+        origin = (float(rng.uniform(-20, 20)), float(rng.uniform(-20, 20)),
+                  float(rng.choice([0.0, rng.uniform(-3, 3)])))
+        mrx = float(rng.choice([1, 9, 60, 300]))
+        B, fov = int(rng.choice([1, 7, 64, 181])), float(rng.choice([4.71, 6.283, -1.0, 0.0]))
+        P = int(rng.integers(1, 12))
+        assert np.array_equal(oracle_mod.edt(occ), N.edt(occ))
+        gx, gy = rng.uniform(-2, cols + 2, P), rng.uniform(-2, rows + 2, P)
+        c, s = np.cos(origin[2]), np.sin(origin[2])
+        poses = np.stack([origin[0] + (c * gx - s * gy) * res, origin[1] + (s * gx + c * gy) * res,
+                          rng.uniform(-7, 7, P)], 1).astype(np.float32)
+        om = oracle_mod.OracleMap(occ, res, origin, mrx)
+        for sc in (0.999, 1.0):
+            r, h, st = om.rm_fan(poses, fov, B, step_coeff=sc)
+            r2, h2, st2 = N.rm_fan(occ, res, origin, mrx, poses, fov, B, sc)
+            assert np.array_equal(r, r2) and np.array_equal(h, h2) and np.array_equal(st, st2), case
