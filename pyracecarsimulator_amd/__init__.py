@@ -4,7 +4,8 @@ Scope: ``ScanSimulator2D.scan/scanMany`` over a ``range_libc``-c
 ``PyOMap`` / ``PyRayMarching[GPU]`` / ``PyCDDTCast`` surface, implemented as hand-written
 HIP kernels for gfx950 behind the C ABI in ``include/scanlib.h``.
 """
-from . import maps, range_libc                      # noqa: F401
+from . import maps, racecar, range_libc             # noqa: F401
 from .scan_simulator import ScanSimulator2D          # noqa: F401
+from .racecar_simulator import RacecarSimulator      # noqa: F401
 
-__all__ = ["maps", "range_libc", "ScanSimulator2D"]
+__all__ = ["maps", "racecar", "range_libc", "ScanSimulator2D", "RacecarSimulator"]

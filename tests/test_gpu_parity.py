@@ -2,6 +2,7 @@
 through the C ABI (libscan_amd.so) and compares with the CPU oracle on the same seeded inputs,
 with the committed golden vectors, or — at BASELINE.json's full sizes — through
 size-independent properties.  Bar: bit-exact ranges / hit cells / step counts for ray marching."""
+import math
 import numpy as np
 import pytest
 
@@ -637,3 +638,73 @@ def test_randomised_parity_fuzz_short():
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     assert fz.run(8.0, 2026) > 10
+
+
+def _ref_config():
+    from pyracecarsimulator_amd import racecar as RC
+    cfg = dict(RC.DEFAULT_CAR)
+    cfg.update(scan_dist_to_base=0.275, batch_size=40, scan_beams=1080, scan_fov=4.71, scan_std=0.01,
+               scan_max_range=15.0, free_thresh=0.8)          # params.yaml:28-39,44-47
+    return cfg
+
+
+def test_racecar_simulator_facade_drives_like_the_reference(oracle_mod):
+    """RacecarSimulator (scripts/racecar_simulator_v2.py) end to end: drive/updatePose against the
+    reference's compiled Car (oracle/_ref, when present) and runScan/checkCollision[Many] against the
+    oracle scan + isCrashed."""
+    import ctypes as C
+    import os
+    from conftest import ROOT
+    from pyracecarsimulator_amd import RacecarSimulator, racecar as RC
+    g = maps.load_colombia()
+    cfg = _ref_config()
+    sim = RacecarSimulator(cfg)
+    omap = range_libc.PyOMap(g)
+    sim.setMap(omap, g.resolution, g.origin)
+    sim.setRaytracingMethod("RMGPU")
+    mrx = int(15.0 / g.resolution)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    start = maps.sample_free_poses(g, 1, 21, 10.0, om.dt)[0]
+    st = np.zeros(11)
+    st[:3] = start
+    sim.setState(st)
+    ref = None
+    so = os.path.join(ROOT, "oracle/_ref/libracecar_ref.so")
+    if os.path.exists(so):
+        L = C.CDLL(so)
+        L.ref_car_create.restype = C.c_void_p
+        L.ref_car_create.argtypes = [C.POINTER(C.c_double)]
+        L.ref_car_control.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.ref_car_update_position.argtypes = [C.c_void_p, C.c_double]
+        L.ref_car_get_state.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.ref_car_set_state.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        ref = L.ref_car_create((C.c_double * 17)(*[cfg[k] for k in RC.CAR_PARAM_ORDER]))
+        L.ref_car_set_state(ref, (C.c_double * 11)(*st))
+    edge = oracle_mod.edge_distances(1080, -4.71 / 2, 4.71 / 1080, 0.275, cfg["width"], cfg["wb"])
+    for i in range(30):
+        sim.drive(2.0 + 0.1 * i, 0.3 * math.sin(i / 3.0))
+        sim.updatePose()
+        if ref is not None:
+            L.ref_car_control(ref, 2.0 + 0.1 * i, 0.3 * math.sin(i / 3.0))
+            L.ref_car_update_position(ref, 0.01)
+            buf = (C.c_double * 11)()
+            L.ref_car_get_state(ref, buf)
+            assert np.allclose(sim.getState(), np.array(buf), rtol=1e-9, atol=1e-9)
+        sim.runScan()
+        pose = np.array([sim.getScanPose()], np.float32)
+        want, _, _ = om.rm_fan(pose, 4.71, 1080, step_coeff=1.0)
+        assert np.array_equal(sim.getScan(), want)
+        assert sim.checkCollision() == oracle_mod.is_crashed(want, 1080, 1, edge, cfg["ttc_thresh"])
+    assert sim.getTravelDistance() > 0 and sim.getMeanVelocity() > 0
+    poses = maps.sample_free_poses(g, 45, 5, 2.0, om.dt)
+    want, _, _ = om.rm_fan(poses[:40], 4.71, 1080, step_coeff=1.0)
+    assert sim.checkCollisionMany(poses) == oracle_mod.is_crashed(want, 1080, 40, edge, cfg["ttc_thresh"])
+    with pytest.raises(IndexError):
+        sim.checkCollisionMany(poses[:10])
+    # batched roll-outs through the façade
+    states = np.tile(sim.getState(), (6, 1))
+    acts = np.stack([np.full((6, 4), 3.0), np.linspace(-0.4, 0.4, 6)[:, None] * np.ones((6, 4))], -1)
+    first, final, vel = sim.rolloutMany(states, acts, n_steps=40)
+    assert first.shape == (6,) and final.shape == (6, 11) and vel.shape == (6, 40)
+    sim.stop()
+    assert not sim.getState().any()
