@@ -450,8 +450,8 @@ static int check_fan_args(const rl_method *h, int n_poses, float fov, int num_ra
     if (!h) return fail(RL_ERR_INVALID, "null method handle");
     if (n_poses < 0) return fail(RL_ERR_INVALID, "n_poses must be >= 0");
     if (num_rays <= 0) return fail(RL_ERR_INVALID, "num_rays must be > 0");
-    if (num_rays > 16384)
-        return fail(RL_ERR_UNSUPPORTED, "num_rays %d exceeds the LDS fan table (16384)", num_rays);
+    if (num_rays > 7680)      // 8 B per beam in LDS next to the other per-workgroup state (<= 64 KiB)
+        return fail(RL_ERR_UNSUPPORTED, "num_rays %d exceeds the LDS fan table (7680 beams)", num_rays);
     if (!(fov == fov)) return fail(RL_ERR_INVALID, "fov is NaN");
     return RL_OK;
 }

@@ -127,6 +127,12 @@ def test_edge_cases(oracle_mod):
     r, h, s = _fan(m, poses, 4.71, 129)
     r0, h0, s0 = om.rm_fan(poses, 4.71, 129)
     assert np.array_equal(r, r0, equal_nan=True) and np.array_equal(h, h0) and np.array_equal(s, s0)
+    # largest supported fan (LDS table), and one beam too many
+    big = np.empty(2 * 7680, np.float32)
+    m.calc_range_fan(poses[:2], big, 6.0, 7680)
+    assert np.array_equal(big, om.rm_fan(poses[:2], 6.0, 7680)[0])
+    with pytest.raises(Exception):
+        m.calc_range_fan(poses[:2], np.empty(2 * 7681, np.float32), 6.0, 7681)
     # empty batch: nothing happens, nothing raises
     out = np.empty(0, np.float32)
     m.calc_range_fan(np.zeros((0, 3), np.float32), out, 4.71, 129)
