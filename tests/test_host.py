@@ -182,3 +182,16 @@ def test_edge_distances_host_table_equals_reference_behaviour(oracle_mod):
         edge = RC.edge_distances(B, -fov / 2.0, fov / B, 0.275, car["width"], car["wb"])
         assert oracle_mod.is_crashed(z["rays_%d" % i], B, P, edge, car["ttc_thresh"]) == int(z["codes"][i])
     assert tuple(RC.CAR_PARAM_ORDER) == tuple(str(k) for k in z["car_keys"])
+
+
+def test_params_yaml_loader_maps_rosparam_names(tmp_path):
+    from pyracecarsimulator_amd import config, racecar as RC
+    y = tmp_path / "params.yaml"
+    y.write_text("wheelbase: 0.5\nscan_beams: 720\nscan_fov: 3.14\nC_S_front: 4.7\nbatch_size: 64\n"
+                 "scan_method: \"RM\"\nmass: 3.5\nsome_topic: \"/x\"\n")
+    cfg = config.load_params(str(y), max_speed=5.0)
+    assert cfg["wb"] == 0.5 and cfg["scan_beams"] == 720 and cfg["cs_f"] == 4.7 and cfg["batch_size"] == 64
+    assert cfg["scan_method"] == "RM" and cfg["max_speed"] == 5.0 and cfg["mass"] == 3.5
+    assert cfg["l_r"] == config.DEFAULTS["l_r"] and "some_topic" not in cfg
+    assert all(k in cfg for k in RC.CAR_PARAM_ORDER)           # everything Car's constructor needs
+    assert config.load_params()["scan_max_range"] == 15.0
