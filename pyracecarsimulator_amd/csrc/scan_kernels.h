@@ -683,7 +683,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 r *= pm.res;
                 if (f.noise_std > 0.0f)
                     r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + oidx);
-                if (out) out[oidx] = r;
+                if (out) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + (oidx << 2)) = r;
                 if (AUX) {
                     if (hits) { hits[2 * (size_t)oidx] = hc; hits[2 * (size_t)oidx + 1] = hr; }
                     // the read that found the border is not a map sample (the CPU statement
@@ -712,8 +712,13 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                         const int j = (int)(ray - spose * (uint32_t)f.num_rays);
                         uint32_t li = 0;
                         if (INLINE) li = 2 * (q >> 6) + (spose - fast_div(blk, sp.div_B));
-                        const uint32_t po = INLINE ? lord[li] : sp.order[seg_lo + spose];
-                        const PoseRec pr_ = INLINE ? lrec[li] : sp.rec[seg_lo + spose];
+                        // SGPR base + 32-bit lane offset (global_load ... s[base]) instead of 64-bit
+                        // per-lane pointers
+                        const uint32_t si = seg_lo + spose;
+                        const uint32_t po = INLINE ? lord[li]
+                            : *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sp.order) + (si << 2));
+                        const PoseRec pr_ = INLINE ? lrec[li]
+                            : *reinterpret_cast<const PoseRec *>(reinterpret_cast<const char *>(sp.rec) + (si << 4));
                         const float2 cs = fan_cs[j];
                         pose = po & ~POSE_INVALID;
                         gx = pr_.gx;

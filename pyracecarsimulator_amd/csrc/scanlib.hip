@@ -137,6 +137,7 @@ struct rl_method {
     bool timed = false;
     DevBuf poses, outs, hits, steps, edge, flag, rec, rec_sorted, order, keys, dbg, hist;
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
+    int slice_log2 = 30;         // launches are cut into pose slices below 2^slice_log2 rays
     int bin_generic = 0;         // diagnostics: force the generic single-workgroup binning kernel
     int inline_prep = 1;         // tiny batches: no binning launch, workgroups derive their own records
     int inline_max = 512;        //   ... below this many poses (measured: wins below ~512, loses above)
@@ -396,6 +397,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
     else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
     else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
+    else if (!strcmp(name, "slice_log2")) h->slice_log2 = value < 8 ? 8 : (value > 30 ? 30 : value);
     else if (!strcmp(name, "inline_max")) h->inline_max = value;
     else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
     else if (!strcmp(name, "wg_threads")) h->wg_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256);
@@ -418,6 +420,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "bin_multi_min")) *value_out = h->bin_multi_min;
     else if (!strcmp(name, "inline_prep")) *value_out = h->inline_prep;
     else if (!strcmp(name, "bin_generic")) *value_out = h->bin_generic;
+    else if (!strcmp(name, "slice_log2")) *value_out = h->slice_log2;
     else if (!strcmp(name, "inline_max")) *value_out = h->inline_max;
     else if (!strcmp(name, "wg_threads")) *value_out = h->wg_threads;
     else if (!strcmp(name, "last_grid")) *value_out = h->last_grid;
@@ -666,6 +669,24 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
 {
     if (n_poses == 0) return RL_OK;
     const rl_map *m = h->map;
+    // the stream kernels index rays with 32-bit byte offsets: batches of 2^30 rays or more
+    // (4 GiB of ranges) go through in pose slices, each its own launch sequence
+    const long slice_rays = 1L << h->slice_log2;
+    if ((long)n_poses * num_rays >= slice_rays && h->variant >= 1 && !crash && n_poses > 1) {
+        const int per = (int)std::max(1L, (slice_rays - 1) / num_rays);
+        const uint64_t base_off = h->ray_offset;
+        int rc = RL_OK;
+        for (int p0 = 0; p0 < n_poses && rc == RL_OK; p0 += per) {
+            const int np = std::min(per, n_poses - p0);
+            const size_t r0 = (size_t)p0 * num_rays;
+            h->ray_offset = base_off + r0;               // noise stays keyed by the global ray id
+            rc = launch_fan(h, d_poses + (size_t)p0 * 3, np, fov, num_rays, d_out ? d_out + r0 : nullptr,
+                            d_hits ? d_hits + 2 * r0 : nullptr, d_steps ? d_steps + r0 : nullptr,
+                            nullptr, stream);
+        }
+        h->ray_offset = base_off;
+        return rc;
+    }
     FanParams f = make_fan(h, n_poses, fov, num_rays);
     if (h->kind != RL_RM && h->kind != RL_RM_GPU) {
         if (crash) return fail(RL_ERR_UNSUPPORTED, "fused crash test needs a ray-marching method");
@@ -700,7 +721,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             hipLaunchKernelGGL(cddt_fan_kernel, dim3(pgrid), dim3(256), 0, stream, m->mp, f, h->cdp,
                                d_poses, d_out);
         } else {
-            if (h->variant >= 1 && (long)n_poses * num_rays < (1L << 31)) {
+            if (h->variant >= 1 && (long)n_poses * num_rays < (1L << 30)) {
                 // K2b: stream schedule on the cache-resident bit map
                 if ((rc = bin_poses(h, d_poses, n_poses, 1, stream))) return rc;
                 StreamParams sp{};
@@ -751,7 +772,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
     CrashParams cp{nullptr, 0.0, nullptr, 1};
     if (crash) cp = *crash;
     const bool aux = d_hits || d_steps;
-    const bool stream_ok = (long)n_poses * num_rays < (1L << 31);
+    const bool stream_ok = (long)n_poses * num_rays < (1L << 30);
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
     if (h->variant >= 1 && stream_ok) {
         // (1) per-pose records + tile-ordered permutation, (2) banded lane-refill march

@@ -53,6 +53,7 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "inline_prep": 0, "bin_generic": 1},         # ... its generic (any size) form
     {"variant": 1, "inline_prep": 0, "bin_multi_min": 64},      # grid-wide binning kernels
     {"variant": 1, "inline_prep": 1, "inline_max": 100000, "xcd_bands": 5},   # workgroups derive their own pose records
+    {"variant": 1, "slice_log2": 14},                           # batch cut into pose slices (>= 2^30 rays in production)
     {"variant": 1, "bin_multi_min": 64},                        # grid-wide binning kernels
     {"variant": 1, "bin_multi_min": 1 << 30},                   # single-workgroup binning
 ])
@@ -209,6 +210,10 @@ def test_noise_statistics_and_shard_invariance(oracle_mod):
     again = np.empty_like(clean)
     m.calc_range_fan(poses, again, 4.71, B)
     assert np.array_equal(noisy, again)                                           # counter-based
+    m.set_option("slice_log2", 13)            # launch cut into pose slices: same global ray ids
+    m.calc_range_fan(poses, again, 4.71, B)
+    assert np.array_equal(noisy, again)
+    m.set_option("slice_log2", 30)
     # sharding: second half scanned alone with ray_offset reproduces the unsharded noise
     half = len(poses) // 2
     m.set_noise(0.01, seed=6, ray_offset=half * B)
