@@ -128,7 +128,7 @@ _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 def load_colombia() -> GridMap:
     """The one map the reference mount still holds (maps/colombia/map.pgm, 435x350,
     0.05 m/px), shipped as data/colombia_map.npz (image bytes + YAML values; made by
-    tools/make_fixtures.py)."""
+    tests/golden/make_fixtures.py)."""
     z = np.load(os.path.join(_DATA, "colombia_map.npz"))
     data = occupancy_from_image(z["image"], int(z["negate"]), float(z["occupied_thresh"]),
                                 float(z["free_thresh"]))

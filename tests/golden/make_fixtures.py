@@ -3,7 +3,7 @@
 
 Run in the build container only (reads /root/reference; the GPU box never does):
 
-* data/colombia_map.npz   the one map the reference mount holds (maps/colombia/map.pgm +
+* pyracecarsimulator_amd/data/colombia_map.npz   the one map the reference mount holds (maps/colombia/map.pgm +
                           map.yaml values), re-encoded — a data file, not source.
 * golden/protocol.json    GOLD-C: call protocol of the reference's own ScanSimulator2D
                           (scripts/scan_simulator.py run through lib2to3 on a /tmp copy, with a
@@ -28,7 +28,7 @@ import types
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 GOLD = os.path.join(ROOT, "tests", "golden")

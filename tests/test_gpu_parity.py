@@ -621,7 +621,7 @@ def test_grouped_crash_device_api_fused_and_generic(oracle_mod):
 
 @pytest.mark.parametrize("variant", [0, 1])
 def test_rays_leaving_an_open_map_count_no_border_sample(oracle_mod, variant):
-    """Map without border walls (found by tools/gpu_fuzz.py, seed 35492827): beams that leave the
+    """Map without border walls (found by tests/gpu_fuzz.py, seed 35492827): beams that leave the
     map must report the oracle's sample count — the border read of the padded EDT is not a sample."""
     g = maps.GridMap(maps.make_maze(212, cell=20, wall=2, p=0.5, seed=3).occ[:, :155].copy()[5:-5, 5:],
                      0.05, (31.0, 17.0, 0.0), "open")
@@ -639,13 +639,13 @@ def test_rays_leaving_an_open_map_count_no_border_sample(oracle_mod, variant):
 
 
 def test_randomised_parity_fuzz_short():
-    """A few seconds of tools/gpu_fuzz.py (random map shapes, origins, yaw, ranges, fans, batch sizes,
+    """A few seconds of tests/gpu_fuzz.py (random map shapes, origins, yaw, ranges, fans, batch sizes,
     every method and kernel variant, crash tests, map updates) — all bit-identical to the oracle.
-    Longer runs: ``python tools/gpu_fuzz.py --seconds 300 --seed N`` (4000+ cases clean in round 1)."""
+    Longer runs: ``python tests/gpu_fuzz.py --seconds 300 --seed N`` (4000+ cases clean in round 1)."""
     import importlib.util
     import os
     from conftest import ROOT
-    spec = importlib.util.spec_from_file_location("gpu_fuzz", os.path.join(ROOT, "tools", "gpu_fuzz.py"))
+    spec = importlib.util.spec_from_file_location("gpu_fuzz", os.path.join(ROOT, "tests", "gpu_fuzz.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     assert fz.run(8.0, 2026) > 10
