@@ -262,6 +262,30 @@ constexpr uint32_t POSE_INVALID = 0x80000000u;   // order[] flag: origin outside
 #define PDT_HIT __builtin_inff()        /* occupied cell (EDT 0)          */
 #define PDT_OUTSIDE 3.0e38f             /* border: the ray left the map   */
 
+// tiled layout (TILED march): 4-row x 8-column tiles of 128 B, tiles row-major, tpr tiles per row:
+//   element(r, c) = ((r>>2)*tpr + (c>>3))*32 + (r&3)*8 + (c&7)      (r, c may be negative: border)
+__device__ __forceinline__ long pdt_tiled_index(int r, int c, int tpr)
+{
+    return ((long)(r >> 2) * tpr + (c >> 3)) * 32 + (r & 3) * 8 + (c & 7);
+}
+
+__global__ __launch_bounds__(256) void pad_dt_tiled_kernel(const float *__restrict__ dt, int rows, int cols,
+                                                           float *__restrict__ pdt, int pad, int tpr,
+                                                           long k_elems, int prow, int pcol)
+{
+    const int pr = blockIdx.y;
+    const int r = pr - pad;
+    for (int pc = blockIdx.x * blockDim.x + threadIdx.x; pc < pcol; pc += gridDim.x * blockDim.x) {
+        const int c = pc - pad;
+        float v = PDT_OUTSIDE;
+        if (r >= 0 && r < rows && c >= 0 && c < cols) {
+            v = dt[(size_t)r * cols + c];
+            if (v <= 0.0f) v = PDT_HIT;
+        }
+        pdt[k_elems + pdt_tiled_index(r, c, tpr)] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void pad_dt_kernel(const float *__restrict__ dt, int rows, int cols,
                                                      float *__restrict__ pdt, int pad, int stride)
 {
@@ -535,12 +559,14 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f)
 //   d  = pdt[(r*stride + c)*4 + k4]     occupied cells read +inf, border cells 3e38
 //   t += max(d*coeff, 1)                 => a hit / leaving the map pushes t past max_range
 // ------------------------------------------------------------------------------
-template <bool UNIT, bool AUX>
+template <bool UNIT, bool AUX, bool TILED>
 __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float gy, float &t, int &c,
                                            int &r, float &d, uint32_t &nstep, const float *pdt,
                                            int stride, uint32_t k4, float max_range, float coeff,
                                            uint32_t low)
 {
+    // TILED: `stride` is tiles per row; 8 instead of 2 address instructions, but the 64 samples of a
+    // wave fall into far fewer 128-B lines (4x8-cell tiles instead of 1x32-cell row pieces)
     float a, b;
     unsigned long long save;
     uint32_t n;
@@ -552,8 +578,19 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
         "v_fma_f32 %[b], %[dy], %[t], %[gy]\n\t"
         "v_cvt_i32_f32_e32 %[c], %[a]\n\t"
         "v_cvt_i32_f32_e32 %[r], %[b]\n\t"
+        ".if %[tiled]\n\t"
+        "v_ashrrev_i32_e32 %[a], 2, %[r]\n\t"
+        "v_ashrrev_i32_e32 %[b], 3, %[c]\n\t"
+        "v_mad_i32_i24 %[a], %[a], %[stride], %[b]\n\t"
+        "v_lshlrev_b32_e32 %[b], 3, %[r]\n\t"
+        "v_and_b32_e32 %[b], 24, %[b]\n\t"
+        "v_and_or_b32 %[b], %[c], 7, %[b]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 5, %[b]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 2, %[k4]\n\t"
+        ".else\n\t"
         "v_mad_i32_i24 %[a], %[r], %[stride], %[c]\n\t"
         "v_lshl_add_u32 %[a], %[a], 2, %[k4]\n\t"
+        ".endif\n\t"
         "global_load_dword %[d], %[a], %[base]\n\t"
         ".if %[aux]\n\t"
         "v_add_u32_e32 %[ns], 1, %[ns]\n\t"
@@ -575,7 +612,8 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
           [b] "=&v"(b), [save] "=&s"(save), [n] "=&s"(n)
         : [dx] "v"(dx), [dy] "v"(dy), [gx] "v"(gx), [gy] "v"(gy),
           [mx] "s"(max_range), [stride] "s"(stride), [k4] "s"(k4), [base] "s"(pdt),
-          [co] "s"(coeff), [low] "s"(low), [unit] "n"(UNIT ? 1 : 0), [aux] "n"(AUX ? 1 : 0)
+          [co] "s"(coeff), [low] "s"(low), [unit] "n"(UNIT ? 1 : 0), [aux] "n"(AUX ? 1 : 0),
+          [tiled] "n"(TILED ? 1 : 0)
         : "vcc", "scc", "memory");
 }
 
@@ -600,7 +638,7 @@ struct StreamParams {
     unsigned long long *dbg; // diagnostics (nullptr in production): 4 words per wave
 };
 
-template <bool AUX, bool CRASH, bool UNIT, int NT, bool INLINE>
+template <bool AUX, bool CRASH, bool UNIT, int NT, bool INLINE, bool TILED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
 void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__restrict__ out,
                           int32_t *__restrict__ hits, uint16_t *__restrict__ steps, CrashParams cp)
@@ -744,7 +782,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         // a wave that can no longer refill is on the launch's critical path (its longest ray
         // decides when the kernel ends): let it win issue arbitration against refilling waves
         if (exhausted && sp.drain_prio) __builtin_amdgcn_s_setprio(3);
-        march_loop<UNIT, AUX>(dx, dy, gx, gy, t, pc, pr, d_last, nstep, pm.pdt, pm.stride, pm.k4,
+        march_loop<UNIT, AUX, TILED>(dx, dy, gx, gy, t, pc, pr, d_last, nstep, pm.pdt, pm.stride, pm.k4,
                               f.max_range, f.step_coeff, exhausted ? 0u : (uint32_t)sp.low_water);
     }
     if (sp.dbg && lane == 0) {

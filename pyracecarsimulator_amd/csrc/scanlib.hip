@@ -137,6 +137,9 @@ struct rl_method {
     bool timed = false;
     DevBuf poses, outs, hits, steps, edge, flag, rec, rec_sorted, order, keys, dbg, hist;
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
+    int tiled = 1;               // padded EDT in 4x8-cell tiles (TILED march); 0 = row-major
+    int pdt_tiled = -1;          // layout the padded copy was built with
+    uint32_t pdt_k4 = 0;
     int slice_log2 = 30;         // launches are cut into pose slices below 2^slice_log2 rays
     int bin_generic = 0;         // diagnostics: force the generic single-workgroup binning kernel
     int inline_prep = 1;         // tiny batches: no binning launch, workgroups derive their own records
@@ -397,6 +400,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
     else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
     else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
+    else if (!strcmp(name, "tiled")) h->tiled = value != 0;
     else if (!strcmp(name, "slice_log2")) h->slice_log2 = value < 8 ? 8 : (value > 30 ? 30 : value);
     else if (!strcmp(name, "inline_max")) h->inline_max = value;
     else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
@@ -420,6 +424,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "bin_multi_min")) *value_out = h->bin_multi_min;
     else if (!strcmp(name, "inline_prep")) *value_out = h->inline_prep;
     else if (!strcmp(name, "bin_generic")) *value_out = h->bin_generic;
+    else if (!strcmp(name, "tiled")) *value_out = h->tiled;
     else if (!strcmp(name, "slice_log2")) *value_out = h->slice_log2;
     else if (!strcmp(name, "inline_max")) *value_out = h->inline_max;
     else if (!strcmp(name, "wg_threads")) *value_out = h->wg_threads;
@@ -781,15 +786,30 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         if ((rc = h->order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
         if ((rc = h->keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
         // padded EDT of this method (border = -1), rebuilt when the map changed
-        if (h->pdt_epoch != m->epoch || !h->pdt.p) {
+        if (h->pdt_epoch != m->epoch || !h->pdt.p || h->pdt_tiled != h->tiled) {
             h->pad = (int)std::ceil(h->max_range) + 2;
-            h->pstride = (m->cols + 2 * h->pad + 31) & ~31;
-            const int prow = m->rows + 2 * h->pad;
-            if ((rc = h->pdt.ensure((size_t)prow * h->pstride * sizeof(float)))) return rc;
-            hipLaunchKernelGGL(pad_dt_kernel, dim3((h->pstride + 255) / 256, prow), dim3(256), 0,
-                               stream, m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad,
-                               h->pstride);
+            if (h->tiled) {
+                h->pad = (h->pad + 7) & ~7;                       // tiles line up with the border
+                const int prow = m->rows + 2 * h->pad, pcol = m->cols + 2 * h->pad;
+                const int tpr = (pcol + 7) / 8, tprow = (prow + 3) / 4;
+                h->pstride = tpr;                                 // tiles per row
+                const long k_elems = ((long)(h->pad / 4) * tpr + h->pad / 8) * 32;
+                if ((rc = h->pdt.ensure((size_t)tprow * tpr * 32 * sizeof(float)))) return rc;
+                hipLaunchKernelGGL(pad_dt_tiled_kernel, dim3((pcol + 255) / 256, prow), dim3(256), 0, stream,
+                                   m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad, tpr, k_elems,
+                                   prow, pcol);
+                h->pdt_k4 = (uint32_t)(k_elems * 4);
+            } else {
+                h->pstride = (m->cols + 2 * h->pad + 31) & ~31;
+                const int prow = m->rows + 2 * h->pad;
+                if ((rc = h->pdt.ensure((size_t)prow * h->pstride * sizeof(float)))) return rc;
+                hipLaunchKernelGGL(pad_dt_kernel, dim3((h->pstride + 255) / 256, prow), dim3(256), 0,
+                                   stream, m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad,
+                                   h->pstride);
+                h->pdt_k4 = (uint32_t)(((size_t)h->pad * h->pstride + h->pad) * 4);
+            }
             h->pdt_epoch = m->epoch;
+            h->pdt_tiled = h->tiled;
         }
         const int bands = n_poses >= 64 ? h->xcd_bands : 1;
         // persistent grid: grid_mult x 256 threads per CU, whatever the workgroup size
@@ -813,7 +833,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         pm.pdt = (const float *)h->pdt.p;
         pm.stride = h->pstride;
         pm.pad = h->pad;
-        pm.k4 = (uint32_t)(((size_t)h->pad * h->pstride + h->pad) * 4);
+        pm.k4 = h->pdt_k4;
         pm.div_stride = make_fastdiv((uint32_t)h->pstride);
         pm.res = m->res;
         StreamParams sp{};
@@ -839,9 +859,15 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         const size_t lds_q = inl ? (((2 + 2 * (size_t)num_rays + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 20)
                                  : lds + 2 * sizeof(float);
         const bool unit = h->step_coeff == 1.0f;
-#define LAUNCH_S(A, C, U, N, I)                                                                   \
-    hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, U, N, I>), dim3(grid), dim3(N), lds_q, stream, \
-                       pm, f, sp, d_out, d_hits, d_steps, cp)
+#define LAUNCH_S(A, C, U, N, I)                                                                          \
+    do {                                                                                                 \
+        if (h->tiled)                                                                                    \
+            hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, U, N, I, true>), dim3(grid), dim3(N), lds_q,  \
+                               stream, pm, f, sp, d_out, d_hits, d_steps, cp);                           \
+        else                                                                                             \
+            hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, U, N, I, false>), dim3(grid), dim3(N), lds_q, \
+                               stream, pm, f, sp, d_out, d_hits, d_steps, cp);                           \
+    } while (0)
 #define LAUNCH_S_N(A, C, U)                                    \
     do {                                                       \
         if (inl) LAUNCH_S(A, C, U, 1024, true);                \

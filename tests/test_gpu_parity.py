@@ -56,6 +56,8 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "slice_log2": 14},                           # batch cut into pose slices (>= 2^30 rays in production)
     {"variant": 1, "bin_multi_min": 64},                        # grid-wide binning kernels
     {"variant": 1, "bin_multi_min": 1 << 30},                   # single-workgroup binning
+    {"variant": 1, "tiled": 0},                                 # row-major padded EDT (default: 4x8-cell tiles)
+    {"variant": 1, "tiled": 0, "inline_prep": 0, "xcd_bands": 1},
 ])
 def test_every_kernel_schedule_is_bit_identical(oracle_mod, opts):
     g = maps.make_maze(400, cell=40, wall=3, p=0.45, seed=21, origin=(-7.0, 3.0, -0.4))

@@ -65,6 +65,8 @@ def main():
     elif a.grid == "prio":
         combos = [dict(variant=1, low_water=lw, wg_threads=1024, grid_mult=8, drain_prio=dp)
                   for lw, dp in itertools.product((16, 24), (0, 1, 0, 1))]
+    elif a.grid == "tiled":
+        combos = [dict(variant=1, tiled=t, low_water=lw) for lw, t in itertools.product((24, 32), (0, 1, 0, 1))]
     elif a.grid == "small":
         combos = [dict(variant=0, grid_mult=8)]
         combos += [dict(variant=1, low_water=lw, wg_threads=nt, grid_mult=8)
