@@ -262,16 +262,23 @@ constexpr uint32_t POSE_INVALID = 0x80000000u;   // order[] flag: origin outside
 #define PDT_HIT __builtin_inff()        /* occupied cell (EDT 0)          */
 #define PDT_OUTSIDE 3.0e38f             /* border: the ray left the map   */
 
-// tiled layout (TILED march): 4-row x 8-column tiles of 128 B, tiles row-major, tpr tiles per row:
-//   element(r, c) = ((r>>2)*tpr + (c>>3))*32 + (r&3)*8 + (c&7)      (r, c may be negative: border)
-__device__ __forceinline__ long pdt_tiled_index(int r, int c, int tpr)
+// tiled layout (TILED march): groups of 4 rows interleaved element-wise,
+//   element(r, c) = (r>>2)*4*pcol + 4*c + (r&3)          (r, c may be negative: border)
+// so one 128-B line holds a 4-row x 8-column block of cells (pcol and the border width are
+// multiples of 8).  In bytes ((r>>2)*4 == r - (r&3)), with S4 = 4*pcol:
+//   byte(r, c) = r*S4 - (r&3)*(S4-4) + 16*c + k4
+// which the march computes in 4 instructions (lshl_add, mad, and, mad).
+__device__ __forceinline__ long pdt_tiled_index(int r, int c, int pcol)
 {
-    return ((long)(r >> 2) * tpr + (c >> 3)) * 32 + (r & 3) * 8 + (c & 7);
+    return (long)(r >> 2) * 4 * pcol + 4 * (long)c + (r & 3);
 }
 
+// Both padded copies hold the march's STEP, not the distance: free cells max(d*coeff, 1) (the
+// two roundings of rm_march, done once per map instead of once per sample), occupied cells +inf,
+// border 3e38 — the stop codes survive because t + code >= max_range either way.
 __global__ __launch_bounds__(256) void pad_dt_tiled_kernel(const float *__restrict__ dt, int rows, int cols,
-                                                           float *__restrict__ pdt, int pad, int tpr,
-                                                           long k_elems, int prow, int pcol)
+                                                           float *__restrict__ pdt, int pad, int pcol,
+                                                           long k_elems, float coeff)
 {
     const int pr = blockIdx.y;
     const int r = pr - pad;
@@ -280,14 +287,15 @@ __global__ __launch_bounds__(256) void pad_dt_tiled_kernel(const float *__restri
         float v = PDT_OUTSIDE;
         if (r >= 0 && r < rows && c >= 0 && c < cols) {
             v = dt[(size_t)r * cols + c];
-            if (v <= 0.0f) v = PDT_HIT;
+            v = v <= 0.0f ? PDT_HIT : __builtin_fmaxf(v * coeff, 1.0f);
         }
-        pdt[k_elems + pdt_tiled_index(r, c, tpr)] = v;
+        pdt[k_elems + pdt_tiled_index(r, c, pcol)] = v;
     }
 }
 
 __global__ __launch_bounds__(256) void pad_dt_kernel(const float *__restrict__ dt, int rows, int cols,
-                                                     float *__restrict__ pdt, int pad, int stride)
+                                                     float *__restrict__ pdt, int pad, int stride,
+                                                     float coeff)
 {
     const int pr = blockIdx.y;                      // padded row
     const int r = pr - pad;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(256) void pad_dt_kernel(const float *__restrict__ d
         float v = PDT_OUTSIDE;
         if (r >= 0 && r < rows && c >= 0 && c < cols) {
             v = dt[(size_t)r * cols + c];
-            if (v <= 0.0f) v = PDT_HIT;
+            v = v <= 0.0f ? PDT_HIT : __builtin_fmaxf(v * coeff, 1.0f);
         }
         pdt[(size_t)pr * stride + pc] = v;
     }
@@ -559,14 +567,14 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f)
 //   d  = pdt[(r*stride + c)*4 + k4]     occupied cells read +inf, border cells 3e38
 //   t += max(d*coeff, 1)                 => a hit / leaving the map pushes t past max_range
 // ------------------------------------------------------------------------------
-template <bool UNIT, bool AUX, bool TILED>
+template <bool AUX, bool TILED>
 __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float gy, float &t, int &c,
                                            int &r, float &d, uint32_t &nstep, const float *pdt,
-                                           int stride, uint32_t k4, float max_range, float coeff,
+                                           int stride, int nstride, uint32_t k4, float max_range,
                                            uint32_t low)
 {
-    // TILED: `stride` is tiles per row; 8 instead of 2 address instructions, but the 64 samples of a
-    // wave fall into far fewer 128-B lines (4x8-cell tiles instead of 1x32-cell row pieces)
+    // TILED: stride = S4 (bytes), nstride = -(S4-4): 4 address instructions instead of 2, but the
+    // samples of a wave fall into fewer 128-B lines (4x8-cell blocks instead of 1x32-cell row pieces)
     float a, b;
     unsigned long long save;
     uint32_t n;
@@ -579,14 +587,10 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
         "v_cvt_i32_f32_e32 %[c], %[a]\n\t"
         "v_cvt_i32_f32_e32 %[r], %[b]\n\t"
         ".if %[tiled]\n\t"
-        "v_ashrrev_i32_e32 %[a], 2, %[r]\n\t"
-        "v_ashrrev_i32_e32 %[b], 3, %[c]\n\t"
-        "v_mad_i32_i24 %[a], %[a], %[stride], %[b]\n\t"
-        "v_lshlrev_b32_e32 %[b], 3, %[r]\n\t"
-        "v_and_b32_e32 %[b], 24, %[b]\n\t"
-        "v_and_or_b32 %[b], %[c], 7, %[b]\n\t"
-        "v_lshl_add_u32 %[a], %[a], 5, %[b]\n\t"
-        "v_lshl_add_u32 %[a], %[a], 2, %[k4]\n\t"
+        "v_lshl_add_u32 %[a], %[c], 4, %[k4]\n\t"
+        "v_and_b32_e32 %[b], 3, %[r]\n\t"
+        "v_mad_i32_i24 %[a], %[r], %[stride], %[a]\n\t"
+        "v_mad_i32_i24 %[a], %[b], %[nstride], %[a]\n\t"
         ".else\n\t"
         "v_mad_i32_i24 %[a], %[r], %[stride], %[c]\n\t"
         "v_lshl_add_u32 %[a], %[a], 2, %[k4]\n\t"
@@ -596,13 +600,7 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
         "v_add_u32_e32 %[ns], 1, %[ns]\n\t"
         ".endif\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-        ".if %[unit]\n\t"
-        "v_max_i32_e32 %[a], 1.0, %[d]\n\t"
-        ".else\n\t"
-        "v_mul_f32_e32 %[a], %[co], %[d]\n\t"
-        "v_max_f32_e32 %[a], 1.0, %[a]\n\t"
-        ".endif\n\t"
-        "v_add_f32_e32 %[t], %[t], %[a]\n\t"
+        "v_add_f32_e32 %[t], %[t], %[d]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], %[t]\n\t"
         "s_bcnt1_i32_b64 %[n], exec\n\t"
         "s_cmp_gt_u32 %[n], %[low]\n\t"
@@ -611,15 +609,15 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
         : [t] "+v"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [ns] "+v"(nstep), [a] "=&v"(a),
           [b] "=&v"(b), [save] "=&s"(save), [n] "=&s"(n)
         : [dx] "v"(dx), [dy] "v"(dy), [gx] "v"(gx), [gy] "v"(gy),
-          [mx] "s"(max_range), [stride] "s"(stride), [k4] "s"(k4), [base] "s"(pdt),
-          [co] "s"(coeff), [low] "s"(low), [unit] "n"(UNIT ? 1 : 0), [aux] "n"(AUX ? 1 : 0),
-          [tiled] "n"(TILED ? 1 : 0)
+          [mx] "s"(max_range), [stride] "s"(stride), [nstride] "s"(nstride), [k4] "s"(k4),
+          [base] "s"(pdt), [low] "s"(low), [aux] "n"(AUX ? 1 : 0), [tiled] "n"(TILED ? 1 : 0)
         : "vcc", "scc", "memory");
 }
 
+
 struct PadMap {
-    const float *pdt;        // padded EDT, (rows+2*pad) x stride, border = -1
-    int stride, pad;
+    const float *pdt;        // padded step map (pad_dt_kernel / pad_dt_tiled_kernel)
+    int stride, nstride, pad; // row-major: elements per row, 0; tiled: S4 = 4*pcol bytes, -(S4-4)
     uint32_t k4;             // byte offset of map cell (0,0): (pad*stride + pad)*4
     FastDiv div_stride;
     float res;
@@ -635,10 +633,11 @@ struct StreamParams {
     const MapParams *map;    //   records of the chunks it owns itself (device copy of the map params)
     int k_max;               // INLINE only: LDS capacity in chunk records
     int drain_prio;          // raise wave priority once the workgroup's stream is exhausted
+    int run_log2;            // a workgroup's stream interleaves RUNS of 2^run_log2 consecutive 64-ray blocks
     unsigned long long *dbg; // diagnostics (nullptr in production): 4 words per wave
 };
 
-template <bool AUX, bool CRASH, bool UNIT, int NT, bool INLINE, bool TILED>
+template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
 void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__restrict__ out,
                           int32_t *__restrict__ hits, uint16_t *__restrict__ steps, CrashParams cp)
@@ -667,8 +666,12 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     // g, g+G, ... — K blocks, 64*K ray slots (any num_rays, no padding lanes)
     const uint32_t seg_rays = (seg_hi - seg_lo) * (uint32_t)f.num_rays;
     const uint32_t seg_chunks = (seg_rays + 63u) >> 6;
-    const uint32_t K = g < seg_chunks ? (seg_chunks - g + G - 1) / G : 0;
+    const uint32_t rl = (uint32_t)sp.run_log2, rmask = (1u << rl) - 1u;
+    const uint32_t seg_runs = (seg_chunks + rmask) >> rl;
+    const uint32_t K = (g < seg_runs ? (seg_runs - g + G - 1) / G : 0) << rl;
     const uint32_t total = K << 6;
+    // i-th block of this workgroup's stream -> first ray of the block
+    auto blk_of = [&](uint32_t i) { return (((g + (i >> rl) * G) << rl) + (i & rmask)) << 6; };
     const unsigned lane = threadIdx.x & 63;
     if (INLINE) {
         // small batches: no binning launch in front of the march — each workgroup turns the poses
@@ -676,7 +679,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         const MapParams mp = *sp.map;
         // (num_rays >= 64 here, so a block of 64 rays touches at most two poses: slots 2k, 2k+1)
         for (uint32_t k2 = threadIdx.x; k2 < 2 * K; k2 += NT) {
-            const uint32_t p0 = fast_div((g + (k2 >> 1) * G) << 6, sp.div_B) + (k2 & 1);
+            const uint32_t p0 = fast_div(blk_of(k2 >> 1), sp.div_B) + (k2 & 1);
             if (seg_lo + p0 < seg_hi) {
                 PoseRec r;
                 const uint32_t kf = pose_record(mp, sp.raw_poses, (int)(seg_lo + p0), 0, 1, 1, r);
@@ -696,7 +699,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     bool has_ray = false;
     float gx = 0, gy = 0, dx = 0, dy = 0;
     float t = INF;                 // t < max_range  <=>  the lane is marching
-    float d_last = 1.0f;           // last sample: PDT_HIT, PDT_OUTSIDE, or the free cell's distance
+    float d_last = 1.0f;           // last sample: PDT_HIT, PDT_OUTSIDE, or the free cell's step
     int pc = 0, pr = 0;            // cell of the last sample
     uint32_t oidx = 0, nstep = 0, pose = 0;
     int jbeam = 0;
@@ -743,7 +746,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 exhausted = qb + cnt >= total;
                 const uint32_t q = qb + rank;
                 if (mine && q < total) {
-                    const uint32_t blk = (g + (q >> 6) * G) << 6;
+                    const uint32_t blk = blk_of(q >> 6);
                     const uint32_t ray = blk + (q & 63);
                     if (ray < seg_rays) {
                         const uint32_t spose = fast_div(ray, sp.div_B);
@@ -782,8 +785,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         // a wave that can no longer refill is on the launch's critical path (its longest ray
         // decides when the kernel ends): let it win issue arbitration against refilling waves
         if (exhausted && sp.drain_prio) __builtin_amdgcn_s_setprio(3);
-        march_loop<UNIT, AUX, TILED>(dx, dy, gx, gy, t, pc, pr, d_last, nstep, pm.pdt, pm.stride, pm.k4,
-                              f.max_range, f.step_coeff, exhausted ? 0u : (uint32_t)sp.low_water);
+        march_loop<AUX, TILED>(dx, dy, gx, gy, t, pc, pr, d_last, nstep, pm.pdt, pm.stride, pm.nstride,
+                               pm.k4, f.max_range, exhausted ? 0u : (uint32_t)sp.low_water);
     }
     if (sp.dbg && lane == 0) {
         const size_t gw = ((size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * 4;
@@ -1168,8 +1171,12 @@ __global__ __launch_bounds__(NT) void bl_fan_stream_kernel(MapParams m, FanParam
     const uint32_t seg_hi = (uint32_t)(((long)f.n_poses * (band + 1)) / nb);
     const uint32_t seg_rays = (seg_hi - seg_lo) * (uint32_t)f.num_rays;
     const uint32_t seg_chunks = (seg_rays + 63u) >> 6;
-    const uint32_t K = g < seg_chunks ? (seg_chunks - g + G - 1) / G : 0;
+    const uint32_t rl = (uint32_t)sp.run_log2, rmask = (1u << rl) - 1u;
+    const uint32_t seg_runs = (seg_chunks + rmask) >> rl;
+    const uint32_t K = (g < seg_runs ? (seg_runs - g + G - 1) / G : 0) << rl;
     const uint32_t total = K << 6;
+    // i-th block of this workgroup's stream -> first ray of the block
+    auto blk_of = [&](uint32_t i) { return (((g + (i >> rl) * G) << rl) + (i & rmask)) << 6; };
     const unsigned lane = threadIdx.x & 63;
     auto occupied = [&](int col, int row) -> bool {
         return (m.bits[(size_t)row * m.bits_stride + (col >> 5)] >> (col & 31)) & 1u;
@@ -1204,7 +1211,7 @@ __global__ __launch_bounds__(NT) void bl_fan_stream_kernel(MapParams m, FanParam
                 qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
                 exhausted = qb + cnt >= total;
                 const uint32_t q = qb + rank;
-                const uint32_t ray = ((g + (q >> 6) * G) << 6) + (q & 63);
+                const uint32_t ray = blk_of(q >> 6) + (q & 63);
                 if (!active && q < total && ray < seg_rays) {
                     const uint32_t spose = fast_div(ray, sp.div_B);
                     const int j = (int)(ray - spose * (uint32_t)f.num_rays);

@@ -137,6 +137,7 @@ struct rl_method {
     bool timed = false;
     DevBuf poses, outs, hits, steps, edge, flag, rec, rec_sorted, order, keys, dbg, hist;
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
+    int run_log2 = -1;           // stream interleave granularity: runs of 2^run_log2 blocks; -1 = by batch size
     int tiled = 1;               // padded EDT in 4x8-cell tiles (TILED march); 0 = row-major
     int pdt_tiled = -1;          // layout the padded copy was built with
     uint32_t pdt_k4 = 0;
@@ -401,6 +402,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
     else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
     else if (!strcmp(name, "tiled")) h->tiled = value != 0;
+    else if (!strcmp(name, "run_log2")) h->run_log2 = value < 0 ? -1 : value > 8 ? 8 : value;
     else if (!strcmp(name, "slice_log2")) h->slice_log2 = value < 8 ? 8 : (value > 30 ? 30 : value);
     else if (!strcmp(name, "inline_max")) h->inline_max = value;
     else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
@@ -425,6 +427,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "inline_prep")) *value_out = h->inline_prep;
     else if (!strcmp(name, "bin_generic")) *value_out = h->bin_generic;
     else if (!strcmp(name, "tiled")) *value_out = h->tiled;
+    else if (!strcmp(name, "run_log2")) *value_out = h->run_log2;
     else if (!strcmp(name, "slice_log2")) *value_out = h->slice_log2;
     else if (!strcmp(name, "inline_max")) *value_out = h->inline_max;
     else if (!strcmp(name, "wg_threads")) *value_out = h->wg_threads;
@@ -789,15 +792,15 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         if (h->pdt_epoch != m->epoch || !h->pdt.p || h->pdt_tiled != h->tiled) {
             h->pad = (int)std::ceil(h->max_range) + 2;
             if (h->tiled) {
-                h->pad = (h->pad + 7) & ~7;                       // tiles line up with the border
-                const int prow = m->rows + 2 * h->pad, pcol = m->cols + 2 * h->pad;
-                const int tpr = (pcol + 7) / 8, tprow = (prow + 3) / 4;
-                h->pstride = tpr;                                 // tiles per row
-                const long k_elems = ((long)(h->pad / 4) * tpr + h->pad / 8) * 32;
-                if ((rc = h->pdt.ensure((size_t)tprow * tpr * 32 * sizeof(float)))) return rc;
+                h->pad = (h->pad + 7) & ~7;                       // 128-B lines line up with the border
+                const int prow = (m->rows + 2 * h->pad + 3) & ~3;
+                const int pcol = (m->cols + 2 * h->pad + 7) & ~7;
+                h->pstride = 4 * pcol;                            // S4: bytes between rows of a 4-row group
+                const long k_elems = (long)h->pad * pcol + 4L * h->pad;
+                if ((rc = h->pdt.ensure((size_t)prow * pcol * sizeof(float)))) return rc;
                 hipLaunchKernelGGL(pad_dt_tiled_kernel, dim3((pcol + 255) / 256, prow), dim3(256), 0, stream,
-                                   m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad, tpr, k_elems,
-                                   prow, pcol);
+                                   m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad, pcol, k_elems,
+                                   h->step_coeff);
                 h->pdt_k4 = (uint32_t)(k_elems * 4);
             } else {
                 h->pstride = (m->cols + 2 * h->pad + 31) & ~31;
@@ -805,7 +808,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
                 if ((rc = h->pdt.ensure((size_t)prow * h->pstride * sizeof(float)))) return rc;
                 hipLaunchKernelGGL(pad_dt_kernel, dim3((h->pstride + 255) / 256, prow), dim3(256), 0,
                                    stream, m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad,
-                                   h->pstride);
+                                   h->pstride, h->step_coeff);
                 h->pdt_k4 = (uint32_t)(((size_t)h->pad * h->pstride + h->pad) * 4);
             }
             h->pdt_epoch = m->epoch;
@@ -832,6 +835,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         PadMap pm{};
         pm.pdt = (const float *)h->pdt.p;
         pm.stride = h->pstride;
+        pm.nstride = h->tiled ? -(h->pstride - 4) : 0;
         pm.pad = h->pad;
         pm.k4 = h->pdt_k4;
         pm.div_stride = make_fastdiv((uint32_t)h->pstride);
@@ -855,33 +859,35 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             if ((rc = h->dbg.ensure((size_t)grid * waves_per_wg * 4 * sizeof(uint64_t)))) return rc;
             sp.dbg = (unsigned long long *)h->dbg.p;
         }
+        // runs of consecutive blocks keep a workgroup on one pose for a while (L1/TA locality) but
+        // coarsen the static balance: 16+ runs per workgroup, at most 32 blocks per run
+        int rl2 = h->run_log2;
+        if (rl2 < 0) {
+            const long per_wg = n_chunks / std::max(grid, 1);
+            for (rl2 = 0; rl2 < 5 && (per_wg >> (rl2 + 1)) >= 16; ++rl2) {}
+        }
+        sp.run_log2 = inl ? 0 : rl2;               // (the inline LDS record table is sized for single blocks)
         h->last_grid = grid * waves_per_wg / WAVES_PER_WG;
         const size_t lds_q = inl ? (((2 + 2 * (size_t)num_rays + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 20)
                                  : lds + 2 * sizeof(float);
-        const bool unit = h->step_coeff == 1.0f;
-#define LAUNCH_S(A, C, U, N, I)                                                                          \
-    do {                                                                                                 \
-        if (h->tiled)                                                                                    \
-            hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, U, N, I, true>), dim3(grid), dim3(N), lds_q,  \
-                               stream, pm, f, sp, d_out, d_hits, d_steps, cp);                           \
-        else                                                                                             \
-            hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, U, N, I, false>), dim3(grid), dim3(N), lds_q, \
-                               stream, pm, f, sp, d_out, d_hits, d_steps, cp);                           \
+#define LAUNCH_S(A, C, N, I)                                                                          \
+    do {                                                                                              \
+        if (h->tiled)                                                                                 \
+            hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, N, I, true>), dim3(grid), dim3(N), lds_q,  \
+                               stream, pm, f, sp, d_out, d_hits, d_steps, cp);                        \
+        else                                                                                          \
+            hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, N, I, false>), dim3(grid), dim3(N), lds_q, \
+                               stream, pm, f, sp, d_out, d_hits, d_steps, cp);                        \
     } while (0)
-#define LAUNCH_S_N(A, C, U)                                    \
-    do {                                                       \
-        if (inl) LAUNCH_S(A, C, U, 1024, true);                \
-        else if (nt == 1024) LAUNCH_S(A, C, U, 1024, false);   \
-        else if (nt == 512) LAUNCH_S(A, C, U, 512, false);     \
-        else LAUNCH_S(A, C, U, 256, false);                    \
+#define LAUNCH_S_N(A, C)                                    \
+    do {                                                    \
+        if (inl) LAUNCH_S(A, C, 1024, true);                \
+        else if (nt == 1024) LAUNCH_S(A, C, 1024, false);   \
+        else if (nt == 512) LAUNCH_S(A, C, 512, false);     \
+        else LAUNCH_S(A, C, 256, false);                    \
     } while (0)
-        if (unit) {
-            if (crash) { if (aux) LAUNCH_S_N(true, true, true); else LAUNCH_S_N(false, true, true); }
-            else       { if (aux) LAUNCH_S_N(true, false, true); else LAUNCH_S_N(false, false, true); }
-        } else {
-            if (crash) { if (aux) LAUNCH_S_N(true, true, false); else LAUNCH_S_N(false, true, false); }
-            else       { if (aux) LAUNCH_S_N(true, false, false); else LAUNCH_S_N(false, false, false); }
-        }
+        if (crash) { if (aux) LAUNCH_S_N(true, true); else LAUNCH_S_N(false, true); }
+        else       { if (aux) LAUNCH_S_N(true, false); else LAUNCH_S_N(false, false); }
 #undef LAUNCH_S_N
 #undef LAUNCH_S
     } else {

@@ -67,6 +67,8 @@ def main():
                   for lw, dp in itertools.product((16, 24), (0, 1, 0, 1))]
     elif a.grid == "tiled":
         combos = [dict(variant=1, tiled=t, low_water=lw) for lw, t in itertools.product((24, 32), (0, 1, 0, 1))]
+    elif a.grid == "runs":
+        combos = [dict(variant=1, inline_prep=0, run_log2=r) for r in (0, 1, 2, 3, 4, 5, 0, 2, 4)]
     elif a.grid == "small":
         combos = [dict(variant=0, grid_mult=8)]
         combos += [dict(variant=1, low_water=lw, wg_threads=nt, grid_mult=8)
