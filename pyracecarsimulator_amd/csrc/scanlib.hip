@@ -137,6 +137,7 @@ struct rl_method {
     bool timed = false;
     DevBuf poses, outs, hits, steps, edge, flag, rec, rec_sorted, order, keys, dbg, hist;
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
+    int inline_map_kb = 2048;    // maps up to this size (f32 cells) never take the binning launch while the records fit LDS
     int run_log2 = -1;           // stream interleave granularity: runs of 2^run_log2 blocks; -1 = by batch size
     int tiled = 1;               // padded EDT in 4x8-cell tiles (TILED march); 0 = row-major
     int pdt_tiled = -1;          // layout the padded copy was built with
@@ -402,6 +403,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
     else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
     else if (!strcmp(name, "tiled")) h->tiled = value != 0;
+    else if (!strcmp(name, "inline_map_kb")) h->inline_map_kb = value < 0 ? 0 : value;
     else if (!strcmp(name, "run_log2")) h->run_log2 = value < 0 ? -1 : value > 8 ? 8 : value;
     else if (!strcmp(name, "slice_log2")) h->slice_log2 = value < 8 ? 8 : (value > 30 ? 30 : value);
     else if (!strcmp(name, "inline_max")) h->inline_max = value;
@@ -427,6 +429,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "inline_prep")) *value_out = h->inline_prep;
     else if (!strcmp(name, "bin_generic")) *value_out = h->bin_generic;
     else if (!strcmp(name, "tiled")) *value_out = h->tiled;
+    else if (!strcmp(name, "inline_map_kb")) *value_out = h->inline_map_kb;
     else if (!strcmp(name, "run_log2")) *value_out = h->run_log2;
     else if (!strcmp(name, "slice_log2")) *value_out = h->slice_log2;
     else if (!strcmp(name, "inline_max")) *value_out = h->inline_max;
@@ -818,8 +821,12 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         // persistent grid: grid_mult x 256 threads per CU, whatever the workgroup size
         int nt = h->wg_threads;
         // small batches: skip the binning launch, workgroups derive the records of their own chunks
-        bool inl = h->inline_prep && n_poses < h->inline_max && n_poses < h->bin_multi_min &&
-                   num_rays >= 64;
+        // ... and whenever the map is small enough to sit in every XCD's L2: tile order buys nothing
+        // there, so the binning launch (~9 us) is pure overhead (colombia, 4096 poses: +15 %)
+        const bool small_map = (size_t)m->rows * m->cols * sizeof(float) <= (size_t)h->inline_map_kb * 1024;
+        bool inl = h->inline_prep && num_rays >= 64 &&
+                   (small_map || (n_poses < h->inline_max && n_poses < h->bin_multi_min));
+        // (small maps: up to the ~40k poses whose records fit a workgroup's LDS, checked below)
         int k_max = 0;
         if (inl) {
             nt = 1024;

@@ -56,6 +56,9 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "slice_log2": 14},                           # batch cut into pose slices (>= 2^30 rays in production)
     {"variant": 1, "bin_multi_min": 64},                        # grid-wide binning kernels
     {"variant": 1, "bin_multi_min": 1 << 30},                   # single-workgroup binning
+    {"variant": 1, "inline_map_kb": 0},                         # big-map policy: binning launch from 512 poses up
+    {"variant": 1, "inline_map_kb": 0, "run_log2": 3},          # ... with runs of 8 blocks per workgroup turn
+    {"variant": 1, "inline_prep": 0, "run_log2": 5, "grid_mult": 1},
     {"variant": 1, "tiled": 0},                                 # row-major padded EDT (default: 4x8-cell tiles)
     {"variant": 1, "tiled": 0, "inline_prep": 0, "xcd_bands": 1},
 ])

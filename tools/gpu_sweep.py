@@ -69,6 +69,10 @@ def main():
         combos = [dict(variant=1, tiled=t, low_water=lw) for lw, t in itertools.product((24, 32), (0, 1, 0, 1))]
     elif a.grid == "runs":
         combos = [dict(variant=1, inline_prep=0, run_log2=r) for r in (0, 1, 2, 3, 4, 5, 0, 2, 4)]
+    elif a.grid == "nosort":
+        combos = [dict(variant=1), dict(variant=1, inline_max=1000000), dict(variant=1, inline_max=1000000, xcd_bands=1),
+                  dict(variant=1, inline_max=512, sort_poses=0), dict(variant=1, inline_max=512, sort_poses=0, xcd_bands=1),
+                  dict(variant=1, inline_max=512, sort_poses=1, xcd_bands=8)]
     elif a.grid == "small":
         combos = [dict(variant=0, grid_mult=8)]
         combos += [dict(variant=1, low_water=lw, wg_threads=nt, grid_mult=8)
