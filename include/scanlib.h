@@ -143,6 +143,24 @@ int rl_check_collision_groups_device(rl_method *h, const float *d_poses_p3, int 
                                      double crash_thresh, int *d_first_crashed,
                                      float *d_ranges_or_null, void *hip_stream);
 
+/* ---- scan consumer: Follow-the-Gap steering --------------------------
+ * Replaces followgap.PyFollowGap(ws, md, ma, angle_inc).eval(lidar, size)
+ * (followgap/followgap.pyx:23-31 -> FollowGap::eval, followgap/followgap.hpp:104-129; built at
+ * scripts/mcts.py:97-99, scripts/two_player/simple_driver.py:31, called at scripts/mcts.py:267,
+ * simple_driver.py:51) for a BATCH of scans: n_scans rows of `size` float32 ranges in, one
+ * steering angle per scan out, one wave per scan.  Bit-identical to the reference's compiled
+ * header (tests/golden/followgap_ref.npz).  size < 10 -> RL_ERR_INVALID (the reference indexes
+ * out of bounds there); a gap consisting of the single last beam reads beam size-1 where the
+ * reference reads one past the array.                                                           */
+typedef struct rl_followgap rl_followgap;
+int rl_followgap_create(int device, int window_size, float max_distance, float max_angle,
+                        float angle_inc, rl_followgap **out);
+void rl_followgap_destroy(rl_followgap *g);
+int rl_followgap_eval(rl_followgap *g, const float *scans, int n_scans, int size, float *angles);
+/* scans and angles resident on the device (e.g. the ranges a scan call just wrote)              */
+int rl_followgap_eval_device(rl_followgap *g, const float *d_scans, int n_scans, int size,
+                             float *d_angles, void *hip_stream);
+
 /* ---- roll-out pose generator ---------------------------------------
  * The step in front of scanMany in MCTS.rollout (scripts/mcts.py:214-231): 200 x
  * {Car::control, Car::updatePosition(dt)} (racecar/src/racecar.cpp:53-98,118-237,294-303) per

@@ -74,6 +74,8 @@ def lib():
                                          C.c_double, _f64p]
         L.orc_is_crashed.argtypes = [_f32p, C.c_int, C.c_int, _f64p, C.c_double]
         L.orc_is_crashed.restype = C.c_int
+        L.orc_followgap_eval.argtypes = [_f32p, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.orc_followgap_eval.restype = C.c_float
         L.orc_max_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -250,6 +252,13 @@ def is_crashed(rays, num_rays, poses, edge, crash_thresh):
     edge = np.ascontiguousarray(edge, dtype=np.float64)
     return int(lib().orc_is_crashed(_p(rays, _f32p), num_rays, poses, _p(edge, _f64p),
                                     crash_thresh))
+
+
+def followgap_eval(lidar, max_distance, max_angle, angle_inc, size=None):
+    """FollowGap::eval restatement (followgap/followgap.hpp:104-129) for one scan."""
+    lidar = np.ascontiguousarray(lidar, dtype=np.float32)
+    n = len(lidar) if size is None else int(size)
+    return float(lib().orc_followgap_eval(_p(lidar, _f32p), n, max_distance, max_angle, angle_inc))
 
 
 def max_threads():

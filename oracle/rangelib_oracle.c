@@ -711,3 +711,52 @@ int orc_is_crashed(const float *rays, int num_rays, int poses, const double *edg
                 return i - 1;
     return -i;
 }
+
+
+/* ------------------------------------------------------------------------------
+ * FollowGap::eval — restated from followgap/followgap.hpp:104-129 with its
+ * helpers preprocessLidar (:18-27), safetyBubble (:67-79), findMaxGap (:29-65), findBestPoint
+ * (:99-102) and getSteerAng (:81-97).  Pinned against the reference header itself, compiled in
+ * place into oracle/_ref/libfollowgap_ref.so (tests/golden/followgap_ref.npz).
+ * Two corners of the reference are undefined and are given a definition here:
+ *   size < 10   : `lidar.size()-10` wraps (size_t) and the loop runs off the vector -> rejected (NaN);
+ *   best == size: happens when the only/first longest gap is the single last beam; the reference
+ *                 reads lidar[size] (one past the end) -> this statement reads lidar[size-1].
+ * ------------------------------------------------------------------------------ */
+float orc_followgap_eval(const float *lidar, int size, float max_distance, float max_angle,
+                         float angle_inc)
+{
+    if (size < 10) return NAN;
+    float *v = (float *)malloc((size_t)size * sizeof(float));
+    for (int i = 0; i < size; ++i) v[i] = lidar[i];
+    for (int i = 0; i < size - 10; ++i)                    /* preprocessLidar :18-27 */
+        if (v[i] > max_distance) v[i] = max_distance;
+    int min_point = 0;                                     /* eval :112-119 */
+    for (int i = 0; i < size; ++i)
+        if (v[i] != 0 && v[i] < v[min_point]) min_point = i;
+    v[min_point] = 0.0f;                                   /* safetyBubble(v, min_point, 5) :67-79 */
+    for (int i = -5; i < 5; ++i)
+        if (min_point + i > 0 && min_point + i < size - 1) v[min_point + i] = 0.0f;
+    int max_start = 0, max_size = 0, c = 0;                /* findMaxGap :29-65 */
+    int cur_start = 0, cur_size = 0;
+    while (c < size) {
+        cur_start = c;
+        cur_size = 0;
+        while (c < size && v[c] > 1.75) { ++cur_size; ++c; }
+        if (cur_size > max_size) { max_start = cur_start; max_size = cur_size; cur_size = 0; }
+        ++c;
+    }
+    int g0, g1;
+    if (cur_size > max_size) { g0 = cur_start; g1 = cur_start + cur_size + 1; }
+    else { g0 = max_start; g1 = max_start + max_size + 1; }
+    free(v);
+    const int best = (g0 + g1) / 2;                        /* findBestPoint :99-102 */
+    const float d = lidar[best < size ? best : size - 1];
+    float angle;                                           /* getSteerAng :81-97 */
+    if (best > size / 2) angle = (float)(-angle_inc * ((size / 2.0) - best));
+    else angle = (float)(angle_inc * (best - (size / 2.0)));
+    angle = 2 * (angle / d);
+    const float lo = -max_angle;
+    const float a1 = (angle < lo) ? lo : angle;            /* std::max(angle, -max_angle) */
+    return (max_angle < a1) ? max_angle : a1;              /* std::min(.., max_angle)    */
+}

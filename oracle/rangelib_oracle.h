@@ -118,6 +118,9 @@ void orc_cddt_rays(const orc_map *m, const orc_cddt *c, float max_range_px,
  * shifted by one increment) and Car::isCrashed :305-328.                       */
 void orc_edge_distances(int num_rays, double min_ang, double inc, double scan_dist_to_base,
                         double width, double wheelbase, double *edge);
+/* FollowGap::eval (followgap/followgap.hpp:104-129); NaN when size < 10 */
+float orc_followgap_eval(const float *lidar, int size, float max_distance, float max_angle,
+                         float angle_inc);
 int orc_is_crashed(const float *rays, int num_rays, int poses, const double *edge,
                    double crash_thresh);
 

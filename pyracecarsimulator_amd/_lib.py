@@ -57,6 +57,12 @@ SYMBOLS = {
     "rl_check_collision_groups_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                                    C.c_int, C.c_void_p, C.c_double, C.c_void_p,
                                                    C.c_void_p, C.c_void_p]),
+    "rl_followgap_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                      C.POINTER(C.c_void_p)]),
+    "rl_followgap_destroy": (None, [C.c_void_p]),
+    "rl_followgap_eval": (C.c_int, [C.c_void_p, f32p, C.c_int, C.c_int, f32p]),
+    "rl_followgap_eval_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p]),
     "rl_car_create": (C.c_int, [C.c_int, f64p, C.POINTER(C.c_void_p)]),
     "rl_car_destroy": (None, [C.c_void_p]),
     "rl_car_rollout": (C.c_int, [C.c_void_p, f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_double, f32p,

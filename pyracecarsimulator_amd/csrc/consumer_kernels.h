@@ -1,0 +1,110 @@
+// consumer_kernels.h — per-scan consumers of a batch of ranges.
+//
+// followgap_kernel: FollowGap::eval (/root/reference/followgap/followgap.hpp:104-129) for a batch
+// of scans, ONE WAVE PER SCAN, the scan held in LDS.  The reference is four serial passes over the
+// beams; here
+//   preprocessLidar (:18-27)  — clamp fused into the load (beams [0, size-10));
+//   min_point (:112-119)      — a running strict minimum over the non-zero beams seeded with beam
+//                               0 == the lexicographic (value, index) minimum over
+//                               {0} ∪ {i : v[i] != 0}: per-lane partial + 6 xor-shuffles;
+//   safetyBubble (:67-79)     — 11 lanes zero their beam;
+//   findMaxGap (:29-65)       — first longest run of beams > 1.75: every lane owns a contiguous
+//                               chunk, a suffix-min over lanes gives the next beam <= 1.75 after the
+//                               chunk, a backward walk yields the run length at every run start,
+//                               then a (length desc, start asc) wave reduction;
+//   getSteerAng (:81-97)      — lane 0, same float/double expression.
+// Undefined corners of the reference are given a definition (include/scanlib.h): size < 10 is
+// rejected by the host; best == size (gap = the single last beam) reads beam size-1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scan {
+
+struct FollowGapParams {
+    float max_distance, max_angle, angle_inc;
+    int size;                // beams per scan (>= 10)
+};
+
+__global__ __launch_bounds__(64) void followgap_kernel(const float *__restrict__ scans, int n_scans,
+                                                       FollowGapParams p, float *__restrict__ angles)
+{
+    extern __shared__ float v[];                       // size beams of this wave's scan
+    const int lane = threadIdx.x;
+    const int size = p.size;
+    for (int s = blockIdx.x; s < n_scans; s += gridDim.x) {
+        const float *lidar = scans + (size_t)s * size;
+        // ---- load + clamp; partial (value, index) minimum over the candidates
+        const float v0 = lidar[0] > p.max_distance && size > 10 ? p.max_distance : lidar[0];
+        float best_v = v0;
+        int best_i = 0;
+        for (int i = lane; i < size; i += 64) {
+            float x = lidar[i];
+            if (i < size - 10 && x > p.max_distance) x = p.max_distance;
+            v[i] = x;
+            // running rule `v[i] != 0 && v[i] < v[min_point]` (NaN never passes)
+            if (x != 0.0f && (x < best_v || (x == best_v && i < best_i))) { best_v = x; best_i = i; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(best_v, off);
+            const int oi = __shfl_xor(best_i, off);
+            // a NaN seed (v[0]) loses to nothing: every lane carries the same seed, so x < NaN is
+            // false everywhere and index 0 survives
+            if (ov < best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+        }
+        __syncthreads();
+        // ---- safety bubble, radius 5
+        if (lane < 11) {
+            const int idx = best_i + lane - 5;         // lane 10 -> the centre itself
+            if (lane == 10) v[best_i] = 0.0f;
+            else if (idx > 0 && idx < size - 1) v[idx] = 0.0f;
+        }
+        __syncthreads();
+        // ---- first longest run of beams > 1.75
+        const int C = (size + 63) >> 6;
+        const int lo = lane * C, hi = min(lo + C, size);
+        int first_zero = 0x7fffffff;
+        for (int i = lo; i < hi; ++i)
+            if (!(v[i] > 1.75f)) { first_zero = i; break; }
+        // exclusive suffix-min over lanes: next beam <= 1.75 after this lane's chunk
+        int nz = first_zero;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_down(nz, off);
+            if (lane + off < 64) nz = min(nz, o);
+        }
+        int next_zero = __shfl_down(nz, 1);
+        if (lane == 63) next_zero = 0x7fffffff;
+        next_zero = min(next_zero, size);
+        int run_len = 0, run_start = 0;
+        for (int i = hi - 1; i >= lo; --i) {
+            if (!(v[i] > 1.75f)) { next_zero = i; continue; }
+            if (i == 0 || !(v[i - 1] > 1.75f)) {       // a run starts here
+                const int len = next_zero - i;
+                if (len >= run_len) { run_len = len; run_start = i; }   // walking backwards: ties -> smaller start
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const int ol = __shfl_xor(run_len, off);
+            const int os = __shfl_xor(run_start, off);
+            if (ol > run_len || (ol == run_len && os < run_start)) { run_len = ol; run_start = os; }
+        }
+        if (lane == 0) {
+            if (run_len == 0) run_start = 0;
+            const int best = (run_start + run_start + run_len + 1) / 2;    // findBestPoint(start, start+len+1)
+            const float d = lidar[best < size ? best : size - 1];
+            float angle;
+            if (best > size / 2) angle = (float)(-p.angle_inc * ((size / 2.0) - best));
+            else angle = (float)(p.angle_inc * (best - (size / 2.0)));
+            angle = 2 * (angle / d);
+            const float lo_a = -p.max_angle;
+            const float a1 = (angle < lo_a) ? lo_a : angle;
+            angles[s] = (p.max_angle < a1) ? p.max_angle : a1;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace scan

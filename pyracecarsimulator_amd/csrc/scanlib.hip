@@ -7,6 +7,7 @@
 #include "../../include/scanlib.h"
 #include "scan_kernels.h"
 #include "car_kernels.h"
+#include "consumer_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -1337,4 +1338,98 @@ extern "C" int rl_last_kernel_ms(rl_method *h, float *ms_out)
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(ms_out, h->ev0, h->ev1));
     return RL_OK;
+}
+
+
+// ---------------------------------------------------------------- FollowGap
+struct rl_followgap {
+    int device = 0;
+    FollowGapParams P{};
+    int window_size = 0;           // kept for the caller; FollowGap::eval never reads it
+    hipStream_t stream = nullptr;
+    DevBuf scans, angles;
+    std::mutex mu;
+};
+
+extern "C" int rl_followgap_create(int device, int window_size, float max_distance, float max_angle,
+                                   float angle_inc, rl_followgap **out)
+{
+    if (!out) return fail(RL_ERR_INVALID, "rl_followgap_create: null pointer");
+    int ndev = rl_device_count();
+    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    rl_followgap *g = new (std::nothrow) rl_followgap();
+    if (!g) return fail(RL_ERR_NOMEM, "out of host memory");
+    g->device = device;
+    g->window_size = window_size;
+    g->P.max_distance = max_distance;
+    g->P.max_angle = max_angle;
+    g->P.angle_inc = angle_inc;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete g;
+        return fail(RL_ERR_HIP, "stream creation failed");
+    }
+    *out = g;
+    return RL_OK;
+}
+
+extern "C" void rl_followgap_destroy(rl_followgap *g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    g->scans.release();
+    g->angles.release();
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+static int followgap_launch(rl_followgap *g, const float *d_scans, int n_scans, int size,
+                            float *d_angles, hipStream_t stream)
+{
+    if (n_scans < 0) return fail(RL_ERR_INVALID, "n_scans must be >= 0");
+    // (the reference's preprocessLidar runs off its vector below 10 beams, followgap.hpp:21)
+    if (size < 10) return fail(RL_ERR_INVALID, "FollowGap needs at least 10 beams per scan (got %d)", size);
+    if (size > 12288) return fail(RL_ERR_UNSUPPORTED, "at most 12288 beams per scan (got %d)", size);
+    if (n_scans == 0) return RL_OK;
+    FollowGapParams p = g->P;
+    p.size = size;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, g->device));
+    const int grid = std::min(n_scans, prop.multiProcessorCount * 32);
+    hipLaunchKernelGGL(followgap_kernel, dim3(grid), dim3(64), (size_t)size * sizeof(float), stream,
+                       d_scans, n_scans, p, d_angles);
+    HIPCHK(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_followgap_eval(rl_followgap *g, const float *scans, int n_scans, int size,
+                                 float *angles)
+{
+    if (!g || !scans || !angles) return fail(RL_ERR_INVALID, "rl_followgap_eval: null pointer");
+    std::lock_guard<std::mutex> lk(g->mu);
+    HIPCHK(hipSetDevice(g->device));
+    if (n_scans < 0 || size < 10)
+        return followgap_launch(g, nullptr, n_scans, size, nullptr, g->stream);   // (argument errors)
+    if (n_scans == 0) return RL_OK;
+    const size_t bytes = (size_t)n_scans * size * sizeof(float);
+    int rc;
+    if ((rc = g->scans.ensure(bytes)) || (rc = g->angles.ensure((size_t)n_scans * sizeof(float)))) return rc;
+    HIPCHK(hipMemcpyAsync(g->scans.p, scans, bytes, hipMemcpyHostToDevice, g->stream));
+    if ((rc = followgap_launch(g, (const float *)g->scans.p, n_scans, size, (float *)g->angles.p, g->stream)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(angles, g->angles.p, (size_t)n_scans * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    return RL_OK;
+}
+
+extern "C" int rl_followgap_eval_device(rl_followgap *g, const float *d_scans, int n_scans, int size,
+                                        float *d_angles, void *hip_stream)
+{
+    if (!g || (n_scans > 0 && (!d_scans || !d_angles)))
+        return fail(RL_ERR_INVALID, "rl_followgap_eval_device: null pointer");
+    std::lock_guard<std::mutex> lk(g->mu);
+    HIPCHK(hipSetDevice(g->device));
+    return followgap_launch(g, d_scans, n_scans, size, d_angles, (hipStream_t)hip_stream);
 }

@@ -82,6 +82,21 @@ class RacecarSimulator:
     def getScan(self):
         return self.scan
 
+    def laserScanFields(self, stamp=None, frame_id="laser"):
+        """The fields RunSimulationViz.lidarPub puts into sensor_msgs/LaserScan
+        (scripts/ros_interface.py:332-348) as a plain dict (there is no ROS on the GPU box): the fan
+        convention every consumer of the scan relies on.  ``ranges`` and ``intensities`` alias the
+        current scan, as the reference's message does."""
+        return {
+            "header": {"stamp": stamp, "frame_id": frame_id},
+            "angle_min": -self.scan_fov / 2.0,
+            "angle_max": self.scan_fov / 2.0,
+            "angle_increment": self.scan_fov / self.num_rays,
+            "range_max": self.config["scan_max_range"],
+            "ranges": self.scan,
+            "intensities": self.scan,
+        }
+
     # -- one tick -------------------------------------------------------------------
     def getScanPose(self):
         """Car::getScanPose (racecar.cpp:378-387): the lidar sits scan_dist_to_base ahead."""

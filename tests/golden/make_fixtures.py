@@ -11,6 +11,9 @@ Run in the build container only (reads /root/reference; the GPU box never does):
                           fov/num_rays arguments, buffer aliasing.
 * golden/car_ref.npz      GOLD-D: outputs of the reference's compiled Car (oracle/_ref):
                           setCarEdgeDistances-driven isCrashed codes on seeded scans.
+* golden/followgap_ref.npz  GOLD-E: steering angles of the reference's compiled FollowGap::eval
+                          (followgap/followgap.hpp via oracle/_ref/libfollowgap_ref.so) on real
+                          scans (rm_colombia ranges), random scans and edge cases.
 * golden/rm_*.npz         GOLD-A/B: ranges, hit cells, step counts of the C oracle on seeded
                           poses (cross-checked here against the independent NumPy statement
                           before being written).
@@ -183,6 +186,70 @@ def car_rollouts():
                         action_every=every, dt=0.01)
 
 
+def followgap_ref():
+    """GOLD-E.  Needs rm_colombia.npz (made by rm_golden) for the real scans."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(os.path.join(ROOT, "oracle/_ref/libfollowgap_ref.so"))
+    L.ref_followgap_eval.restype = C.c_float
+    L.ref_followgap_eval.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+    rng = np.random.default_rng(77)
+    scans = []
+    z = np.load(os.path.join(GOLD, "rm_colombia.npz"))
+    B = int(z["num_rays"])
+    real = z["ranges_gpu"].reshape(-1, B)
+    scans += [real[i].copy() for i in range(len(real))]                    # 1081-beam scans
+    scans += [real[i, 180:900].copy() for i in range(0, len(real), 3)]     # the policy's 720-beam window
+    for size in (10, 11, 17, 63, 64, 65, 128, 720, 1081, 2000):
+        for kind in range(6):
+            if kind == 0:
+                v = rng.uniform(0.0, 20.0, size)
+            elif kind == 1:
+                v = rng.uniform(0.0, 1.7, size)                            # no beam above the 1.75 m gap level
+            elif kind == 2:
+                v = np.where(rng.random(size) < 0.3, 0.0, rng.uniform(0.5, 16.0, size))   # zeros
+            elif kind == 3:
+                v = np.full(size, 3.0)                                     # all equal (argmin tie -> 0)
+            elif kind == 4:
+                v = rng.choice([1.75, 1.7500001, 1.7499999, 15.0, 15.000001, 30.0], size)  # thresholds
+            else:
+                v = rng.normal(3.0, 3.0, size)                             # negative ranges (noise)
+            scans.append(v.astype(np.float32))
+    params = (10, 15.0, 0.4189, 0.004)                                     # scripts/mcts.py:97-99
+    keep, angles = [], []
+    for v in scans:
+        # the reference reads one past the array when the chosen gap is the single last beam: skip
+        w = v.copy()
+        w[: len(w) - 10] = np.minimum(w[: len(w) - 10], np.float32(params[1]))
+        mp = 0
+        for i in range(len(w)):
+            if w[i] != 0 and w[i] < w[mp]:
+                mp = i
+        w[mp] = 0
+        for i in range(-5, 5):
+            if 0 < mp + i < len(w) - 1:
+                w[mp + i] = 0
+        f = np.concatenate([[0], (w > 1.75).astype(np.int8), [0]])
+        d = np.diff(f)
+        starts, ends = np.where(d == 1)[0], np.where(d == -1)[0]
+        if len(starts):
+            k = int(np.argmax(ends - starts))
+            best = (2 * int(starts[k]) + int(ends[k] - starts[k]) + 1) // 2
+            if best >= len(v):
+                continue
+        buf = np.ascontiguousarray(v, dtype=np.float32)
+        a = L.ref_followgap_eval(buf.ctypes.data_as(C.POINTER(C.c_float)), len(buf), *params)
+        keep.append(buf)
+        angles.append(a)
+        assert np.float32(O.followgap_eval(buf, *params[1:])).tobytes() == np.float32(a).tobytes() or \
+            (np.isnan(a) and np.isnan(O.followgap_eval(buf, *params[1:]))), (len(buf), a)
+    offs = np.cumsum([0] + [len(k) for k in keep])
+    np.savez_compressed(os.path.join(GOLD, "followgap_ref.npz"), scans=np.concatenate(keep),
+                        offsets=offs, angles=np.array(angles, np.float32),
+                        params=np.array(params, np.float64))
+    print("followgap_ref", len(keep), "scans",
+          os.path.getsize(os.path.join(GOLD, "followgap_ref.npz")) // 1024, "KiB")
+
+
 def rm_golden(name, g, n_poses, seed, mrx=300, fov=4.71, num_rays=1081):
     om = O.OracleMap.from_gridmap(g, mrx)
     assert np.array_equal(om.dt, N.edt(g.occ)), "EDT: C oracle vs scipy statement"
@@ -217,6 +284,7 @@ def main():
     g = maps.make_maze(192, cell=24, wall=2, p=0.5, seed=9, resolution=0.1,
                        origin=(-3.0, 2.5, 0.6))           # rotated origin (yaw != 0)
     rm_golden("rm_maze192_yaw", g, 16, 103, mrx=120, fov=6.0, num_rays=360)
+    followgap_ref()
 
 
 if __name__ == "__main__":

@@ -3,11 +3,13 @@ through the C ABI (libscan_amd.so) and compares with the CPU oracle on the same 
 with the committed golden vectors, or — at BASELINE.json's full sizes — through
 size-independent properties.  Bar: bit-exact ranges / hit cells / step counts for ray marching."""
 import math
+import os
+
 import numpy as np
 import pytest
 
-from conftest import load_golden
-from pyracecarsimulator_amd import ScanSimulator2D, maps, range_libc, workloads
+from conftest import GOLD, load_golden
+from pyracecarsimulator_amd import ScanSimulator2D, _lib, maps, range_libc, workloads
 
 pytestmark = pytest.mark.gpu
 
@@ -724,3 +726,71 @@ def test_racecar_simulator_facade_drives_like_the_reference(oracle_mod):
     assert first.shape == (6,) and final.shape == (6, 11) and vel.shape == (6, 40)
     sim.stop()
     assert not sim.getState().any()
+
+
+# ---------------------------------------------------------------- FollowGap consumer
+@pytest.mark.gpu
+def test_followgap_kernel_reproduces_reference_build_vectors():
+    """GOLD-E through the C ABI: one wave per scan, bit-identical to the reference's compiled header."""
+    from pyracecarsimulator_amd.followgap import PyFollowGap
+    z = np.load(os.path.join(GOLD, "followgap_ref.npz"))
+    offs, prm = z["offsets"], z["params"]
+    fg = PyFollowGap(int(prm[0]), float(prm[1]), float(prm[2]), float(prm[3]))
+    for i in range(len(offs) - 1):
+        v = np.ascontiguousarray(z["scans"][offs[i]:offs[i + 1]])
+        got = np.float32(fg.eval(v, len(v)))
+        assert got.tobytes() == np.float32(z["angles"][i]).tobytes(), (i, len(v), got, z["angles"][i])
+    with pytest.raises(_lib.ScanLibError):
+        fg.eval(np.ones(9, np.float32), 9)
+    with pytest.raises(ValueError):
+        fg.eval(np.ones(20, np.float64), 20)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [10, 64, 65, 720, 1081, 4097])
+def test_followgap_batches_equal_the_oracle(oracle_mod, size):
+    from pyracecarsimulator_amd.followgap import PyFollowGap
+    rng = np.random.default_rng(size)
+    n = 257
+    scans = rng.uniform(0.0, 20.0, (n, size)).astype(np.float32)
+    scans[rng.random((n, size)) < 0.15] = 0.0
+    scans[::7] = np.minimum(scans[::7], 1.7)                     # no gap at all
+    scans[1::7, : size // 2] = 1.0                               # one long gap on the right
+    scans[2::7] = rng.normal(2.0, 2.0, (len(scans[2::7]), size)).astype(np.float32)   # negatives
+    scans[3, :] = 3.0                                            # all equal
+    scans[4, 0] = np.nan                                         # NaN seed: min_point stays 0
+    scans[5, 3:9] = np.nan
+    scans[6, :] = 0.0
+    scans[8, -1], scans[8, :-1] = 5.0, 1.0                       # gap = the single last beam
+    fg = PyFollowGap(10, 15.0, 0.4189, 0.004)
+    got = fg.eval_many(scans)
+    want = np.array([oracle_mod.followgap_eval(scans[i], 15.0, 0.4189, 0.004) for i in range(n)], np.float32)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), np.where(~same)[0][:10]
+    flat = fg.eval_many(scans.reshape(-1), size)
+    assert np.array_equal(flat.view(np.uint32), got.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_followgap_consumes_a_scanned_batch_on_the_device(oracle_mod):
+    """scan -> steering without the ranges leaving HBM: calc_range_fan_device feeds
+    rl_followgap_eval_device on the same stream."""
+    import torch
+    from pyracecarsimulator_amd.followgap import PyFollowGap
+    g = maps.load_colombia()
+    omap = range_libc.PyOMap(g)
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    poses = maps.sample_free_poses(g, 300, 11, dt=om.dt)
+    m = range_libc.PyRayMarchingGPU(omap, 300)
+    fg = PyFollowGap(10, 15.0, 0.4189, 0.004)
+    d_poses = torch.from_numpy(poses).cuda()
+    d_out = torch.empty(len(poses) * 1081, dtype=torch.float32, device="cuda")
+    d_ang = torch.empty(len(poses), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    m.calc_range_fan_device(d_poses.data_ptr(), len(poses), 4.71, 1081, d_out.data_ptr(), stream=st)
+    fg.eval_many_device(d_out.data_ptr(), len(poses), 1081, d_ang.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    r0, _, _ = om.rm_fan(poses, 4.71, 1081, step_coeff=1.0)
+    r0 = r0.reshape(len(poses), 1081)
+    want = np.array([oracle_mod.followgap_eval(r0[i], 15.0, 0.4189, 0.004) for i in range(len(poses))], np.float32)
+    assert np.array_equal(d_ang.cpu().numpy().view(np.uint32), want.view(np.uint32))

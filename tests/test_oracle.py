@@ -283,3 +283,42 @@ def test_random_maps_c_oracle_vs_numpy_statement(oracle_mod):
             r, h, st = om.rm_fan(poses, fov, B, step_coeff=sc)
             r2, h2, st2 = N.rm_fan(occ, res, origin, mrx, poses, fov, B, sc)
             assert np.array_equal(r, r2) and np.array_equal(h, h2) and np.array_equal(st, st2), case
+
+
+# ---------------------------------------------------------------- FollowGap
+def _followgap_cases():
+    z = np.load(os.path.join(GOLD, "followgap_ref.npz"))
+    offs = z["offsets"]
+    return [z["scans"][offs[i]:offs[i + 1]] for i in range(len(offs) - 1)], z["angles"], z["params"]
+
+
+def test_followgap_restatement_equals_reference_build_vectors(oracle_mod):
+    """GOLD-E: orc_followgap_eval vs the angles the reference's own followgap.hpp produced (compiled
+    in place into oracle/_ref, tests/golden/make_fixtures.py::followgap_ref): bit-identical."""
+    scans, angles, prm = _followgap_cases()
+    assert len(scans) >= 90
+    for v, a in zip(scans, angles):
+        got = np.float32(oracle_mod.followgap_eval(v, float(prm[1]), float(prm[2]), float(prm[3])))
+        assert got.tobytes() == np.float32(a).tobytes(), (len(v), got, a)
+    assert np.isnan(oracle_mod.followgap_eval(np.ones(9, np.float32), 15.0, 0.4, 0.004))   # size < 10
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle/_ref/libfollowgap_ref.so")),
+                    reason="oracle/_ref not built")
+def test_followgap_restatement_equals_live_reference_build(oracle_mod):
+    L = C.CDLL(os.path.join(ROOT, "oracle/_ref/libfollowgap_ref.so"))
+    L.ref_followgap_eval.restype = C.c_float
+    L.ref_followgap_eval.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+    rng = np.random.default_rng(5)
+    n = 0
+    for trial in range(300):
+        size = int(rng.integers(12, 1500))
+        v = rng.uniform(0.0, rng.choice([2.0, 5.0, 20.0]), size).astype(np.float32)
+        v[rng.random(size) < 0.1] = 0.0
+        v[-1] = 0.5                       # keeps the chosen gap off the last beam (reference reads past the end there)
+        md, ma, inc = 15.0, float(rng.choice([0.4189, 0.2])), float(rng.choice([0.004, 0.00436]))
+        ref = L.ref_followgap_eval(v.ctypes.data_as(C.POINTER(C.c_float)), size, 10, md, ma, inc)
+        got = oracle_mod.followgap_eval(v, md, ma, inc)
+        assert np.float32(got).tobytes() == np.float32(ref).tobytes() or (np.isnan(got) and np.isnan(ref))
+        n += 1
+    assert n == 300
