@@ -957,11 +957,23 @@ __global__ __launch_bounds__(256) void lut_fan_lds_kernel(MapParams m, FanParams
         inb = gx >= 0.0f && gx < m.fcols && gy >= 0.0f && gy < m.frows;
         const uint32_t *row = reinterpret_cast<const uint32_t *>(
             lp.lut + (inb ? ((size_t)(int)gy * m.cols + (int)gx) * lp.theta_disc : 0));
+        // only the bins the fan can touch: beam angles grow with j, so the bins are the circular run
+        // from the first beam's bin over `span` bins (fov 4.71 at theta_disc 1442: 1081 of 1442 —
+        // a quarter of the row's bytes stay in HBM)
+        const float u0 = __builtin_rintf((thg + fan_alpha(f, 0)) * lp.bins_per_rad);
+        const float u1 = __builtin_rintf((thg + fan_alpha(f, f.num_rays - 1)) * lp.bins_per_rad);
+        const float spanf = u1 - u0;
+        const bool all = !(spanf >= 0.0f && spanf < td_f - 8.0f) || !(__builtin_fabsf(u0) < 8388608.0f);
+        const int span = all ? 0 : (int)spanf;
+        const int b0 = all ? 0 : lut_bin_fast(thg + fan_alpha(f, 0), lp, td_f, inv_td);
 #pragma unroll
         for (int n = 0; n < NL; ++n) {
-            const int idx = (n * 64 + lane) * 4;
+            const int idx = (n * 64 + lane) * 4;               // dword index; bins 2*idx .. 2*idx+7
             regs[n] = make_uint4(0, 0, 0, 0);
-            if (inb && idx < D) regs[n] = *reinterpret_cast<const uint4 *>(row + idx);
+            int d = 2 * idx - b0;                              // chunk start relative to the first bin
+            d = d < 0 ? d + lp.theta_disc : d;
+            const bool need = all || d <= span || d >= lp.theta_disc - 7;
+            if (inb && idx < D && need) regs[n] = *reinterpret_cast<const uint4 *>(row + idx);
         }
     };
 

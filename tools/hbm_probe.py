@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""What does HBM actually deliver on this box?  copy (read+write), fill (write only), sum (read only)
+on 2 GiB float32 tensors, HIP-event timed — the practical ceiling next to the 8 TB/s spec that
+bench.py's roofline uses."""
+import torch
+
+n = 512 * 1024 * 1024          # 2 GiB of float32
+a = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+b = torch.empty_like(a)
+
+
+def timed(fn, reps=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+gb = n * 4 / 1e9
+t = timed(lambda: b.copy_(a))
+print("copy  (read %.1f GB + write %.1f GB): %.0f GB/s" % (gb, gb, 2 * gb / t))
+t = timed(lambda: b.fill_(1.0))
+print("fill  (write only)              : %.0f GB/s" % (gb / t))
+t = timed(lambda: a.sum())
+print("sum   (read only)               : %.0f GB/s" % (gb / t))
