@@ -691,8 +691,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     __syncthreads();
     const float INF = __builtin_inff();
 
-    unsigned long long t_start = 0;
-    uint32_t n_serv = 0;
+    unsigned long long t_start = 0, t_drain = 0;   // diagnostics (sp.dbg): launch / stream-exhausted stamps
+    uint32_t n_serv = 0, ns_drain = 0, drain_samples = 0;
     if (sp.dbg) t_start = wall_clock64();
 
     bool exhausted = total == 0;
@@ -726,6 +726,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                     r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + oidx);
                 if (out) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + (oidx << 2)) = r;
                 if (AUX) {
+                    if (sp.dbg && t_drain && nstep - ns_drain > drain_samples) drain_samples = nstep - ns_drain;
                     if (hits) { hits[2 * (size_t)oidx] = hc; hits[2 * (size_t)oidx + 1] = hr; }
                     // the read that found the border is not a map sample (the CPU statement
                     // leaves the loop before reading)
@@ -785,15 +786,26 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         // a wave that can no longer refill is on the launch's critical path (its longest ray
         // decides when the kernel ends): let it win issue arbitration against refilling waves
         if (exhausted && sp.drain_prio) __builtin_amdgcn_s_setprio(3);
+        if (AUX && sp.dbg && exhausted && !t_drain) {       // drain phase starts: samples so far per lane
+            t_drain = wall_clock64();
+            ns_drain = nstep;
+        }
         march_loop<AUX, TILED>(dx, dy, gx, gy, t, pc, pr, d_last, nstep, pm.pdt, pm.stride, pm.nstride,
                                pm.k4, f.max_range, exhausted ? 0u : (uint32_t)sp.low_water);
+    }
+    uint32_t ds_max = 0;
+    if (AUX && sp.dbg) {                                   // longest chain of samples marched after exhaustion
+        ds_max = drain_samples;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ds_max = max(ds_max, (uint32_t)__shfl_xor((int)ds_max, off));
     }
     if (sp.dbg && lane == 0) {
         const size_t gw = ((size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * 4;
         sp.dbg[gw] = t_start;
         sp.dbg[gw + 1] = wall_clock64();
-        sp.dbg[gw + 2] = ((unsigned long long)n_serv << 32);
-        sp.dbg[gw + 3] = ((unsigned long long)K << 32) | (uint32_t)band;
+        sp.dbg[gw + 2] = ((unsigned long long)n_serv << 32) | ds_max;
+        sp.dbg[gw + 3] = ((unsigned long long)(uint32_t)(t_drain ? t_drain - t_start : 0) << 32) |
+                         ((unsigned long long)(K & 0xffffffu) << 8) | (uint32_t)(band & 0xff);
     }
 }
 
