@@ -144,6 +144,15 @@ struct CrashParams {
     int group;               // poses per group (roll-out); the whole batch is one group by default
 };
 
+// first crashed pose of a group: a ray only sends its atomic when it can still lower the value
+// (a pose scraping a wall crashes on hundreds of beams; same-word atomics retire ~10 per us)
+__device__ __forceinline__ void crash_note(const CrashParams &cp, uint32_t pose)
+{
+    int *slot = &cp.first_crashed[pose / (uint32_t)cp.group];
+    const int idx = (int)(pose % (uint32_t)cp.group);
+    if (idx < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, idx);
+}
+
 template <bool AUX, bool CRASH>
 __global__ __launch_bounds__(WG) void rm_fan_kernel(MapParams m, FanParams f,
                                                     const float *__restrict__ poses,
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(WG) void rm_fan_kernel(MapParams m, FanParams f,
                 const bool crashed = ((double)r - cp.edge[j]) < cp.thresh;
                 if (__ballot(crashed)) {
                     if (lane == __ffsll((long long)__ballot(crashed)) - 1)
-                        atomicMin(&cp.first_crashed[pose / cp.group], pose % cp.group);
+                        crash_note(cp, (uint32_t)pose);
                 }
             }
         }
@@ -735,7 +744,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 }
                 if (CRASH) {
                     if (((double)r - cp.edge[jbeam]) < cp.thresh)
-                        atomicMin(&cp.first_crashed[pose / (uint32_t)cp.group], (int)(pose % (uint32_t)cp.group));
+                        crash_note(cp, pose);
                 }
                 has_ray = false;
             }

@@ -794,3 +794,33 @@ def test_followgap_consumes_a_scanned_batch_on_the_device(oracle_mod):
     r0 = r0.reshape(len(poses), 1081)
     want = np.array([oracle_mod.followgap_eval(r0[i], 15.0, 0.4189, 0.004) for i in range(len(poses))], np.float32)
     assert np.array_equal(d_ang.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_small_host_calls_zero_copy_equals_staged_path(oracle_mod):
+    """scan()/scanMany()-sized host calls go through pinned, device-mapped memory (no staging
+    copies); same bits as the staged path and as the oracle, for every method."""
+    from pyracecarsimulator_amd import racecar as RC
+    g = maps.load_colombia()
+    omap = range_libc.PyOMap(g)
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    poses = maps.sample_free_poses(g, 50, 21, dt=om.dt)
+    edge = RC.edge_distances(1081, -4.71 / 2, 4.71 / 1081, 0.275, 0.2032, 0.3302)
+    for cls, args in ((range_libc.PyRayMarchingGPU, ()), (range_libc.PyRayMarching, ()),
+                      (range_libc.PyBresenhamsLine, ()), (range_libc.PyCDDTCast, (108,))):
+        m = cls(omap, 300, *args)
+        outs = {}
+        for mode in (65536, 0):
+            m.set_option("pinned_max_rays", mode)
+            for n in (1, 7, 50):
+                r = np.full(n * 1081, -1.0, np.float32)
+                m.calc_range_fan(poses[:n], r, 4.71, 1081)
+                outs[(mode, n)] = r
+                c = m.check_collision_many(poses[:n], 4.71, 1081, edge, 0.001)
+                outs[(mode, n, "c")] = c
+        for n in (1, 7, 50):
+            assert np.array_equal(outs[(65536, n)], outs[(0, n)]), (cls.__name__, n)
+            assert outs[(65536, n, "c")] == outs[(0, n, "c")]
+        if cls is range_libc.PyRayMarchingGPU:
+            r0, _, _ = om.rm_fan(poses, 4.71, 1081, step_coeff=1.0)
+            assert np.array_equal(outs[(65536, 50)], r0)
