@@ -186,7 +186,9 @@ int rl_car_rollout_check(rl_car *c, rl_method *h, const double *states_in, const
 
 /* device time of the last enqueued launch sequence of this handle, from HIP events
  * recorded on the launch stream (blocks until that work has finished).  Events are only
- * recorded after rl_method_set_option(h, "timing", 1): they cost microseconds per launch. */
+ * recorded after rl_method_set_option(h, "timing", 1): they cost microseconds per launch.
+ * "timing" = 2 brackets the ray-marching kernel alone (the pose-binning launches in front of it
+ * excluded), which is the duration a kernel trace reports for it.                              */
 int rl_last_kernel_ms(rl_method *h, float *ms_out);
 
 /* tuning / diagnostics: integer options by name ("variant", "grid_mult", ...)     */

@@ -116,7 +116,8 @@ struct rl_method {
     int low_water = 24;          // queue kernel: refill when <= this many lanes still march
     int sort_poses = 1;          // queue kernel: order poses by map tile
     int xcd_bands = 8;           // queue kernel: bands of the sorted list, one per XCD
-    int timing = 0;              // record HIP events around every launch (rl_last_kernel_ms)
+    int timing = 0;              // 1: HIP events around every launch sequence (rl_last_kernel_ms);
+                                 // 2: around the march kernel only (pose binning excluded)
     int lut_debug = 0;
     int drain_prio = 0;
     int wg_threads = 1024;       // stream kernel: workgroup size (256/512/1024) sharing one ray stream
@@ -408,7 +409,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "sort_poses")) h->sort_poses = value != 0;
     else if (!strcmp(name, "debug_stamps")) h->debug_stamps = value != 0;
     else if (!strcmp(name, "drain_prio")) h->drain_prio = value != 0;
-    else if (!strcmp(name, "timing")) h->timing = value != 0;
+    else if (!strcmp(name, "timing")) h->timing = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
     else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
     else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
@@ -889,6 +890,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         h->last_grid = grid * waves_per_wg / WAVES_PER_WG;
         const size_t lds_q = inl ? (((2 + 2 * (size_t)num_rays + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 20)
                                  : lds + 2 * sizeof(float);
+        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel alone
 #define LAUNCH_S(A, C, N, I)                                                                          \
     do {                                                                                              \
         if (h->tiled)                                                                                 \
