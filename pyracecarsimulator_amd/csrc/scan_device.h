@@ -104,6 +104,23 @@ __device__ __forceinline__ float gauss_noise(uint64_t seed, uint64_t ray_id)
 }
 
 // ---- sphere tracing on the float32 distance transform (rows a8 / a11) -------------
+// Correctly rounded sqrt for the hit distance sqrt(xd^2 + yd^2): the argument is 0 or >= 2^-46
+// (xd, yd are differences of cell indices and in-map coordinates), never denormal, never inf, so the
+// compiler's general sequence (range scaling in front, class test behind: 16 instructions) reduces
+// to the hardware estimate (<= 1 ulp) and the two-sided residual fix-up (9 instructions).  Same bits
+// as sqrtf for every such argument (tests compare against the CPU's IEEE sqrtf).
+__device__ __forceinline__ float hit_sqrtf(float x)
+{
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    const float yp = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    const float rm = __builtin_fmaf(-ym, y, x);
+    const float rp = __builtin_fmaf(-yp, y, x);
+    float r = rm <= 0.0f ? ym : y;
+    r = rp > 0.0f ? yp : r;
+    return r;
+}
+
 struct RayResult {
     float range_px;
     int hit_c, hit_r;

@@ -728,7 +728,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                     hc = pc;
                     hr = pr;
                     const float xd = (float)hc - gx, yd = (float)hr - gy;
-                    r = __builtin_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+                    r = hit_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
                 }
                 r *= pm.res;
                 if (f.noise_std > 0.0f)
