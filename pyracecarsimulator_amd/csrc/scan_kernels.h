@@ -232,20 +232,25 @@ __global__ __launch_bounds__(WG) void rm_rays_kernel(MapParams m, FanParams f,
 // ==============================================================================
 // K1b: the MI355X-shaped ray-marching path (variant 1, default).
 //
-//  (0) pad_dt_kernel — per method: the float32 EDT copied into an array with a border of
-//      ceil(max_range)+2 cells holding 3e38 ("outside the map"), occupied cells +inf.  A
-//      ray whose origin is inside the map stays within max_range of it while it is live, so
-//      the march loop needs no bounds test, no address clamp and no hit test: leaving the
-//      map or hitting adds a huge step and t leaves the [0, max_range) window.  (Origins outside the map are misses before the first sample —
-//      decided once per pose.)
-//  (1) pose_bin_kernel — one 1024-lane workgroup turns the pose list into per-pose
-//      records (gx, gy, cos th, sin th) ordered by the map tile the pose stands in
-//      (LDS histogram -> scan -> scatter).  Costs O(P); the march costs O(P*B*samples).
+//  (0) pad_dt_tiled_kernel — per method: the STEP MAP.  The float32 EDT with a border of
+//      ceil(max_range)+2 cells, holding what the march adds to t at that cell: free cells
+//      max(d*coeff, 1), occupied cells +inf, border 3e38.  A ray whose origin is inside the
+//      map stays within max_range of it while it is live, so the march loop needs no bounds
+//      test, no address clamp, no hit test and no per-sample max: leaving the map or hitting
+//      adds a huge step and t leaves the [0, max_range) window.  (Origins outside the map are
+//      misses before the first sample — decided once per pose.)  Rows are interleaved in
+//      groups of 4 so that a 128-B line is a 4x8 block of cells (see pdt_tiled_index).
+//  (1) pose binning — pose_bin_small_kernel (one 1024-lane workgroup, < 8192 poses) or
+//      pose_prep/tile_scan/pose_scatter (grid-wide): per-pose records (gx, gy, cos th, sin th)
+//      ordered by the map tile the pose stands in (LDS histogram -> scan -> scatter).  Small
+//      batches and maps that fit every XCD's L2 skip it: the march kernel derives the records
+//      of its own ray blocks into LDS (INLINE).
 //  (2) rm_fan_stream_kernel.  The tile-ordered pose list is cut into 8 contiguous BANDS,
 //      band x marched only by workgroups with blockIdx % 8 == x — one XCD under
 //      round-robin dispatch (speed only, never correctness) — so each XCD's 4 MiB L2
-//      holds one band of the map.  Inside a band, workgroup g owns the 64-beam chunks
-//      g, g+G, g+2G, ... (interleaved: every workgroup sees the band's average cost).
+//      holds one band of the map.  Inside a band, workgroup g owns runs of 2^k consecutive
+//      64-ray blocks, interleaved with the band's other workgroups (every workgroup sees the
+//      band's average cost; a run keeps it on one pose's fan for a while).
 //      A workgroup's 16 waves share ONE stream of ray slots through an LDS counter: a
 //      wave marches while more than `low_water` of its lanes are live, then every
 //      finished lane stores its range and claims the next slot (ballot + mbcnt ranks,
@@ -253,11 +258,10 @@ __global__ __launch_bounds__(WG) void rm_rays_kernel(MapParams m, FanParams f,
 //      average and ~25 at the wave maximum.  (A global work counter per band was tried
 //      first and rejected: returning atomics on one contended word retire at ~10/us on
 //      MI355X, which made the launch atomic-bound.)
-//      rocprofv3 showed this kernel is instruction-issue bound (L1 hit 76 %, L2 latency
-//      ~130 cycles, ~60 VALU+SALU per sample in the first version), so the march loop is
-//      written predicated — every lane executes every instruction, a finished lane has
-//      t = +inf and re-reads its origin cell — with no EXEC-mask traffic:
-//      10 VALU + 1 load + 4 SALU per sample (march_loop below).
+//      The first version was instruction-issue bound (~60 VALU+SALU per sample); the march
+//      loop is now hand-scheduled assembly with EXEC as the live mask:
+//      10 VALU + 1 load + 4 SALU per sample (march_loop below).  What bounds it today —
+//      the CU's gather rate (~3.85 lanes/clk) and load latency — is in DESIGN.md section 4.
 // Results are bit-identical to K1 (same arithmetic; only the schedule differs).
 // ==============================================================================
 struct PoseRec {
@@ -266,7 +270,7 @@ struct PoseRec {
 
 constexpr uint32_t POSE_INVALID = 0x80000000u;   // order[] flag: origin outside the map / non-finite
 
-// Stop codes stored in the padded EDT instead of 0 / "outside": adding them to t ends the march
+// Stop codes stored in the step map instead of 0 / "outside": adding them to t ends the march
 // through the ordinary `t < max_range` test, so the loop needs no separate hit test.
 #define PDT_HIT __builtin_inff()        /* occupied cell (EDT 0)          */
 #define PDT_OUTSIDE 3.0e38f             /* border: the ray left the map   */
@@ -571,10 +575,10 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f)
 // (v_cmpx drops a lane the moment its t reaches max_range, hits, or leaves the map),
 // so finished lanes cost nothing but their slot and keep (c, r, d) of their last
 // sample; the loop leaves when at most `low` lanes are still live.
-// Per sample: 10 VALU + 1 global load + 4 SALU (unit step coefficient).
+// Per sample: 10 VALU + 1 global load + 4 SALU (either step coefficient).
 //   fx = fma(dx,t,gx); fy = fma(dy,t,gy); c = (int)fx; r = (int)fy      (Appendix A "march")
-//   d  = pdt[(r*stride + c)*4 + k4]     occupied cells read +inf, border cells 3e38
-//   t += max(d*coeff, 1)                 => a hit / leaving the map pushes t past max_range
+//   d  = step map at (r, c)              = max(dt*coeff, 1) | +inf (occupied) | 3e38 (border)
+//   t += d                               => a hit / leaving the map pushes t past max_range
 // ------------------------------------------------------------------------------
 template <bool AUX, bool TILED>
 __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float gy, float &t, int &c,

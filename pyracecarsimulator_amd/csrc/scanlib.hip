@@ -114,8 +114,8 @@ struct rl_method {
     int variant = 1;             // 0: chunk kernel (K1); 1: binned + banded + lane-refill stream kernel (K1b)
     int grid_mult = 8;           // workgroups per CU for the persistent launches (8 resident: <= 80 SGPRs, <= 64 VGPRs)
     int low_water = 12;          // stream kernel: refill when <= this many lanes still march (re-tuned for the 10-VALU loop)
-    int sort_poses = 1;          // queue kernel: order poses by map tile
-    int xcd_bands = 8;           // queue kernel: bands of the sorted list, one per XCD
+    int sort_poses = 1;          // stream kernel: order poses by map tile
+    int xcd_bands = 8;           // stream kernel: bands of the sorted list, one per XCD
     int timing = 0;              // 1: HIP events around every launch sequence (rl_last_kernel_ms);
                                  // 2: around the march kernel only (pose binning excluded)
     int lut_debug = 0;
@@ -148,7 +148,7 @@ struct rl_method {
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
     int inline_map_kb = 2048;    // maps up to this size (f32 cells) never take the binning launch while the records fit LDS
     int run_log2 = -1;           // stream interleave granularity: runs of 2^run_log2 blocks; -1 = by batch size
-    int tiled = 1;               // padded EDT in 4x8-cell tiles (TILED march); 0 = row-major
+    int tiled = 1;               // step map with 4 rows interleaved (a 128-B line = 4x8 cells); 0 = row-major
     int pdt_tiled = -1;          // layout the padded copy was built with
     uint32_t pdt_k4 = 0;
     int slice_log2 = 30;         // launches are cut into pose slices below 2^slice_log2 rays
@@ -804,7 +804,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         if ((rc = h->rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
         if ((rc = h->order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
         if ((rc = h->keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
-        // padded EDT of this method (border = -1), rebuilt when the map changed
+        // step map of this method, rebuilt when the map (or the layout option) changed
         if (h->pdt_epoch != m->epoch || !h->pdt.p || h->pdt_tiled != h->tiled) {
             h->pad = (int)std::ceil(h->max_range) + 2;
             if (h->tiled) {
