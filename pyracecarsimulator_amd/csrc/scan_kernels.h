@@ -647,8 +647,122 @@ struct StreamParams {
     int k_max;               // INLINE only: LDS capacity in chunk records
     int drain_prio;          // raise wave priority once the workgroup's stream is exhausted
     int run_log2;            // a workgroup's stream interleaves RUNS of 2^run_log2 consecutive 64-ray blocks
+    int stripe;              // INLINE only: bands are row stripes of the map, compacted by every workgroup
+                             //   itself (stripe_band_list) instead of ranges of the caller's pose order
     unsigned long long *dbg; // diagnostics (nullptr in production): 4 words per wave
 };
+
+
+// ------------------------------------------------------------------------------
+// INLINE + stripe: XCD locality without a binning launch (512..8192 poses on maps larger than L2).
+// Every workgroup ranks all P poses by (row bin of the pose, pose index) — 64 bins over the map's
+// rows, an LDS histogram — and band b is ranks [P*b/nb, P*(b+1)/nb): a horizontal stripe of the
+// map with exactly the pose count the contiguous split would give it (so the host's LDS sizing
+// holds).  The workgroup then compacts the poses of ITS band, in pose-index order, into `list`:
+// whole bins strictly inside the band, plus the first/last few poses of the two boundary bins
+// (ordered counts by ballot + wave prefix).  All workgroups of a band compute the same list.
+// Costs ~3 us per workgroup at 4096 poses instead of a ~9.5 us single-workgroup launch in front.
+// ------------------------------------------------------------------------------
+constexpr int STRIPE_BINS = 64;
+constexpr int STRIPE_MAX_PER_LANE = 8;          // poses per lane of a 1024-thread workgroup: P <= 8192
+
+__device__ __forceinline__ int stripe_row_bin(const MapParams &m, const float *__restrict__ poses, int p)
+{
+    float gx, gy, thg;
+    world_to_grid(m, poses[3 * (size_t)p], poses[3 * (size_t)p + 1], 0.0f, gx, gy, thg);   // (heading not needed)
+    const float u = gy * ((float)STRIPE_BINS / m.frows);
+    return u >= 0.0f ? (u < (float)STRIPE_BINS ? (int)u : STRIPE_BINS - 1) : 0;     // NaN -> bin 0
+}
+
+// per-wave counts c[0..nw) in LDS (nw <= 64) -> sum of the waves before `wave`, and the total: one
+// LDS read per lane and a shuffle scan instead of every lane walking the array
+__device__ __forceinline__ void wave_counts_prefix(const int *c, int nw, int lane, int wave, int &pre, int &tot)
+{
+    const int v = lane < nw ? c[lane] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    tot = __shfl(incl, 63);
+    pre = __shfl(incl - v, wave);
+}
+
+// scratch: STRIPE_BINS + 3*(NT/64) + 4 ints.  Returns the number of poses written to list
+// (== hi_rank - lo_rank).  Ends with a __syncthreads().
+template <int NT>
+__device__ __forceinline__ uint32_t stripe_band_list(const MapParams &m, const float *__restrict__ poses,
+                                                     int P, uint32_t lo_rank, uint32_t hi_rank,
+                                                     uint32_t *__restrict__ list, int *__restrict__ scratch)
+{
+    constexpr int NW = NT / 64;
+    int *hist = scratch, *wc = scratch + STRIPE_BINS, *meta = wc + 3 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < STRIPE_BINS) hist[tid] = 0;
+    __syncthreads();
+    // every pose is read once: up to STRIPE_MAX_PER_LANE row bins per lane stay in registers (all the
+    // loads of a lane are in flight together — 512 workgroups read the same 48 KB at the same time)
+    // (one byte per pose, 0xff = none: two registers, so that this prologue does not raise the
+    //  kernel's VGPR count and cost the march its 8 waves per SIMD)
+    unsigned long long packed = ~0ull;
+#pragma unroll
+    for (int u = 0; u < STRIPE_MAX_PER_LANE; ++u) {
+        const int p = u * NT + tid;
+        if (p < P) {
+            const int b = stripe_row_bin(m, poses, p);
+            packed = (packed & ~(0xffull << (8 * u))) | ((unsigned long long)b << (8 * u));
+            atomicAdd(&hist[b], 1);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {                                   // 64 bins = one wave: inclusive scan by shuffles
+        const int h = hist[lane];
+        int incl = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const int excl = incl - h;
+        if (h > 0 && excl <= (int)lo_rank && (int)lo_rank < incl) { meta[0] = lane; meta[1] = (int)lo_rank - excl; }
+        if (h > 0 && excl <= (int)hi_rank - 1 && (int)hi_rank - 1 < incl) { meta[2] = lane; meta[3] = (int)hi_rank - excl; }
+    }
+    __syncthreads();
+    const int cl = meta[0], skip_lo = meta[1], ch = meta[2], take_hi = meta[3];
+    int cnt_cl = 0, cnt_ch = 0;
+    uint32_t npos = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (int u = 0; u * NT < P; ++u) {
+        const int p = u * NT + tid;
+        const int byte = (int)((packed >> (8 * u)) & 0xffull);
+        const int bin = byte == 0xff ? -1 : byte;
+        const bool is_cl = bin == cl, is_ch = bin == ch && ch != cl;
+        const unsigned long long b_cl = __ballot(is_cl), b_ch = __ballot(is_ch);
+        if (lane == 0) wc[wave] = __popcll(b_cl) | (__popcll(b_ch) << 16);     // (both <= 64 per wave, sums <= 8192)
+        __syncthreads();
+        int pre, tot;
+        wave_counts_prefix(wc, NW, lane, wave, pre, tot);
+        const int pre_cl = pre & 0xffff, pre_ch = pre >> 16, tot_cl = tot & 0xffff, tot_ch = tot >> 16;
+        const int idx_cl = cnt_cl + pre_cl + __popcll(b_cl & below);
+        const int idx_ch = cnt_ch + pre_ch + __popcll(b_ch & below);
+        const bool member = (bin > cl && bin < ch) ||
+                            (is_cl && idx_cl >= skip_lo && (cl != ch || idx_cl < take_hi)) ||
+                            (is_ch && idx_ch < take_hi);
+        const unsigned long long b_m = __ballot(member);
+        if (lane == 0) wc[2 * NW + wave] = __popcll(b_m);
+        __syncthreads();
+        int pre_m, tot_m;
+        wave_counts_prefix(wc + 2 * NW, NW, lane, wave, pre_m, tot_m);
+        if (member) list[npos + pre_m + __popcll(b_m & below)] = (uint32_t)p;
+        cnt_cl += tot_cl;
+        cnt_ch += tot_ch;
+        npos += (uint32_t)tot_m;
+        __syncthreads();
+    }
+    return npos;
+}
 
 template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
@@ -690,14 +804,20 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         // small batches: no binning launch in front of the march — each workgroup turns the poses
         // of its own chunks into records (a few hundred, one per lane) and keeps them in LDS
         const MapParams mp = *sp.map;
+        // stripe mode: this band's poses (a row stripe of the map) compacted here, in LDS
+        uint32_t *list = lord + sp.k_max;
+        if (sp.stripe && seg_hi > seg_lo)
+            stripe_band_list<NT>(mp, sp.raw_poses, f.n_poses, seg_lo, seg_hi, list,
+                                 reinterpret_cast<int *>(list + (seg_hi - seg_lo) + 1));
         // (num_rays >= 64 here, so a block of 64 rays touches at most two poses: slots 2k, 2k+1)
         for (uint32_t k2 = threadIdx.x; k2 < 2 * K; k2 += NT) {
             const uint32_t p0 = fast_div(blk_of(k2 >> 1), sp.div_B) + (k2 & 1);
             if (seg_lo + p0 < seg_hi) {
+                const uint32_t pid = sp.stripe ? list[p0] : seg_lo + p0;
                 PoseRec r;
-                const uint32_t kf = pose_record(mp, sp.raw_poses, (int)(seg_lo + p0), 0, 1, 1, r);
+                const uint32_t kf = pose_record(mp, sp.raw_poses, (int)pid, 0, 1, 1, r);
                 lrec[k2] = r;
-                lord[k2] = (seg_lo + p0) | (kf & POSE_INVALID);
+                lord[k2] = pid | (kf & POSE_INVALID);
             }
         }
     }

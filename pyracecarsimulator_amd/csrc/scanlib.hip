@@ -146,6 +146,8 @@ struct rl_method {
     std::vector<double> edge_host; // the car-outline table last uploaded to `edge` (re-sent only when it changes)
     int *pin_flag = nullptr;       // pinned landing slot for the crash index
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
+    int stripe_max = 3072;       // big maps, inline_max..stripe_max poses: no binning launch, workgroups compact
+                                 // their own row-stripe band of the pose list (0 = off)
     int inline_map_kb = 2048;    // maps up to this size (f32 cells) never take the binning launch while the records fit LDS
     int run_log2 = -1;           // stream interleave granularity: runs of 2^run_log2 blocks; -1 = by batch size
     int tiled = 1;               // step map with 4 rows interleaved (a 128-B line = 4x8 cells); 0 = row-major
@@ -416,6 +418,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "tiled")) h->tiled = value != 0;
     else if (!strcmp(name, "pinned_max_rays")) h->pinned_max_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "inline_map_kb")) h->inline_map_kb = value < 0 ? 0 : value;
+    else if (!strcmp(name, "stripe_max")) h->stripe_max = value < 0 ? 0 : value;
     else if (!strcmp(name, "run_log2")) h->run_log2 = value < 0 ? -1 : value > 8 ? 8 : value;
     else if (!strcmp(name, "slice_log2")) h->slice_log2 = value < 8 ? 8 : (value > 30 ? 30 : value);
     else if (!strcmp(name, "inline_max")) h->inline_max = value;
@@ -443,6 +446,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "tiled")) *value_out = h->tiled;
     else if (!strcmp(name, "pinned_max_rays")) *value_out = h->pinned_max_rays;
     else if (!strcmp(name, "inline_map_kb")) *value_out = h->inline_map_kb;
+    else if (!strcmp(name, "stripe_max")) *value_out = h->stripe_max;
     else if (!strcmp(name, "run_log2")) *value_out = h->run_log2;
     else if (!strcmp(name, "slice_log2")) *value_out = h->slice_log2;
     else if (!strcmp(name, "inline_max")) *value_out = h->inline_max;
@@ -840,13 +844,21 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         bool inl = h->inline_prep && num_rays >= 64 &&
                    (small_map || (n_poses < h->inline_max && n_poses < h->bin_multi_min));
         // (small maps: up to the ~40k poses whose records fit a workgroup's LDS, checked below)
+        // big maps, mid-size batches: still no binning launch — every workgroup compacts the poses of
+        // its own band (a row stripe of the map) from the caller's list, see stripe_band_list
+        const bool stripe = h->inline_prep && num_rays >= 64 && !inl && bands > 1 && h->sort_poses &&
+                            n_poses >= 64 && n_poses <= std::min(h->stripe_max, 1024 * STRIPE_MAX_PER_LANE);
+        if (stripe) inl = true;
         int k_max = 0;
+        size_t lds_extra = 0;
         if (inl) {
             nt = 1024;
             const long g_min = std::max(1L, std::min((n_chunks + 15) / 16, (long)m->n_cu * h->grid_mult * WG / nt) / bands);
             const long seg_chunks_max = ((((long)n_poses + bands - 1) / bands) * num_rays + 63) / 64;
             k_max = 2 * ((int)((seg_chunks_max + g_min - 1) / g_min) + 1);   // two records per block
-            if ((size_t)k_max * 20 + lds + 32 > 56 * 1024) inl = false;
+            if (stripe)                                   // band list + histogram / wave counts / cuts
+                lds_extra = ((size_t)(n_poses + bands - 1) / bands + 2 + STRIPE_BINS + 3 * (nt / 64) + 4) * 4;
+            if ((size_t)k_max * 20 + lds + lds_extra + 32 > 56 * 1024) inl = false;
         }
         if (!inl) {
             nt = h->wg_threads;
@@ -886,9 +898,10 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             const long per_wg = n_chunks / std::max(grid, 1);
             for (rl2 = 0; rl2 < 5 && (per_wg >> (rl2 + 1)) >= 16; ++rl2) {}
         }
+        sp.stripe = (inl && stripe) ? 1 : 0;
         sp.run_log2 = inl ? 0 : rl2;               // (the inline LDS record table is sized for single blocks)
         h->last_grid = grid * waves_per_wg / WAVES_PER_WG;
-        const size_t lds_q = inl ? (((2 + 2 * (size_t)num_rays + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 20)
+        const size_t lds_q = inl ? (((2 + 2 * (size_t)num_rays + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 20 + lds_extra)
                                  : lds + 2 * sizeof(float);
         if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel alone
 #define LAUNCH_S(A, C, N, I)                                                                          \

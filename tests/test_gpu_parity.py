@@ -61,6 +61,9 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "inline_map_kb": 0},                         # big-map policy: binning launch from 512 poses up
     {"variant": 1, "inline_map_kb": 0, "run_log2": 3},          # ... with runs of 8 blocks per workgroup turn
     {"variant": 1, "inline_prep": 0, "run_log2": 5, "grid_mult": 1},
+    {"variant": 1, "inline_map_kb": 0, "inline_max": 0},        # stripe bands compacted inside the march kernel
+    {"variant": 1, "inline_map_kb": 0, "inline_max": 0, "xcd_bands": 5, "grid_mult": 2},
+    {"variant": 1, "inline_map_kb": 0, "stripe_max": 0},        # ... switched off: binning launch
     {"variant": 1, "tiled": 0},                                 # row-major padded EDT (default: 4x8-cell tiles)
     {"variant": 1, "tiled": 0, "inline_prep": 0, "xcd_bands": 1},
 ])
@@ -824,3 +827,37 @@ def test_small_host_calls_zero_copy_equals_staged_path(oracle_mod):
         if cls is range_libc.PyRayMarchingGPU:
             r0, _, _ = om.rm_fan(poses, 4.71, 1081, step_coeff=1.0)
             assert np.array_equal(outs[(65536, 50)], r0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["one_row", "two_rows", "column", "uniform", "few"])
+def test_stripe_bands_partition_clustered_poses(oracle_mod, layout):
+    """Stripe mode ranks poses by (row bin, index) and cuts the ranks into equal bands; poses piled
+    into one or two row bins put every cut inside a bin (ordered boundary counts)."""
+    g = maps.make_maze(640, cell=40, wall=3, p=0.45, seed=5)
+    om = oracle_mod.OracleMap.from_gridmap(g, 200)
+    omap = range_libc.PyOMap(g)
+    rng = np.random.default_rng(8)
+    n = {"few": 70}.get(layout, 1500)
+    free = maps.sample_free_poses(g, 4000, 3, dt=om.dt)
+    gy = (free[:, 1] - g.origin[1]) / g.resolution
+    gx = (free[:, 0] - g.origin[0]) / g.resolution
+    if layout == "one_row":
+        k = np.argsort(np.abs(gy - 321.0))[:n]
+    elif layout == "two_rows":
+        k = np.concatenate([np.argsort(np.abs(gy - 100.0))[: n // 3], np.argsort(np.abs(gy - 500.0))[: n - n // 3]])
+    elif layout == "column":
+        k = np.argsort(np.abs(gx - 200.0))[:n]
+    else:
+        k = rng.permutation(len(free))[:n]
+    poses = free[k].copy()
+    rng.shuffle(poses)
+    poses[3] = [np.nan, 0.0, 0.0]
+    poses[11] = [1e7, -1e7, 0.3]
+    m = range_libc.PyRayMarchingGPU(omap, 200)
+    for k_, v in {"inline_map_kb": 0, "inline_max": 0}.items():
+        m.set_option(k_, v)
+    B = 361
+    r, h, s = _fan(m, poses, 4.0, B)
+    r0, h0, s0 = om.rm_fan(poses, 4.0, B, step_coeff=1.0, nthreads=4)
+    assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0)
