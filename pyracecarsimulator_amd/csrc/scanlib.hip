@@ -704,6 +704,11 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         const int per = (int)std::max(1L, (slice_rays - 1) / num_rays);
         const uint64_t base_off = h->ray_offset;
         int rc = RL_OK;
+        // one event pair around the whole sliced sequence (the per-slice pairs would leave the
+        // last slice only)
+        const int timing = h->timing;
+        h->timing = 0;
+        if (timing) HIPCHK(hipEventRecord(h->ev0, stream));
         for (int p0 = 0; p0 < n_poses && rc == RL_OK; p0 += per) {
             const int np = std::min(per, n_poses - p0);
             const size_t r0 = (size_t)p0 * num_rays;
@@ -713,6 +718,8 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
                             nullptr, stream);
         }
         h->ray_offset = base_off;
+        h->timing = timing;
+        if (timing && rc == RL_OK) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
         return rc;
     }
     FanParams f = make_fan(h, n_poses, fov, num_rays);

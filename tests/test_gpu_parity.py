@@ -223,6 +223,15 @@ def test_noise_statistics_and_shard_invariance(oracle_mod):
     m.set_option("slice_log2", 13)            # launch cut into pose slices: same global ray ids
     m.calc_range_fan(poses, again, 4.71, B)
     assert np.array_equal(noisy, again)
+    for mode in (1, 2):                       # the event pair spans every slice, not the last one
+        m.set_option("timing", mode)
+        m.set_option("slice_log2", 30)
+        m.calc_range_fan(poses, again, 4.71, B)
+        whole = m.last_kernel_ms()
+        m.set_option("slice_log2", 13)
+        m.calc_range_fan(poses, again, 4.71, B)
+        assert m.last_kernel_ms() > 1.5 * whole > 0.0
+    m.set_option("timing", 0)
     m.set_option("slice_log2", 30)
     # sharding: second half scanned alone with ray_offset reproduces the unsharded noise
     half = len(poses) // 2
