@@ -1008,6 +1008,19 @@ extern "C" int rl_calc_range_many_device(rl_method *h, const float *d_ins, float
 }
 
 // host-pointer forms ---------------------------------------------------------------
+// pinned, device-mapped host staging of at least `bytes` (small host calls run zero-copy through it)
+static int pin_ensure(rl_method *h, size_t bytes)
+{
+    if (bytes <= h->pin_cap) return RL_OK;
+    if (h->pin) (void)hipHostFree(h->pin);
+    h->pin = nullptr;
+    h->pin_cap = 0;
+    if (hipHostMalloc(&h->pin, bytes * 2, hipHostMallocDefault) != hipSuccess)
+        return fail(RL_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes * 2);
+    h->pin_cap = bytes * 2;
+    return RL_OK;
+}
+
 // car-outline table -> h->edge, re-sent only when its contents changed since the last call
 static int upload_edge(rl_method *h, const double *edge, int num_rays)
 {
@@ -1039,15 +1052,7 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     const size_t off_out = ((size_t)n_poses * 3 * sizeof(float) + 255) & ~(size_t)255;
     const size_t off_end = off_out + ((n_rays * sizeof(float) + 255) & ~(size_t)255);
     if (zc) {
-        const size_t need = off_end;
-        if (need > h->pin_cap) {
-            if (h->pin) (void)hipHostFree(h->pin);
-            h->pin = nullptr;
-            h->pin_cap = 0;
-            if (hipHostMalloc(&h->pin, need * 2, hipHostMallocDefault) != hipSuccess)
-                return fail(RL_ERR_NOMEM, "hipHostMalloc(%zu) failed", need * 2);
-            h->pin_cap = need * 2;
-        }
+        if ((rc = pin_ensure(h, off_end))) return rc;
         memcpy(h->pin, poses, (size_t)n_poses * 3 * sizeof(float));
     } else {
         if ((rc = h->poses.ensure((size_t)n_poses * 3 * sizeof(float)))) return rc;
@@ -1145,6 +1150,16 @@ extern "C" int rl_calc_range_many(rl_method *h, const float *ins, float *outs, i
     std::lock_guard<std::mutex> lk(h->mu);
     int rc = set_device(h->map);
     if (rc) return rc;
+    if (n <= h->pinned_max_rays) {                       // one scan's worth of rows: zero-copy
+        const size_t off_out = ((size_t)n * 3 * sizeof(float) + 255) & ~(size_t)255;
+        if ((rc = pin_ensure(h, off_out + (size_t)n * sizeof(float)))) return rc;
+        memcpy(h->pin, ins, (size_t)n * 3 * sizeof(float));
+        float *p_out = (float *)((char *)h->pin + off_out);
+        if ((rc = launch_rays(h, (const float *)h->pin, n, p_out, nullptr, nullptr, h->stream))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(outs, p_out, (size_t)n * sizeof(float));
+        return RL_OK;
+    }
     if ((rc = h->poses.ensure((size_t)n * 3 * sizeof(float)))) return rc;
     if ((rc = h->outs.ensure((size_t)n * sizeof(float)))) return rc;
     HIPCHK(hipMemcpyAsync(h->poses.p, ins, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice,

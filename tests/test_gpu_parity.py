@@ -833,6 +833,16 @@ def test_small_host_calls_zero_copy_equals_staged_path(oracle_mod):
         for n in (1, 7, 50):
             assert np.array_equal(outs[(65536, n)], outs[(0, n)]), (cls.__name__, n)
             assert outs[(65536, n, "c")] == outs[(0, n, "c")]
+        # the 2-argument per-ray form (scripts/two_player/scan.py:69-70), zero-copy vs staged
+        ang = poses[0, 2] + np.linspace(-2.0, 2.0, 777, dtype=np.float32)
+        ins = np.ascontiguousarray(np.stack([np.full(777, poses[0, 0]), np.full(777, poses[0, 1]), ang], 1),
+                                   dtype=np.float32)
+        two = {}
+        for mode in (65536, 0):
+            m.set_option("pinned_max_rays", mode)
+            two[mode] = np.full(777, -1.0, np.float32)
+            m.calc_range_many(ins, two[mode])
+        assert np.array_equal(two[65536], two[0]) and (two[0] >= 0).all()
         if cls is range_libc.PyRayMarchingGPU:
             r0, _, _ = om.rm_fan(poses, 4.71, 1081, step_coeff=1.0)
             assert np.array_equal(outs[(65536, 50)], r0)
