@@ -880,3 +880,28 @@ def test_stripe_bands_partition_clustered_poses(oracle_mod, layout):
     r, h, s = _fan(m, poses, 4.0, B)
     r0, h0, s0 = om.rm_fan(poses, 4.0, B, step_coeff=1.0, nthreads=4)
     assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0)
+
+
+@pytest.mark.gpu
+def test_two_player_front_end_rebuilds_in_place(oracle_mod):
+    """scripts/two_player/scan.py driven like rcs_two_player.py:110-124: build(map) + scan(pose)
+    every tick with the other car stamped into the grid; same ranges as the oracle's CDDT on each
+    tick's map, device objects reused."""
+    from pyracecarsimulator_amd.two_player import ScanSimulator2D as TwoPlayerScan
+    g = maps.load_colombia()
+    om0 = oracle_mod.OracleMap.from_gridmap(g, 300)
+    pose = maps.sample_free_poses(g, 1, 77, dt=om0.dt)[0]
+    B, fov, td = 1080, 4.71, 112
+    sim = TwoPlayerScan(B, fov, 0.01)
+    first_method = None
+    for tick in range(4):
+        occ = g.occ.copy()
+        occ[40 + 7 * tick: 48 + 7 * tick, 200:212] = 1                   # the other car's outline moves
+        sim.build(maps.GridMap(occ, g.resolution, g.origin, name="tick"), 300, td)
+        first_method = first_method or sim.scan_method
+        assert sim.scan_method is first_method                           # no new device objects
+        out = sim.scan(float(pose[0]), float(pose[1]), float(pose[2]))
+        assert out is sim.output_vector
+        om = oracle_mod.OracleMap(occ, g.resolution, g.origin, 300)
+        want = om.cddt_rays(td, sim.input_vector)
+        assert np.array_equal(out, want), tick
