@@ -412,6 +412,10 @@ __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float
 // Up to 8192 poses: the same binning with every lane keeping its (up to 8) pose records in
 // registers between the histogram and the scatter pass — no scratch round trip through memory,
 // and the 8 pose loads of a lane are in flight together.
+// KEYS_ONLY: only the tile order is produced (order[slot] = pose id) — no sincos, no records: the
+// march kernel derives the records of the blocks it owns itself (INLINE prologue, pose ids from
+// `order`), so the ~100 instructions per pose of the record leave this one-workgroup critical path.
+template <bool KEYS_ONLY>
 __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const float *__restrict__ poses,
                                                               int n, PoseRec *__restrict__ rec_sorted,
                                                               uint32_t *__restrict__ order,
@@ -430,7 +434,15 @@ __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const
         const int p = tid + u * 1024;
         kf[u] = 0;
         if (p < n) {
-            kf[u] = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r[u], walk_outside != 0);
+            if (KEYS_ONLY) {
+                float gx, gy, thg;
+                world_to_grid(m, poses[3 * (size_t)p], poses[3 * (size_t)p + 1], 0.0f, gx, gy, thg);
+                const bool inb = gx > -1.0f && gx < m.fcols && gy > -1.0f && gy < m.frows;   // (NaN -> false)
+                kf[u] = inb ? (uint32_t)(((int)gy >> tile_shift) * tiles_x + ((int)gx >> tile_shift))
+                            : (uint32_t)n_tiles - 1;
+            } else {
+                kf[u] = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r[u], walk_outside != 0);
+            }
             atomicAdd(&hist[kf[u] & ~POSE_INVALID], 1u);
         }
     }
@@ -441,15 +453,29 @@ __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const
         int i = tid * E + e;
         if (i < n_tiles) local += hist[i];
     }
-    part[tid] = local;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    // exclusive scan of the 1024 per-lane sums: shuffle scan inside each wave, the 16 wave totals
+    // through LDS (2 barriers instead of the 20 of a Hillis-Steele pass over `part`)
+    uint32_t incl = local;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += o;
     }
-    uint32_t base = part[tid] - local;
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    {
+        const uint32_t v = lane < 16 ? part[lane] : 0u;
+        uint32_t wi = v;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)wi, off);
+            if (lane >= off) wi += o;
+        }
+        wave_base = (uint32_t)__shfl((int)(wi - v), wave);
+    }
+    uint32_t base = wave_base + incl - local;
     for (int e = 0; e < E; ++e) {
         int i = tid * E + e;
         if (i < n_tiles) {
@@ -465,7 +491,7 @@ __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const
         if (p < n) {
             const uint32_t slot = atomicAdd(&hist[kf[u] & ~POSE_INVALID], 1u);
             order[slot] = (uint32_t)p | (kf[u] & POSE_INVALID);
-            rec_sorted[slot] = r[u];
+            if (!KEYS_ONLY) rec_sorted[slot] = r[u];
         }
     }
 }
@@ -647,8 +673,10 @@ struct StreamParams {
     int k_max;               // INLINE only: LDS capacity in chunk records
     int drain_prio;          // raise wave priority once the workgroup's stream is exhausted
     int run_log2;            // a workgroup's stream interleaves RUNS of 2^run_log2 consecutive 64-ray blocks
-    int stripe;              // INLINE only: bands are row stripes of the map, compacted by every workgroup
-                             //   itself (stripe_band_list) instead of ranges of the caller's pose order
+    int stripe;              // INLINE only, where the band's pose ids come from: 0 = the caller's order
+                             //   (band = index range), 1 = row stripes of the map compacted by every
+                             //   workgroup itself (stripe_band_list), 2 = `order` (tile order from the
+                             //   keys-only binning launch)
     unsigned long long *dbg; // diagnostics (nullptr in production): 4 words per wave
 };
 
@@ -806,14 +834,15 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         const MapParams mp = *sp.map;
         // stripe mode: this band's poses (a row stripe of the map) compacted here, in LDS
         uint32_t *list = lord + sp.k_max;
-        if (sp.stripe && seg_hi > seg_lo)
+        if (sp.stripe == 1 && seg_hi > seg_lo)
             stripe_band_list<NT>(mp, sp.raw_poses, f.n_poses, seg_lo, seg_hi, list,
                                  reinterpret_cast<int *>(list + (seg_hi - seg_lo) + 1));
         // (num_rays >= 64 here, so a block of 64 rays touches at most two poses: slots 2k, 2k+1)
         for (uint32_t k2 = threadIdx.x; k2 < 2 * K; k2 += NT) {
             const uint32_t p0 = fast_div(blk_of(k2 >> 1), sp.div_B) + (k2 & 1);
             if (seg_lo + p0 < seg_hi) {
-                const uint32_t pid = sp.stripe ? list[p0] : seg_lo + p0;
+                const uint32_t pid = sp.stripe == 1 ? list[p0]
+                                   : sp.stripe == 2 ? (sp.order[seg_lo + p0] & ~POSE_INVALID) : seg_lo + p0;
                 PoseRec r;
                 const uint32_t kf = pose_record(mp, sp.raw_poses, (int)pid, 0, 1, 1, r);
                 lrec[k2] = r;

@@ -146,7 +146,8 @@ struct rl_method {
     std::vector<double> edge_host; // the car-outline table last uploaded to `edge` (re-sent only when it changes)
     int *pin_flag = nullptr;       // pinned landing slot for the crash index
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
-    int stripe_max = 3072;       // big maps, inline_max..stripe_max poses: no binning launch, workgroups compact
+    int order_inline = 1;        // big maps, stripe_max..8192 poses: keys-only binning launch + INLINE march
+    int stripe_max = 2560;       // big maps, inline_max..stripe_max poses: no binning launch, workgroups compact
                                  // their own row-stripe band of the pose list (0 = off)
     int inline_map_kb = 2048;    // maps up to this size (f32 cells) never take the binning launch while the records fit LDS
     int run_log2 = -1;           // stream interleave granularity: runs of 2^run_log2 blocks; -1 = by batch size
@@ -419,6 +420,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "pinned_max_rays")) h->pinned_max_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "inline_map_kb")) h->inline_map_kb = value < 0 ? 0 : value;
     else if (!strcmp(name, "stripe_max")) h->stripe_max = value < 0 ? 0 : value;
+    else if (!strcmp(name, "order_inline")) h->order_inline = value != 0;
     else if (!strcmp(name, "run_log2")) h->run_log2 = value < 0 ? -1 : value > 8 ? 8 : value;
     else if (!strcmp(name, "slice_log2")) h->slice_log2 = value < 8 ? 8 : (value > 30 ? 30 : value);
     else if (!strcmp(name, "inline_max")) h->inline_max = value;
@@ -447,6 +449,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "pinned_max_rays")) *value_out = h->pinned_max_rays;
     else if (!strcmp(name, "inline_map_kb")) *value_out = h->inline_map_kb;
     else if (!strcmp(name, "stripe_max")) *value_out = h->stripe_max;
+    else if (!strcmp(name, "order_inline")) *value_out = h->order_inline;
     else if (!strcmp(name, "run_log2")) *value_out = h->run_log2;
     else if (!strcmp(name, "slice_log2")) *value_out = h->slice_log2;
     else if (!strcmp(name, "inline_max")) *value_out = h->inline_max;
@@ -621,8 +624,13 @@ static BlParams make_bl(const rl_method *h, int num_rays, size_t &lds_bytes)
 
 // pose records in map-tile order (rec_sorted / order), by the binning kernel set that fits the
 // batch size; walk_outside = Bresenham semantics (origins outside the map still walk)
+static bool bin_keys_only_ok(const rl_method *h, int n_poses)
+{
+    return h->sort_poses && n_poses >= 64 && n_poses < h->bin_multi_min && n_poses <= 8192 && !h->bin_generic;
+}
+
 static int bin_poses(rl_method *h, const float *d_poses, int n_poses, int walk_outside,
-                     hipStream_t stream)
+                     hipStream_t stream, bool keys_only = false)
 {
     const rl_map *m = h->map;
     int rc;
@@ -664,10 +672,16 @@ static int bin_poses(rl_method *h, const float *d_poses, int n_poses, int walk_o
                                (uint32_t *)h->order.p, walk_outside);
         }
     } else if (do_sort && n_poses <= 8192 && !h->bin_generic) {
-        hipLaunchKernelGGL(pose_bin_small_kernel, dim3(1), dim3(1024),
-                           (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
-                           n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)h->order.p, shift,
-                           tiles_x, n_tiles, walk_outside);
+        if (keys_only)
+            hipLaunchKernelGGL(pose_bin_small_kernel<true>, dim3(1), dim3(1024),
+                               (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
+                               n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)h->order.p, shift,
+                               tiles_x, n_tiles, walk_outside);
+        else
+            hipLaunchKernelGGL(pose_bin_small_kernel<false>, dim3(1), dim3(1024),
+                               (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
+                               n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)h->order.p, shift,
+                               tiles_x, n_tiles, walk_outside);
     } else {
         hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
                            (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
@@ -856,6 +870,12 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         const bool stripe = h->inline_prep && num_rays >= 64 && !inl && bands > 1 && h->sort_poses &&
                             n_poses >= 64 && n_poses <= std::min(h->stripe_max, 1024 * STRIPE_MAX_PER_LANE);
         if (stripe) inl = true;
+        // big maps, up to 8192 poses: a keys-only binning launch (tile order, no records) in front of
+        // an INLINE march that takes its pose ids from `order` — the per-pose sincos leaves the
+        // one-workgroup binning kernel
+        const bool order_inl = h->inline_prep && h->order_inline && num_rays >= 64 && !inl && bands > 1 &&
+                               bin_keys_only_ok(h, n_poses);
+        if (order_inl) inl = true;
         int k_max = 0;
         size_t lds_extra = 0;
         if (inl) {
@@ -870,6 +890,8 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         if (!inl) {
             nt = h->wg_threads;
             if ((rc = bin_poses(h, d_poses, n_poses, 0, stream))) return rc;
+        } else if (order_inl) {
+            if ((rc = bin_poses(h, d_poses, n_poses, 0, stream, true))) return rc;
         }
         PadMap pm{};
         pm.pdt = (const float *)h->pdt.p;
@@ -905,7 +927,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             const long per_wg = n_chunks / std::max(grid, 1);
             for (rl2 = 0; rl2 < 5 && (per_wg >> (rl2 + 1)) >= 16; ++rl2) {}
         }
-        sp.stripe = (inl && stripe) ? 1 : 0;
+        sp.stripe = (inl && stripe) ? 1 : (inl && order_inl) ? 2 : 0;
         sp.run_log2 = inl ? 0 : rl2;               // (the inline LDS record table is sized for single blocks)
         h->last_grid = grid * waves_per_wg / WAVES_PER_WG;
         const size_t lds_q = inl ? (((2 + 2 * (size_t)num_rays + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 20 + lds_extra)

@@ -63,7 +63,9 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "inline_prep": 0, "run_log2": 5, "grid_mult": 1},
     {"variant": 1, "inline_map_kb": 0, "inline_max": 0},        # stripe bands compacted inside the march kernel
     {"variant": 1, "inline_map_kb": 0, "inline_max": 0, "xcd_bands": 5, "grid_mult": 2},
-    {"variant": 1, "inline_map_kb": 0, "stripe_max": 0},        # ... switched off: binning launch
+    {"variant": 1, "inline_map_kb": 0, "stripe_max": 0},        # keys-only binning launch + records derived in the march
+    {"variant": 1, "inline_map_kb": 0, "stripe_max": 0, "xcd_bands": 3, "grid_mult": 1},
+    {"variant": 1, "inline_map_kb": 0, "stripe_max": 0, "order_inline": 0},   # classic: binning launch writes the records
     {"variant": 1, "tiled": 0},                                 # row-major padded EDT (default: 4x8-cell tiles)
     {"variant": 1, "tiled": 0, "inline_prep": 0, "xcd_bands": 1},
 ])

@@ -77,6 +77,8 @@ def main():
         combos = [dict(variant=1, low_water=lw) for lw in (0, 2, 4, 6, 8, 10, 12, 16, 4, 8, 12)]
     elif a.grid == "stripe":
         combos = [dict(variant=1, stripe_max=v) for v in (0, 8192, 0, 8192)]
+    elif a.grid == "oi":
+        combos = [dict(variant=1, order_inline=v) for v in (0, 1, 0, 1)]
     elif a.grid == "small":
         combos = [dict(variant=0, grid_mult=8)]
         combos += [dict(variant=1, low_water=lw, wg_threads=nt, grid_mult=8)
