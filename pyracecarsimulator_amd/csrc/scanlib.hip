@@ -873,6 +873,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         // big maps, up to 8192 poses: a keys-only binning launch (tile order, no records) in front of
         // an INLINE march that takes its pose ids from `order` — the per-pose sincos leaves the
         // one-workgroup binning kernel
+        // (above 8192 poses the grid-wide binning is off the critical path and INLINE loses 2-3 %)
         const bool order_inl = h->inline_prep && h->order_inline && num_rays >= 64 && !inl && bands > 1 &&
                                bin_keys_only_ok(h, n_poses);
         if (order_inl) inl = true;
