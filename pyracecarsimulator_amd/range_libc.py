@@ -143,6 +143,7 @@ class _RangeMethod:
         self._h = C.c_void_p()
         _lib.check(_lib.lib().rl_method_create(omap._h, self.KIND, self.max_range_px,
                                                self.theta_disc, C.byref(self._h)))
+        self._fan_raw = _lib.raw("rl_calc_range_many_fan")
 
     # -- the reference's entry point ----------------------------------------
     def calc_range_many(self, ins, outs, fov=None, num_rays=None):
@@ -162,6 +163,13 @@ class _RangeMethod:
                                                 outs.ctypes.data_as(f32p), ins.shape[0],
                                                 float(fov), int(num_rays)))
         return None
+
+    def _fan_rows_ptr(self, ins_addr, outs_addr, n_rows, fov, num_rays):
+        """4-argument calc_range_many on buffers whose addresses the caller keeps (ScanSimulator2D's
+        cached vectors): same C entry point, no per-call ctypes pointer objects, no re-validation."""
+        rc = self._fan_raw(self._h, ins_addr, outs_addr, n_rows, fov, num_rays)
+        if rc:
+            _lib.check(rc)
 
     def calc_range(self, x, y, heading):
         """Scalar query in world coordinates (upstream's RayMarchingGPU does not support

@@ -36,6 +36,7 @@ class ScanSimulator2D:
         self.output_vector = np.zeros(self.num_rays, dtype=np.float32)
         self.noise = np.zeros(self.num_rays, dtype=np.float32)
         self.input_vector = np.zeros((self.num_rays, 3), dtype=np.float32)
+        self._addr_of = (None, None, 0, 0)       # (input_vector, output_vector, their addresses)
         self.output_vector_many = np.zeros(batch_size * self.num_rays, dtype=np.float32)
         self.input_vector_many = np.zeros((batch_size * self.num_rays, 3), dtype=np.float32)
         self._poses_many = np.zeros((batch_size, 3), dtype=np.float32)
@@ -94,8 +95,16 @@ class ScanSimulator2D:
         self.input_vector[0, 0] = x
         self.input_vector[0, 1] = y
         self.input_vector[0, 2] = theta
-        self.scan_method.calc_range_many(self.input_vector, self.output_vector, self.fov,
-                                         self.num_rays)
+        fast = getattr(self.scan_method, "_fan_rows_ptr", None)
+        if fast is not None:
+            # same call (scan_simulator.py:103-106) on the cached vectors' addresses
+            if self._addr_of[0] is not self.input_vector or self._addr_of[1] is not self.output_vector:
+                self._addr_of = (self.input_vector, self.output_vector,
+                                 self.input_vector.ctypes.data, self.output_vector.ctypes.data)
+            fast(self._addr_of[2], self._addr_of[3], self.num_rays, self.fov, self.num_rays)
+        else:                                    # a foreign range_libc object: the public form
+            self.scan_method.calc_range_many(self.input_vector, self.output_vector, self.fov,
+                                             self.num_rays)
         return self.output_vector.copy() if copy else self.output_vector
 
     def scanMany(self, poses, copy=False):
