@@ -55,12 +55,26 @@ def one_case(seed):
                     ("BL", range_libc.PyBresenhamsLine, (), lambda: om.bl_fan(poses, fov, B))):
                 for variant in (1, 0):
                     m = cls(omap, mrx, *args); m.set_option("variant", variant)
+                    # random schedule: every path the host policy can take, whatever the map size
+                    sched = {}
+                    if variant == 1 and r.random() < 0.7:
+                        sched = {"inline_map_kb": int(r.choice([0, 2048])), "inline_max": int(r.choice([0, 512])),
+                                 "stripe_max": int(r.choice([0, 2560, 8192])), "order_inline": int(r.integers(0, 2)),
+                                 "tiled": int(r.integers(0, 2)), "low_water": int(r.choice([0, 5, 12, 24, 40])),
+                                 "run_log2": int(r.choice([-1, 0, 2, 5])), "xcd_bands": int(r.choice([1, 3, 8])),
+                                 "grid_mult": int(r.choice([1, 8])), "wg_threads": int(r.choice([256, 512, 1024])),
+                                 "bin_multi_min": int(r.choice([64, 8192])), "pinned_max_rays": int(r.choice([0, 262144]))}
+                        for k_, v_ in sched.items():
+                            m.set_option(k_, v_)
                     out = np.empty(n, np.float32); hits = np.empty((n, 2), np.int32); st = np.empty(n, np.uint16)
                     m.calc_range_fan(poses, out, fov, B, hit_cells=hits, steps=st)
                     r0, h0, s0 = ofun()
-                    assert np.array_equal(out, r0), "%s v%d ranges" % (name, variant)
-                    assert np.array_equal(hits, h0), "%s v%d hits" % (name, variant)
-                    assert np.array_equal(st, s0), "%s v%d steps" % (name, variant)
+                    assert np.array_equal(out, r0), "%s v%d ranges %s" % (name, variant, sched)
+                    assert np.array_equal(hits, h0), "%s v%d hits %s" % (name, variant, sched)
+                    assert np.array_equal(st, s0), "%s v%d steps %s" % (name, variant, sched)
+                    if sched:                      # ranges-only launch takes the non-diagnostic kernels
+                        out2 = np.empty(n, np.float32); m.calc_range_fan(poses, out2, fov, B)
+                        assert np.array_equal(out2, r0), "%s v%d ranges-only %s" % (name, variant, sched)
                     m.close()
             if rows * cols <= 20000:
                 td = int(r.choice([2, 16, 112, 113, 360]))
