@@ -206,13 +206,18 @@ def main():
 
     # untimed diagnostics launch: mean samples per ray (feeds the algorithmic-bytes figure)
     mean_steps = 0.0
+    p99_steps = max_steps = 0.0
     if method in ("RM", "RMGPU", "BL"):
         d_steps = torch.empty(n * B, dtype=torch.int16, device=dev)
         meth.calc_range_fan_device(d_poses.data_ptr(), n, w.fov, B, scan.local.data_ptr(),
                                    d_steps_ptr=d_steps.data_ptr(), stream=stream)
         torch.cuda.synchronize()
-        mean_steps = float(d_steps.to(torch.int32).bitwise_and(0xFFFF).float().mean().item())
-        del d_steps
+        st = d_steps.to(torch.int32).bitwise_and(0xFFFF).float()
+        mean_steps = float(st.mean().item())
+        sub = st[:: max(1, st.numel() // (1 << 20))]            # <= ~1M rays for the quantile
+        p99_steps = float(torch.quantile(sub, 0.99).item())
+        max_steps = float(st.max().item())
+        del d_steps, st, sub
 
     def step():
         if mode == "crash":
@@ -296,7 +301,8 @@ def main():
                               "crash": "fused crash test per %d-pose roll-out, all-gather of int32 "
                                        "crash indices" % group}[mode]},
         "kernel_ms_avg": round(k_ms, 4), "step_ms_avg": round(step_ms, 4),
-        "mean_samples_per_ray": round(mean_steps, 3),
+        "mean_samples_per_ray": round(mean_steps, 3), "p99_samples_per_ray": round(p99_steps, 1),
+        "max_samples_per_ray": round(max_steps, 1),
     }
     if world == 1:
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
