@@ -142,7 +142,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(CarParams P, const double *
 
 // per-group first crashed pose over finished ranges (Car::isCrashed racecar.cpp:305-328 applied to
 // each roll-out of a batch): first[g] = min{k : exists j, (double)r[(g*G+k)*B + j] - edge[j] < thresh}
-// or -(G+1).  first[] must be initialised to INT_MAX; crash_finalize_kernel maps INT_MAX -> -(G+1).
+// or -(G+1).  Called with group = 1 on a per-pose array initialised to INT_MAX; crash_reduce_kernel
+// then finds every group's first marked pose.
 __global__ __launch_bounds__(256) void crash_groups_kernel(const float *__restrict__ ranges,
                                                            const double *__restrict__ edge,
                                                            double thresh, int n_poses, int num_rays,
@@ -159,10 +160,24 @@ __global__ __launch_bounds__(256) void crash_groups_kernel(const float *__restri
     }
 }
 
-__global__ void crash_finalize_kernel(int *first, int n_groups, int group)
+// per-pose crash marks -> first crashed pose of every group (roll-out): one wave per group.
+// The march kernels mark POSES (pose_first[p] = 0, each pose its own word): a word per group was
+// the target of thousands of same-address atomics, which the L2 retires one at a time (~10 per us)
+// — measured +100 % kernel time at 4096 poses in 32 groups, +9 % with a word per pose.
+__global__ __launch_bounds__(256) void crash_reduce_kernel(const int *__restrict__ pose_first, int n_groups,
+                                                           int group, int *__restrict__ first)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n_groups && first[g] == 0x7fffffff) first[g] = -(group + 1);
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    for (int g = wave; g < n_groups; g += n_waves) {
+        int best = 0x7fffffff;
+        for (int k = lane; k < group && best == 0x7fffffff; k += 64)
+            if (pose_first[(size_t)g * group + k] != 0x7fffffff) best = k;   // lowest index this lane owns
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off));
+        if (lane == 0) first[g] = best == 0x7fffffff ? -(group + 1) : best;
+    }
 }
 
 __global__ void fill_int_kernel(int *p, int n, int v)

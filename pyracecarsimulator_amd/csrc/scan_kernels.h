@@ -792,6 +792,9 @@ __device__ __forceinline__ uint32_t stripe_band_list(const MapParams &m, const f
     return npos;
 }
 
+// LDS header of the stream kernels in floats: [0] slot counter, [1] spare, [2..66) crash_seen
+constexpr int STREAM_HDR = 66;
+
 template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
 void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__restrict__ out,
@@ -799,15 +802,26 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
 {
     extern __shared__ float lds_f[];
     uint32_t *q_next = reinterpret_cast<uint32_t *>(lds_f);     // shared slot counter
-    float2 *fan_cs = reinterpret_cast<float2 *>(lds_f + 2);     // num_rays float2
+    // [2 .. STREAM_HDR): CRASH only — poses this workgroup has already reported as crashed
+    // (direct-mapped): a pose scraping a wall crashes on hundreds of beams, all marched by this
+    // workgroup, and only the first of them needs to touch the group's word in global memory
+    uint32_t *crash_seen = reinterpret_cast<uint32_t *>(lds_f + 2);
+    float2 *fan_cs = reinterpret_cast<float2 *>(lds_f + STREAM_HDR);     // num_rays float2
+    // CRASH: the car-outline table next to the fan table (read when a ray finishes: from LDS it does
+    // not sit behind the range store in vmcnt — a global read there made every refill wait for the
+    // store's acknowledgement and the kernel 2.5x slower)
+    double *edge_l = reinterpret_cast<double *>(lds_f + STREAM_HDR + 2 * (size_t)f.num_rays);
+    const size_t tables = STREAM_HDR + (CRASH ? 4 : 2) * (size_t)f.num_rays;
     // INLINE: per owned chunk {gx, gy, cos, sin} and pose id | invalid flag, filled below
-    PoseRec *lrec = reinterpret_cast<PoseRec *>(lds_f + ((2 + 2 * (size_t)f.num_rays + 3) & ~(size_t)3));   // 16-B aligned
+    PoseRec *lrec = reinterpret_cast<PoseRec *>(lds_f + ((tables + 3) & ~(size_t)3));   // 16-B aligned
     uint32_t *lord = reinterpret_cast<uint32_t *>(lrec + (INLINE ? sp.k_max : 0));
     if (threadIdx.x == 0) *q_next = 0;
+    if (CRASH && threadIdx.x < STREAM_HDR - 2) crash_seen[threadIdx.x] = 0xffffffffu;
     for (int j = threadIdx.x; j < f.num_rays; j += NT) {
         float s, c;
         det_sincosf(fan_alpha(f, j), s, c);
         fan_cs[j] = make_float2(c, s);
+        if (CRASH) edge_l[j] = cp.edge[j];
     }
 
     // ---- which band of the sorted pose list, and which workgroups share it
@@ -896,8 +910,13 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                     if (steps) steps[oidx] = (uint16_t)(nstep > 65535u ? 65535u : nstep);
                 }
                 if (CRASH) {
-                    if (((double)r - cp.edge[jbeam]) < cp.thresh)
-                        crash_note(cp, pose);
+                    if (((double)r - edge_l[jbeam]) < cp.thresh) {
+                        uint32_t *seen = &crash_seen[pose & (STREAM_HDR - 3)];
+                        if (*seen != pose) {            // (a race only costs a redundant atomic)
+                            *seen = pose;
+                            crash_note(cp, pose);
+                        }
+                    }
                 }
                 has_ray = false;
             }

@@ -137,7 +137,7 @@ struct rl_method {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf poses, outs, hits, steps, edge, flag, rec, rec_sorted, order, keys, dbg, hist;
+    DevBuf poses, outs, hits, steps, edge, flag, pose_first, rec, rec_sorted, order, keys, dbg, hist;
     // small host calls (scan(): one pose, scanMany(): a roll-out): poses and ranges go through ONE
     // pinned, device-mapped host buffer the kernels read / write directly — no staging copies
     void *pin = nullptr;
@@ -371,6 +371,7 @@ extern "C" void rl_method_destroy(rl_method *h)
     h->steps.release();
     h->edge.release();
     h->flag.release();
+    h->pose_first.release();
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->pin_flag) (void)hipHostFree(h->pin_flag);
     h->rec.release();
@@ -877,16 +878,23 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         const bool order_inl = h->inline_prep && h->order_inline && num_rays >= 64 && !inl && bands > 1 &&
                                bin_keys_only_ok(h, n_poses);
         if (order_inl) inl = true;
-        int k_max = 0;
+        int k_max = 0, inl_rl = 0;
         size_t lds_extra = 0;
         if (inl) {
             nt = 1024;
             const long g_min = std::max(1L, std::min((n_chunks + 15) / 16, (long)m->n_cu * h->grid_mult * WG / nt) / bands);
             const long seg_chunks_max = ((((long)n_poses + bands - 1) / bands) * num_rays + 63) / 64;
-            k_max = 2 * ((int)((seg_chunks_max + g_min - 1) / g_min) + 1);   // two records per block
+            // runs of 2^rl blocks (same rule as below, for the grid an INLINE launch gets)
+            const long grid_i = std::max((long)bands, std::min((n_chunks + 15) / 16, std::max((long)m->n_cu * h->grid_mult * WG / nt, 1L)));
+            inl_rl = h->run_log2;
+            if (inl_rl < 0)
+                for (inl_rl = 0; inl_rl < 5 && ((n_chunks / grid_i) >> (inl_rl + 1)) >= 16; ++inl_rl) {}
+            const long seg_runs_max = (seg_chunks_max + (1L << inl_rl) - 1) >> inl_rl;
+            const long k_blocks = ((seg_runs_max + g_min - 1) / g_min) << inl_rl;
+            k_max = 2 * ((int)k_blocks + 1);                                 // two records per block
             if (stripe)                                   // band list + histogram / wave counts / cuts
                 lds_extra = ((size_t)(n_poses + bands - 1) / bands + 2 + STRIPE_BINS + 3 * (nt / 64) + 4) * 4;
-            if ((size_t)k_max * 20 + lds + lds_extra + 32 > 56 * 1024) inl = false;
+            if ((size_t)k_max * 20 + lds * (crash ? 2 : 1) + lds_extra + 32 + STREAM_HDR * 4 > 56 * 1024) inl = false;
         }
         if (!inl) {
             nt = h->wg_threads;
@@ -929,10 +937,11 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             for (rl2 = 0; rl2 < 5 && (per_wg >> (rl2 + 1)) >= 16; ++rl2) {}
         }
         sp.stripe = (inl && stripe) ? 1 : (inl && order_inl) ? 2 : 0;
-        sp.run_log2 = inl ? 0 : rl2;               // (the inline LDS record table is sized for single blocks)
+        sp.run_log2 = inl ? inl_rl : rl2;          // (the inline LDS record table was sized for inl_rl)
         h->last_grid = grid * waves_per_wg / WAVES_PER_WG;
-        const size_t lds_q = inl ? (((2 + 2 * (size_t)num_rays + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 20 + lds_extra)
-                                 : lds + 2 * sizeof(float);
+        const size_t tab_floats = STREAM_HDR + (crash ? 4 : 2) * (size_t)num_rays;   // fan table (+ edge table, f64)
+        const size_t lds_q = inl ? (((tab_floats + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 20 + lds_extra)
+                                 : tab_floats * sizeof(float);
         if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel alone
 #define LAUNCH_S(A, C, N, I)                                                                          \
     do {                                                                                              \
@@ -1088,18 +1097,28 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     }
     const float *d_poses = zc ? (const float *)h->pin : (const float *)h->poses.p;
     CrashParams cp{nullptr, 0.0, nullptr, 1};
+    const bool crash_direct = first_crashed && n_poses <= 512;
     if (first_crashed) {
         if ((rc = upload_edge(h, edge, num_rays))) return rc;
         if ((rc = h->flag.ensure(sizeof(int)))) return rc;
-        // the crash flag stays in device memory (target of an atomicMin); set by a 1-lane kernel,
-        // read back into a pinned slot — no pageable-memory staging on either side
-        hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, h->stream, (int *)h->flag.p, 1, INT_MAX);
         if (!h->pin_flag && hipHostMalloc((void **)&h->pin_flag, 64, hipHostMallocDefault) != hipSuccess)
             return fail(RL_ERR_NOMEM, "hipHostMalloc(64) failed");
         cp.edge = (const double *)h->edge.p;
         cp.thresh = crash_thresh;
-        cp.first_crashed = (int *)h->flag.p;
-        cp.group = n_poses;
+        if (crash_direct) {
+            // one roll-out: atomicMin straight into the result word (few poses, little contention)
+            hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, h->stream, (int *)h->flag.p, 1, INT_MAX);
+            cp.first_crashed = (int *)h->flag.p;
+            cp.group = n_poses;
+        } else {
+            // big batches: the kernel marks crashed poses (a word per pose), the first one is reduced
+            // on the device afterwards (see crash_reduce_kernel)
+            if ((rc = h->pose_first.ensure((size_t)n_poses * sizeof(int)))) return rc;
+            hipLaunchKernelGGL(fill_int_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, h->stream,
+                               (int *)h->pose_first.p, n_poses, INT_MAX);
+            cp.first_crashed = (int *)h->pose_first.p;
+            cp.group = 1;
+        }
     }
     float *d_out = (outs || !first_crashed) ? (zc ? (float *)((char *)h->pin + off_out) : (float *)h->outs.p) : nullptr;
     rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_out,
@@ -1115,14 +1134,19 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     if (steps)
         HIPCHK(hipMemcpyAsync(steps, h->steps.p, n_rays * sizeof(uint16_t), hipMemcpyDeviceToHost,
                               h->stream));
-    if (first_crashed)
+    if (first_crashed) {
+        if (!crash_direct)
+            hipLaunchKernelGGL(crash_reduce_kernel, dim3(1), dim3(64), 0, h->stream,
+                               (const int *)h->pose_first.p, 1, n_poses, (int *)h->flag.p);
         HIPCHK(hipMemcpyAsync(h->pin_flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
-    const int flag = first_crashed ? *h->pin_flag : INT_MAX;
+    int flag = first_crashed ? *h->pin_flag : 0;
+    if (crash_direct && flag == INT_MAX) flag = -(n_poses + 1);
     if (zc) {
         if (outs) memcpy(outs, (char *)h->pin + off_out, n_rays * sizeof(float));
     }
-    if (first_crashed) *first_crashed = flag == INT_MAX ? -(n_poses + 1) : flag;
+    if (first_crashed) *first_crashed = flag;      // first crashed pose, or -(n_poses + 1)
     return RL_OK;
 }
 
@@ -1258,12 +1282,16 @@ static int crash_groups_device(rl_method *h, const float *d_poses, int n_groups,
                                int num_rays, const double *d_edge, double thresh, int *d_first,
                                float *d_ranges, bool finalize, hipStream_t stream)
 {
+    (void)finalize;
     const int n_poses = n_groups * group;
-    hipLaunchKernelGGL(fill_int_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, stream, d_first,
-                       n_groups, INT_MAX);
+    // the kernels mark crashed POSES (one word each, no contended atomics); groups are reduced after
     int rc;
+    if ((rc = h->pose_first.ensure((size_t)n_poses * sizeof(int)))) return rc;
+    int *d_pose_first = (int *)h->pose_first.p;
+    hipLaunchKernelGGL(fill_int_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, stream, d_pose_first,
+                       n_poses, INT_MAX);
     if (h->kind == RL_RM || h->kind == RL_RM_GPU) {
-        CrashParams cp{d_edge, thresh, d_first, group};
+        CrashParams cp{d_edge, thresh, d_pose_first, 1};
         if ((rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_ranges, nullptr, nullptr, &cp, stream)))
             return rc;
     } else {
@@ -1272,11 +1300,11 @@ static int crash_groups_device(rl_method *h, const float *d_poses, int n_groups,
             return rc;
         const int grid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4, (long)h->map->n_cu * 8));
         hipLaunchKernelGGL(crash_groups_kernel, dim3(grid), dim3(256), 0, stream, d_ranges, d_edge,
-                           thresh, n_poses, num_rays, group, d_first);
+                           thresh, n_poses, num_rays, 1, d_pose_first);
     }
-    if (finalize)
-        hipLaunchKernelGGL(crash_finalize_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, stream,
-                           d_first, n_groups, group);
+    const int rgrid = (int)std::max(1L, std::min(((long)n_groups + 3) / 4, (long)h->map->n_cu * 8));
+    hipLaunchKernelGGL(crash_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, d_pose_first, n_groups,
+                       group, d_first);
     HIPCHK(hipGetLastError());
     return RL_OK;
 }

@@ -907,3 +907,27 @@ def test_two_player_front_end_rebuilds_in_place(oracle_mod):
         om = oracle_mod.OracleMap(occ, g.resolution, g.origin, 300)
         want = om.cddt_rays(td, sim.input_vector)
         assert np.array_equal(out, want), tick
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [200, 513, 3000])
+def test_fused_crash_marks_poses_then_reduces(oracle_mod, n):
+    """Whole-batch and grouped crash index for batches on both sides of the direct / per-pose-mark
+    switch (512 poses), many poses crashing at once; equal to isCrashed on the oracle's ranges."""
+    from pyracecarsimulator_amd import racecar as RC
+    g = maps.load_colombia()
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    omap = range_libc.PyOMap(g)
+    poses = maps.sample_free_poses(g, n, 31, dt=om.dt)
+    B, fov = 360, 4.71
+    edge = RC.edge_distances(B, -fov / 2, fov / B, 0.275, 0.2032, 0.3302) + 0.25      # wide car: many crashes
+    r0, _, _ = om.rm_fan(poses, fov, B, step_coeff=1.0, nthreads=4)
+    m = range_libc.PyRayMarchingGPU(omap, 300)
+    want = oracle_mod.is_crashed(r0, B, n, edge, 0.001)
+    assert m.check_collision_many(poses, fov, B, edge, 0.001) == want
+    far = np.full(B, -100.0)                                                          # nothing crashes
+    assert m.check_collision_many(poses, fov, B, far, 0.001) == -(n + 1)
+    grp = next(k for k in (40, 27, 25, 19, 8, 3, 1) if n % k == 0)
+    got = m.check_collision_groups(poses, grp, fov, B, edge, 0.001)
+    exp = [oracle_mod.is_crashed(r0[k * grp * B:(k + 1) * grp * B], B, grp, edge, 0.001) for k in range(n // grp)]
+    assert got.tolist() == exp
