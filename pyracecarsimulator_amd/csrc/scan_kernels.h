@@ -140,14 +140,22 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *__restric
 struct CrashParams {
     const double *edge;      // num_rays doubles (Car::setCarEdgeDistances) or nullptr
     double thresh;
-    int *first_crashed;      // atomicMin targets, one per group, initialised to INT_MAX
-    int group;               // poses per group (roll-out); the whole batch is one group by default
+    int *first_crashed;      // group > 0: atomicMin targets, one per group, initialised to INT_MAX
+                             // group == 0: one word per POSE, a crashed pose gets `mark` stored
+    int group;               // poses per group (roll-out), or 0 = per-pose marks
+    int mark;                // group == 0: this launch's mark (the caller's epoch: no clearing pass)
 };
 
-// first crashed pose of a group: a ray only sends its atomic when it can still lower the value
-// (a pose scraping a wall crashes on hundreds of beams; same-word atomics retire ~10 per us)
+// A crashed pose is recorded.  Per-pose marks (group == 0) are plain idempotent stores — what the
+// batched paths use, followed by crash_reduce_kernel.  The single-word form (small single roll-outs)
+// only sends its atomic when it can still lower the value: a pose scraping a wall crashes on
+// hundreds of beams and same-word atomics retire ~10 per us.
 __device__ __forceinline__ void crash_note(const CrashParams &cp, uint32_t pose)
 {
+    if (cp.group == 0) {
+        cp.first_crashed[pose] = cp.mark;
+        return;
+    }
     int *slot = &cp.first_crashed[pose / (uint32_t)cp.group];
     const int idx = (int)(pose % (uint32_t)cp.group);
     if (idx < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, idx);

@@ -143,6 +143,7 @@ struct rl_method {
     void *pin = nullptr;
     size_t pin_cap = 0;
     int pinned_max_rays = 262144; // 0 = always stage through device buffers
+    int crash_epoch = 0;           // mark value of the last per-pose crash launch (pose_marks)
     std::vector<double> edge_host; // the car-outline table last uploaded to `edge` (re-sent only when it changes)
     int *pin_flag = nullptr;       // pinned landing slot for the crash index
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
@@ -1040,6 +1041,21 @@ extern "C" int rl_calc_range_many_device(rl_method *h, const float *d_ins, float
 }
 
 // host-pointer forms ---------------------------------------------------------------
+// per-pose crash marks: an int per pose that is never cleared between launches — every launch
+// writes its own epoch (zeroed when the buffer grows or the epoch wraps)
+static int pose_marks(rl_method *h, int n_poses, hipStream_t stream, int &mark)
+{
+    const size_t cap_before = h->pose_first.cap;
+    int rc = h->pose_first.ensure((size_t)n_poses * sizeof(int));
+    if (rc) return rc;
+    if (h->pose_first.cap != cap_before || h->crash_epoch >= INT_MAX - 1) {
+        HIPCHK(hipMemsetAsync(h->pose_first.p, 0, h->pose_first.cap, stream));
+        h->crash_epoch = 0;
+    }
+    mark = ++h->crash_epoch;
+    return RL_OK;
+}
+
 // pinned, device-mapped host staging of at least `bytes` (small host calls run zero-copy through it)
 static int pin_ensure(rl_method *h, size_t bytes)
 {
@@ -1096,7 +1112,7 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
                               hipMemcpyHostToDevice, h->stream));
     }
     const float *d_poses = zc ? (const float *)h->pin : (const float *)h->poses.p;
-    CrashParams cp{nullptr, 0.0, nullptr, 1};
+    CrashParams cp{nullptr, 0.0, nullptr, 1, 0};
     const bool crash_direct = first_crashed && n_poses <= 512;
     if (first_crashed) {
         if ((rc = upload_edge(h, edge, num_rays))) return rc;
@@ -1113,11 +1129,9 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
         } else {
             // big batches: the kernel marks crashed poses (a word per pose), the first one is reduced
             // on the device afterwards (see crash_reduce_kernel)
-            if ((rc = h->pose_first.ensure((size_t)n_poses * sizeof(int)))) return rc;
-            hipLaunchKernelGGL(fill_int_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, h->stream,
-                               (int *)h->pose_first.p, n_poses, INT_MAX);
+            if ((rc = pose_marks(h, n_poses, h->stream, cp.mark))) return rc;
             cp.first_crashed = (int *)h->pose_first.p;
-            cp.group = 1;
+            cp.group = 0;
         }
     }
     float *d_out = (outs || !first_crashed) ? (zc ? (float *)((char *)h->pin + off_out) : (float *)h->outs.p) : nullptr;
@@ -1137,7 +1151,7 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     if (first_crashed) {
         if (!crash_direct)
             hipLaunchKernelGGL(crash_reduce_kernel, dim3(1), dim3(64), 0, h->stream,
-                               (const int *)h->pose_first.p, 1, n_poses, (int *)h->flag.p);
+                               (const int *)h->pose_first.p, cp.mark, 1, n_poses, (int *)h->flag.p);
         HIPCHK(hipMemcpyAsync(h->pin_flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1286,12 +1300,11 @@ static int crash_groups_device(rl_method *h, const float *d_poses, int n_groups,
     const int n_poses = n_groups * group;
     // the kernels mark crashed POSES (one word each, no contended atomics); groups are reduced after
     int rc;
-    if ((rc = h->pose_first.ensure((size_t)n_poses * sizeof(int)))) return rc;
+    int mark;
+    if ((rc = pose_marks(h, n_poses, stream, mark))) return rc;
     int *d_pose_first = (int *)h->pose_first.p;
-    hipLaunchKernelGGL(fill_int_kernel, dim3((n_poses + 255) / 256), dim3(256), 0, stream, d_pose_first,
-                       n_poses, INT_MAX);
     if (h->kind == RL_RM || h->kind == RL_RM_GPU) {
-        CrashParams cp{d_edge, thresh, d_pose_first, 1};
+        CrashParams cp{d_edge, thresh, d_pose_first, 0, mark};
         if ((rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_ranges, nullptr, nullptr, &cp, stream)))
             return rc;
     } else {
@@ -1300,11 +1313,11 @@ static int crash_groups_device(rl_method *h, const float *d_poses, int n_groups,
             return rc;
         const int grid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4, (long)h->map->n_cu * 8));
         hipLaunchKernelGGL(crash_groups_kernel, dim3(grid), dim3(256), 0, stream, d_ranges, d_edge,
-                           thresh, n_poses, num_rays, 1, d_pose_first);
+                           thresh, n_poses, num_rays, 0, mark, d_pose_first);
     }
     const int rgrid = (int)std::max(1L, std::min(((long)n_groups + 3) / 4, (long)h->map->n_cu * 8));
-    hipLaunchKernelGGL(crash_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, d_pose_first, n_groups,
-                       group, d_first);
+    hipLaunchKernelGGL(crash_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, d_pose_first, mark,
+                       n_groups, group, d_first);
     HIPCHK(hipGetLastError());
     return RL_OK;
 }
