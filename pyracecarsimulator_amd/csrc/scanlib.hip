@@ -888,8 +888,11 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             // runs of 2^rl blocks (same rule as below, for the grid an INLINE launch gets)
             const long grid_i = std::max((long)bands, std::min((n_chunks + 15) / 16, std::max((long)m->n_cu * h->grid_mult * WG / nt, 1L)));
             inl_rl = h->run_log2;
-            if (inl_rl < 0)
-                for (inl_rl = 0; inl_rl < 5 && ((n_chunks / grid_i) >> (inl_rl + 1)) >= 16; ++inl_rl) {}
+            if (inl_rl < 0) {
+                inl_rl = 0;                               // (stripe batches are small: single blocks)
+                if (!stripe)
+                    for (; inl_rl < 5 && ((n_chunks / grid_i) >> (inl_rl + 1)) >= 16; ++inl_rl) {}
+            }
             const long seg_runs_max = (seg_chunks_max + (1L << inl_rl) - 1) >> inl_rl;
             const long k_blocks = ((seg_runs_max + g_min - 1) / g_min) << inl_rl;
             k_max = 2 * ((int)k_blocks + 1);                                 // two records per block
