@@ -79,6 +79,9 @@ def main():
         combos = [dict(variant=1, stripe_max=v) for v in (0, 8192, 0, 8192)]
     elif a.grid == "oi":
         combos = [dict(variant=1, order_inline=v) for v in (0, 1, 0, 1)]
+    elif a.grid == "gm":
+        combos = [dict(variant=1, grid_mult=g_, low_water=lw) for g_ in (4, 6, 7, 8, 10, 12, 16) for lw in (12,)]
+        combos += [dict(variant=1, grid_mult=8, low_water=lw) for lw in (6, 8, 16, 20)]
     elif a.grid == "small":
         combos = [dict(variant=0, grid_mult=8)]
         combos += [dict(variant=1, low_water=lw, wg_threads=nt, grid_mult=8)
