@@ -191,14 +191,22 @@ int rl_car_rollout_check(rl_car *c, rl_method *h, const double *states_in, const
  * excluded), which is the duration a kernel trace reports for it.                              */
 int rl_last_kernel_ms(rl_method *h, float *ms_out);
 
-/* tuning / diagnostics: integer options by name ("variant", "grid_mult", ...)     */
+/* tuning / diagnostics: integer options by name.  None changes a result bit; defaults are the
+ * measured optima on MI355X.
+ *   schedule   variant (1 stream kernel | 0 chunk-per-wave), grid_mult, wg_threads, low_water,
+ *              run_log2 (-1 auto), xcd_bands, sort_poses, tiled (step-map layout)
+ *   binning    inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min,
+ *              bin_generic
+ *   launches   slice_log2 (pose slices below 2^n rays), pinned_max_rays (zero-copy host calls)
+ *   diagnosis  timing (1 launch sequence | 2 march kernel only), debug_stamps, drain_prio, lut_debug */
 int rl_method_set_option(rl_method *h, const char *name, int value);
 int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
 /* test hook (RL_GIANT_LUT): builds the table if needed and copies rows [row0,row1) of
  * uint16 lut[row][col][theta_bin] (entry = rint(min(range_px,max_range)*65535/max_range)). */
 int rl_method_read_lut(rl_method *h, int row0, int row1, uint16_t *out);
 /* diagnostics: after a launch with option "debug_stamps"=1, copies 4 words per wave of the
- * stream kernel (start, end in 100 MHz ticks; services<<32|iterations; chunks<<32|band);
+ * stream kernel (start, end in 100 MHz ticks; services<<32 | longest drain chain;
+ * (drain start - start)<<32 | blocks<<8 | band);
  * returns the number of words copied (>= 0) or a negative rl_status.                       */
 int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words);
 
