@@ -42,6 +42,10 @@ def parse_args():
                          "of the int32 crash indices (what MCTS.rollout consumes); 'ranges' = all-gather "
                          "of every range (4 B/ray); 'none' = shards stay on their GPU")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="'crash' mode: steps per all-gather bucket (every step's indices are exchanged, "
+                         "M steps per collective: a collective per 60-us step costs more in stream "
+                         "events and host time than the 128 B it moves)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
@@ -193,10 +197,12 @@ def main():
         edge = RC.edge_distances(B, -w.fov / 2.0, w.fov / B, 0.275, RC.DEFAULT_CAR["width"],
                                  RC.DEFAULT_CAR["wb"])
         d_edge = torch.from_numpy(edge).to(dev)
-        # double-buffered so the (latency-bound, ~100 B) all-gather of step i overlaps the march of
-        # step i+1 on RCCL's stream; every gather is complete before the timed region closes
-        d_first = [torch.empty(n_groups, dtype=torch.int32, device=dev) for _ in range(2)]
-        d_first_all = [torch.empty(world * n_groups, dtype=torch.int32, device=dev) for _ in range(2)]
+        # buckets of M steps, double-buffered: the (latency-bound, M x ~100 B) all-gather of bucket b
+        # overlaps the marches of bucket b+1 on RCCL's stream; every gather is complete before the
+        # timed region closes
+        M = max(1, a.gather_every)
+        d_first = [torch.empty(M * n_groups, dtype=torch.int32, device=dev) for _ in range(2)]
+        d_first_all = [torch.empty(world * M * n_groups, dtype=torch.int32, device=dev) for _ in range(2)]
     pending = [None, None]
     tick = [0]
 
@@ -221,18 +227,28 @@ def main():
 
     def step():
         if mode == "crash":
-            k = tick[0] & 1
+            b, slot = divmod(tick[0], M)
+            k = b & 1
             tick[0] += 1
-            if pending[k] is not None:
-                pending[k].wait()                  # the gather issued two steps ago used this buffer
+            if slot == 0 and pending[k] is not None:
+                pending[k].wait()                  # the gather issued two buckets ago used this buffer
+                pending[k] = None
             meth.check_collision_groups_device(d_poses.data_ptr(), n_groups, group, w.fov, B,
-                                               d_edge.data_ptr(), 0.001, d_first[k].data_ptr(),
+                                               d_edge.data_ptr(), 0.001,
+                                               d_first[k].data_ptr() + slot * n_groups * 4,
                                                scan.local.data_ptr(), stream=stream)
-            pending[k] = dist.all_gather_into_tensor(d_first_all[k], d_first[k], async_op=True)
+            if slot == M - 1:
+                pending[k] = dist.all_gather_into_tensor(d_first_all[k], d_first[k], async_op=True)
         else:
             scan.step(compute)
 
     def drain():
+        if mode == "crash" and tick[0] % M:            # a partly filled bucket: exchange it too
+            k = (tick[0] // M) & 1
+            if pending[k] is not None:
+                pending[k].wait()
+            pending[k] = dist.all_gather_into_tensor(d_first_all[k], d_first[k], async_op=True)
+            tick[0] += M - tick[0] % M
         for k in range(2):
             if pending[k] is not None:
                 pending[k].wait()
@@ -299,7 +315,7 @@ def main():
                    "gather": {"none": "none",
                               "ranges": "all-gather ranges (4 B/ray), %d overlap chunks" % len(scan.chunks),
                               "crash": "fused crash test per %d-pose roll-out, all-gather of int32 "
-                                       "crash indices" % group}[mode]},
+                                       "crash indices in buckets of %d steps" % (group, max(1, a.gather_every))}[mode]},
         "kernel_ms_avg": round(k_ms, 4), "step_ms_avg": round(step_ms, 4),
         "mean_samples_per_ray": round(mean_steps, 3), "p99_samples_per_ray": round(p99_steps, 1),
         "max_samples_per_ray": round(max_steps, 1),
