@@ -200,11 +200,8 @@ def main():
         # buckets of M steps, double-buffered: the (latency-bound, M x ~100 B) all-gather of bucket b
         # overlaps the marches of bucket b+1 on RCCL's stream; every gather is complete before the
         # timed region closes
-        M = max(1, a.gather_every)
-        d_first = [torch.empty(M * n_groups, dtype=torch.int32, device=dev) for _ in range(2)]
-        d_first_all = [torch.empty(world * M * n_groups, dtype=torch.int32, device=dev) for _ in range(2)]
-    pending = [None, None]
-    tick = [0]
+        from pyracecarsimulator_amd.distributed import BucketedIndexGather
+        crash_gather = BucketedIndexGather(n_groups, a.gather_every, dev)
 
     def compute(clo, chi, view):
         meth.calc_range_fan_device(d_poses.data_ptr() + clo * 12, chi - clo, w.fov, B,
@@ -227,32 +224,17 @@ def main():
 
     def step():
         if mode == "crash":
-            b, slot = divmod(tick[0], M)
-            k = b & 1
-            tick[0] += 1
-            if slot == 0 and pending[k] is not None:
-                pending[k].wait()                  # the gather issued two buckets ago used this buffer
-                pending[k] = None
             meth.check_collision_groups_device(d_poses.data_ptr(), n_groups, group, w.fov, B,
                                                d_edge.data_ptr(), 0.001,
-                                               d_first[k].data_ptr() + slot * n_groups * 4,
+                                               crash_gather.slot_view().data_ptr(),
                                                scan.local.data_ptr(), stream=stream)
-            if slot == M - 1:
-                pending[k] = dist.all_gather_into_tensor(d_first_all[k], d_first[k], async_op=True)
+            crash_gather.step_done()
         else:
             scan.step(compute)
 
     def drain():
-        if mode == "crash" and tick[0] % M:            # a partly filled bucket: exchange it too
-            k = (tick[0] // M) & 1
-            if pending[k] is not None:
-                pending[k].wait()
-            pending[k] = dist.all_gather_into_tensor(d_first_all[k], d_first[k], async_op=True)
-            tick[0] += M - tick[0] % M
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+        if mode == "crash":
+            crash_gather.flush()
 
     def barrier():
         if world > 1:

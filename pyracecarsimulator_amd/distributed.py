@@ -105,3 +105,71 @@ class ShardedScan:
 
 
 __all__ = ["broadcast_map", "chunk_bounds", "ShardedScan", "shard_range"]
+
+
+class BucketedIndexGather:
+    """Exchange of small per-step results (the int32 crash index of every roll-out) in buckets of
+    ``every`` steps, double-buffered.
+
+    ``slot_view()`` returns where the current step must write its ``n_items`` values (a view into
+    the bucket being filled); ``step_done()`` advances and, when a bucket is full, issues ONE async
+    all-gather of the whole bucket — on the GPU it runs on RCCL's stream while the next bucket's
+    marches run on the compute stream.  ``flush()`` exchanges a partly filled bucket and waits for
+    everything; ``latest()`` returns the last completed gather as (world, steps_in_bucket, n_items).
+    A collective per 60-us step would cost more in host time and stream events than it moves.
+    """
+
+    def __init__(self, n_items: int, every: int, device, dtype=None):
+        import torch
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.n_items, self.every = int(n_items), max(1, int(every))
+        dtype = dtype or torch.int32
+        self.local = [torch.zeros(self.every * self.n_items, dtype=dtype, device=device) for _ in range(2)]
+        self.gathered = [torch.zeros(self.world * self.every * self.n_items, dtype=dtype, device=device)
+                         for _ in range(2)]
+        self.pending = [None, None]
+        self.tick = 0
+        self._last = None
+
+    def slot_view(self):
+        b, slot = divmod(self.tick, self.every)
+        k = b & 1
+        if slot == 0 and self.pending[k] is not None:      # the gather issued two buckets ago used this buffer
+            self.pending[k].wait()
+            self.pending[k] = None
+        return self.local[k][slot * self.n_items:(slot + 1) * self.n_items]
+
+    def _issue(self, k, filled):
+        if self.world > 1:
+            self.pending[k] = self.dist.all_gather_into_tensor(self.gathered[k], self.local[k], async_op=True)
+        else:
+            self.gathered[k].copy_(self.local[k])
+        self._last = (k, filled)
+
+    def step_done(self):
+        b, slot = divmod(self.tick, self.every)
+        self.tick += 1
+        if slot == self.every - 1:
+            self._issue(b & 1, self.every)
+
+    def flush(self):
+        b, slot = divmod(self.tick, self.every)
+        if slot:                                            # a partly filled bucket: exchange it too
+            k = b & 1
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+            self._issue(k, slot)
+            self.tick += self.every - slot
+        for k in range(2):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+
+    def latest(self):
+        """(world, filled_steps, n_items) view of the most recently issued bucket (call after flush())."""
+        if self._last is None:
+            return None
+        k, filled = self._last
+        return self.gathered[k].view(self.world, self.every, self.n_items)[:, :filled]

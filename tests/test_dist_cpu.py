@@ -13,7 +13,8 @@ import torch.multiprocessing as mp
 
 from conftest import ROOT
 from pyracecarsimulator_amd import maps
-from pyracecarsimulator_amd.distributed import ShardedScan, broadcast_map, chunk_bounds, shard_range
+from pyracecarsimulator_amd.distributed import (BucketedIndexGather, ShardedScan, broadcast_map,
+                                                chunk_bounds, shard_range)
 
 
 def _free_port():
@@ -79,3 +80,49 @@ def test_chunk_bounds_and_shards():
     assert chunk_bounds(7, 4) == [(0, 7)]
     assert chunk_bounds(3, 8) == [(0, 1), (1, 2), (2, 3)]
     assert [shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+
+
+def _bucket_worker(rank, world, port, n_items, every, n_steps, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bg = BucketedIndexGather(n_items, every, "cpu")
+        seen = []
+        for step in range(n_steps):
+            v = bg.slot_view()
+            v.copy_(torch.arange(n_items, dtype=torch.int32) + 1000 * step + 100000 * rank)
+            bg.step_done()
+            if (step + 1) % every == 0:                  # a full bucket went out: read it once complete
+                bg.flush()
+                seen.append(bg.latest().clone().numpy())
+        bg.flush()
+        if n_steps % every:
+            seen.append(bg.latest().clone().numpy())
+        q.put((rank, seen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("every,n_steps", [(1, 5), (4, 8), (4, 10), (8, 3)])
+def test_bucketed_index_gather_world2(every, n_steps):
+    """bench.py's N>1 exchange: every step's crash indices reach every rank, `every` steps per
+    collective, partly filled last bucket included."""
+    world, n_items = 2, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, n_items, every, n_steps, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, seen in res:
+        got = np.concatenate(seen, axis=1)               # (world, n_steps, n_items)
+        assert got.shape == (world, n_steps, n_items)
+        for r in range(world):
+            for step in range(n_steps):
+                assert np.array_equal(got[r, step], np.arange(n_items) + 1000 * step + 100000 * r)
