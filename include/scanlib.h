@@ -19,7 +19,17 @@
  *     pointers + a hipStream_t (as void*) and only enqueue work;
  *   - there is NO CPU fallback: without a usable HIP device rl_map_create fails.
  *   - a handle may be shared by threads (each call locks the handle), as the
- *     reference's rospy callbacks do (scripts/ros_interface.py:115,142,189).
+ *     reference's rospy callbacks do (scripts/ros_interface.py:115,142,189);
+ *     rl_map_update waits for every scan in progress on the map's methods (host calls
+ *     hold a shared lock until their results have landed; launches the *_device entry
+ *     points left in flight are waited for with a device synchronisation);
+ *   - streams: *_device calls on ONE method handle may use different streams and then run
+ *     concurrently on the GPU (that is how bench.py pipelines consecutive pose batches).
+ *     Per-launch scratch is kept per stream (up to 4 streams per handle without any
+ *     synchronisation, more are served after a device synchronisation), lazily built
+ *     tables are guarded by events.  The caller's own buffers (poses, ranges) are the
+ *     caller's to order.  A stream must not be destroyed while a launch enqueued on it
+ *     through this library is still running.
  *
  * Coordinates: occ[r*cols + c], r = row = world y, c = col = world x, row 0 at the
  * smallest world y (the layout of nav_msgs/OccupancyGrid.data that PyOMap reads).
@@ -209,6 +219,14 @@ int rl_method_read_lut(rl_method *h, int row0, int row1, uint16_t *out);
  * (drain start - start)<<32 | blocks<<8 | band);
  * returns the number of words copied (>= 0) or a negative rl_status.                       */
 int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words);
+
+/* diagnostics: how fast a CU of this device retires a wave-wide global_load_dword whose
+ * `active_lanes` live lanes read unrelated cells of a cache-resident table — the instruction the
+ * ray-marching kernels are bound by (tools/probes/tcp_probe3.hip is the same
+ * probe stand-alone).  Returns active lanes per clock per CU; chip peak in samples/s =
+ * lanes_per_clk_per_cu * n_cu * clock_hz.  bench.py reports `roofline_gather` against it.        */
+int rl_probe_gather_rate(int device, int active_lanes, double *lanes_per_clk_per_cu,
+                         double *clock_hz_or_null, int *n_cu_or_null);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,9 @@ def lib():
         L.orc_lut_fan.argtypes = [mp, _u16p, C.c_int, C.c_float, _f32p, C.c_int, C.c_float,
                                   C.c_int, _f32p, C.c_int]
         L.orc_lut_rays.argtypes = [mp, _u16p, C.c_int, C.c_float, _f32p, C.c_int, _f32p, C.c_int]
+        L.orc_lut_pose_cells.argtypes = [mp, _f32p, C.c_int, _i32p, _i32p]
+        L.orc_lut_fan_rows.argtypes = [mp, _u16p, C.c_int, C.c_float, _f32p, C.c_int, C.c_float,
+                                       C.c_int, _f32p]
         L.orc_cddt_build.argtypes = [mp, C.c_int]
         L.orc_cddt_build.restype = C.c_void_p
         L.orc_cddt_free.argtypes = [C.c_void_p]
@@ -209,6 +212,27 @@ class OracleMap:
         lib().orc_lut_fan(C.byref(self._m), _p(lut, _u16p), lut.shape[2], self.max_range_px,
                           _p(poses, _f32p), poses.shape[0], fov, num_rays, _p(ranges, _f32p),
                           nthreads)
+        return ranges
+
+    def lut_pose_cells(self, poses):
+        """(row, col) of the table cell each pose reads (-1, -1 outside the map)."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        r = np.empty(poses.shape[0], np.int32)
+        c = np.empty(poses.shape[0], np.int32)
+        lib().orc_lut_pose_cells(C.byref(self._m), _p(poses, _f32p), poses.shape[0], _p(r, _i32p),
+                                 _p(c, _i32p))
+        return r, c
+
+    def lut_fan_rows(self, pose_rows, poses, fov, num_rays):
+        """Fan query with one theta row per pose (``pose_rows`` uint16 (P, theta_disc)): for
+        tables too large for the host."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        pose_rows = np.ascontiguousarray(pose_rows, dtype=np.uint16)
+        assert pose_rows.shape[0] == poses.shape[0]
+        ranges = np.empty(poses.shape[0] * num_rays, dtype=np.float32)
+        lib().orc_lut_fan_rows(C.byref(self._m), _p(pose_rows, _u16p), pose_rows.shape[1],
+                               self.max_range_px, _p(poses, _f32p), poses.shape[0], fov, num_rays,
+                               _p(ranges, _f32p))
         return ranges
 
     def lut_rays(self, lut, ins, nthreads=1):

@@ -480,6 +480,41 @@ void orc_lut_fan(const orc_map *m, const uint16_t *lut, int theta_disc, float ma
     }
 }
 
+/* The same fan query with the table handed over as ONE theta row per pose (the row of the
+ * pose's own cell; ignored for poses outside the map): lets a test check fan queries on a
+ * table too large for the host (cfg3: 2000^2 x 1442 bins = 11.5 GB) by fetching only the rows
+ * of the sampled poses.  rows_out[p] <- row index (int)gy, cols_out[p] <- (int)gx, or -1. */
+void orc_lut_pose_cells(const orc_map *m, const float *poses, int n_poses, int *rows_out, int *cols_out)
+{
+    const float fcols = (float)m->cols, frows = (float)m->rows;
+    for (int p = 0; p < n_poses; ++p) {
+        float gx, gy, thg;
+        world_to_grid(m, poses[3 * p], poses[3 * p + 1], poses[3 * p + 2], &gx, &gy, &thg);
+        const int in = gx >= 0.0f && gx < fcols && gy >= 0.0f && gy < frows;
+        rows_out[p] = in ? (int)gy : -1;
+        cols_out[p] = in ? (int)gx : -1;
+    }
+}
+
+void orc_lut_fan_rows(const orc_map *m, const uint16_t *pose_rows /* n_poses * theta_disc */,
+                      int theta_disc, float max_range_px, const float *poses, int n_poses,
+                      float fov, int num_rays, float *ranges)
+{
+    const float fcols = (float)m->cols, frows = (float)m->rows;
+    for (int p = 0; p < n_poses; ++p) {
+        float gx, gy, thg;
+        world_to_grid(m, poses[3 * p], poses[3 * p + 1], poses[3 * p + 2], &gx, &gy, &thg);
+        const int in = gx >= 0.0f && gx < fcols && gy >= 0.0f && gy < frows;
+        const uint16_t *row = pose_rows + (size_t)p * theta_disc;
+        for (int j = 0; j < num_rays; ++j) {
+            const float th = thg + fan_alpha(fov, num_rays, j);
+            ranges[(size_t)p * num_rays + j] =
+                in ? lut_dequant(row[lut_bin(th, theta_disc)], max_range_px) * m->res
+                   : max_range_px * m->res;
+        }
+    }
+}
+
 void orc_lut_rays(const orc_map *m, const uint16_t *lut, int theta_disc, float max_range_px,
                   const float *ins, int n, float *ranges, int nthreads)
 {

@@ -90,6 +90,10 @@ void orc_lut_build(const orc_map *m, const float *dt, float max_range_px, float 
 void orc_lut_fan(const orc_map *m, const uint16_t *lut, int theta_disc, float max_range_px,
                  const float *poses, int n_poses, float fov, int num_rays,
                  float *ranges, int nthreads);
+void orc_lut_pose_cells(const orc_map *m, const float *poses, int n_poses, int *rows_out, int *cols_out);
+void orc_lut_fan_rows(const orc_map *m, const uint16_t *pose_rows /* n_poses*theta_disc */,
+                      int theta_disc, float max_range_px, const float *poses, int n_poses,
+                      float fov, int num_rays, float *ranges);
 void orc_lut_rays(const orc_map *m, const uint16_t *lut, int theta_disc, float max_range_px,
                   const float *ins, int n, float *ranges, int nthreads);
 

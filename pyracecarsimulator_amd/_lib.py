@@ -75,6 +75,7 @@ SYMBOLS = {
     "rl_method_get_info": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "rl_method_read_lut": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u16p]),
     "rl_debug_read_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
+    "rl_probe_gather_rate": (C.c_int, [C.c_int, C.c_int, f64p, f64p, C.POINTER(C.c_int)]),
 }
 
 
@@ -99,6 +100,31 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels carry their own copy of the HIP/HSA runtime (torch/lib/libamdhip64.so, same
+    SONAME as /opt/rocm's).  A process must run ONE runtime: if libscan_amd.so pulls in the system
+    copy first and torch is imported later, torch's HSA runtime finds the device already taken
+    ("No HIP GPUs are available").  So when torch is installed but not imported yet, its runtime is
+    loaded first and libscan_amd.so binds to it — the same arrangement as importing torch before
+    this package.  Without torch (or with SCANLIB_SYSTEM_HIP=1) the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("SCANLIB_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libscan_amd.so; raises if it has not been built (no fallback)."""
     global _LIB
@@ -107,6 +133,7 @@ def lib():
             raise ImportError(
                 "libscan_amd.so is missing: run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or make -C pyracecarsimulator_amd/csrc). There is no CPU fallback.")
+        _share_torch_hip_runtime()
         L = C.CDLL(_SO)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

@@ -8,6 +8,7 @@
 #include "scan_kernels.h"
 #include "car_kernels.h"
 #include "consumer_kernels.h"
+#include "probe_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -18,7 +19,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -72,11 +75,16 @@ struct rl_map {
     uint32_t *d_bits = nullptr;
     int bits_stride = 0;
     hipStream_t stream = nullptr;
-    uint64_t epoch = 0;          // bumped by rl_map_update; derived tables rebuild lazily
+    std::atomic<uint64_t> epoch{0};   // bumped by rl_map_update; derived tables rebuild lazily
     MapParams mp{};
     MapParams *d_mp = nullptr;   // device copy (kernels that take the map by pointer)
     int n_cu = 256;
     std::mutex mu;
+    // readers: every launch path of every method of this map (held for the whole call, i.e. until
+    // the results of a host-pointer call have landed); writer: rl_map_update while it rewrites
+    // occ / EDT / bit map.  A map callback thread and a scan thread may share the objects
+    // (scripts/ros_interface.py:107-115).
+    std::shared_mutex tables_mu;
 };
 
 struct DevBuf {
@@ -101,6 +109,34 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
     }
+};
+
+// Per-launch scratch of a method (pose records, tile order, binning histograms, crash marks) is
+// kept PER STREAM: a *_device call only enqueues work, so a second call on another stream may run
+// concurrently with the first on the GPU (bench.py pipelines consecutive batches on two streams so
+// that batch k+1 fills the CUs batch k's tail leaves idle).  Calls on one stream reuse one context
+// in stream order.  More distinct streams than contexts: the least recently used context is handed
+// over after a device synchronisation (rare, and needs no handle of the old stream, which the
+// caller may have destroyed).
+struct LaunchCtx {
+    hipStream_t stream = nullptr;
+    bool bound = false;
+    uint64_t last_use = 0;
+    DevBuf rec, rec_sorted, order, keys, hist, pose_first, dbg;
+    int crash_epoch = 0;           // mark value of the last per-pose crash launch (pose_marks)
+    void release()
+    {
+        for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg}) b->release();
+    }
+};
+constexpr int N_LAUNCH_CTX = 4;
+
+// A derived table (step map, GiantLUT, CDDT) is built lazily on the stream of the call that needs
+// it first; launches on OTHER streams must not start before the build has finished.
+struct TableDep {
+    hipEvent_t ev = nullptr;
+    hipStream_t built_on = nullptr;
+    bool pending = false;
 };
 
 struct rl_method {
@@ -137,13 +173,15 @@ struct rl_method {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf poses, outs, hits, steps, edge, flag, pose_first, rec, rec_sorted, order, keys, dbg, hist;
+    DevBuf poses, outs, hits, steps, edge, flag;
+    LaunchCtx ctx[N_LAUNCH_CTX];
+    uint64_t use_clock = 0;
+    TableDep pdt_dep, lut_dep, cddt_dep;
     // small host calls (scan(): one pose, scanMany(): a roll-out): poses and ranges go through ONE
     // pinned, device-mapped host buffer the kernels read / write directly — no staging copies
     void *pin = nullptr;
     size_t pin_cap = 0;
     int pinned_max_rays = 262144; // 0 = always stage through device buffers
-    int crash_epoch = 0;           // mark value of the last per-pose crash launch (pose_marks)
     std::vector<double> edge_host; // the car-outline table last uploaded to `edge` (re-sent only when it changes)
     int *pin_flag = nullptr;       // pinned landing slot for the crash index
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
@@ -161,6 +199,7 @@ struct rl_method {
     int inline_max = 512;        //   ... below this many poses (measured: wins below ~512, loses above)
     int debug_stamps = 0;        // diagnostics: per-wave start/end stamps of the stream kernel
     int last_grid = 0;
+    void *last_dbg = nullptr;    // stamps buffer of the last launch (in its context)
     std::vector<float> h_poses;
     std::mutex mu;
 };
@@ -283,8 +322,12 @@ extern "C" int rl_map_update(rl_map *m, const uint8_t *occ)
 {
     if (!m || !occ) return fail(RL_ERR_INVALID, "rl_map_update: null pointer");
     std::lock_guard<std::mutex> lk(m->mu);
+    // exclusive: no host-pointer call of any method of this map is in progress; the device
+    // synchronisation covers launches the asynchronous *_device entry points left in flight
+    std::unique_lock<std::shared_mutex> wl(m->tables_mu);
     int rc = set_device(m);
     if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyAsync(m->d_occ, occ, (size_t)m->rows * m->cols, hipMemcpyHostToDevice,
                           m->stream));
     rc = map_build_tables(m);
@@ -372,15 +415,11 @@ extern "C" void rl_method_destroy(rl_method *h)
     h->steps.release();
     h->edge.release();
     h->flag.release();
-    h->pose_first.release();
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->pin_flag) (void)hipHostFree(h->pin_flag);
-    h->rec.release();
-    h->rec_sorted.release();
-    h->hist.release();
-    h->order.release();
-    h->keys.release();
-    h->dbg.release();
+    for (LaunchCtx &c : h->ctx) c.release();
+    for (TableDep *d : {&h->pdt_dep, &h->lut_dep, &h->cddt_dep})
+        if (d->ev) (void)hipEventDestroy(d->ev);
     h->pdt.release();
     h->lut.release();
     for (DevBuf *b : {&h->cd_cos, &h->cd_sin, &h->cd_trans, &h->cd_width, &h->cd_boff, &h->cd_offsets,
@@ -492,13 +531,61 @@ static int check_fan_args(const rl_method *h, int n_poses, float fov, int num_ra
     return RL_OK;
 }
 
+
+// ------------------------------------------------------------------------------
+// launch contexts and table dependencies (see LaunchCtx / TableDep)
+// ------------------------------------------------------------------------------
+static int acquire_ctx(rl_method *h, hipStream_t stream, LaunchCtx **out)
+{
+    LaunchCtx *pick = nullptr;
+    for (LaunchCtx &c : h->ctx)
+        if (c.bound && c.stream == stream) { pick = &c; break; }
+    if (!pick)
+        for (LaunchCtx &c : h->ctx)
+            if (!c.bound) { pick = &c; break; }
+    if (!pick) {
+        for (LaunchCtx &c : h->ctx)
+            if (!pick || c.last_use < pick->last_use) pick = &c;
+        // hand-over: whatever the old stream still has in flight on this scratch must finish first
+        HIPCHK(hipDeviceSynchronize());
+    }
+    pick->bound = true;
+    pick->stream = stream;
+    pick->last_use = ++h->use_clock;
+    *out = pick;
+    return RL_OK;
+}
+
+// after (re)building a table on `stream`
+static int table_built(TableDep &d, hipStream_t stream)
+{
+    if (!d.ev) HIPCHK(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(d.ev, stream));
+    d.built_on = stream;
+    d.pending = true;
+    return RL_OK;
+}
+
+// before a launch on `stream` reads the table
+static int table_wait(TableDep &d, hipStream_t stream)
+{
+    if (!d.pending || stream == d.built_on) return RL_OK;      // (same stream: stream order)
+    if (hipEventQuery(d.ev) == hipSuccess) {
+        d.pending = false;
+        return RL_OK;
+    }
+    HIPCHK(hipStreamWaitEvent(stream, d.ev, 0));
+    return RL_OK;
+}
+
 // ------------------------------------------------------------------------------
 // derived tables (built lazily on the launch stream, rebuilt when the map changed)
 // ------------------------------------------------------------------------------
 static int ensure_lut(rl_method *h, hipStream_t stream)
 {
     rl_map *m = h->map;
-    if (h->lut_epoch == m->epoch && h->lut.p) return RL_OK;
+    if (h->lut_epoch == m->epoch && h->lut.p) return table_wait(h->lut_dep, stream);
+    HIPCHK(hipDeviceSynchronize());     // launches of other streams may still read the old table
     const size_t n = (size_t)m->rows * m->cols * h->theta_disc;
     int rc = h->lut.ensure(n * sizeof(uint16_t) + 64);      // + slack: rows are read in 16-B pieces
     if (rc) return rc;
@@ -516,13 +603,14 @@ static int ensure_lut(rl_method *h, hipStream_t stream)
                        h->step_coeff, 0, m->rows);
     HIPCHK(hipGetLastError());
     h->lut_epoch = m->epoch;
-    return RL_OK;
+    return table_built(h->lut_dep, stream);
 }
 
 static int ensure_cddt(rl_method *h, hipStream_t stream)
 {
     rl_map *m = h->map;
-    if (h->cddt_epoch == m->epoch && h->cd_xs.p) return RL_OK;
+    if (h->cddt_epoch == m->epoch && h->cd_xs.p) return table_wait(h->cddt_dep, stream);
+    HIPCHK(hipDeviceSynchronize());     // launches of other streams may still read the old table
     const int td = h->theta_disc, nb = (td + 1) / 2;
     std::vector<float> cosv(nb), sinv(nb), trans(nb);
     std::vector<int> width(nb);
@@ -609,7 +697,7 @@ static int ensure_cddt(rl_method *h, hipStream_t stream)
     cp.xs = (float *)h->cd_xs.p;
     HIPCHK(hipGetLastError());
     h->cddt_epoch = m->epoch;
-    return RL_OK;
+    return table_built(h->cddt_dep, stream);
 }
 
 static BlParams make_bl(const rl_method *h, int num_rays, size_t &lds_bytes)
@@ -631,15 +719,15 @@ static bool bin_keys_only_ok(const rl_method *h, int n_poses)
     return h->sort_poses && n_poses >= 64 && n_poses < h->bin_multi_min && n_poses <= 8192 && !h->bin_generic;
 }
 
-static int bin_poses(rl_method *h, const float *d_poses, int n_poses, int walk_outside,
+static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_poses, int walk_outside,
                      hipStream_t stream, bool keys_only = false)
 {
     const rl_map *m = h->map;
     int rc;
-    if ((rc = h->rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
-    if ((rc = h->order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
-    if ((rc = h->keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
-    if ((rc = h->rec_sorted.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
+    if ((rc = cx.rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
+    if ((rc = cx.order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
+    if ((rc = cx.keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
+    if ((rc = cx.rec_sorted.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
     const int do_sort = (h->sort_poses && n_poses >= 64) ? 1 : 0;
     int shift = 6;
     while ((long)((m->cols >> shift) + 1) * ((m->rows >> shift) + 1) > 8192) ++shift;
@@ -655,40 +743,40 @@ static int bin_poses(rl_method *h, const float *d_poses, int n_poses, int walk_o
             const int ctx = (m->cols >> cshift) + 1;
             const int cnt = ctx * ((m->rows >> cshift) + 1);
             const size_t n_ctr = (size_t)cnt * n_wg;
-            if ((rc = h->hist.ensure(n_ctr * sizeof(uint32_t)))) return rc;
+            if ((rc = cx.hist.ensure(n_ctr * sizeof(uint32_t)))) return rc;
             hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
-                               m->mp, d_poses, n_poses, (PoseRec *)h->rec.p,
-                               (uint32_t *)h->keys.p, (uint32_t *)h->hist.p, n_wg, cshift, ctx,
+                               m->mp, d_poses, n_poses, (PoseRec *)cx.rec.p,
+                               (uint32_t *)cx.keys.p, (uint32_t *)cx.hist.p, n_wg, cshift, ctx,
                                cnt, (uint32_t *)nullptr, walk_outside);
             hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream,
-                               (uint32_t *)h->hist.p, (int)n_ctr);
+                               (uint32_t *)cx.hist.p, (int)n_ctr);
             hipLaunchKernelGGL(pose_scatter_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
-                               n_poses, (const PoseRec *)h->rec.p, (const uint32_t *)h->keys.p,
-                               (const uint32_t *)h->hist.p, n_wg, cnt, (PoseRec *)h->rec_sorted.p,
-                               (uint32_t *)h->order.p);
+                               n_poses, (const PoseRec *)cx.rec.p, (const uint32_t *)cx.keys.p,
+                               (const uint32_t *)cx.hist.p, n_wg, cnt, (PoseRec *)cx.rec_sorted.p,
+                               (uint32_t *)cx.order.p);
         } else {
             // caller's order kept: one fully parallel pass, records land in place
             hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), 0, stream, m->mp, d_poses,
-                               n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)nullptr,
+                               n_poses, (PoseRec *)cx.rec_sorted.p, (uint32_t *)nullptr,
                                (uint32_t *)nullptr, n_wg, shift, tiles_x, n_tiles,
-                               (uint32_t *)h->order.p, walk_outside);
+                               (uint32_t *)cx.order.p, walk_outside);
         }
     } else if (do_sort && n_poses <= 8192 && !h->bin_generic) {
         if (keys_only)
             hipLaunchKernelGGL(pose_bin_small_kernel<true>, dim3(1), dim3(1024),
                                (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
-                               n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)h->order.p, shift,
+                               n_poses, (PoseRec *)cx.rec_sorted.p, (uint32_t *)cx.order.p, shift,
                                tiles_x, n_tiles, walk_outside);
         else
             hipLaunchKernelGGL(pose_bin_small_kernel<false>, dim3(1), dim3(1024),
                                (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
-                               n_poses, (PoseRec *)h->rec_sorted.p, (uint32_t *)h->order.p, shift,
+                               n_poses, (PoseRec *)cx.rec_sorted.p, (uint32_t *)cx.order.p, shift,
                                tiles_x, n_tiles, walk_outside);
     } else {
         hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
                            (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
-                           n_poses, (PoseRec *)h->rec.p, (PoseRec *)h->rec_sorted.p,
-                           (uint32_t *)h->order.p, (uint32_t *)h->keys.p, shift, tiles_x,
+                           n_poses, (PoseRec *)cx.rec.p, (PoseRec *)cx.rec_sorted.p,
+                           (uint32_t *)cx.order.p, (uint32_t *)cx.keys.p, shift, tiles_x,
                            n_tiles, do_sort, walk_outside);
     }
     return RL_OK;
@@ -713,6 +801,11 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
 {
     if (n_poses == 0) return RL_OK;
     const rl_map *m = h->map;
+    LaunchCtx *cx = nullptr;
+    {
+        int rc_ = acquire_ctx(h, stream, &cx);
+        if (rc_) return rc_;
+    }
     // the stream kernels index rays with 32-bit byte offsets: batches of 2^30 rays or more
     // (4 GiB of ranges) go through in pose slices, each its own launch sequence
     const long slice_rays = 1L << h->slice_log2;
@@ -774,10 +867,10 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         } else {
             if (h->variant >= 1 && (long)n_poses * num_rays < (1L << 30)) {
                 // K2b: stream schedule on the cache-resident bit map
-                if ((rc = bin_poses(h, d_poses, n_poses, 1, stream))) return rc;
+                if ((rc = bin_poses(h, *cx, d_poses, n_poses, 1, stream))) return rc;
                 StreamParams sp{};
-                sp.rec = (const PoseRec *)h->rec_sorted.p;
-                sp.order = (const uint32_t *)h->order.p;
+                sp.rec = (const PoseRec *)cx->rec_sorted.p;
+                sp.order = (const uint32_t *)cx->order.p;
                 sp.div_B = make_fastdiv((uint32_t)num_rays);
                 sp.low_water = h->low_water;
                 sp.n_bands = n_poses >= 64 ? h->xcd_bands : 1;
@@ -828,11 +921,12 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
     if (h->variant >= 1 && stream_ok) {
         // (1) per-pose records + tile-ordered permutation, (2) banded lane-refill march
         int rc;
-        if ((rc = h->rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
-        if ((rc = h->order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
-        if ((rc = h->keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
+        if ((rc = cx->rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
+        if ((rc = cx->order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
+        if ((rc = cx->keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
         // step map of this method, rebuilt when the map (or the layout option) changed
         if (h->pdt_epoch != m->epoch || !h->pdt.p || h->pdt_tiled != h->tiled) {
+            if (h->pdt.p) HIPCHK(hipDeviceSynchronize());   // launches of other streams may still read the old copy
             h->pad = (int)std::ceil(h->max_range) + 2;
             if (h->tiled) {
                 h->pad = (h->pad + 7) & ~7;                       // 128-B lines line up with the border
@@ -856,6 +950,9 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             }
             h->pdt_epoch = m->epoch;
             h->pdt_tiled = h->tiled;
+            if ((rc = table_built(h->pdt_dep, stream))) return rc;
+        } else if ((rc = table_wait(h->pdt_dep, stream))) {
+            return rc;
         }
         const int bands = n_poses >= 64 ? h->xcd_bands : 1;
         // persistent grid: grid_mult x 256 threads per CU, whatever the workgroup size
@@ -902,9 +999,9 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         }
         if (!inl) {
             nt = h->wg_threads;
-            if ((rc = bin_poses(h, d_poses, n_poses, 0, stream))) return rc;
+            if ((rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream))) return rc;
         } else if (order_inl) {
-            if ((rc = bin_poses(h, d_poses, n_poses, 0, stream, true))) return rc;
+            if ((rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, true))) return rc;
         }
         PadMap pm{};
         pm.pdt = (const float *)h->pdt.p;
@@ -915,8 +1012,8 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         pm.div_stride = make_fastdiv((uint32_t)h->pstride);
         pm.res = m->res;
         StreamParams sp{};
-        sp.rec = (const PoseRec *)h->rec_sorted.p;
-        sp.order = (const uint32_t *)h->order.p;
+        sp.rec = (const PoseRec *)cx->rec_sorted.p;
+        sp.order = (const uint32_t *)cx->order.p;
         sp.div_B = make_fastdiv((uint32_t)num_rays);
         sp.low_water = h->low_water;
         sp.n_bands = bands;
@@ -930,8 +1027,9 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         long cap_q = (long)m->n_cu * h->grid_mult * WG / nt;
         grid = (int)std::max((long)bands, std::min(want_q, std::max(cap_q, 1L)));
         if (h->debug_stamps) {
-            if ((rc = h->dbg.ensure((size_t)grid * waves_per_wg * 4 * sizeof(uint64_t)))) return rc;
-            sp.dbg = (unsigned long long *)h->dbg.p;
+            if ((rc = cx->dbg.ensure((size_t)grid * waves_per_wg * 4 * sizeof(uint64_t)))) return rc;
+            sp.dbg = (unsigned long long *)cx->dbg.p;
+            h->last_dbg = cx->dbg.p;
         }
         // runs of consecutive blocks keep a workgroup on one pose for a while (L1/TA locality) but
         // coarsen the static balance: 16+ runs per workgroup, at most 32 blocks per run
@@ -1024,6 +1122,7 @@ extern "C" int rl_calc_range_fan_device(rl_method *h, const float *d_poses, int 
     if (n_poses > 0 && (!d_poses || !d_outs))
         return fail(RL_ERR_INVALID, "rl_calc_range_fan_device: null device pointer");
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     rc = set_device(h->map);
     if (rc) return rc;
     return launch_fan(h, d_poses, n_poses, fov, num_rays, d_outs, d_hits, d_steps, nullptr,
@@ -1038,6 +1137,7 @@ extern "C" int rl_calc_range_many_device(rl_method *h, const float *d_ins, float
     if (n > 0 && (!d_ins || !d_outs))
         return fail(RL_ERR_INVALID, "rl_calc_range_many_device: null device pointer");
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     int rc = set_device(h->map);
     if (rc) return rc;
     return launch_rays(h, d_ins, n, d_outs, nullptr, nullptr, (hipStream_t)hip_stream);
@@ -1046,16 +1146,20 @@ extern "C" int rl_calc_range_many_device(rl_method *h, const float *d_ins, float
 // host-pointer forms ---------------------------------------------------------------
 // per-pose crash marks: an int per pose that is never cleared between launches — every launch
 // writes its own epoch (zeroed when the buffer grows or the epoch wraps)
-static int pose_marks(rl_method *h, int n_poses, hipStream_t stream, int &mark)
+static int pose_marks(rl_method *h, int n_poses, hipStream_t stream, int &mark, int **d_marks)
 {
-    const size_t cap_before = h->pose_first.cap;
-    int rc = h->pose_first.ensure((size_t)n_poses * sizeof(int));
+    LaunchCtx *cx = nullptr;
+    int rc = acquire_ctx(h, stream, &cx);
     if (rc) return rc;
-    if (h->pose_first.cap != cap_before || h->crash_epoch >= INT_MAX - 1) {
-        HIPCHK(hipMemsetAsync(h->pose_first.p, 0, h->pose_first.cap, stream));
-        h->crash_epoch = 0;
+    const size_t cap_before = cx->pose_first.cap;
+    rc = cx->pose_first.ensure((size_t)n_poses * sizeof(int));
+    if (rc) return rc;
+    if (cx->pose_first.cap != cap_before || cx->crash_epoch >= INT_MAX - 1) {
+        HIPCHK(hipMemsetAsync(cx->pose_first.p, 0, cx->pose_first.cap, stream));
+        cx->crash_epoch = 0;
     }
-    mark = ++h->crash_epoch;
+    mark = ++cx->crash_epoch;
+    *d_marks = (int *)cx->pose_first.p;
     return RL_OK;
 }
 
@@ -1132,8 +1236,7 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
         } else {
             // big batches: the kernel marks crashed poses (a word per pose), the first one is reduced
             // on the device afterwards (see crash_reduce_kernel)
-            if ((rc = pose_marks(h, n_poses, h->stream, cp.mark))) return rc;
-            cp.first_crashed = (int *)h->pose_first.p;
+            if ((rc = pose_marks(h, n_poses, h->stream, cp.mark, &cp.first_crashed))) return rc;
             cp.group = 0;
         }
     }
@@ -1154,7 +1257,7 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     if (first_crashed) {
         if (!crash_direct)
             hipLaunchKernelGGL(crash_reduce_kernel, dim3(1), dim3(64), 0, h->stream,
-                               (const int *)h->pose_first.p, cp.mark, 1, n_poses, (int *)h->flag.p);
+                               (const int *)cp.first_crashed, cp.mark, 1, n_poses, (int *)h->flag.p);
         HIPCHK(hipMemcpyAsync(h->pin_flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1175,6 +1278,7 @@ extern "C" int rl_calc_range_fan(rl_method *h, const float *poses, int n_poses, 
     if (n_poses > 0 && (!poses || !outs))
         return fail(RL_ERR_INVALID, "rl_calc_range_fan: null pointer");
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     return fan_host(h, poses, n_poses, fov, num_rays, outs, hits, steps, nullptr, 0.0, nullptr);
 }
 
@@ -1192,6 +1296,7 @@ extern "C" int rl_calc_range_many_fan(rl_method *h, const float *ins_rows3, floa
     if (n_poses > 0 && (!ins_rows3 || !outs))
         return fail(RL_ERR_INVALID, "rl_calc_range_many_fan: null pointer");
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     // gather the live row of every pose (row p*num_rays): 12 B per pose cross PCIe,
     // not the reference's 12 B per ray (scripts/scan_simulator.py:39-40)
     h->h_poses.resize((size_t)n_poses * 3);
@@ -1212,6 +1317,7 @@ extern "C" int rl_calc_range_many(rl_method *h, const float *ins, float *outs, i
     if (n == 0) return RL_OK;
     if (!ins || !outs) return fail(RL_ERR_INVALID, "rl_calc_range_many: null pointer");
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     int rc = set_device(h->map);
     if (rc) return rc;
     if (n <= h->pinned_max_rays) {                       // one scan's worth of rows: zero-copy
@@ -1253,6 +1359,7 @@ extern "C" int rl_check_collision_many(rl_method *h, const float *poses, int n_p
         return rl_check_collision_groups(h, poses, 1, n_poses, fov, num_rays, edge, crash_thresh,
                                          first_crashed, ranges_or_null);
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     return fan_host(h, poses, n_poses, fov, num_rays, ranges_or_null, nullptr, nullptr, edge,
                     crash_thresh, first_crashed);
 }
@@ -1262,6 +1369,7 @@ extern "C" int rl_method_read_lut(rl_method *h, int row0, int row1, uint16_t *ou
     if (!h || !out) return fail(RL_ERR_INVALID, "rl_method_read_lut: null pointer");
     if (h->kind != RL_GIANT_LUT) return fail(RL_ERR_INVALID, "not a GiantLUT method");
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     int rc = set_device(h->map);
     if (rc) return rc;
     if (row0 < 0 || row1 > h->map->rows || row0 > row1)
@@ -1282,10 +1390,10 @@ extern "C" int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words)
     int rc = set_device(h->map);
     if (rc) return rc;
     size_t words = (size_t)h->last_grid * WAVES_PER_WG * 4;
-    if (!h->dbg.p || words == 0) return fail(RL_ERR_INVALID, "no stamps recorded (set debug_stamps=1)");
+    if (!h->last_dbg || words == 0) return fail(RL_ERR_INVALID, "no stamps recorded (set debug_stamps=1)");
     if ((size_t)max_words < words) words = (size_t)max_words;
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, h->dbg.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, h->last_dbg, words * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return (int)words;
 }
 
@@ -1304,8 +1412,8 @@ static int crash_groups_device(rl_method *h, const float *d_poses, int n_groups,
     // the kernels mark crashed POSES (one word each, no contended atomics); groups are reduced after
     int rc;
     int mark;
-    if ((rc = pose_marks(h, n_poses, stream, mark))) return rc;
-    int *d_pose_first = (int *)h->pose_first.p;
+    int *d_pose_first = nullptr;
+    if ((rc = pose_marks(h, n_poses, stream, mark, &d_pose_first))) return rc;
     if (h->kind == RL_RM || h->kind == RL_RM_GPU) {
         CrashParams cp{d_edge, thresh, d_pose_first, 0, mark};
         if ((rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_ranges, nullptr, nullptr, &cp, stream)))
@@ -1339,6 +1447,7 @@ extern "C" int rl_check_collision_groups_device(rl_method *h, const float *d_pos
     if (!d_poses || !d_edge || !d_first_crashed)
         return fail(RL_ERR_INVALID, "rl_check_collision_groups_device: null device pointer");
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     if ((rc = set_device(h->map))) return rc;
     return crash_groups_device(h, d_poses, n_groups, group, fov, num_rays, d_edge, crash_thresh,
                                d_first_crashed, d_ranges_or_null, true, (hipStream_t)hip_stream);
@@ -1357,6 +1466,7 @@ extern "C" int rl_check_collision_groups(rl_method *h, const float *poses, int n
     if (n_groups == 0) return RL_OK;
     if (!poses || !edge || !first_crashed) return fail(RL_ERR_INVALID, "rl_check_collision_groups: null pointer");
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     if ((rc = set_device(h->map))) return rc;
     const size_t n_rays = (size_t)n_poses * num_rays;
     if ((rc = h->poses.ensure((size_t)n_poses * 12)) || (rc = h->outs.ensure(n_rays * 4)) ||
@@ -1460,6 +1570,7 @@ extern "C" int rl_car_rollout_check(rl_car *c, rl_method *h, const double *state
         return fail(RL_ERR_INVALID, "rl_car_rollout_check: null pointer");
     if (c->device != h->map->device) return fail(RL_ERR_INVALID, "car and range method live on different devices");
     std::scoped_lock lk(c->mu, h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     int rc = car_rollout_device(c, states_in, actions, R, n_steps, every, dt, states_out != nullptr, vel_out != nullptr);
     if (rc || R == 0) return rc;
     if ((rc = check_fan_args(h, R * n_steps, fov, num_rays))) return rc;
@@ -1583,4 +1694,67 @@ extern "C" int rl_followgap_eval_device(rl_followgap *g, const float *d_scans, i
     std::lock_guard<std::mutex> lk(g->mu);
     HIPCHK(hipSetDevice(g->device));
     return followgap_launch(g, d_scans, n_scans, size, d_angles, (hipStream_t)hip_stream);
+}
+
+// ---------------------------------------------------------------- diagnostics: gather-rate probe
+extern "C" int rl_probe_gather_rate(int device, int active_lanes, double *lanes_per_clk_per_cu,
+                                    double *clock_hz, int *n_cu_out)
+{
+    if (!lanes_per_clk_per_cu) return fail(RL_ERR_INVALID, "rl_probe_gather_rate: null pointer");
+    if (active_lanes < 1 || active_lanes > 64) return fail(RL_ERR_INVALID, "active_lanes must be in [1,64]");
+    int ndev = rl_device_count();
+    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    const int n_cu = prop.multiProcessorCount;
+    const double clk = (double)prop.clockRate * 1e3;
+    float *tab = nullptr, *sink = nullptr;
+    int *d_off = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr;
+    int rc = RL_OK;
+    auto cleanup = [&]() {
+        if (tab) (void)hipFree(tab);
+        if (sink) (void)hipFree(sink);
+        if (d_off) (void)hipFree(d_off);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (st) (void)hipStreamDestroy(st);
+    };
+    // random cells of a 32x32 window in the 4-row-interleaved layout of the step map, fixed seed
+    int off[64];
+    uint32_t lcg = 12345u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (lcg >> 8) & 0xffffu; };
+    for (int l = 0; l < 64; ++l) {
+        const int r = (int)(rnd() % 32), c = (int)(rnd() % 32) + 3;
+        off[l] = (r >> 2) * 4 * 64 + 4 * c + (r & 3);
+    }
+    unsigned long long mask = 0;
+    while (__builtin_popcountll(mask) < active_lanes) mask |= 1ull << (rnd() % 64);
+    const int iters = 2000, grid = n_cu * 2;
+    float ms = 0.f;
+    if (hipMalloc((void **)&tab, 4 * 2048 * sizeof(float)) != hipSuccess || hipMalloc((void **)&sink, 4) != hipSuccess ||
+        hipMalloc((void **)&d_off, sizeof off) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+        hipEventCreate(&e1) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+        hipMemsetAsync(tab, 0, 4 * 2048 * sizeof(float), st) != hipSuccess ||
+        hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, st) != hipSuccess) {
+        rc = fail(RL_ERR_HIP, "gather probe: setup failed");
+    } else {
+        hipLaunchKernelGGL(gather_probe_kernel, dim3(grid), dim3(1024), 0, st, tab, d_off, mask, 10, sink);
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(gather_probe_kernel, dim3(grid), dim3(1024), 0, st, tab, d_off, mask, iters, sink);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f))
+            rc = fail(RL_ERR_HIP, "gather probe: launch failed");
+    }
+    cleanup();
+    if (rc) return rc;
+    // 2 workgroups x 16 waves per CU, each iters x 8 wave-loads
+    const double clk_per_wave_load = (double)ms * 1e-3 * clk / (2.0 * 16 * iters * 8);
+    *lanes_per_clk_per_cu = (double)active_lanes / clk_per_wave_load;
+    if (clock_hz) *clock_hz = clk;
+    if (n_cu_out) *n_cu_out = n_cu;
+    return RL_OK;
 }

@@ -57,50 +57,105 @@ def chunk_bounds(n_local: int, n_chunks: int):
     return [(i * step, (i + 1) * step) for i in range(c)]
 
 
+class _Slot:
+    __slots__ = ("local", "gathered", "stream", "handles")
+
+
 class ShardedScan:
     """Scan a global pose batch with every rank taking a contiguous block.
 
-    ``compute(lo, hi, out_view)`` must enqueue the scan of local poses [lo, hi) into
-    ``out_view`` (a (hi-lo)*num_rays float32 tensor) on the current stream — on the GPU that
-    is ``method.calc_range_fan_device``; the CPU tests pass a NumPy stand-in.
+    ``compute(lo, hi, out_view, stream)`` must enqueue the scan of local poses [lo, hi) into
+    ``out_view`` (a (hi-lo)*num_rays float32 tensor) on ``stream`` (a raw stream pointer, 0 on
+    CPU) — on the GPU that is ``method.calc_range_fan_device``; the CPU tests pass a NumPy stand-in.
+
+    ``depth`` consecutive steps are kept in flight: step k runs on slot ``k % depth`` (own output
+    buffers, own stream when ``streams`` are given), and only waits for the gathers that used
+    that slot ``depth`` steps earlier, so the all-gathers of step k run on RCCL's stream while
+    the marches of steps k+1 .. k+depth-1 run on theirs.  ``finish()`` waits for everything
+    (call it before reading results or stopping a clock).
     """
 
-    def __init__(self, n_local: int, num_rays: int, device, n_chunks: int = 4, gather=True):
+    def __init__(self, n_local: int, num_rays: int, device, n_chunks: int = 4, gather=True,
+                 depth: int = 1, streams=None):
         import torch
         import torch.distributed as dist
+        self.torch = torch
         self.dist = dist
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.n_local, self.num_rays = n_local, num_rays
         self.gather = gather and self.world > 1
         self.chunks = chunk_bounds(n_local, n_chunks if self.gather else 1)
-        self.local = torch.empty(n_local * num_rays, dtype=torch.float32, device=device)
-        # chunk-major gather buffer: [chunk][rank][poses_in_chunk * num_rays]
-        self.gathered = (torch.empty(self.world * n_local * num_rays, dtype=torch.float32,
-                                     device=device) if self.gather else None)
+        if streams is not None:
+            depth = max(depth, len(streams))
+        self.depth = max(1, int(depth))
+        self.slots = []
+        for k in range(self.depth):
+            sl = _Slot()
+            sl.local = torch.empty(n_local * num_rays, dtype=torch.float32, device=device)
+            # chunk-major gather buffer: [chunk][rank][poses_in_chunk * num_rays]
+            sl.gathered = (torch.empty(self.world * n_local * num_rays, dtype=torch.float32,
+                                       device=device) if self.gather else None)
+            sl.stream = streams[k % len(streams)] if streams else None
+            sl.handles = []
+            self.slots.append(sl)
+        self.tick = 0
+        self.last = self.slots[0]
+
+    # the first slot's buffers (depth 1: the only ones)
+    @property
+    def local(self):
+        return self.last.local
+
+    @property
+    def gathered(self):
+        return self.last.gathered
+
+    def _on(self, sl):
+        import contextlib
+        return self.torch.cuda.stream(sl.stream) if sl.stream is not None else contextlib.nullcontext()
 
     def step(self, compute):
         B = self.num_rays
-        handles = []
-        for ci, (lo, hi) in enumerate(self.chunks):
-            view = self.local[lo * B:hi * B]
-            compute(lo, hi, view)
-            if self.gather:
-                per = (hi - lo) * B
-                dst = self.gathered[ci * self.world * per:(ci + 1) * self.world * per]
-                handles.append(self.dist.all_gather_into_tensor(dst, view, async_op=True))
-        for h in handles:
-            h.wait()
-        return self.gathered if self.gather else self.local
+        sl = self.slots[self.tick % self.depth]
+        self.tick += 1
+        with self._on(sl):
+            for h in sl.handles:          # gathers of the step that used this slot `depth` steps ago
+                h.wait()
+            sl.handles = []
+            sptr = sl.stream.cuda_stream if sl.stream is not None else 0
+            for ci, (lo, hi) in enumerate(self.chunks):
+                view = sl.local[lo * B:hi * B]
+                compute(lo, hi, view, sptr)
+                if self.gather:
+                    per = (hi - lo) * B
+                    dst = sl.gathered[ci * self.world * per:(ci + 1) * self.world * per]
+                    sl.handles.append(self.dist.all_gather_into_tensor(dst, view, async_op=True))
+        self.last = sl
+        return sl
 
-    def global_order(self):
+    def finish(self):
+        """Every enqueued march and gather of every slot is complete (device-side order; follow
+        with a device synchronisation before reading on the host)."""
+        for sl in self.slots:
+            with self._on(sl):
+                for h in sl.handles:
+                    h.wait()
+                sl.handles = []
+        if self.slots[0].stream is not None:
+            cur = self.torch.cuda.current_stream()
+            for sl in self.slots:
+                cur.wait_stream(sl.stream)
+
+    def global_order(self, slot=None):
         """Gathered ranges re-ordered to global pose order: rank-major blocks, i.e. exactly what
         one GPU scanning the whole batch writes.  Returns a (world*n_local*num_rays,) tensor."""
+        sl = slot or self.last
         if not self.gather:
-            return self.local
+            return sl.local
         B, W = self.num_rays, self.world
         per = (self.chunks[0][1] - self.chunks[0][0]) * B
-        g = self.gathered.view(len(self.chunks), W, per)
+        g = sl.gathered.view(len(self.chunks), W, per)
         return g.permute(1, 0, 2).reshape(-1)
 
 

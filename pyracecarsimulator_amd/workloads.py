@@ -37,6 +37,12 @@ class Workload:
     noise_std: float = 0.0
     noise_seed: int = 0
     note: str = ""
+    pose_kind: str = "uniform"    # "uniform": seeded free-cell poses; "rollout": MCTS roll-out poses
+
+    @property
+    def pose_note(self) -> str:
+        return ("seeded MCTS roll-out poses (rl_car_rollout, scripts/mcts.py:214-231 schedule)"
+                if self.pose_kind == "rollout" else "seeded free-space poses")
 
     def describe(self) -> str:
         return "%s: %s %dx%d, %d poses x %d beams, method %s%s" % (
@@ -66,7 +72,10 @@ def cfg3(n_poses: int = 65536) -> Workload:
 def cfg4(n_poses: int = 1 << 20) -> Workload:
     g = maps.load_colombia()
     return Workload("cfg4", g, n_poses, 1081, SCAN_FOV, MAX_RANGE_PX, "RMGPU", 7,
-                    note="maps/colombia, MCTS roll-out style poses")
+                    note="maps/colombia, MCTS roll-out poses: %d roll-outs x %d steps, random (speed, "
+                         "steer) every %d steps, dt %g" % (-(-n_poses // ROLLOUT_STEPS), ROLLOUT_STEPS,
+                                                          ROLLOUT_ACTION_EVERY, ROLLOUT_DT),
+                    pose_kind="rollout")
 
 
 def cfg5(n_poses: int = 262144) -> Workload:
@@ -76,14 +85,62 @@ def cfg5(n_poses: int = 262144) -> Workload:
                     note="policy window lidar[180:900] (scripts/policy.py:32) + Gaussian noise")
 
 
+#: MCTS.rollout (scripts/mcts.py:202-231): max_iterations 200 (params.yaml:126), a new random action
+#: every 10 steps, simulator step dt 0.01 (scripts/racecar_simulator_v2.py:84 via params.yaml:49)
+ROLLOUT_STEPS = 200
+ROLLOUT_ACTION_EVERY = 10
+ROLLOUT_DT = 0.01
+
+
+def rollout_inputs(w: "Workload", n_rollouts: int, seed: int, dt=None):
+    """Seeded start states (R, 11) and action schedules (R, 20, 2) of ``n_rollouts`` MCTS roll-outs:
+    starts on free cells with >= 2 px clearance, heading uniform, initial speed U[0, max_speed/2];
+    actions as MCTS.rollout draws them: speed U[0, max_speed], steer U[-max_steer_ang, max_steer_ang]
+    (scripts/mcts.py:216-221; limits params.yaml:9-10)."""
+    from .racecar import DEFAULT_CAR
+    starts = maps.sample_free_poses(w.gmap, n_rollouts, seed, 2.0, dt)
+    rng = np.random.default_rng(seed + 7919)
+    states = np.zeros((n_rollouts, 11), dtype=np.float64)
+    states[:, 0:3] = starts
+    states[:, 3] = rng.uniform(0.0, DEFAULT_CAR["max_speed"] / 2.0, n_rollouts)
+    n_act = -(-ROLLOUT_STEPS // ROLLOUT_ACTION_EVERY)
+    actions = np.empty((n_rollouts, n_act, 2), dtype=np.float64)
+    actions[:, :, 0] = rng.uniform(0.0, DEFAULT_CAR["max_speed"], (n_rollouts, n_act))
+    actions[:, :, 1] = rng.uniform(-DEFAULT_CAR["max_steer_ang"], DEFAULT_CAR["max_steer_ang"],
+                                   (n_rollouts, n_act))
+    return states, actions
+
+
+def rollout_poses(w: "Workload", n_poses: int, seed: int, dt=None, device: int = 0) -> np.ndarray:
+    """configs[3]'s pose batch as SURVEY.md §8(d) defines it: ceil(n/200) roll-outs x 200 steps
+    integrated by the roll-out generator of this library (``rl_car_rollout``: Car::control +
+    Car::updatePosition on the GPU, pinned to the reference's compiled Car by
+    tests/golden/car_rollouts_ref.npz), truncated to ``n_poses``.  Needs the MI355X."""
+    from .racecar import CarBatch
+    R = -(-n_poses // ROLLOUT_STEPS)
+    states, actions = rollout_inputs(w, R, seed, dt)
+    cars = CarBatch(device=device)
+    poses, _, _ = cars.rollout(states, actions, ROLLOUT_STEPS, ROLLOUT_ACTION_EVERY, ROLLOUT_DT)
+    cars.close()
+    return np.ascontiguousarray(poses.reshape(-1, 3)[:n_poses])
+
+
 CONFIGS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}
 
 
 def make_poses(w: Workload, dt=None, n_poses=None, seed=None) -> np.ndarray:
     """Seeded free-space poses for a workload.  ``dt`` (cells) restricts the draw to cells
     with >= 2 px clearance; without it any free cell qualifies."""
-    return maps.sample_free_poses(w.gmap, w.n_poses if n_poses is None else n_poses,
-                                  w.pose_seed if seed is None else seed, 2.0, dt)
+    n = w.n_poses if n_poses is None else n_poses
+    seed = w.pose_seed if seed is None else seed
+    if w.pose_kind == "rollout":
+        return rollout_poses(w, n, seed, dt)
+    return maps.sample_free_poses(w.gmap, n, seed, 2.0, dt)
+
+
+def make_global_poses(w: Workload, world: int = 1, dt=None) -> np.ndarray:
+    """The seeded global batch of ``world * n_poses`` poses; rank r scans block ``shard_range(r)``."""
+    return make_poses(w, dt=dt, n_poses=w.n_poses * world)
 
 
 def shard_range(n: int, rank: int, world: int):

@@ -46,3 +46,24 @@ def need_gpu():
     if gpu_count() <= 0:
         pytest.fail("no HIP device visible: GPU tests must run on the MI355X box "
                     "(they never fall back to a CPU path)")
+
+
+def occupancy_grid_msg(gmap, binarise=True):
+    """A nav_msgs/OccupancyGrid-shaped object for ``gmap`` the way the reference receives and
+    rewrites it (/root/reference/scripts/ros_interface.py:77-86): map_server data in {-1, 0, 100}
+    (unknown cells sprinkled over free space), optionally binarised to {0, 255} with ``data > 0``;
+    origin pose with the yaw as a quaternion (ros_interface.py:212-216)."""
+    import math
+    from types import SimpleNamespace as NS
+    rng = np.random.default_rng(1234)
+    data = np.where(gmap.occ != 0, 100, 0).astype(np.int16)
+    unknown = (rng.random(data.shape) < 0.05) & (gmap.occ == 0)
+    data[unknown] = -1
+    flat = data.ravel()
+    if binarise:
+        flat = np.where(flat > 0, 255, 0)
+    yaw = float(gmap.origin[2])
+    q = NS(x=0.0, y=0.0, z=math.sin(yaw / 2.0), w=math.cos(yaw / 2.0))
+    info = NS(width=gmap.cols, height=gmap.rows, resolution=gmap.resolution,
+              origin=NS(position=NS(x=gmap.origin[0], y=gmap.origin[1], z=0.0), orientation=q))
+    return NS(info=info, data=tuple(int(v) for v in flat))

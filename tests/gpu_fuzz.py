@@ -83,7 +83,7 @@ def one_case(seed):
                 assert np.array_equal(out, om.cddt_fan(td, poses, fov, B)), "CDDT td=%d" % td
                 m.close()
             if rows * cols <= 6000:
-                td = int(r.choice([2, 30, 180, 181]))
+                td = int(r.choice([2, 30, 180, 181, 514, 720, 1024, 1442]))   # 16-B row loads per lane: 1, 2, 3
                 m = range_libc.PyGiantLUTCast(omap, mrx, td)
                 lut = om.lut_build(td, nthreads=8)
                 assert np.array_equal(m.table(), lut), "LUT table td=%d" % td

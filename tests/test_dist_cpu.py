@@ -42,10 +42,11 @@ def _worker(rank, world, port, n_total, B, chunks, q):
         mine = poses_all[lo:hi]
         scan = ShardedScan(hi - lo, B, "cpu", n_chunks=chunks)
 
-        def compute(clo, chi, view):
+        def compute(clo, chi, view, stream=0):
             view.copy_(torch.from_numpy(_fake_ranges(mine[clo:chi], B)))
 
         scan.step(compute)
+        scan.finish()
         got = scan.global_order().numpy().copy()
         q.put((rank, g.occ.sum(), g.origin, g.resolution, got, len(scan.chunks)))
     finally:

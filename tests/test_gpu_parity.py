@@ -13,6 +13,8 @@ from pyracecarsimulator_amd import ScanSimulator2D, _lib, maps, range_libc, work
 
 pytestmark = pytest.mark.gpu
 
+SCAN_FOV_720 = 4.71 * 720.0 / 1080.0
+
 
 @pytest.fixture(scope="module", autouse=True)
 def _gpu(need_gpu):
@@ -106,6 +108,25 @@ def test_rm_fan_reproduces_golden_vectors(name):
         assert np.array_equal(r, z["ranges_" + tag]), tag
         assert np.array_equal(h, z["hits_" + tag].astype(np.int32)), tag
         assert np.array_equal(s, z["steps_" + tag]), tag
+
+
+def test_pyomap_from_occupancy_grid_message_scans_like_the_oracle(oracle_mod):
+    """Row a6 end to end: PyOMap(map_msg) with a quaternion origin (yaw != 0) and map_server data
+    binarised as /root/reference/scripts/ros_interface.py:80-86 does -> ScanSimulator2D.scan."""
+    from conftest import occupancy_grid_msg
+    g = maps.make_maze(200, cell=25, wall=2, p=0.5, seed=12, resolution=0.05, origin=(-3.0, 1.5, 0.7))
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    poses = maps.sample_free_poses(g, 40, 3, dt=om.dt)
+    want = om.rm_fan(poses, 4.71, 1081, step_coeff=0.999, nthreads=4)[0]
+    for binarise in (True, False):
+        omap = range_libc.PyOMap(occupancy_grid_msg(g, binarise))
+        assert (omap.height, omap.width) == (g.rows, g.cols)
+        assert np.array_equal(omap.distance_transform(), om.dt)
+        sim = ScanSimulator2D(1081, 4.71, 0.01, batch_size=40)
+        sim.setMap(omap, 300, g.resolution, omap.origin)
+        sim.setRaytracingMethod("RM")
+        assert np.array_equal(sim.scanMany(poses), want)
+        assert np.array_equal(sim.scan(*poses[7]), want[7 * 1081:8 * 1081])
 
 
 # ---------------------------------------------------------------- K1 vs oracle, seeded sweeps
@@ -426,6 +447,45 @@ def test_giant_lut_table_and_queries_bit_equal_to_oracle(oracle_mod):
         m.calc_range_fan(poses, out, 4.71, 271, hit_cells=np.empty((50 * 271, 2), np.int32))
 
 
+# theta_disc decides how many 16-B loads per lane fetch a pose's theta row into LDS (NL = 1..3; wider
+# rows take the per-beam kernel): every width, with the trimmed fetch (fov < 2pi), the whole-row
+# fetch (fov >= 2pi, negative fov), headings that wrap the bin range, 12- and 17-chunk fans
+@pytest.mark.parametrize("td", [510, 514, 720, 1024, 1026, 1442, 1536, 1538, 1443])
+def test_giant_lut_fan_every_row_width_bit_equal_to_oracle(oracle_mod, td):
+    g = maps.make_maze(56, cell=14, wall=2, p=0.5, seed=td, origin=(2.0, -1.5, -0.3))
+    mrx = 60
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyGiantLUTCast(omap, mrx, td)
+    lut0 = om.lut_build(td, nthreads=oracle_mod.max_threads())
+    assert np.array_equal(m.table(), lut0)
+    rng = np.random.default_rng(td)
+    poses = maps.sample_free_poses(g, 96, td)
+    poses[:, 2] = rng.uniform(-7.0, 7.0, len(poses)).astype(np.float32)
+    # headings that put the first beam's bin right at the wrap of the row
+    for k, b in enumerate((0.0, 0.49, 0.51, td - 1.0, td - 0.5, td / 2.0)):
+        poses[8 + k, 2] = np.float32(b * 2 * math.pi / td + 4.71 / 2 - g.origin[2])
+    poses[0] = [-50.0, 0.0, 0.0]
+    poses[1] = [np.nan, 0.0, 0.0]
+    poses[2, 2] = 1e4
+    poses[3, 2] = -3e7                                      # |bin index| > 2^23: integer path
+    for B, fov in ((1081, 4.71), (271, 4.71), (1081, 2 * math.pi), (1088, 7.0), (720, -2.0), (64, 0.0),
+                   (1081, 6.25), (700, 6.2831855)):
+        out = np.empty(len(poses) * B, np.float32)
+        m.calc_range_fan(poses, out, fov, B)
+        want = om.lut_fan(lut0, poses, fov, B)
+        assert np.array_equal(out, want), (td, B, fov, int((out != want).sum()))
+    # the last cell of the table: the row's 16-B tail loads stay inside the allocation
+    corner = np.array([[g.origin[0], g.origin[1], 0.3]], np.float32)
+    c, s_ = math.cos(g.origin[2]), math.sin(g.origin[2])
+    gx, gy = g.cols - 0.5, g.rows - 0.5
+    corner[0, 0] += (c * gx - s_ * gy) * g.resolution
+    corner[0, 1] += (s_ * gx + c * gy) * g.resolution
+    out = np.empty(1081, np.float32)
+    m.calc_range_fan(corner, out, 4.71, 1081)
+    assert np.array_equal(out, om.lut_fan(lut0, corner, 4.71, 1081))
+
+
 # ---------------------------------------------------------------- K3b: CDDT
 @pytest.mark.parametrize("td", [112, 720, 113])        # 112: scripts/two_player/rcs_two_player.py:121
 def test_cddt_queries_bit_equal_to_oracle(oracle_mod, td):
@@ -470,6 +530,27 @@ def test_cfg3_giant_lut_full_size(oracle_mod):
     again = np.empty_like(out)
     m.calc_range_fan(poses, again, w.fov, B)
     assert np.array_equal(out, again)
+    # the production kernel (theta_disc 1442 -> lut_fan_lds_kernel<3,17>, trimmed row fetch) bit for
+    # bit against the oracle's fan query on a pose subsample: the oracle reads the DEVICE table rows
+    # of the sampled poses' cells (the table itself is pinned by the slab above; 11.5 GB do not fit
+    # the host), so every bin a beam reads must be the bin the oracle reads
+    sub = np.concatenate([np.arange(0, len(poses), 683), [len(poses) - 1]])
+    rr, cc = om.lut_pose_cells(poses[sub])
+    assert (rr >= 0).all()
+    row_cache = {}
+    pose_rows = np.empty((len(sub), td), np.uint16)
+    for i, (r_, c_) in enumerate(zip(rr, cc)):
+        if int(r_) not in row_cache:
+            row_cache[int(r_)] = m.table(int(r_), int(r_) + 1)[0]
+        pose_rows[i] = row_cache[int(r_)][int(c_)]
+    pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
+    want = om.lut_fan_rows(pose_rows, poses[sub], w.fov, B)
+    assert np.array_equal(out[pick], want), int((out[pick] != want).sum())
+    # ... also with the whole-row fetch (fov >= 2pi) and a negative fov, same poses
+    for fov2, B2 in ((2 * math.pi, 1081), (-4.71, 1081), (SCAN_FOV_720, 720)):
+        o2 = np.empty(len(sub) * B2, np.float32)
+        m.calc_range_fan(poses[sub], o2, fov2, B2)
+        assert np.array_equal(o2, om.lut_fan_rows(pose_rows, poses[sub], fov2, B2)), (fov2, B2)
     # against exact ray marching on a pose subsample: within 2 cells for nearly all beams
     sub = np.arange(0, len(poses), 1024)
     rm, _, _ = om.rm_fan(poses[sub], w.fov, B, nthreads=oracle_mod.max_threads())
@@ -484,70 +565,106 @@ def _free_poses(g, dt, n, seed):
 
 
 def test_cfg4_colombia_rollout_shard_properties(oracle_mod):
-    """configs[3]: maps/colombia, 2^20 poses sharded 8 ways -> this is ONE rank's block
-    (131072 poses x 1081 beams = 141.7 M rays), checked through properties + an oracle subsample,
-    and the sharding contract: scanning a block in two halves == scanning it whole."""
+    """configs[3]: maps/colombia, 2^20 MCTS roll-out poses (5243 roll-outs x 200 steps through
+    rl_car_rollout with the scripts/mcts.py:214-231 action schedule) sharded 8 ways ->
+    this is ONE rank's block (131072 poses x 1081 beams = 141.7 M rays), checked against the oracle on
+    a subsample, through properties, and through the sharding contract (halves == whole)."""
     w = workloads.cfg4()
+    assert w.pose_kind == "rollout"
     g, B, mrx = w.gmap, w.num_rays, w.max_range_px
     omap = range_libc.PyOMap(g)
     dt = omap.distance_transform()
+    all_poses = workloads.make_poses(w, dt=dt)
+    assert all_poses.shape == (1 << 20, 3) and np.isfinite(all_poses).all()
+    # roll-out structure: consecutive poses of one roll-out are one 0.01 s step apart (<= 7 m/s)
+    ro = all_poses[:200 * 5242].reshape(5242, 200, 3)
+    hop = np.hypot(np.diff(ro[:, :, 0], axis=1), np.diff(ro[:, :, 1], axis=1))
+    assert hop.max() <= 7.0 * 0.01 * 1.05 and hop.mean() > 0.005
+    # ... and the generator is pinned: the same inputs through the reference-pinned host API
+    st, ac = workloads.rollout_inputs(w, 5243, w.pose_seed, dt)
+    from pyracecarsimulator_amd import racecar as RC
+    again = RC.CarBatch().rollout(st[:64], ac[:64], 200, 10, 0.01)[0].reshape(-1, 3)
+    assert np.array_equal(again, all_poses[:64 * 200])
     lo, hi = workloads.shard_range(1 << 20, 3, 8)              # rank 3 of 8
     assert hi - lo == 131072
-    poses = _free_poses(g, dt, hi - lo, 1000 + 3)
+    poses = np.ascontiguousarray(all_poses[lo:hi])
     m = range_libc.PyRayMarchingGPU(omap, mrx)
     out = np.empty(len(poses) * B, np.float32)
-    m.calc_range_fan(poses, out, w.fov, B)
+    steps = np.empty(len(poses) * B, np.uint16)
+    m.calc_range_fan(poses, out, w.fov, B, steps=steps)
     assert out.min() >= 0.0 and out.max() <= (mrx + 1.5) * g.resolution
-    # oracle on every 512th pose, bit-exact
+    # oracle on every 512th pose, bit-exact (ranges and sample counts)
     sub = np.arange(0, len(poses), 512)
     om = oracle_mod.OracleMap.from_gridmap(g, mrx)
-    r0, _, _ = om.rm_fan(poses[sub], w.fov, B, step_coeff=1.0, nthreads=8)
+    r0, _, s0 = om.rm_fan(poses[sub], w.fov, B, step_coeff=1.0, nthreads=8)
     pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
-    assert np.array_equal(out[pick], r0)
+    assert np.array_equal(out[pick], r0) and np.array_equal(steps[pick], s0)
+    # how the clustered roll-out poses differ from uniform free-cell poses (reported, not asserted on)
+    uni = _free_poses(g, dt, 4096, 1003)
+    su = np.empty(len(uni) * B, np.uint16)
+    m.calc_range_fan(uni, np.empty(len(uni) * B, np.float32), w.fov, B, steps=su)
+    print("cfg4 samples/ray: roll-out poses %.3f (p99 %d), uniform free-cell poses %.3f; poses outside the "
+          "map or inside walls: %.2f %%" % (steps.mean(), np.percentile(steps[::97], 99), su.mean(),
+                                            100.0 * (steps.reshape(-1, B).max(axis=1) <= 1).mean()))
     # two half-blocks reproduce the block (what all-gather of shards relies on)
     half = len(poses) // 2
     a, b = np.empty(half * B, np.float32), np.empty((len(poses) - half) * B, np.float32)
     m.calc_range_fan(poses[:half], a, w.fov, B)
     m.calc_range_fan(poses[half:], b, w.fov, B)
     assert np.array_equal(out[:half * B], a) and np.array_equal(out[half * B:], b)
-    # fused crash test over the whole block == isCrashed over the ranges
+    # fused crash test: whole block == isCrashed over the ranges, and per 200-pose roll-out
     edge = oracle_mod.edge_distances(B, -w.fov / 2, w.fov / B, 0.275, 0.2032, 0.3302)
     code = m.check_collision_many(poses, w.fov, B, edge, 0.001)
     assert code == oracle_mod.is_crashed(out, B, len(poses), edge, 0.001)
+    n_ro = 640
+    first = m.check_collision_groups(poses[:n_ro * 200], 200, w.fov, B, edge, 0.001)
+    exp = [oracle_mod.is_crashed(out[k * 200 * B:(k + 1) * 200 * B], B, 200, edge, 0.001) for k in range(n_ro)]
+    assert first.tolist() == exp
+    assert sum(e >= 0 for e in exp) > 0 and sum(e < 0 for e in exp) > 0     # both outcomes occur
 
 
 def test_cfg5_noise_shard_reproduces_unsharded(oracle_mod):
-    """configs[4]: 4096^2 maze, 720 beams + Gaussian noise, pose batch sharded.  A rank that scans
-    its block with ray_offset = first global ray id must reproduce the unsharded noisy scan bit for
-    bit; noise-free ranges match the oracle on a subsample; noise has the configured sigma."""
+    """configs[4]: 4096^2 maze, 262144 poses x 720 beams + Gaussian noise, pose batch sharded 8 ways.
+    One rank's TRUE shard (32768 poses) against the oracle on a subsample; the FULL batch through
+    size-independent properties: a rank that scans its block with ray_offset = first global ray id
+    reproduces the unsharded noisy scan bit for bit, noise has the configured sigma, noise-free ranges
+    are idempotent."""
     w = workloads.cfg5()
     g, B, mrx = w.gmap, w.num_rays, w.max_range_px
     omap = range_libc.PyOMap(g)
     dt = omap.distance_transform()
-    n = 16384                                                   # 2 "ranks" of 8192 poses
-    poses = _free_poses(g, dt, n, 55)
+    n = w.n_poses
+    assert n == 262144
+    poses = workloads.make_poses(w, dt=dt)
     m = range_libc.PyRayMarchingGPU(omap, mrx)
     clean = np.empty(n * B, np.float32)
     m.calc_range_fan(poses, clean, w.fov, B)
-    sub = np.arange(0, n, 256)
+    assert clean.min() >= 0.0 and clean.max() <= (mrx + 1.5) * g.resolution
     om = oracle_mod.OracleMap.from_gridmap(g, mrx)
     om._dt = dt
+    # rank 5's shard, every 128th pose of it, against the oracle
+    lo5, hi5 = workloads.shard_range(n, 5, 8)
+    assert hi5 - lo5 == 32768
+    sub = np.arange(lo5, hi5, 128)
     r0, _, _ = om.rm_fan(poses[sub], w.fov, B, step_coeff=1.0, nthreads=8)
     pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
     assert np.array_equal(clean[pick], r0)
+    shard = np.empty((hi5 - lo5) * B, np.float32)
+    m.calc_range_fan(poses[lo5:hi5], shard, w.fov, B)
+    assert np.array_equal(shard, clean[lo5 * B:hi5 * B])
+    # noise on the full batch
     m.set_noise(w.noise_std, w.noise_seed, 0)
     whole = np.empty(n * B, np.float32)
     m.calc_range_fan(poses, whole, w.fov, B)
-    d = (whole - clean).astype(np.float64)
+    d = (whole[::7] - clean[::7]).astype(np.float64)
     assert abs(d.mean()) < 1e-4 and abs(d.std() - w.noise_std) < 1e-4
-    parts = []
-    for r in range(2):
-        lo, hi = workloads.shard_range(n, r, 2)
+    # every rank's block with its own ray_offset reproduces its part of the unsharded scan
+    for r in range(8):
+        lo, hi = workloads.shard_range(n, r, 8)
         m.set_noise(w.noise_std, w.noise_seed, lo * B)
         part = np.empty((hi - lo) * B, np.float32)
         m.calc_range_fan(poses[lo:hi], part, w.fov, B)
-        parts.append(part)
-    assert np.array_equal(np.concatenate(parts), whole)
+        assert np.array_equal(part, whole[lo * B:hi * B]), r
 
 
 # ---------------------------------------------------------------- "next" rows: roll-outs + crash

@@ -195,3 +195,21 @@ def test_params_yaml_loader_maps_rosparam_names(tmp_path):
     assert cfg["l_r"] == config.DEFAULTS["l_r"] and "some_topic" not in cfg
     assert all(k in cfg for k in RC.CAR_PARAM_ORDER)           # everything Car's constructor needs
     assert config.load_params()["scan_max_range"] == 15.0
+
+
+def test_pyomap_ingests_an_occupancy_grid_message_like_the_reference():
+    """Row a6: the reference's real call form is PyOMap(map_msg) (/root/reference/scripts/
+    ros_interface.py:210, mcts_driver.py:278, two_player/scan.py:45) after rewriting map_msg.data to
+    {0, 255} (ros_interface.py:80-86); origin yaw comes from the quaternion (ros_interface.py:212-220)."""
+    from conftest import occupancy_grid_msg
+    g = maps.make_maze(48, cell=12, wall=2, p=0.5, seed=2, resolution=0.05, origin=(-1.5, 2.25, 0.6))
+    for binarise in (True, False):                 # {0,255} as the reference feeds it; raw {-1,0,100} too
+        msg = occupancy_grid_msg(g, binarise)
+        occ, res, org = range_libc.PyOMap._ingest(msg, None, None, None)
+        assert occ.shape == (g.rows, g.cols) and np.array_equal(occ.astype(np.uint8), (g.occ != 0).astype(np.uint8))
+        assert res == g.resolution and org[0] == g.origin[0] and org[1] == g.origin[1]
+        assert abs(org[2] - g.origin[2]) < 1e-12
+    # yaw outside (-pi/2, pi/2) and negative
+    for yaw in (2.5, -3.0, -0.4, 0.0):
+        g2 = maps.GridMap(g.occ, g.resolution, (0.0, 0.0, yaw), "yaw")
+        assert abs(range_libc.PyOMap._ingest(occupancy_grid_msg(g2), None, None, None)[2][2] - yaw) < 1e-12
