@@ -194,6 +194,19 @@ int rl_car_rollout_check(rl_car *c, rl_method *h, const double *states_in, const
                          int num_rays, const double *edge, double crash_thresh, int *first_crashed,
                          double *states_out_or_null, double *velocities_out_or_null);
 
+/* Car::setCarEdgeDistances (racecar/src/racecar.cpp:239-292; called at
+ * scripts/racecar_simulator_v2.py:47-50): distance from the lidar to the car's outline along each of
+ * num_rays beams starting one increment after min_ang — the table every crash test above takes as
+ * `edge`.  Host arithmetic (a one-off table), no device needed; the reference's quirks are kept
+ * (shifted by one beam, pi = 3.145, about -1016 m for a beam at exactly 0 rad).                   */
+int rl_car_edge_distances(int num_rays, double min_ang, double ang_inc, double scan_dist_to_base,
+                          double width, double wheelbase, double *edge_out);
+/* Car::isCrashed (racecar/src/racecar.cpp:305-328) over ranges already on the host: index of the
+ * first of n_scans scans with a beam j where (double)range - edge[j] < crash_thresh, else
+ * -(n_scans+1).  (Scanned batches use the fused device test: rl_check_collision_*.)               */
+int rl_car_is_crashed(const float *ranges, int num_rays, int n_scans, const double *edge,
+                      double crash_thresh, int *first_crashed);
+
 /* device time of the last enqueued launch sequence of this handle, from HIP events
  * recorded on the launch stream (blocks until that work has finished).  Events are only
  * recorded after rl_method_set_option(h, "timing", 1): they cost microseconds per launch.

@@ -55,7 +55,9 @@ def lib():
                                  C.c_int, _f32p, _i32p, _u16p, C.c_int]
         L.orc_rm_rays.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, _f32p, _i32p,
                                   _u16p, C.c_int]
-        L.orc_rm_rays_libm.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, _f32p]
+        L.orc_rm_rays_libm.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, _f32p, _i32p, _u16p]
+        L.orc_rm_fan_libm.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, C.c_float, C.c_int,
+                                      _f32p, _i32p, _u16p]
         L.orc_bl_fan.argtypes = [mp, C.c_float, _f32p, C.c_int, C.c_float, C.c_int, _f32p, _i32p,
                                  _u16p, C.c_int]
         L.orc_bl_rays.argtypes = [mp, C.c_float, _f32p, C.c_int, _f32p, _i32p, _u16p, C.c_int]
@@ -167,12 +169,29 @@ class OracleMap:
                           nthreads)
         return ranges, hits, steps
 
-    def rm_rays_libm(self, ins, step_coeff=0.999):
+    def rm_rays_libm(self, ins, step_coeff=0.999, full=False):
+        """Upstream-literal form (libm trig, unfused, calc_range(y, x, theta')).  ``full``: also the
+        hit cells (col, row) and sample counts."""
         ins = np.ascontiguousarray(ins, dtype=np.float32).reshape(-1, 3)
-        ranges = np.empty(ins.shape[0], dtype=np.float32)
+        n = ins.shape[0]
+        ranges = np.empty(n, dtype=np.float32)
+        hits = np.empty((n, 2), dtype=np.int32) if full else None
+        steps = np.empty(n, dtype=np.uint16) if full else None
         lib().orc_rm_rays_libm(C.byref(self._m), _p(self.dt, _f32p), self.max_range_px, step_coeff,
-                               _p(ins, _f32p), ins.shape[0], _p(ranges, _f32p))
-        return ranges
+                               _p(ins, _f32p), n, _p(ranges, _f32p), _p(hits, _i32p), _p(steps, _u16p))
+        return (ranges, hits, steps) if full else ranges
+
+    def rm_fan_libm(self, poses, fov, num_rays, step_coeff=0.999):
+        """The 4-arg fan stated literally: one libm cast per beam at theta + (-fov/2 + j*fov/B)."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        n = poses.shape[0] * num_rays
+        ranges = np.empty(n, dtype=np.float32)
+        hits = np.empty((n, 2), dtype=np.int32)
+        steps = np.empty(n, dtype=np.uint16)
+        lib().orc_rm_fan_libm(C.byref(self._m), _p(self.dt, _f32p), self.max_range_px, step_coeff,
+                              _p(poses, _f32p), poses.shape[0], fov, num_rays, _p(ranges, _f32p),
+                              _p(hits, _i32p), _p(steps, _u16p))
+        return ranges, hits, steps
 
     # -- BresenhamsLine ----------------------------------------------------
     def bl_fan(self, poses, fov, num_rays, nthreads=1):

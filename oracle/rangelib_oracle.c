@@ -268,37 +268,75 @@ void orc_rm_rays(const orc_map *m, const float *dt, float max_range_px, float st
  * marches (first=row, second=col) along (cosf, sinf) of theta' with libm trig and
  * un-fused multiply-add.  Used only to show the canonical form is the same
  * geometry (tests compare within one cell).                                    */
+/* one upstream-literal cast from world (xw, yw, theta_w); hit = (col, row) or (-1, -1) */
+static float rm_cast_libm(const orc_map *m, const float *dt, float max_range_px, float step_coeff,
+                          float rotation_const, float wsin, float wcos, float xw, float yw, float thw,
+                          int32_t *hit, uint16_t *steps)
+{
+    float theta = -thw + rotation_const;
+    float x = (xw - m->ox) * m->inv_res;
+    float y = (yw - m->oy) * m->inv_res;
+    float temp = x;
+    x = wcos * x - wsin * y;
+    y = wsin * temp + wcos * y;
+    /* calc_range(y, x, theta): first coordinate indexes rows */
+    float x0 = y, y0 = x;
+    float rdx = cosf(theta), rdy = sinf(theta);
+    float t = 0.0f, out = max_range_px;
+    int hc = -1, hr = -1;
+    unsigned n = 0;
+    while (t < max_range_px) {
+        int px = (int)(x0 + rdx * t);
+        int py = (int)(y0 + rdy * t);
+        if (px >= m->rows || px < 0 || py < 0 || py >= m->cols) break;
+        float d = dt[(size_t)px * m->cols + py];
+        ++n;
+        if (d <= 0.0f) {
+            float xd = (float)px - x0, yd = (float)py - y0;
+            out = sqrtf(xd * xd + yd * yd);
+            hc = py;
+            hr = px;
+            break;
+        }
+        float st = d * step_coeff;
+        t += st > 1.0f ? st : 1.0f;
+    }
+    if (hit) { hit[0] = hc; hit[1] = hr; }
+    if (steps) *steps = (uint16_t)(n > 65535u ? 65535u : n);
+    return out * m->res;
+}
+
 void orc_rm_rays_libm(const orc_map *m, const float *dt, float max_range_px, float step_coeff,
-                      const float *ins, int n, float *ranges)
+                      const float *ins, int n, float *ranges, int32_t *hits, uint16_t *steps)
 {
     float rotation_const = (float)(-1.0 * (double)m->wa - 3.0 * M_PI / 2.0);
     float wsin = (float)sin((double)m->wa), wcos = (float)cos((double)m->wa);
-    for (int i = 0; i < n; ++i) {
-        float theta = -ins[3 * i + 2] + rotation_const;
-        float x = (ins[3 * i] - m->ox) * m->inv_res;
-        float y = (ins[3 * i + 1] - m->oy) * m->inv_res;
-        float temp = x;
-        x = wcos * x - wsin * y;
-        y = wsin * temp + wcos * y;
-        /* calc_range(y, x, theta): first coordinate indexes rows */
-        float x0 = y, y0 = x;
-        float rdx = cosf(theta), rdy = sinf(theta);
-        float t = 0.0f, out = max_range_px;
-        while (t < max_range_px) {
-            int px = (int)(x0 + rdx * t);
-            int py = (int)(y0 + rdy * t);
-            if (px >= m->rows || px < 0 || py < 0 || py >= m->cols) break;
-            float d = dt[(size_t)px * m->cols + py];
-            if (d <= 0.0f) {
-                float xd = (float)px - x0, yd = (float)py - y0;
-                out = sqrtf(xd * xd + yd * yd);
-                break;
-            }
-            float st = d * step_coeff;
-            t += st > 1.0f ? st : 1.0f;
+    for (int i = 0; i < n; ++i)
+        ranges[i] = rm_cast_libm(m, dt, max_range_px, step_coeff, rotation_const, wsin, wcos, ins[3 * i],
+                                 ins[3 * i + 1], ins[3 * i + 2], hits ? hits + 2 * (size_t)i : NULL,
+                                 steps ? steps + i : NULL);
+}
+
+/* the fork's 4-arg form stated literally: beam j of pose p is one libm cast at
+ * theta_p + (-fov/2 + j * (fov / num_rays)), every operation a separate float32 rounding (no fma,
+ * no shared per-pose sincos, no angle-addition formula) — scripts/scan_simulator.py:103-106,
+ * fan convention scripts/ros_interface.py:342-344.                                           */
+void orc_rm_fan_libm(const orc_map *m, const float *dt, float max_range_px, float step_coeff,
+                     const float *poses, int n_poses, float fov, int num_rays, float *ranges,
+                     int32_t *hits, uint16_t *steps)
+{
+    float rotation_const = (float)(-1.0 * (double)m->wa - 3.0 * M_PI / 2.0);
+    float wsin = (float)sin((double)m->wa), wcos = (float)cos((double)m->wa);
+    const float amin = -0.5f * fov, inc = fov / (float)num_rays;
+    for (int p = 0; p < n_poses; ++p)
+        for (int j = 0; j < num_rays; ++j) {
+            const size_t i = (size_t)p * num_rays + j;
+            volatile float aj = (float)j * inc;      /* (volatile: keep the two roundings apart) */
+            const float th = poses[3 * p + 2] + (amin + aj);
+            ranges[i] = rm_cast_libm(m, dt, max_range_px, step_coeff, rotation_const, wsin, wcos,
+                                     poses[3 * p], poses[3 * p + 1], th, hits ? hits + 2 * i : NULL,
+                                     steps ? steps + i : NULL);
         }
-        ranges[i] = out * m->res;
-    }
 }
 
 /* ------------------------------------------------------------------------ */

@@ -70,7 +70,11 @@ void orc_rm_rays(const orc_map *m, const float *dt, float max_range_px, float st
 /* upstream-literal variant (libm cosf/sinf of -th + rot_const, calc_range(y,x,.)):
  * CPU-only cross-check of the canonical form, tolerance-compared in tests.      */
 void orc_rm_rays_libm(const orc_map *m, const float *dt, float max_range_px, float step_coeff,
-                      const float *ins, int n, float *ranges);
+                      const float *ins, int n, float *ranges, int32_t *hits_or_null,
+                      uint16_t *steps_or_null);
+void orc_rm_fan_libm(const orc_map *m, const float *dt, float max_range_px, float step_coeff,
+                     const float *poses, int n_poses, float fov, int num_rays, float *ranges,
+                     int32_t *hits_or_null, uint16_t *steps_or_null);
 
 /* ---- BresenhamsLine (row a12) ------------------------------------------ */
 void orc_bl_fan(const orc_map *m, float max_range_px,

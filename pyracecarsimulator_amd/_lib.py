@@ -70,6 +70,9 @@ SYMBOLS = {
     "rl_car_rollout_check": (C.c_int, [C.c_void_p, C.c_void_p, f64p, f64p, C.c_int, C.c_int, C.c_int,
                                        C.c_double, C.c_float, C.c_int, f64p, C.c_double,
                                        C.POINTER(C.c_int), f64p, f64p]),
+    "rl_car_edge_distances": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                        f64p]),
+    "rl_car_is_crashed": (C.c_int, [f32p, C.c_int, C.c_int, f64p, C.c_double, C.POINTER(C.c_int)]),
     "rl_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rl_method_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "rl_method_get_info": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),

@@ -47,51 +47,52 @@ __device__ inline void car_step(const CarParams &P, CarState &cs, double input_s
     if (fabs(dif_steer) > 0.0001) steer_ang_vel = dif_steer > 0 ? P.MAX_STEER_VEL : -P.MAX_STEER_VEL;
     else steer_ang_vel = 0;
 
-    const double p_x = cs.x, p_y = cs.y;
-    const double thresh = cs.st_dyn ? ST_THRESH : K_THRESH;
-    if (cs.velocity < thresh) {
+    const double x_before = cs.x, y_before = cs.y;
+    const double switch_at = cs.st_dyn ? ST_THRESH : K_THRESH;
+    if (cs.velocity < switch_at) {
         // updateNormal (:171-194): kinematic single track
-        const double x_dot = cs.velocity * cos(cs.theta);
-        const double y_dot = cs.velocity * sin(cs.theta);
-        const double theta_dot = cs.velocity / P.WB * tan(cs.steer_angle);
-        cs.x += x_dot * dt;
-        cs.y += y_dot * dt;
-        cs.theta += theta_dot * dt;
+        const double vx = cs.velocity * cos(cs.theta);
+        const double vy = cs.velocity * sin(cs.theta);
+        const double yaw_rate = cs.velocity / P.WB * tan(cs.steer_angle);
+        cs.x += vx * dt;
+        cs.y += vy * dt;
+        cs.theta += yaw_rate * dt;
         cs.velocity += accel * dt;
         cs.steer_angle += steer_ang_vel * dt;
         cs.angular_velocity = 0;
         cs.slip_angle = 0;
         cs.st_dyn = false;
     } else {
-        // updateSingle (:196-237): dynamic single track
-        const double x_dot = cs.velocity * cos(cs.theta + cs.slip_angle);
-        const double y_dot = cs.velocity * sin(cs.theta + cs.slip_angle);
-        const double theta_dot = cs.angular_velocity;
-        const double r_val = G * P.L_R - accel * P.H_CG;
-        const double f_val = G * P.L_F + accel * P.H_CG;
-        const double vel_ratio = cs.angular_velocity / cs.velocity;
-        const double first_term = P.FC / (cs.velocity * (P.L_R + P.L_F));
-        const double theta_double_dot =
+        // updateSingle (:196-237): dynamic single track.  The operation order of every expression is
+        // the reference's (parity with its compiled Car is <= 1e-9, tests/golden/car_rollouts_ref.npz).
+        const double vx = cs.velocity * cos(cs.theta + cs.slip_angle);
+        const double vy = cs.velocity * sin(cs.theta + cs.slip_angle);
+        const double yaw_rate = cs.angular_velocity;
+        const double load_rear = G * P.L_R - accel * P.H_CG;        // axle loads under longitudinal acceleration
+        const double load_front = G * P.L_F + accel * P.H_CG;
+        const double yaw_per_speed = cs.angular_velocity / cs.velocity;
+        const double slip_gain = P.FC / (cs.velocity * (P.L_R + P.L_F));
+        const double yaw_accel =
             (P.FC * P.MASS / (P.I_Z * P.WB)) *
-            (P.L_F * P.CS_F * cs.steer_angle * r_val +
-             cs.slip_angle * (P.L_R * P.CS_R * f_val - P.L_F * P.CS_F * r_val) -
-             vel_ratio * ((P.L_F * P.L_F) * P.CS_F * r_val + (P.L_R * P.L_R) * P.CS_R * f_val));
-        const double slip_angle_dot =
-            first_term * (P.CS_F * cs.steer_angle * (r_val) -
-                          cs.slip_angle * (P.CS_R * f_val + P.CS_F * r_val) +
-                          vel_ratio * (P.CS_R * P.L_R * f_val - P.CS_F * P.L_F * r_val)) -
+            (P.L_F * P.CS_F * cs.steer_angle * load_rear +
+             cs.slip_angle * (P.L_R * P.CS_R * load_front - P.L_F * P.CS_F * load_rear) -
+             yaw_per_speed * ((P.L_F * P.L_F) * P.CS_F * load_rear + (P.L_R * P.L_R) * P.CS_R * load_front));
+        const double slip_rate =
+            slip_gain * (P.CS_F * cs.steer_angle * (load_rear) -
+                         cs.slip_angle * (P.CS_R * load_front + P.CS_F * load_rear) +
+                         yaw_per_speed * (P.CS_R * P.L_R * load_front - P.CS_F * P.L_F * load_rear)) -
             cs.angular_velocity;
-        cs.x += x_dot * dt;
-        cs.y += y_dot * dt;
-        cs.theta += theta_dot * dt;
+        cs.x += vx * dt;
+        cs.y += vy * dt;
+        cs.theta += yaw_rate * dt;
         cs.velocity += accel * dt;
         cs.steer_angle += steer_ang_vel * dt;
-        cs.angular_velocity += theta_double_dot * dt;
-        cs.slip_angle += slip_angle_dot * dt;
+        cs.angular_velocity += yaw_accel * dt;
+        cs.slip_angle += slip_rate * dt;
         cs.st_dyn = true;
     }
-    const double d_x = p_x - cs.x, d_y = p_y - cs.y;
-    cs.travel_dist += sqrt(d_x * d_x + d_y * d_y);
+    const double moved_x = x_before - cs.x, moved_y = y_before - cs.y;
+    cs.travel_dist += sqrt(moved_x * moved_x + moved_y * moved_y);
     cs.total_velo += cs.velocity;
     cs.update_count++;
     cs.velocity = clampd(cs.velocity, -P.MAX_SPEED, P.MAX_SPEED);

@@ -1595,45 +1595,248 @@ struct CddtParams {
     float bins_per_rad;
 };
 
+constexpr int EDGE_ROWS_PER_WG = 8;
+
 __global__ __launch_bounds__(256) void cddt_edges_kernel(const uint8_t *__restrict__ occ, int rows,
                                                          int cols, uint32_t *__restrict__ n_edges,
                                                          uint32_t *__restrict__ edges /* r<<16|c */)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c >= cols || r >= rows) return;
-    if (!occ[(size_t)r * cols + c]) return;
-    // occupied cell with a free 4-neighbour; border cells count as edges
-    bool edge = r == 0 || c == 0 || r == rows - 1 || c == cols - 1;
-    if (!edge)
-        edge = !occ[(size_t)(r - 1) * cols + c] || !occ[(size_t)(r + 1) * cols + c] ||
-               !occ[(size_t)r * cols + c - 1] || !occ[(size_t)r * cols + c + 1];
-    if (edge) edges[atomicAdd(n_edges, 1u)] = ((uint32_t)r << 16) | (uint32_t)c;
+    // a workgroup owns 256 columns x EDGE_ROWS_PER_WG rows; ONE global atomic per workgroup reserves
+    // its run of the list (same-word atomics retire ~10 per us: per-cell or per-wave atomics would
+    // dominate a 2049^2 map).  The order of the list is irrelevant: every bucket is sorted afterwards.
+    __shared__ uint32_t s_cnt[4 * EDGE_ROWS_PER_WG + 1];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long bal[EDGE_ROWS_PER_WG];
+    uint32_t edge_bits = 0;
+#pragma unroll
+    for (int k = 0; k < EDGE_ROWS_PER_WG; ++k) {
+        const int r = blockIdx.y * EDGE_ROWS_PER_WG + k;
+        bool edge = false;
+        if (c < cols && r < rows && occ[(size_t)r * cols + c]) {
+            // occupied cell with a free 4-neighbour; border cells count as edges
+            edge = r == 0 || c == 0 || r == rows - 1 || c == cols - 1;
+            if (!edge)
+                edge = !occ[(size_t)(r - 1) * cols + c] || !occ[(size_t)(r + 1) * cols + c] ||
+                       !occ[(size_t)r * cols + c - 1] || !occ[(size_t)r * cols + c + 1];
+        }
+        bal[k] = __ballot(edge);
+        edge_bits |= (edge ? 1u : 0u) << k;
+        if (lane == 0) s_cnt[k * 4 + wave] = (uint32_t)__popcll(bal[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < 4 * EDGE_ROWS_PER_WG; ++i) { const uint32_t v = s_cnt[i]; s_cnt[i] = tot; tot += v; }
+        s_cnt[4 * EDGE_ROWS_PER_WG] = tot ? atomicAdd(n_edges, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t base = s_cnt[4 * EDGE_ROWS_PER_WG];
+#pragma unroll
+    for (int k = 0; k < EDGE_ROWS_PER_WG; ++k)
+        if ((edge_bits >> k) & 1u) {
+            const int r = blockIdx.y * EDGE_ROWS_PER_WG + k;
+            edges[base + s_cnt[k * 4 + wave] + (uint32_t)__popcll(bal[k] & ((1ull << lane) - 1ull))] =
+                ((uint32_t)r << 16) | (uint32_t)c;
+        }
 }
 
-// FILL = false: count bucket sizes into offsets[]; FILL = true: write xs at the cursors
+// Projection of the edge cells into the buckets of every theta bin, in two passes around an exclusive
+// scan: COUNT (bucket sizes into counts[]) and FILL (values into xs at the CSR offsets).
+// A straight wall parallel to a bin's direction lands in ONE bucket, so a lane-per-(cell, bin) kernel
+// with global atomics serialises hundreds of same-word atomics (~10 per us: 34 us on the 435x350
+// colombia map).  Here a workgroup owns (a chunk of CDDT_CHUNK edge cells) x (ONE theta bin) and
+// histograms its chunk in LDS first; only one global atomic per touched bucket leaves the workgroup.
+// FILL reserves each bucket's run with atomicSub on counts[] — the counts return to zero, so the next
+// rebuild needs no memset and the scan's input is consumed in place — then hands out positions from
+// LDS cursors in a second sweep.  The order inside a bucket is irrelevant (sorted afterwards).
+constexpr int CDDT_CHUNK = 2048;
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void cddt_project_kernel(CddtParams cp, const uint32_t *__restrict__ edges,
                                                            const uint32_t *__restrict__ n_edges,
-                                                           uint32_t *__restrict__ cursor)
+                                                           uint32_t *__restrict__ counts)
 {
-    const long total = (long)(*n_edges) * cp.n_bins;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const uint32_t e = edges[i / cp.n_bins];
-        const int a = (int)(i % cp.n_bins);
+    extern __shared__ uint32_t lh[];              // width[a] local counters (+ width[a] bases when FILL)
+    const int a = blockIdx.y;
+    const uint32_t ne = *n_edges;
+    const uint32_t e0 = blockIdx.x * (uint32_t)CDDT_CHUNK;
+    if (e0 >= ne) return;
+    const uint32_t e1 = min(ne, e0 + (uint32_t)CDDT_CHUNK);
+    const int wdt = cp.width[a];
+    const float cs = cp.cosv[a], sn = cp.sinv[a], tr = cp.trans[a];
+    const float half = (fabsf(sn) + fabsf(cs)) * 0.5f;
+    const uint32_t b0 = cp.bucket_off[a];
+    for (int i = threadIdx.x; i < wdt; i += 256) lh[i] = 0;
+    __syncthreads();
+    auto span = [&](uint32_t e, float &lx, int &lower, int &upper) {
         const float px = (float)(e & 0xFFFFu) + 0.5f, py = (float)(e >> 16) + 0.5f;
-        const float cs = cp.cosv[a], sn = cp.sinv[a];
-        const float half = (fabsf(sn) + fabsf(cs)) * 0.5f;
-        const float lx = __builtin_fmaf(px, cs, -(py * sn));
-        const float ly = __builtin_fmaf(px, sn, py * cs) + cp.trans[a];
-        int upper = (int)((ly + half) - CDDT_EPS);
-        int lower = (int)((ly - half) + CDDT_EPS);
+        lx = __builtin_fmaf(px, cs, -(py * sn));
+        const float ly = __builtin_fmaf(px, sn, py * cs) + tr;
+        upper = (int)((ly + half) - CDDT_EPS);
+        lower = (int)((ly - half) + CDDT_EPS);
         if (lower < 0) lower = 0;
-        if (upper >= cp.width[a]) upper = cp.width[a] - 1;
-        for (int k = lower; k <= upper; ++k) {
-            const uint32_t b = cp.bucket_off[a] + (uint32_t)k;
-            if (FILL) cp.xs[atomicAdd(&cursor[b], 1u)] = lx;
-            else atomicAdd(&cursor[b], 1u);
+        if (upper >= wdt) upper = wdt - 1;
+    };
+    for (uint32_t ei = e0 + threadIdx.x; ei < e1; ei += 256) {
+        float lx;
+        int lower, upper;
+        span(edges[ei], lx, lower, upper);
+        for (int k = lower; k <= upper; ++k) atomicAdd(&lh[k], 1u);
+    }
+    __syncthreads();
+    if (!FILL) {
+        for (int i = threadIdx.x; i < wdt; i += 256) {
+            const uint32_t c = lh[i];
+            if (c) atomicAdd(&counts[b0 + (uint32_t)i], c);
+        }
+        return;
+    }
+    uint32_t *base = lh + wdt;
+    for (int i = threadIdx.x; i < wdt; i += 256) {
+        const uint32_t c = lh[i];
+        if (c) base[i] = cp.offsets[b0 + (uint32_t)i] + atomicSub(&counts[b0 + (uint32_t)i], c) - c;
+        lh[i] = 0;
+    }
+    __syncthreads();
+    for (uint32_t ei = e0 + threadIdx.x; ei < e1; ei += 256) {
+        float lx;
+        int lower, upper;
+        span(edges[ei], lx, lower, upper);
+        for (int k = lower; k <= upper; ++k) cp.xs[base[k] + atomicAdd(&lh[k], 1u)] = lx;
+    }
+}
+
+// Exclusive scan of the bucket counters -> CSR offsets, out of place (the counts stay: FILL consumes
+// them), in two small launches with one workgroup per theta bin: (1) scan inside the bin's own run of
+// buckets (coalesced 256-wide tiles, running carry) and publish the bin's total, (2) add the totals
+// of the bins in front.  (One workgroup walking all ~30 000 counters with a lane-strided pattern
+// took 42 us on colombia.)  Pass 2 also queues the buckets too large for the one-wave sort.
+__device__ __forceinline__ uint32_t wg256_excl_scan(uint32_t v, uint32_t *part /* 4 */, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += o;
+    }
+    __syncthreads();                                   // (part[] of the previous tile has been read)
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += part[w];
+    total = part[0] + part[1] + part[2] + part[3];
+    return before + incl - v;
+}
+
+__global__ __launch_bounds__(256) void cddt_scan_bins_kernel(CddtParams cp, const uint32_t *__restrict__ counts,
+                                                             uint32_t *__restrict__ bin_total)
+{
+    __shared__ uint32_t part[4];
+    const int a = blockIdx.x;
+    const int wdt = cp.width[a];
+    const uint32_t b0 = cp.bucket_off[a];
+    uint32_t carry = 0;
+    for (int i0 = 0; i0 < wdt; i0 += 256) {
+        const int i = i0 + (int)threadIdx.x;
+        const uint32_t v = i < wdt ? counts[b0 + (uint32_t)i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = wg256_excl_scan(v, part, tot);
+        if (i < wdt) cp.offsets[b0 + (uint32_t)i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) bin_total[a] = carry;
+}
+
+__global__ __launch_bounds__(256) void cddt_scan_add_kernel(CddtParams cp, const uint32_t *__restrict__ counts,
+                                                            const uint32_t *__restrict__ bin_total,
+                                                            uint32_t *__restrict__ big_list,
+                                                            uint32_t *__restrict__ big_count)
+{
+    __shared__ uint32_t part[4];
+    const int a = blockIdx.x;
+    uint32_t mine = 0;
+    for (int k = threadIdx.x; k < a; k += 256) mine += bin_total[k];
+    uint32_t base;
+    (void)wg256_excl_scan(mine, part, base);           // base = sum of the totals of bins 0 .. a-1
+    const int wdt = cp.width[a];
+    const uint32_t b0 = cp.bucket_off[a];
+    for (int i = threadIdx.x; i < wdt; i += 256) {
+        cp.offsets[b0 + (uint32_t)i] += base;
+        if (counts[b0 + (uint32_t)i] > 64u) big_list[atomicAdd(big_count, 1u)] = b0 + (uint32_t)i;
+    }
+    if (a == cp.n_bins - 1 && threadIdx.x == 0) cp.offsets[b0 + (uint32_t)wdt] = base + bin_total[a];
+}
+
+// Sort of every bucket, src -> dst (same CSR offsets), ONE launch.  No library call: hipcub's
+// segmented sort reads segment statistics back to the host, and the two-player tick must stay a pure
+// enqueue.
+//  * workgroups >= n_big_wg: buckets of up to 64 values — nearly all of them — one wave each: a lane
+//    holds one value and finds its rank among the others with a loop of lane broadcasts (ties broken
+//    by position, so the ranks are a permutation);
+//  * workgroups < n_big_wg: the queued buckets of more than 64 values (long straight walls parallel to
+//    a bin's direction), one workgroup each: bitonic sort in LDS up to lds_cap values, beyond that a
+//    rank sort straight from global memory (quadratic, but such a bucket needs a wall of > 5000 cells).
+constexpr uint32_t CDDT_LDS_SORT = 16384;
+
+__global__ __launch_bounds__(256) void cddt_sort_kernel(const uint32_t *__restrict__ offsets, uint32_t n_buckets,
+                                                        const float *__restrict__ src, float *__restrict__ dst,
+                                                        const uint32_t *__restrict__ big_list,
+                                                        const uint32_t *__restrict__ big_count,
+                                                        uint32_t n_big_wg, uint32_t lds_cap)
+{
+    extern __shared__ float sv[];                      // lds_cap (<= CDDT_LDS_SORT) floats
+    if (blockIdx.x >= n_big_wg) {
+        const int lane = threadIdx.x & 63;
+        const uint32_t wave = (blockIdx.x - n_big_wg) * 4u + (threadIdx.x >> 6);
+        const uint32_t n_waves = (gridDim.x - n_big_wg) * 4u;
+        for (uint32_t b = wave; b < n_buckets; b += n_waves) {
+            const uint32_t lo = offsets[b], n = offsets[b + 1] - lo;
+            if (n == 0 || n > 64u) continue;
+            const float x = (uint32_t)lane < n ? src[lo + lane] : __builtin_inff();
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                const float xj = __shfl(x, (int)j);
+                rank += (xj < x || (xj == x && j < (uint32_t)lane)) ? 1u : 0u;
+            }
+            if ((uint32_t)lane < n) dst[lo + rank] = x;
+        }
+        return;
+    }
+    const uint32_t nbig = *big_count;
+    for (uint32_t q = blockIdx.x; q < nbig; q += n_big_wg) {
+        const uint32_t b = big_list[q];
+        const uint32_t lo = offsets[b], n = offsets[b + 1] - lo;
+        if (n <= lds_cap) {
+            uint32_t m2 = 128;
+            while (m2 < n) m2 <<= 1;
+            for (uint32_t i = threadIdx.x; i < m2; i += 256) sv[i] = i < n ? src[lo + i] : __builtin_inff();
+            __syncthreads();
+            for (uint32_t k = 2; k <= m2; k <<= 1)
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t i = threadIdx.x; i < m2; i += 256) {
+                        const uint32_t p = i ^ j;
+                        if (p > i) {
+                            const float x = sv[i], y = sv[p];
+                            const bool up = (i & k) == 0;
+                            if ((x > y) == up) { sv[i] = y; sv[p] = x; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (uint32_t i = threadIdx.x; i < n; i += 256) dst[lo + i] = sv[i];
+            __syncthreads();
+        } else {
+            for (uint32_t i = threadIdx.x; i < n; i += 256) {
+                const float x = src[lo + i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < n; ++j) {
+                    const float xj = src[lo + j];
+                    rank += (xj < x || (xj == x && j < i)) ? 1u : 0u;
+                }
+                dst[lo + rank] = x;
+            }
         }
     }
 }
@@ -1665,6 +1868,97 @@ __device__ __forceinline__ float cddt_query(const MapParams &m, const CddtParams
         }
     }
     return out * m.res;
+}
+
+// query of ONE theta bin (raw index in [0, theta_disc)) from a grid origin: what cddt_query computes
+// once the bin is known.  The bisection stops at 8 candidates, which are read with 8 independent loads
+// (one or two cache lines): position = number of stored values below (not above, for the flipped half
+// turn) the origin — the same index the bisection would end at, the bucket being sorted — and the
+// answer is picked from those registers.
+__device__ __forceinline__ float cddt_query_bin(const CddtParams &cp, float max_range, float gx, float gy,
+                                                int raw_bin)
+{
+    int b = raw_bin;
+    bool flipped = false;
+    if (b >= cp.n_bins) { b -= cp.theta_disc / 2; flipped = true; }
+    if (b >= cp.n_bins) b = cp.n_bins - 1;
+    const float cs = cp.cosv[b], sn = cp.sinv[b];
+    const float lx = __builtin_fmaf(gx, cs, -(gy * sn));
+    const float ly = __builtin_fmaf(gx, sn, gy * cs) + cp.trans[b];
+    float out = max_range;
+    if (ly >= 0.0f && ly < (float)cp.width[b]) {
+        const uint32_t bk = cp.bucket_off[b] + (uint32_t)(int)ly;
+        const uint32_t lo = cp.offsets[bk], hi = cp.offsets[bk + 1];
+        uint32_t a = lo, z = hi;
+        // bisection down to 8 candidates (every probe is a different cache line of a table far larger
+        // than L2: a 9-ary search with 8 probes per round was tried and is 1.5x SLOWER — the kernel is
+        // bound by the number of lines it touches, not by the dependent-load chain)
+        while (z - a > 8u) {
+            const uint32_t mid = (a + z) >> 1;
+            const float pv = cp.xs[mid];
+            if (flipped ? pv <= lx : pv < lx) a = mid + 1; else z = mid;
+        }
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a + (uint32_t)k < z ? cp.xs[a + k] : __builtin_inff();
+        uint32_t below = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) below += (flipped ? v[k] <= lx : v[k] < lx) ? 1u : 0u;
+        // the neighbour of the insertion point is among the 8 values just read, unless it lies just
+        // outside the window
+        if (!flipped) {                        // first stored x >= lx: xs[a + below]
+            if (a + below < hi) {
+                float hit = below == 0 ? v[0] : below == 1 ? v[1] : below == 2 ? v[2] : below == 3 ? v[3]
+                          : below == 4 ? v[4] : below == 5 ? v[5] : below == 6 ? v[6] : v[7];
+                if (below >= 8u || a + below >= z) hit = cp.xs[a + below];
+                out = __builtin_fminf(hit - lx, max_range);
+            }
+        } else {                               // last stored x <= lx: xs[a + below - 1]
+            if (a + below > lo) {
+                float hit = below <= 1 ? v[0] : below == 2 ? v[1] : below == 3 ? v[2] : below == 4 ? v[3]
+                          : below == 5 ? v[4] : below == 6 ? v[5] : below == 7 ? v[6] : v[7];
+                if (below == 0) hit = cp.xs[a - 1];
+                out = __builtin_fminf(lx - hit, max_range);
+            }
+        }
+    }
+    return out;
+}
+
+// The fan form.  A CDDT answer depends on the ray's ORIGIN and its theta BIN only, so every beam of a
+// pose whose heading falls into one bin gets the same range (theta_disc 108 over a 4.71-rad fan of
+// 1081 beams: ~13 beams per bin).  One workgroup per pose with one lane per theta bin (up to 1024
+// lanes; more bins: several per lane): theta_disc bucket searches per pose instead of num_rays, all of
+// them in flight at once, the per-bin constants read with coalesced loads (lane <-> bin); the results
+// are parked in LDS and the beams only look their bin up — the kernel turns from a latency-bound
+// search per ray into a stream of range stores.  Bit-identical to the per-ray statement (same bin
+// index arithmetic, same query).
+__global__ __launch_bounds__(1024) void cddt_fan_bins_kernel(MapParams m, FanParams f, CddtParams cp,
+                                                             const float *__restrict__ poses,
+                                                             float *__restrict__ out)
+{
+    extern __shared__ float bin_range[];                 // theta_disc floats (this workgroup's pose)
+    const int nt = (int)blockDim.x;
+    LutParams lp{};
+    lp.theta_disc = cp.theta_disc;
+    lp.bins_per_rad = cp.bins_per_rad;
+    const float td_f = (float)cp.theta_disc, inv_td = 1.0f / (float)cp.theta_disc;
+    for (int pose = blockIdx.x; pose < f.n_poses; pose += gridDim.x) {
+        float gx, gy, thg;
+        world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
+                      poses[3 * (size_t)pose + 2], gx, gy, thg);
+        for (int bin = threadIdx.x; bin < cp.theta_disc; bin += nt)
+            bin_range[bin] = cddt_query_bin(cp, f.max_range, gx, gy, bin) * m.res;
+        __syncthreads();
+        float *dst = out + (size_t)pose * f.num_rays;
+        for (int j = threadIdx.x; j < f.num_rays; j += nt) {
+            float r = bin_range[lut_bin_fast(-(thg + fan_alpha(f, j)), lp, td_f, inv_td)];
+            if (f.noise_std > 0.0f)
+                r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (size_t)pose * f.num_rays + j);
+            dst[j] = r;
+        }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(256) void cddt_fan_kernel(MapParams m, FanParams f, CddtParams cp,

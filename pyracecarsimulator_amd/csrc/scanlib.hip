@@ -11,7 +11,6 @@
 #include "probe_kernels.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <climits>
@@ -78,6 +77,13 @@ struct rl_map {
     std::atomic<uint64_t> epoch{0};   // bumped by rl_map_update; derived tables rebuild lazily
     MapParams mp{};
     MapParams *d_mp = nullptr;   // device copy (kernels that take the map by pointer)
+    // edge cells (occupied with a free 4-neighbour), the input of every CDDT table of this map: built
+    // with the other map tables once a CDDT method exists, so that a table rebuild knows the count on
+    // the host without a read-back of its own (rl_map_update synchronises anyway)
+    bool want_edges = false;
+    uint32_t *d_edges = nullptr, *d_n_edges = nullptr;
+    uint32_t *pin_n_edges = nullptr;
+    uint32_t n_edges = 0;
     int n_cu = 256;
     std::mutex mu;
     // readers: every launch path of every method of this map (held for the whole call, i.e. until
@@ -162,11 +168,18 @@ struct rl_method {
     uint64_t lut_epoch = ~0ull;
     LutParams lp{};
     // CDDT (K3b)
-    DevBuf cd_cos, cd_sin, cd_trans, cd_width, cd_boff, cd_offsets, cd_xs, cd_xs2, cd_edges, cd_cnt,
-        cd_cursor, cd_tmp;
+    DevBuf cd_cos, cd_sin, cd_trans, cd_width, cd_boff, cd_offsets, cd_xs, cd_xs2, cd_cursor, cd_tmp;
     uint64_t cddt_epoch = ~0ull;
     CddtParams cdp{};
     uint32_t cd_buckets = 0;
+    std::vector<float> cd_h_cos, cd_h_sin, cd_h_trans;     // per-bin constants (host copies stay alive:
+    std::vector<int> cd_h_width;                           //  their uploads are asynchronous)
+    std::vector<uint32_t> cd_h_boff;
+    int cd_geom_rows = -1, cd_geom_cols = -1;              // map shape the constants were made for
+    bool cd_sort_attr = false;
+    bool cd_counts_clean = false;                          // bucket counters are all zero (see ensure_cddt)
+    int cddt_lds_sort = (int)CDDT_LDS_SORT;                // buckets up to this size are sorted in LDS (diagnostics: lower it)
+    int cddt_bins_kernel = 1;                              // 1: one query per (pose, theta bin); 0: per ray
     DevBuf pdt;                  // EDT with a border of `pad` cells of -1 (stream kernel)
     int pad = 0, pstride = 0;
     uint64_t pdt_epoch = ~0ull;  // map epoch the padded copy was built from
@@ -249,8 +262,21 @@ static int map_build_tables(rl_map *m)
                        m->stream, m->d_g, rows, cols, m->d_dt);
     hipLaunchKernelGGL(pack_bits_kernel, dim3((m->bits_stride + 255) / 256, rows), dim3(256), 0,
                        m->stream, m->d_occ, rows, cols, m->bits_stride, m->d_bits);
+    if (m->want_edges) {
+        if (!m->d_edges) {
+            HIPCHK(hipMalloc((void **)&m->d_edges, (size_t)rows * cols * sizeof(uint32_t)));
+            HIPCHK(hipMalloc((void **)&m->d_n_edges, 256));
+            HIPCHK(hipHostMalloc((void **)&m->pin_n_edges, 64, hipHostMallocDefault));
+        }
+        HIPCHK(hipMemsetAsync(m->d_n_edges, 0, 4, m->stream));
+        hipLaunchKernelGGL(cddt_edges_kernel, dim3((cols + 255) / 256, (rows + EDGE_ROWS_PER_WG - 1) / EDGE_ROWS_PER_WG),
+                           dim3(256), 0, m->stream,
+                           m->d_occ, rows, cols, m->d_n_edges, m->d_edges);
+        HIPCHK(hipMemcpyAsync(m->pin_n_edges, m->d_n_edges, 4, hipMemcpyDeviceToHost, m->stream));
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->want_edges) m->n_edges = *m->pin_n_edges;
     return RL_OK;
 }
 
@@ -345,6 +371,9 @@ extern "C" void rl_map_destroy(rl_map *m)
     if (m->d_dt) (void)hipFree(m->d_dt);
     if (m->d_bits) (void)hipFree(m->d_bits);
     if (m->d_mp) (void)hipFree(m->d_mp);
+    if (m->d_edges) (void)hipFree(m->d_edges);
+    if (m->d_n_edges) (void)hipFree(m->d_n_edges);
+    if (m->pin_n_edges) (void)hipHostFree(m->pin_n_edges);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -394,6 +423,20 @@ extern "C" int rl_method_create(rl_map *m, int kind, float max_range_px, int the
     h->max_range = max_range_px;
     h->theta_disc = theta_disc;
     h->step_coeff = kind == RL_RM_GPU ? 1.0f : 0.999f;   // kernels.cu STEP_COEFF vs RayMarching (also seeds the LUT)
+    if (kind == RL_CDDT) {
+        // the map starts keeping its edge list (and rebuilds it with every rl_map_update)
+        std::lock_guard<std::mutex> lk(m->mu);
+        std::unique_lock<std::shared_mutex> wl(m->tables_mu);
+        if (!m->want_edges) {
+            m->want_edges = true;
+            int rc_ = hipSetDevice(m->device) == hipSuccess ? map_build_tables(m) : fail(RL_ERR_HIP, "hipSetDevice failed");
+            if (rc_) {
+                m->want_edges = false;
+                delete h;
+                return rc_;
+            }
+        }
+    }
     if (hipSetDevice(m->device) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -423,7 +466,7 @@ extern "C" void rl_method_destroy(rl_method *h)
     h->pdt.release();
     h->lut.release();
     for (DevBuf *b : {&h->cd_cos, &h->cd_sin, &h->cd_trans, &h->cd_width, &h->cd_boff, &h->cd_offsets,
-                      &h->cd_xs, &h->cd_xs2, &h->cd_edges, &h->cd_cnt, &h->cd_cursor, &h->cd_tmp})
+                      &h->cd_xs, &h->cd_xs2, &h->cd_cursor, &h->cd_tmp})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -468,6 +511,8 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
     else if (!strcmp(name, "wg_threads")) h->wg_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256);
     else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
+    else if (!strcmp(name, "cddt_bins")) h->cddt_bins_kernel = value != 0;
+    else if (!strcmp(name, "cddt_lds_sort")) { h->cddt_lds_sort = value < 128 ? 128 : (value > (int)CDDT_LDS_SORT ? (int)CDDT_LDS_SORT : value); h->cddt_epoch = ~0ull; }
     else return fail(RL_ERR_INVALID, "unknown option '%s'", name);
     return RL_OK;
 }
@@ -497,6 +542,8 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "wg_threads")) *value_out = h->wg_threads;
     else if (!strcmp(name, "last_grid")) *value_out = h->last_grid;
     else if (!strcmp(name, "xcd_bands")) *value_out = h->xcd_bands;
+    else if (!strcmp(name, "cddt_bins")) *value_out = h->cddt_bins_kernel;
+    else if (!strcmp(name, "cddt_lds_sort")) *value_out = h->cddt_lds_sort;
     else if (!strcmp(name, "map_epoch")) *value_out = (int64_t)h->map->epoch;
     else return fail(RL_ERR_INVALID, "unknown info '%s'", name);
     return RL_OK;
@@ -606,47 +653,57 @@ static int ensure_lut(rl_method *h, hipStream_t stream)
     return table_built(h->lut_dep, stream);
 }
 
+// CDDT table of the current map, ENQUEUED on `stream` with no host synchronisation and no read-back:
+// the two-player front-end rebuilds it before every scan (scripts/two_player/rcs_two_player.py:110-121).
+// Sizes the host needs are known without asking the device: bucket counts follow from the map shape,
+// and the number of stored values is bounded by 3 per (edge cell, theta bin) — a cell's footprint
+// (half-width <= sqrt(2)/2) covers at most 3 buckets — with the edge count kept by the map.
 static int ensure_cddt(rl_method *h, hipStream_t stream)
 {
     rl_map *m = h->map;
     if (h->cddt_epoch == m->epoch && h->cd_xs.p) return table_wait(h->cddt_dep, stream);
-    HIPCHK(hipDeviceSynchronize());     // launches of other streams may still read the old table
+    if (h->cd_xs.p) HIPCHK(hipDeviceSynchronize());     // launches of other streams may still read the old table
     const int td = h->theta_disc, nb = (td + 1) / 2;
-    std::vector<float> cosv(nb), sinv(nb), trans(nb);
-    std::vector<int> width(nb);
-    std::vector<uint32_t> boff(nb + 1);
-    uint32_t nbk = 0;
-    const float W = (float)m->cols, H = (float)m->rows;
-    for (int a = 0; a < nb; ++a) {
-        float s, c;
-        host_sincosf((float)a * (6.283185307179586f / (float)td), s, c);
-        cosv[a] = c;
-        sinv[a] = s;
-        // buckets = height of the rotated map's bounding box; translation lifts the lowest
-        // rotated corner to bucket 0
-        width[a] = (int)ceilf((fabsf(W * s) + fabsf(H * c)) - CDDT_EPS) + 1;
-        const float lt = H * c, rt = fmaf(W, s, H * c), rb = W * s;
-        trans[a] = fmaxf(0.0f, -fminf(lt, fminf(rt, rb)) - CDDT_EPS);
-        boff[a] = nbk;
-        nbk += (uint32_t)width[a];
-    }
-    boff[nb] = nbk;
-    h->cd_buckets = nbk;
     int rc;
-    if ((rc = h->cd_cos.ensure(nb * 4)) || (rc = h->cd_sin.ensure(nb * 4)) ||
-        (rc = h->cd_trans.ensure(nb * 4)) || (rc = h->cd_width.ensure(nb * 4)) ||
-        (rc = h->cd_boff.ensure((nb + 1) * 4)) || (rc = h->cd_offsets.ensure(((size_t)nbk + 1) * 4)) ||
-        (rc = h->cd_cursor.ensure(((size_t)nbk + 1) * 4)) || (rc = h->cd_cnt.ensure(256)) ||
-        (rc = h->cd_edges.ensure((size_t)m->rows * m->cols * 4)))
-        return rc;
-    HIPCHK(hipMemcpyAsync(h->cd_cos.p, cosv.data(), nb * 4, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(h->cd_sin.p, sinv.data(), nb * 4, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(h->cd_trans.p, trans.data(), nb * 4, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(h->cd_width.p, width.data(), nb * 4, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(h->cd_boff.p, boff.data(), (nb + 1) * 4, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemsetAsync(h->cd_cnt.p, 0, 256, stream));
-    HIPCHK(hipMemsetAsync(h->cd_cursor.p, 0, ((size_t)nbk + 1) * 4, stream));
-    HIPCHK(hipStreamSynchronize(stream));   // host vectors go out of scope below
+    if (h->cd_geom_rows != m->rows || h->cd_geom_cols != m->cols) {
+        // per-bin geometry: depends on the map SHAPE only, uploaded once
+        h->cd_h_cos.resize(nb); h->cd_h_sin.resize(nb); h->cd_h_trans.resize(nb);
+        h->cd_h_width.resize(nb); h->cd_h_boff.resize(nb + 1);
+        uint32_t nbk = 0;
+        const float W = (float)m->cols, H = (float)m->rows;
+        for (int a = 0; a < nb; ++a) {
+            float s, c;
+            host_sincosf((float)a * (6.283185307179586f / (float)td), s, c);
+            h->cd_h_cos[a] = c;
+            h->cd_h_sin[a] = s;
+            // buckets = height of the rotated map's bounding box; translation lifts the lowest
+            // rotated corner to bucket 0
+            h->cd_h_width[a] = (int)ceilf((fabsf(W * s) + fabsf(H * c)) - CDDT_EPS) + 1;
+            const float lt = H * c, rt = fmaf(W, s, H * c), rb = W * s;
+            h->cd_h_trans[a] = fmaxf(0.0f, -fminf(lt, fminf(rt, rb)) - CDDT_EPS);
+            h->cd_h_boff[a] = nbk;
+            nbk += (uint32_t)h->cd_h_width[a];
+        }
+        h->cd_h_boff[nb] = nbk;
+        h->cd_buckets = nbk;
+        if ((rc = h->cd_cos.ensure(nb * 4)) || (rc = h->cd_sin.ensure(nb * 4)) ||
+            (rc = h->cd_trans.ensure(nb * 4)) || (rc = h->cd_width.ensure(nb * 4)) ||
+            (rc = h->cd_boff.ensure((nb + 1) * 4)) || (rc = h->cd_offsets.ensure(((size_t)nbk + 1) * 4)) ||
+            (rc = h->cd_cursor.ensure(((size_t)nbk + 1) * 4)))
+            return rc;
+        HIPCHK(hipMemcpyAsync(h->cd_cos.p, h->cd_h_cos.data(), nb * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(h->cd_sin.p, h->cd_h_sin.data(), nb * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(h->cd_trans.p, h->cd_h_trans.data(), nb * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(h->cd_width.p, h->cd_h_width.data(), nb * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(h->cd_boff.p, h->cd_h_boff.data(), (nb + 1) * 4, hipMemcpyHostToDevice, stream));
+        h->cd_geom_rows = m->rows;
+        h->cd_geom_cols = m->cols;
+        h->cd_counts_clean = false;
+    }
+    const uint32_t nbk = h->cd_buckets;
+    const size_t cap = std::max<size_t>((size_t)m->n_edges * nb * 3, 1);    // stored values, upper bound
+    if (cap > (size_t)INT_MAX) return fail(RL_ERR_UNSUPPORTED, "CDDT table too large (%zu values)", cap);
+    if ((rc = h->cd_xs.ensure(cap * 4)) || (rc = h->cd_xs2.ensure(cap * 4))) return rc;
     CddtParams &cp = h->cdp;
     cp.theta_disc = td;
     cp.n_bins = nb;
@@ -656,44 +713,55 @@ static int ensure_cddt(rl_method *h, hipStream_t stream)
     cp.width = (const int *)h->cd_width.p;
     cp.bucket_off = (const uint32_t *)h->cd_boff.p;
     cp.offsets = (uint32_t *)h->cd_offsets.p;
-    cp.xs = nullptr;
-    cp.bins_per_rad = (float)td * 0.15915494309189535f;
-    uint32_t *n_edges = (uint32_t *)h->cd_cnt.p;
-    hipLaunchKernelGGL(cddt_edges_kernel, dim3((m->cols + 255) / 256, m->rows), dim3(256), 0, stream,
-                       m->d_occ, m->rows, m->cols, n_edges, (uint32_t *)h->cd_edges.p);
-    const int pgrid = m->n_cu * 16;
-    hipLaunchKernelGGL(cddt_project_kernel<false>, dim3(pgrid), dim3(256), 0, stream, cp,
-                       (const uint32_t *)h->cd_edges.p, n_edges, (uint32_t *)h->cd_cursor.p);
-    // exclusive scan of the bucket sizes -> CSR offsets
-    size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (uint32_t *)h->cd_cursor.p,
-                                            (uint32_t *)h->cd_offsets.p, (int)nbk + 1, stream));
-    if ((rc = h->cd_tmp.ensure(tmp_bytes))) return rc;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->cd_tmp.p, tmp_bytes, (uint32_t *)h->cd_cursor.p,
-                                            (uint32_t *)h->cd_offsets.p, (int)nbk + 1, stream));
-    uint32_t total = 0;
-    HIPCHK(hipMemcpyAsync(&total, (uint32_t *)h->cd_offsets.p + nbk, 4, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    if ((rc = h->cd_xs.ensure(std::max<size_t>(total, 1) * 4)) ||
-        (rc = h->cd_xs2.ensure(std::max<size_t>(total, 1) * 4)))
-        return rc;
-    HIPCHK(hipMemcpyAsync(h->cd_cursor.p, h->cd_offsets.p, ((size_t)nbk + 1) * 4,
-                          hipMemcpyDeviceToDevice, stream));
     cp.xs = (float *)h->cd_xs2.p;
-    hipLaunchKernelGGL(cddt_project_kernel<true>, dim3(pgrid), dim3(256), 0, stream, cp,
-                       (const uint32_t *)h->cd_edges.p, n_edges, (uint32_t *)h->cd_cursor.p);
-    // sort every bucket
-    if (total > 0) {
-        tmp_bytes = 0;
-        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(
-            nullptr, tmp_bytes, (const float *)h->cd_xs2.p, (float *)h->cd_xs.p, (int)total, (int)nbk,
-            (const uint32_t *)h->cd_offsets.p, (const uint32_t *)h->cd_offsets.p + 1, 0, 32, stream));
-        if ((rc = h->cd_tmp.ensure(tmp_bytes))) return rc;
-        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(
-            h->cd_tmp.p, tmp_bytes, (const float *)h->cd_xs2.p, (float *)h->cd_xs.p, (int)total,
-            (int)nbk, (const uint32_t *)h->cd_offsets.p, (const uint32_t *)h->cd_offsets.p + 1, 0, 32,
-            stream));
+    cp.bins_per_rad = (float)td * 0.15915494309189535f;
+    if ((rc = h->cd_tmp.ensure(((size_t)nbk + nb + 64) * 4))) return rc;   // big-bucket count, bin totals, list
+    if (!h->cd_sort_attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cddt_sort_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CDDT_LDS_SORT * sizeof(float))));
+        h->cd_sort_attr = true;
     }
+    // bucket counters: zeroed once; every complete build returns them to zero (FILL subtracts what
+    // COUNT added), so a rebuild starts without a memset
+    if (!h->cd_counts_clean) {
+        HIPCHK(hipMemsetAsync(h->cd_cursor.p, 0, ((size_t)nbk + 1) * 4, stream));
+        h->cd_counts_clean = true;
+    }
+    // one workgroup per (chunk of edge cells, theta bin), bucket histogram of the bin in LDS
+    int wmax = 0;
+    for (int a = 0; a < nb; ++a) wmax = std::max(wmax, h->cd_h_width[a]);
+    const size_t lds_fill = (size_t)wmax * 2 * sizeof(uint32_t);
+    if (lds_fill > 150 * 1024) return fail(RL_ERR_UNSUPPORTED, "CDDT: map too large for the LDS bucket histogram");
+    if (lds_fill > 48 * 1024) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cddt_project_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cddt_project_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill));
+    }
+    const dim3 pgrid((unsigned)std::max<uint32_t>(1u, (m->n_edges + CDDT_CHUNK - 1) / CDDT_CHUNK), (unsigned)nb);
+    // count -> exclusive scan (CSR offsets) -> fill -> sort every bucket
+    hipLaunchKernelGGL(cddt_project_kernel<false>, pgrid, dim3(256), lds_fill / 2, stream, cp,
+                       (const uint32_t *)m->d_edges, (const uint32_t *)m->d_n_edges, (uint32_t *)h->cd_cursor.p);
+    // [0] big-bucket count (zeroed by the sort's last reader), [1..64) spare, [64..64+nb) bin totals, then the list
+    uint32_t *big_count = (uint32_t *)h->cd_tmp.p, *bin_total = (uint32_t *)h->cd_tmp.p + 64;
+    uint32_t *big_list = bin_total + nb;
+    HIPCHK(hipMemsetAsync(big_count, 0, 4, stream));
+    hipLaunchKernelGGL(cddt_scan_bins_kernel, dim3(nb), dim3(256), 0, stream, cp, (const uint32_t *)h->cd_cursor.p,
+                       bin_total);
+    hipLaunchKernelGGL(cddt_scan_add_kernel, dim3(nb), dim3(256), 0, stream, cp, (const uint32_t *)h->cd_cursor.p,
+                       (const uint32_t *)bin_total, big_list, big_count);
+    hipLaunchKernelGGL(cddt_project_kernel<true>, pgrid, dim3(256), lds_fill, stream, cp,
+                       (const uint32_t *)m->d_edges, (const uint32_t *)m->d_n_edges, (uint32_t *)h->cd_cursor.p);
+    // two launches of the sort kernel: the large buckets (workgroup each, 64 KB of LDS) and the small ones
+    // (wave each, no LDS — in one launch the LDS size of the large path would cap everybody's occupancy)
+    const uint32_t n_big_wg = (uint32_t)m->n_cu;
+    hipLaunchKernelGGL(cddt_sort_kernel, dim3(n_big_wg), dim3(256), (size_t)h->cddt_lds_sort * sizeof(float), stream,
+                       (const uint32_t *)h->cd_offsets.p, nbk, (const float *)h->cd_xs2.p, (float *)h->cd_xs.p,
+                       (const uint32_t *)big_list, (const uint32_t *)big_count, n_big_wg, (uint32_t)h->cddt_lds_sort);
+    const int sgrid = (int)std::max(1L, std::min(((long)nbk + 3) / 4, (long)m->n_cu * 32));
+    hipLaunchKernelGGL(cddt_sort_kernel, dim3(sgrid), dim3(256), 0, stream,
+                       (const uint32_t *)h->cd_offsets.p, nbk, (const float *)h->cd_xs2.p, (float *)h->cd_xs.p,
+                       (const uint32_t *)big_list, (const uint32_t *)big_count, 0u, (uint32_t)h->cddt_lds_sort);
     cp.xs = (float *)h->cd_xs.p;
     HIPCHK(hipGetLastError());
     h->cddt_epoch = m->epoch;
@@ -862,8 +930,17 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
                                    h->lp, d_poses, d_out);
         } else if (h->kind == RL_CDDT) {
             if ((rc = ensure_cddt(h, stream))) return rc;
-            hipLaunchKernelGGL(cddt_fan_kernel, dim3(pgrid), dim3(256), 0, stream, m->mp, f, h->cdp,
-                               d_poses, d_out);
+            // one bucket search per (pose, theta bin) when that is fewer than one per ray
+            if (h->cddt_bins_kernel && h->theta_disc <= num_rays && h->theta_disc <= 8192) {
+                // one lane per theta bin, up to 1024; the grid keeps every CU's 2048 lanes occupied
+                const int bnt = std::min(1024, ((h->theta_disc + 63) / 64) * 64);
+                const int bgrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * (2048 / bnt)));
+                hipLaunchKernelGGL(cddt_fan_bins_kernel, dim3(bgrid), dim3(bnt), (size_t)h->theta_disc * sizeof(float),
+                                   stream, m->mp, f, h->cdp, d_poses, d_out);
+            } else {
+                hipLaunchKernelGGL(cddt_fan_kernel, dim3(pgrid), dim3(256), 0, stream, m->mp, f, h->cdp,
+                                   d_poses, d_out);
+            }
         } else {
             if (h->variant >= 1 && (long)n_poses * num_rays < (1L << 30)) {
                 // K2b: stream schedule on the cache-resident bit map
@@ -1756,5 +1833,55 @@ extern "C" int rl_probe_gather_rate(int device, int active_lanes, double *lanes_
     *lanes_per_clk_per_cu = (double)active_lanes / clk_per_wave_load;
     if (clock_hz) *clock_hz = clk;
     if (n_cu_out) *n_cu_out = n_cu;
+    return RL_OK;
+}
+
+// ---------------------------------------------------------------- Car outline table and crash test (host)
+// Car::setCarEdgeDistances (racecar/src/racecar.cpp:239-292): for every beam, how far from the lidar
+// the car's own outline lies.  A one-off table per configuration, so it is host C++ (the crash test
+// over scanned batches is fused into the march kernels, see CrashParams).  The reference's quirks are
+// part of the contract (the crash codes scripts/mcts.py acts on depend on them): the beam angle is
+// advanced BEFORE it is used (the table is shifted by one increment, :256), pi is 3.145
+// (racecar.hpp:117), and a beam at exactly 0 rad is nudged to +1e-4 rad while still being treated as a
+// non-positive angle, so its side distance is width/2 / sin(-1e-4): about -1016 m, and that beam
+// reports a crash for any range (:277-283).  The nudge stays in the running angle.
+extern "C" int rl_car_edge_distances(int num_rays, double min_ang, double ang_inc, double scan_dist_to_base,
+                                     double width, double wheelbase, double *edge_out)
+{
+    if (num_rays < 0 || (num_rays > 0 && !edge_out))
+        return fail(RL_ERR_INVALID, "rl_car_edge_distances: bad arguments");
+    const double quarter_turn = 3.145 / 2.0;
+    const double to_side = width / 2.0, to_front = wheelbase - scan_dist_to_base, to_back = scan_dist_to_base;
+    double beam = min_ang;
+    for (int j = 0; j < num_rays; ++j) {
+        beam += ang_inc;
+        const bool left = beam > 0.0;                           // decided before the nudge
+        if (!left && beam == 0.0) beam += 0.0001;
+        const double turned = left ? beam : -beam;              // angle away from straight ahead
+        const bool ahead = turned < quarter_turn;               // hits the front edge, else the rear edge
+        const double off_axis = ahead ? turned : turned - quarter_turn;
+        const double along = (ahead ? to_front : to_back) / cos(off_axis);
+        const double across = to_side / sin(off_axis);
+        edge_out[j] = across < along ? across : along;
+    }
+    return RL_OK;
+}
+
+// Car::isCrashed (racecar/src/racecar.cpp:305-328) over host ranges: index of the first scan with a
+// beam inside the car outline (+ threshold), else -(n_scans + 1).
+extern "C" int rl_car_is_crashed(const float *ranges, int num_rays, int n_scans, const double *edge,
+                                 double crash_thresh, int *first_crashed)
+{
+    if (!first_crashed || num_rays < 0 || n_scans < 0 || ((size_t)num_rays * n_scans > 0 && (!ranges || !edge)))
+        return fail(RL_ERR_INVALID, "rl_car_is_crashed: bad arguments");
+    *first_crashed = -(n_scans + 1);
+    for (int k = 0; k < n_scans; ++k) {
+        const float *scan = ranges + (size_t)k * num_rays;
+        for (int j = 0; j < num_rays; ++j)
+            if (((double)scan[j] - edge[j]) < crash_thresh) {
+                *first_crashed = k;
+                return RL_OK;
+            }
+    }
     return RL_OK;
 }

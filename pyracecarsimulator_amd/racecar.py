@@ -18,7 +18,6 @@ device (poses and ranges never cross PCIe).
 from __future__ import annotations
 
 import ctypes as C
-import math
 
 import numpy as np
 
@@ -38,35 +37,28 @@ DEFAULT_CAR = dict(wb=0.3302, fc=1.0, h_cg=0.08255, l_f=0.15875, l_r=0.17145, cs
 
 def edge_distances(num_rays, min_ang, scan_ang_inc, scan_dist_to_base, width, wheelbase):
     """Car::setCarEdgeDistances (racecar.cpp:239-292) as float64[num_rays]: distance from the lidar
-    to the car's outline along each beam.  Kept as the reference computes it: the angle is
-    incremented BEFORE use (table shifted by one beam, :256), ``PI = 3.145`` (racecar.hpp:117), and a
-    beam at exactly 0 rad gets ``side / sin(-0.0001)`` (a large negative number, :277-283)."""
-    PI = 3.145
-    side = width / 2.0
-    front = wheelbase - scan_dist_to_base
-    back = scan_dist_to_base
-    out = np.empty(num_rays, dtype=np.float64)
-    ang = float(min_ang)
-    for i in range(num_rays):
-        ang += scan_ang_inc
-        if ang > 0.0:
-            if ang < PI / 2.0:
-                a, d2 = ang, front / math.cos(ang)
-            else:
-                a = ang - PI / 2.0
-                d2 = back / math.cos(a)
-        else:
-            if ang == 0.0:
-                ang += 0.0001
-            if ang > -PI / 2.0:
-                a = -ang
-                d2 = front / math.cos(a)
-            else:
-                a = -ang - PI / 2.0
-                d2 = back / math.cos(a)
-        d1 = side / math.sin(a)
-        out[i] = min(d1, d2)
+    to the car's outline along each beam — native (``rl_car_edge_distances``, host C++ of
+    libscan_amd.so; needs no GPU).  Kept as the reference computes it: the angle is incremented BEFORE
+    use (table shifted by one beam, :256), ``PI = 3.145`` (racecar.hpp:117), and a beam at exactly
+    0 rad gets ``side / sin(-0.0001)`` (a large negative number, :277-283)."""
+    out = np.empty(int(num_rays), dtype=np.float64)
+    _lib.check(_lib.lib().rl_car_edge_distances(int(num_rays), float(min_ang), float(scan_ang_inc),
+                                                float(scan_dist_to_base), float(width), float(wheelbase),
+                                                out.ctypes.data_as(f64p)))
     return out
+
+
+def is_crashed(rays, num_rays, poses, edge, crash_thresh):
+    """Car::isCrashed (racecar.cpp:305-328) over host ranges (``rl_car_is_crashed``): index of the
+    first crashed scan, else ``-(poses+1)``."""
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    edge = np.ascontiguousarray(edge, dtype=np.float64)
+    if rays.size < num_rays * poses or edge.size < num_rays:
+        raise ValueError("is_crashed: rays needs poses*num_rays values, edge num_rays")
+    first = C.c_int(0)
+    _lib.check(_lib.lib().rl_car_is_crashed(rays.ctypes.data_as(f32p), int(num_rays), int(poses),
+                                            edge.ctypes.data_as(f64p), float(crash_thresh), C.byref(first)))
+    return int(first.value)
 
 
 class CarBatch:

@@ -131,6 +131,15 @@ def _check_ins_outs(ins, outs):
         raise ValueError("outs is shorter than ins")
 
 
+def _check_ranges_out(ranges, n):
+    """An optional ranges buffer the C side will fill with n float32 values."""
+    if ranges is None:
+        return
+    if not isinstance(ranges, np.ndarray) or ranges.dtype != np.float32 or not ranges.flags.c_contiguous \
+            or ranges.size < n:
+        raise ValueError("ranges must be a C-contiguous float32 array with n_poses*num_rays elements")
+
+
 class _RangeMethod:
     KIND = None
 
@@ -220,6 +229,7 @@ class _RangeMethod:
         edge = np.ascontiguousarray(edge_distances, dtype=np.float64)
         if edge.size < num_rays:
             raise ValueError("edge_distances needs num_rays entries")
+        _check_ranges_out(ranges, poses.shape[0] * int(num_rays))
         first = C.c_int(0)
         _lib.check(_lib.lib().rl_check_collision_many(
             self._h, poses.ctypes.data_as(f32p), poses.shape[0], float(fov), int(num_rays),
@@ -236,6 +246,9 @@ class _RangeMethod:
             raise ValueError("number of poses is not a multiple of the group size")
         n_groups = poses.shape[0] // group
         edge = np.ascontiguousarray(edge_distances, dtype=np.float64)
+        if edge.size < num_rays:
+            raise ValueError("edge_distances needs num_rays entries")
+        _check_ranges_out(ranges, poses.shape[0] * int(num_rays))
         first = np.zeros(n_groups, dtype=np.int32)
         _lib.check(_lib.lib().rl_check_collision_groups(
             self._h, poses.ctypes.data_as(f32p), n_groups, int(group), float(fov), int(num_rays),

@@ -279,8 +279,8 @@ def main():
     protocol()
     car_ref()
     car_rollouts()
-    rm_golden("rm_colombia", maps.load_colombia(), 24, 101)
-    rm_golden("rm_maze256", maps.make_maze(256, cell=32, wall=2, p=0.45, seed=7), 24, 102)
+    rm_golden("rm_colombia", maps.load_colombia(), 64, 101)        # GOLD-A: 64 poses
+    rm_golden("rm_maze256", maps.make_maze(256, cell=32, wall=2, p=0.45, seed=7), 64, 102)   # GOLD-B
     g = maps.make_maze(192, cell=24, wall=2, p=0.5, seed=9, resolution=0.1,
                        origin=(-3.0, 2.5, 0.6))           # rotated origin (yaw != 0)
     rm_golden("rm_maze192_yaw", g, 16, 103, mrx=120, fov=6.0, num_rays=360)

@@ -512,6 +512,42 @@ def test_cddt_queries_bit_equal_to_oracle(oracle_mod, td):
     assert np.array_equal(outs, om2.cddt_rays(td, ins))
 
 
+@pytest.mark.parametrize("lds_sort", [16384, 128])      # 128: buckets above it take the global rank sort
+def test_cddt_long_walls_fill_large_buckets(oracle_mod, lds_sort):
+    """Straight walls parallel to a bin's direction put thousands of values into ONE bucket: the
+    workgroup-per-bucket sorts (LDS bitonic, global rank sort) and the LDS bucket histograms of the
+    projection, against the oracle; per-bin fan kernel and per-ray kernel."""
+    occ = np.zeros((60, 2600), np.uint8)
+    occ[10, 5:2590] = 1                                   # 2585 edge cells in one bucket of bin 0
+    occ[30:33, 100:2000] = 1                              # 3 thick
+    occ[5:55, 1300] = 1                                   # a vertical wall (bin theta_disc/4)
+    for i in range(50):                                   # a diagonal
+        occ[5 + i, 2100 + i] = 1
+    g = maps.GridMap(occ, 0.05, (-3.0, 1.0, 0.0), "walls")
+    mrx = 400
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    poses = maps.sample_free_poses(g, 40, 3)
+    for td in (16, 112):
+        m = range_libc.PyCDDTCast(omap, mrx, td)
+        m.set_option("cddt_lds_sort", lds_sort)
+        want = om.cddt_fan(td, poses, 4.71, 1081)
+        for bins in (1, 0):
+            m.set_option("cddt_bins", bins)
+            out = np.empty(len(poses) * 1081, np.float32)
+            m.calc_range_fan(poses, out, 4.71, 1081)
+            assert np.array_equal(out, want), (td, bins)
+        # a rebuild (map update) goes through the same enqueue-only path again
+        occ2 = occ.copy()
+        occ2[40, 50:2500] = 1
+        omap.update(occ2)
+        om2 = oracle_mod.OracleMap(occ2, g.resolution, g.origin, mrx)
+        out = np.empty(len(poses) * 1081, np.float32)
+        m.calc_range_fan(poses, out, 4.71, 1081)
+        assert np.array_equal(out, om2.cddt_fan(td, poses, 4.71, 1081)), td
+        omap.update(occ)
+
+
 def test_cfg3_giant_lut_full_size(oracle_mod):
     """configs[2]: 2000^2 maze, theta_disc 1442 (11.5 GB table), 65536 poses x 1081 beams."""
     w = workloads.cfg3()

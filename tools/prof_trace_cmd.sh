@@ -11,7 +11,7 @@ find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" 
 find "$OUT/trace" -name '*kernel_trace.csv' -exec cp {} "$OUT/kernel_trace.csv" \;
 rm -rf "$OUT/trace"
 if [ -f "$OUT/kernel_trace.csv" ]; then
-  (head -1 "$OUT/kernel_trace.csv"; grep -E "rm_fan|pose_bin|pose_prep|pose_scatter|tile_scan|rm_rays|bl_|lut_|cddt_|crash_" "$OUT/kernel_trace.csv" | tail -${KEEP:-400}) > "$OUT/kernel_trace_tail.csv"
+  (head -1 "$OUT/kernel_trace.csv"; grep -E "${PAT:-rm_fan|pose_bin|pose_prep|pose_scatter|tile_scan|rm_rays|bl_|lut_|cddt_|crash_}" "$OUT/kernel_trace.csv" | tail -${KEEP:-400}) > "$OUT/kernel_trace_tail.csv"
   rm -f "$OUT/kernel_trace.csv"
 fi
 head -12 "$OUT/kernel_stats.csv" 2>/dev/null
