@@ -9,8 +9,8 @@ process touches the GPU) and exits with the children's return code.
 A "step" is one pass of the hot path over one synthetic pose batch: the fan-expanding ray march of
 ``n_poses x num_rays`` rays (ScanSimulator2D.scanMany -> calc_range_many,
 /root/reference/scripts/scan_simulator.py:113-135) with poses and ranges resident in HBM.
-Consecutive steps are enqueued round robin on ``--pipeline`` streams (default 3) so that step k+1
-fills the CUs step k's last long rays leave idle; every step is complete (and, for N>1, every
+Consecutive steps are enqueued round robin on ``--pipeline`` streams (default: 3 for batches up to
+32768 poses) so that step k+1 fills the CUs step k's last long rays leave idle; every step is complete (and, for N>1, every
 all-gather) before the clock stops.  ``--pipeline 1`` is the strictly serial schedule.
 For N>1 every rank scans its own ``n_poses`` block (weak scaling) and the ranges are all-gathered
 over xGMI, chunk by chunk, overlapped with the marches of the following steps (BASELINE.json
@@ -49,9 +49,11 @@ def parse_args():
                     help="cfg2 (default: 2049^2 maze, 4096x1081, RMGPU) | cfg3 | cfg4 | cfg5")
     ap.add_argument("--poses", type=int, default=0, help="poses per GPU (0 = workload default)")
     ap.add_argument("--method", default="", help="override: RM | RMGPU | BL | CDDT | GLT")
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=0,
                     help="steps in flight: consecutive steps go round robin to this many concurrent "
-                         "streams (1 = serial: step k+1 starts after step k's last ray)")
+                         "streams (1 = serial: step k+1 starts after step k's last ray; 0 = auto: 3, "
+                         "except ray-marching batches above 32768 poses, which fill the machine on their "
+                         "own and lose L2 locality when two of them are co-resident)")
     ap.add_argument("--grid-mult", type=int, default=0,
                     help="workgroups (x256 threads) per CU of one launch; 0 = 4 when pipelined (two "
                          "launches co-resident on every CU), the library default 8 when serial")
@@ -216,7 +218,7 @@ def main():
 
     mode = "none" if (a.no_gather or world == 1) else a.gather
     # streams that really run concurrently (HIP maps streams onto a few hardware queues)
-    P = max(1, a.pipeline)
+    P = a.pipeline if a.pipeline > 0 else (1 if (method in ("RM", "RMGPU", "BL") and n > 32768) else 3)
     streams = concurrent_streams(P) if P > 1 else [torch.cuda.current_stream()]
     P = len(streams)
     default_gm = meth.get_info("grid_mult")

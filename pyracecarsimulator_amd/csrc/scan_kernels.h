@@ -1355,6 +1355,114 @@ __global__ __launch_bounds__(256) void bl_fan_kernel(MapParams m, FanParams f, B
     }
 }
 
+// ------------------------------------------------------------------------------
+// occ_fan_lds (variant 2 of the ray-marching methods): the kernel shape
+// BASELINE.json's north_star spells out — bit-packed occupancy window of the pose and the angle fan
+// staged in LDS, wave ballot for early-hit termination — as an A/B partner of K1b.  There is no
+// distance field here, so the march takes UNIT steps: the 64 lanes of a wave test 64 consecutive
+// samples t = t0 .. t0+63 of ONE ray against the LDS window, and ballot + ffs picks the first event
+// (occupied cell -> hit at that cell, sample outside the map -> miss).  A ray costs one wave pass per
+// 64 cells of range.  Samples are denser than sphere tracing's, so results are NOT bit-identical to
+// RayMarching: ranges agree within one cell on all but corner-grazing rays (acceptance of step 5).
+// Measured against K1b in profiles/r02/ab_occ_lds.txt (4096 poses x 1081 beams): 1380 us against 58 us
+// on the 2049^2 maze, 1317 us against 35 us on colombia — a wave pass (~40 instructions) per ray and
+// per 64 cells of range here, against ~5 wave instructions per ray for 64 rays sphere-tracing side by
+// side on the cache-resident step map, plus 51 KB of window staging per pose — which is why the
+// product's default stays K1b.
+// ------------------------------------------------------------------------------
+template <bool AUX>
+__global__ __launch_bounds__(256) void occ_fan_lds_kernel(MapParams m, FanParams f, BlParams bp,
+                                                          const float *__restrict__ poses,
+                                                          float *__restrict__ out,
+                                                          int32_t *__restrict__ hits,
+                                                          uint16_t *__restrict__ steps)
+{
+    extern __shared__ uint32_t lds_u[];
+    float2 *fan_cs = reinterpret_cast<float2 *>(lds_u);                  // num_rays float2
+    uint32_t *win = lds_u + 2 * (size_t)f.num_rays;                      // (2R+1) * ww words
+    for (int j = threadIdx.x; j < f.num_rays; j += blockDim.x) {
+        float s, c;
+        det_sincosf(fan_alpha(f, j), s, c);
+        fan_cs[j] = make_float2(c, s);
+    }
+    const int WH = 2 * bp.R + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float flane = (float)lane;
+    for (int pose = blockIdx.x; pose < f.n_poses; pose += gridDim.x) {
+        float gx, gy, thg, st, ct;
+        world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
+                      poses[3 * (size_t)pose + 2], gx, gy, thg);
+        det_sincosf(thg, st, ct);
+        const bool inb = gx > -1.0f && gx < m.fcols && gy > -1.0f && gy < m.frows && (ct - ct) + (st - st) == 0.0f;
+        const int cx = inb ? (int)gx : 0, cy = inb ? (int)gy : 0;
+        const int wx0 = ((cx - bp.R) >> 5) << 5;        // word-aligned window origin (may lie outside: zeros)
+        const int wy0 = cy - bp.R;
+        __syncthreads();                                // the previous pose's rays are done
+        for (int i = threadIdx.x; i < WH * bp.ww; i += blockDim.x) {
+            const int wr = i / bp.ww, wc = i - wr * bp.ww;
+            const int r = wy0 + wr, w = (wx0 >> 5) + wc;
+            uint32_t v = 0;
+            if (r >= 0 && r < m.rows && w >= 0 && w < m.bits_stride) v = m.bits[(size_t)r * m.bits_stride + w];
+            win[i] = v;
+        }
+        __syncthreads();
+        // a wave takes blocks of 64 consecutive beams; lane k keeps beam k's result for one coalesced store
+        for (int j0 = wave * 64; j0 < f.num_rays; j0 += (int)(blockDim.x >> 6) * 64) {
+            float my_r = f.max_range;
+            int my_c = -1, my_rw = -1;
+            unsigned my_n = 0;
+            const int jn = min(64, f.num_rays - j0);
+            for (int k = 0; k < jn; ++k) {
+                const float2 cs = fan_cs[j0 + k];                          // (broadcast read)
+                const float dx = __builtin_fmaf(ct, cs.x, -(st * cs.y));
+                const float dy = __builtin_fmaf(st, cs.x, ct * cs.y);
+                float range = f.max_range;
+                int hc = -1, hr = -1;
+                unsigned n = 0;
+                if (inb) {
+                    for (float t0 = 0.0f; t0 < f.max_range; t0 += 64.0f) {
+                        const float t = t0 + flane;
+                        const float fx = __builtin_fmaf(dx, t, gx), fy = __builtin_fmaf(dy, t, gy);
+                        const bool live = t < f.max_range;
+                        const bool inside = fx > -1.0f && fx < m.fcols && fy > -1.0f && fy < m.frows;
+                        const int pc = (int)fx, pr = (int)fy;
+                        bool occ = false;
+                        if (live && inside) {
+                            const int x = pc - wx0, y = pr - wy0;
+                            occ = (win[y * bp.ww + (x >> 5)] >> (x & 31)) & 1u;
+                        }
+                        const unsigned long long ev = __ballot(live && (occ || !inside));
+                        if (ev) {
+                            const int first = __ffsll((long long)ev) - 1;
+                            const int f_occ = __shfl((int)occ, first);
+                            n += (unsigned)first + (f_occ ? 1u : 0u);
+                            if (f_occ) {
+                                hc = __shfl(pc, first);
+                                hr = __shfl(pr, first);
+                                const float xd = (float)hc - gx, yd = (float)hr - gy;
+                                range = hit_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+                            }
+                            break;
+                        }
+                        n += 64u;
+                    }
+                }
+                if (lane == k) { my_r = range; my_c = hc; my_rw = hr; my_n = n; }
+            }
+            if (lane < jn) {
+                const size_t i = (size_t)pose * f.num_rays + j0 + lane;
+                float r = my_r * m.res;
+                if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + i);
+                out[i] = r;
+                if (AUX) {
+                    if (hits) { hits[2 * i] = my_c; hits[2 * i + 1] = my_rw; }
+                    if (steps) steps[i] = (uint16_t)(my_n > 65535u ? 65535u : my_n);
+                }
+            }
+        }
+    }
+}
+
 // K2b: the same walk on the K1b schedule (tile-ordered poses, XCD bands, a workgroup's waves
 // sharing one ray stream with lane refill), reading the bit-packed map straight through L1/L2
 // (2049^2 cells = 0.5 MB: the whole map is cache resident).  Staging a per-pose LDS window

@@ -995,7 +995,26 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
     const bool aux = d_hits || d_steps;
     const bool stream_ok = (long)n_poses * num_rays < (1L << 30);
     if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
-    if (h->variant >= 1 && stream_ok) {
+    if (h->variant == 2) {
+        // occ_fan_lds: unit-step march on an LDS-resident occupancy window (A/B partner, approximate)
+        if (crash) return fail(RL_ERR_UNSUPPORTED, "the fused crash test needs variant 0 or 1");
+        size_t lds_occ = 0;
+        BlParams bp = make_bl(h, num_rays, lds_occ);
+        if (!bp.use_lds) return fail(RL_ERR_UNSUPPORTED, "occupancy window of max_range %g does not fit LDS", h->max_range);
+        if (lds_occ > 48 * 1024) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&occ_fan_lds_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_occ));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&occ_fan_lds_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_occ));
+        }
+        const int ogrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * 2));
+        if (aux)
+            hipLaunchKernelGGL((occ_fan_lds_kernel<true>), dim3(ogrid), dim3(256), lds_occ, stream, m->mp, f, bp,
+                               d_poses, d_out, d_hits, d_steps);
+        else
+            hipLaunchKernelGGL((occ_fan_lds_kernel<false>), dim3(ogrid), dim3(256), lds_occ, stream, m->mp, f, bp,
+                               d_poses, d_out, d_hits, d_steps);
+    } else if (h->variant >= 1 && stream_ok) {
         // (1) per-pose records + tile-ordered permutation, (2) banded lane-refill march
         int rc;
         if ((rc = cx->rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--pipes", default="1,2,3,4")
     ap.add_argument("--grid-mults", default="8,4,2")
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--sweep", action="store_true", help="cfg2 tuning grid: workgroup size x record source x grid x streams")
     a = ap.parse_args()
     w = workloads.CONFIGS[a.workload]()
     if a.poses:
@@ -70,6 +71,35 @@ def main():
     pmax = len(streams)
     outs = [torch.empty(n * B, dtype=torch.float32, device="cuda") for _ in range(pmax)]
     ref = None
+    if a.sweep:
+        import itertools
+        best = []
+        for nt, oi in ((1024, 1), (1024, 0), (512, 0), (256, 0)):
+            meth.set_option("wg_threads", nt)
+            meth.set_option("order_inline", oi)
+            for gm, P in itertools.product((2, 3, 4, 5, 6, 8), (2, 3, 4)):
+                if P > pmax:
+                    continue
+                meth.set_option("grid_mult", gm)
+
+                def run(k):
+                    for i in range(k):
+                        s_ = i % P
+                        meth.calc_range_fan_device(d_poses.data_ptr(), n, w.fov, B, outs[s_].data_ptr(),
+                                                   stream=streams[s_].cuda_stream)
+                run(20)
+                torch.cuda.synchronize()
+                t = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    run(a.steps)
+                    torch.cuda.synchronize()
+                    t = min(t, (time.perf_counter() - t0) / a.steps)
+                best.append((t, nt, oi, gm, P))
+                print("wg %4d order_inline %d grid_mult %d streams %d  %7.2f us/batch" % (nt, oi, gm, P, t * 1e6), flush=True)
+        best.sort()
+        print("best:", ["%.2f us wg%d oi%d gm%d P%d" % (t * 1e6, nt, oi, gm, P) for t, nt, oi, gm, P in best[:6]])
+        return
     for gm in (int(g) for g in a.grid_mults.split(",")):
         meth.set_option("grid_mult", gm)
         for P in (int(p) for p in a.pipes.split(",") if int(p) <= pmax):
