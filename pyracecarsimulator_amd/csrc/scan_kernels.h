@@ -609,7 +609,8 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f)
 // (v_cmpx drops a lane the moment its t reaches max_range, hits, or leaves the map),
 // so finished lanes cost nothing but their slot and keep (c, r, d) of their last
 // sample; the loop leaves when at most `low` lanes are still live.
-// Per sample: 10 VALU + 1 global load + 4 SALU (either step coefficient).
+// Per sample: 9 VALU (the two position fmas are one packed instruction) + 1 global load + 4 SALU
+// (either step coefficient).
 //   fx = fma(dx,t,gx); fy = fma(dy,t,gy); c = (int)fx; r = (int)fy      (Appendix A "march")
 //   d  = step map at (r, c)              = max(dt*coeff, 1) | +inf (occupied) | 3e38 (border)
 //   t += d                               => a hit / leaving the map pushes t past max_range
@@ -622,43 +623,47 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
 {
     // TILED: stride = S4 (bytes), nstride = -(S4-4): 4 address instructions instead of 2, but the
     // samples of a wave fall into fewer 128-B lines (4x8-cell blocks instead of 1x32-cell row pieces)
-    float a, b;
+    // The two position fmas are ONE packed instruction (v_pk_fma_f32: both halves IEEE-fused, the same
+    // bits as two v_fma_f32).  Packed operands are even-aligned register pairs, and inline asm cannot
+    // name the halves of a 64-bit operand, so the pairs are fixed registers, in the order the refill
+    // code leaves the values in (no copies in front of the block): direction (dy, dx) v[22:23] — its
+    // halves are crossed by op_sel —, origin (gx, gy) v[24:25], t v20 broadcast to both halves (v21 is
+    // named by the encoding, never read), position / address scratch v[26:27].
     unsigned long long save;
     uint32_t n;
     asm volatile(
         "s_mov_b64 %[save], exec\n\t"
-        "v_cmpx_gt_f32_e32 %[mx], %[t]\n"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n"
         "L_march_%=:\n\t"
-        "v_fma_f32 %[a], %[dx], %[t], %[gx]\n\t"
-        "v_fma_f32 %[b], %[dy], %[t], %[gy]\n\t"
-        "v_cvt_i32_f32_e32 %[c], %[a]\n\t"
-        "v_cvt_i32_f32_e32 %[r], %[b]\n\t"
+        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[c], v26\n\t"
+        "v_cvt_i32_f32_e32 %[r], v27\n\t"
         ".if %[tiled]\n\t"
-        "v_lshl_add_u32 %[a], %[c], 4, %[k4]\n\t"
-        "v_and_b32_e32 %[b], 3, %[r]\n\t"
-        "v_mad_i32_i24 %[a], %[r], %[stride], %[a]\n\t"
-        "v_mad_i32_i24 %[a], %[b], %[nstride], %[a]\n\t"
+        "v_lshl_add_u32 v26, %[c], 4, %[k4]\n\t"
+        "v_and_b32_e32 v27, 3, %[r]\n\t"
+        "v_mad_i32_i24 v26, %[r], %[stride], v26\n\t"
+        "v_mad_i32_i24 v26, v27, %[nstride], v26\n\t"
         ".else\n\t"
-        "v_mad_i32_i24 %[a], %[r], %[stride], %[c]\n\t"
-        "v_lshl_add_u32 %[a], %[a], 2, %[k4]\n\t"
+        "v_mad_i32_i24 v26, %[r], %[stride], %[c]\n\t"
+        "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
         ".endif\n\t"
-        "global_load_dword %[d], %[a], %[base]\n\t"
+        "global_load_dword %[d], v26, %[base]\n\t"
         ".if %[aux]\n\t"
         "v_add_u32_e32 %[ns], 1, %[ns]\n\t"
         ".endif\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-        "v_add_f32_e32 %[t], %[t], %[d]\n\t"
-        "v_cmpx_gt_f32_e32 %[mx], %[t]\n\t"
+        "v_add_f32_e32 v20, v20, %[d]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
         "s_bcnt1_i32_b64 %[n], exec\n\t"
         "s_cmp_gt_u32 %[n], %[low]\n\t"
         "s_cbranch_scc1 L_march_%=\n\t"
         "s_mov_b64 exec, %[save]\n\t"
-        : [t] "+v"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [ns] "+v"(nstep), [a] "=&v"(a),
-          [b] "=&v"(b), [save] "=&s"(save), [n] "=&s"(n)
-        : [dx] "v"(dx), [dy] "v"(dy), [gx] "v"(gx), [gy] "v"(gy),
+        : [t] "+{v20}"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [ns] "+v"(nstep),
+          [save] "=&s"(save), [n] "=&s"(n)
+        : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy),
           [mx] "s"(max_range), [stride] "s"(stride), [nstride] "s"(nstride), [k4] "s"(k4),
           [base] "s"(pdt), [low] "s"(low), [aux] "n"(AUX ? 1 : 0), [tiled] "n"(TILED ? 1 : 0)
-        : "vcc", "scc", "memory");
+        : "v26", "v27", "vcc", "scc", "memory");
 }
 
 
@@ -966,11 +971,12 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 }
             }
         }
-        const unsigned long long act = __ballot(t < f.max_range);
-        if (!act) {
-            if (exhausted && !__ballot(has_ray)) break;
-            continue;
-        }
+        // (no live lane and nothing left: done.  No live lane but slots left — every claimed ray was
+        //  born finished, e.g. poses outside the map — falls through: the march loop below leaves at
+        //  once when EXEC is empty, and keeping it unconditional keeps the ray state in place: a branch
+        //  around the asm block made the compiler copy t / cell / step registers in and out of it,
+        //  15 v_mov per service round)
+        if (exhausted && !__ballot(t < f.max_range) && !__ballot(has_ray)) break;
         // ---------------- march while enough lanes are live (or nothing is left to claim)
         // a wave that can no longer refill is on the launch's critical path (its longest ray
         // decides when the kernel ends): let it win issue arbitration against refilling waves
