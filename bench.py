@@ -57,7 +57,10 @@ def parse_args():
     ap.add_argument("--grid-mult", type=int, default=0,
                     help="workgroups (x256 threads) per CU of one launch; 0 = 4 when pipelined (two "
                          "launches co-resident on every CU), the library default 8 when serial")
-    ap.add_argument("--chunks", type=int, default=4, help="all-gather overlap chunks per step (N>1)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="all-gather chunks per step (N>1); 0 = auto: 1 when steps are pipelined (the gather of "
+                         "step k overlaps the marches of the following steps; every extra collective costs "
+                         "~29 us of host time), 4 on the serial schedule (gather of chunk k overlaps march k+1)")
     ap.add_argument("--gather", default="ranges", choices=["ranges", "crash", "none"],
                     help="N>1 exchange per step: 'ranges' (default) = all-gather of every range, 4 B/ray "
                          "(BASELINE.json north_star); 'crash' = fused per-roll-out crash test, all-gather "
@@ -72,6 +75,9 @@ def parse_args():
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
     ap.add_argument("--opt", action="append", default=[], help="kernel option name=int (tuning)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="with --gpus 1: still create the process group (one rank) and all-gather the ranges "
+                         "through it — the RCCL code path on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true",
                     help="dry run of the N>1 code path on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     return ap.parse_args()
@@ -184,8 +190,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or a.dist_single:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.dist_single and world == 1:
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            s_.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -198,8 +211,9 @@ def main():
     B = w.num_rays
 
     # map: built on rank 0, broadcast over RCCL (north_star), tables built per GPU
+    multi = world > 1 or a.dist_single            # a process group exists
     gmap = w.gmap
-    if world > 1:
+    if multi:
         gmap = broadcast_map(w.gmap if rank == 0 else None, 0, dev)
     omap = range_libc.PyOMap(gmap, device=local_rank)
     meth = make_method(range_libc, omap, w, method)
@@ -216,7 +230,7 @@ def main():
     d_poses = torch.from_numpy(poses).to(dev)
     n = len(poses)
 
-    mode = "none" if (a.no_gather or world == 1) else a.gather
+    mode = "none" if (a.no_gather or (world == 1 and not a.dist_single)) else a.gather
     # streams that really run concurrently (HIP maps streams onto a few hardware queues)
     P = a.pipeline if a.pipeline > 0 else (1 if (method in ("RM", "RMGPU", "BL") and n > 32768) else 3)
     streams = concurrent_streams(P) if P > 1 else [torch.cuda.current_stream()]
@@ -227,7 +241,9 @@ def main():
     for kv in a.opt:
         k, v = kv.split("=")
         meth.set_option(k, int(v))
-    scan = ShardedScan(n, B, dev, n_chunks=a.chunks, gather=(mode == "ranges"), streams=streams)
+    n_chunks = a.chunks or (1 if P > 1 else 4)
+    scan = ShardedScan(n, B, dev, n_chunks=n_chunks, gather=(mode == "ranges"), streams=streams,
+                       gather_single_rank=a.dist_single)
 
     def compute(clo, chi, view, sptr):
         meth.calc_range_fan_device(d_poses.data_ptr() + clo * 12, chi - clo, w.fov, B,
@@ -238,7 +254,7 @@ def main():
     group = next(gsz for gsz in range(min(200, n), 0, -1) if n % gsz == 0)
     n_groups = n // group
     crash_gather = d_edge = None
-    if world > 1 and method in ("RM", "RMGPU"):
+    if multi and method in ("RM", "RMGPU"):
         from pyracecarsimulator_amd import racecar as RC
         from pyracecarsimulator_amd.distributed import BucketedIndexGather
         edge = RC.edge_distances(B, -w.fov / 2.0, w.fov / B, 0.275, RC.DEFAULT_CAR["width"],
@@ -248,7 +264,7 @@ def main():
         # overlaps the marches of bucket b+1 on RCCL's stream
         crash_gather = BucketedIndexGather(n_groups, a.gather_every, dev)
     elif mode == "crash":
-        mode = "ranges" if world > 1 else "none"
+        mode = "ranges" if (world > 1 or a.dist_single) else "none"
     cur_stream = torch.cuda.current_stream().cuda_stream
 
     # untimed diagnostics launch: mean samples per ray (feeds the algorithmic-bytes figure)
@@ -274,7 +290,7 @@ def main():
         crash_gather.step_done()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -298,7 +314,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         dev_ms = e0.elapsed_time(e1) / steps
-        if world > 1:
+        if multi:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -309,6 +325,10 @@ def main():
     else:
         elapsed, step_ms = timed(lambda: scan.step(compute), scan.finish, a.steps, a.warmup)
 
+    if a.dist_single and world == 1 and mode == "ranges":
+        torch.cuda.synchronize()
+        if not torch.equal(scan.global_order(), scan.local):
+            raise SystemExit("dist-single: gathered ranges differ from the local ranges")
     rays_per_step = n * B * world
     value = rays_per_step * a.steps / elapsed / 1e6
     bpr = algorithmic_bytes_per_ray(method, mean_steps, B, w)
@@ -336,7 +356,7 @@ def main():
         "mean_samples_per_ray": round(mean_steps, 3), "p99_samples_per_ray": round(p99_steps, 1),
         "max_samples_per_ray": round(max_steps, 1),
     }
-    if world > 1:
+    if multi:
         out["rccl_world"] = world
         out["gather_bytes_per_step"] = {"ranges": 4 * n * B * world, "crash": 4 * n_groups * world,
                                         "none": 0}[mode]
@@ -398,7 +418,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, gmap, poses_all, method, a.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or a.dist_single:
         dist.destroy_process_group()
 
 

@@ -76,7 +76,7 @@ class ShardedScan:
     """
 
     def __init__(self, n_local: int, num_rays: int, device, n_chunks: int = 4, gather=True,
-                 depth: int = 1, streams=None):
+                 depth: int = 1, streams=None, gather_single_rank: bool = False):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -84,7 +84,9 @@ class ShardedScan:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.n_local, self.num_rays = n_local, num_rays
-        self.gather = gather and self.world > 1
+        # (gather_single_rank: run the collectives even in a one-rank group — exercises the RCCL code
+        #  path, stream ordering included, on a box with one GPU)
+        self.gather = gather and (self.world > 1 or (gather_single_rank and dist.is_initialized()))
         self.chunks = chunk_bounds(n_local, n_chunks if self.gather else 1)
         if streams is not None:
             depth = max(depth, len(streams))

@@ -84,3 +84,18 @@ def test_bench_spawns_its_own_ranks():
     assert "all-gather ranges" in d["config"]["gather"]
     assert d["gather_bytes_per_step"] == 4 * 512 * 1081 * 2
     assert d["crash_mode"]["value"] > 0
+
+
+def test_bench_single_rank_through_rccl():
+    """The N>1 code path on real RCCL with the one GPU of the box: a one-rank process group, ranges
+    all-gathered chunk by chunk through it on the pipelined streams (async collectives ordered against
+    the marches by stream), gathered == local checked inside the bench."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-single", "--steps", "12",
+           "--warmup", "3", "--poses", "1024", "--no-cpu-baseline"]
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "all-gather ranges" in d["config"]["gather"] and d["value"] > 0
