@@ -9,7 +9,7 @@ process touches the GPU) and exits with the children's return code.
 A "step" is one pass of the hot path over one synthetic pose batch: the fan-expanding ray march of
 ``n_poses x num_rays`` rays (ScanSimulator2D.scanMany -> calc_range_many,
 /root/reference/scripts/scan_simulator.py:113-135) with poses and ranges resident in HBM.
-Consecutive steps are enqueued round robin on ``--pipeline`` streams (default: 3 for batches up to
+Consecutive steps are enqueued round robin on ``--pipeline`` streams (default: 4 for batches up to
 32768 poses) so that step k+1 fills the CUs step k's last long rays leave idle; every step is complete (and, for N>1, every
 all-gather) before the clock stops.  ``--pipeline 1`` is the strictly serial schedule.
 For N>1 every rank scans its own ``n_poses`` block (weak scaling) and the ranges are all-gathered
@@ -51,12 +51,13 @@ def parse_args():
     ap.add_argument("--method", default="", help="override: RM | RMGPU | BL | CDDT | GLT")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="steps in flight: consecutive steps go round robin to this many concurrent "
-                         "streams (1 = serial: step k+1 starts after step k's last ray; 0 = auto: 3, "
+                         "streams (1 = serial: step k+1 starts after step k's last ray; 0 = auto: 4, "
                          "except ray-marching batches above 32768 poses, which fill the machine on their "
                          "own and lose L2 locality when two of them are co-resident)")
     ap.add_argument("--grid-mult", type=int, default=0,
-                    help="workgroups (x256 threads) per CU of one launch; 0 = 4 when pipelined (two "
-                         "launches co-resident on every CU), the library default 8 when serial")
+                    help="workgroups (x256 threads) per CU of one launch; 0 = 3 when pipelined (launches of "
+                         "0.75 workgroups of 1024 per CU, two rays per lane: several launches co-resident on "
+                         "every CU), the library default 8 when serial")
     ap.add_argument("--chunks", type=int, default=0,
                     help="all-gather chunks per step (N>1); 0 = auto: 1 when steps are pipelined (the gather of "
                          "step k overlaps the marches of the following steps; every extra collective costs "
@@ -232,12 +233,14 @@ def main():
 
     mode = "none" if (a.no_gather or (world == 1 and not a.dist_single)) else a.gather
     # streams that really run concurrently (HIP maps streams onto a few hardware queues)
-    P = a.pipeline if a.pipeline > 0 else (1 if (method in ("RM", "RMGPU", "BL") and n > 32768) else 3)
+    P = a.pipeline if a.pipeline > 0 else (1 if (method in ("RM", "RMGPU", "BL") and n > 32768) else 4)
     streams = concurrent_streams(P) if P > 1 else [torch.cuda.current_stream()]
     P = len(streams)
     default_gm = meth.get_info("grid_mult")
-    gm = a.grid_mult or (4 if P > 1 else default_gm)
+    gm = a.grid_mult or (3 if P > 1 else default_gm)
     meth.set_option("grid_mult", gm)
+    if P > 1 and method in ("RM", "RMGPU"):
+        meth.set_option("slots", 2)               # two rays per lane: what several launches in flight want
     for kv in a.opt:
         k, v = kv.split("=")
         meth.set_option(k, int(v))
@@ -345,7 +348,8 @@ def main():
                    "global_poses": n * world, "num_rays": B, "fov": w.fov,
                    "max_range_px": w.max_range_px, "map": "%dx%d" % (gmap.rows, gmap.cols),
                    "parallelism": "pose-batch dp%d" % world,
-                   "pipeline": "%d steps in flight on %d concurrent streams, grid_mult %d" % (P, P, gm)
+                   "pipeline": "%d steps in flight on %d concurrent streams, grid_mult %d%s" % (
+                       P, P, gm, ", two rays per lane" if method in ("RM", "RMGPU") else "")
                                if P > 1 else "serial (one stream), grid_mult %d" % gm,
                    "gather": {"none": "none",
                               "ranges": "all-gather ranges (4 B/ray), %d chunks per step, overlapped with "
@@ -364,6 +368,7 @@ def main():
             # the reduced exchange on the same poses, serial schedule (its own timed loop)
             k2 = max(10, a.steps // 4)
             meth.set_option("grid_mult", default_gm)
+            meth.set_option("slots", 0)
             el2, _ = timed(crash_step, crash_gather.flush, k2, min(a.warmup, 5))
             out["crash_mode"] = {"value": round(rays_per_step * k2 / el2 / 1e6, 2), "unit": "Mrays/s",
                                  "ms_per_step": round(el2 / k2 * 1e3, 4), "steps": k2,
@@ -381,6 +386,8 @@ def main():
         eff_ms = step_ms
         achieved = bpr * n * B / (eff_ms * 1e-3) / 1e9
         meth.set_option("grid_mult", default_gm)
+        if method in ("RM", "RMGPU"):
+            meth.set_option("slots", 0)
         meth.set_option("timing", 2)
         ks = []
         solo_out = scan.slots[0].local
@@ -389,6 +396,8 @@ def main():
             ks.append(meth.last_kernel_ms())
         meth.set_option("timing", 0)
         meth.set_option("grid_mult", gm)
+        if P > 1 and method in ("RM", "RMGPU"):
+            meth.set_option("slots", 2)
         k_ms = float(np.mean(ks))
         serial_ach = bpr * n * B / (k_ms * 1e-3) / 1e9
         out["kernel_ms_avg"] = round(eff_ms, 4)

@@ -216,8 +216,10 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
 
 /* tuning / diagnostics: integer options by name.  None changes a result bit; defaults are the
  * measured optima on MI355X.
- *   schedule   variant (1 stream kernel | 0 chunk-per-wave), grid_mult, wg_threads, low_water,
- *              run_log2 (-1 auto), xcd_bands, sort_poses, tiled (step-map layout)
+ *   schedule   variant (1 stream kernel | 0 chunk-per-wave | 2 occ_fan_lds: unit steps on an LDS occupancy
+ *              window, approximate), grid_mult, wg_threads, low_water, run_log2 (-1 auto), xcd_bands,
+ *              sort_poses, tiled (step-map layout), slots (rays per lane: 1 | 2 | 0 auto),
+ *              cddt_bins (one search per pose and theta bin), cddt_lds_sort
  *   binning    inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min,
  *              bin_generic
  *   launches   slice_log2 (pose slices below 2^n rays), pinned_max_rays (zero-copy host calls)

@@ -178,6 +178,10 @@ struct rl_method {
     int cd_geom_rows = -1, cd_geom_cols = -1;              // map shape the constants were made for
     bool cd_sort_attr = false;
     bool cd_counts_clean = false;                          // bucket counters are all zero (see ensure_cddt)
+    int slots = 0;               // stream kernel: rays per lane; 2 = plain-range launches on the tiled step map keep two
+                                 // loads in flight per lane; 0 = auto (2 from 2^23 rays per launch up: +3..5 % there, while a
+                                 // lone small launch ends 8 % later with its tail on half as many waves; callers that keep
+                                 // several launches in flight set 2: +15..20 %)
     int cddt_lds_sort = (int)CDDT_LDS_SORT;                // buckets up to this size are sorted in LDS (diagnostics: lower it)
     int cddt_bins_kernel = 1;                              // 1: one query per (pose, theta bin); 0: per ray
     DevBuf pdt;                  // EDT with a border of `pad` cells of -1 (stream kernel)
@@ -511,6 +515,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
     else if (!strcmp(name, "wg_threads")) h->wg_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256);
     else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
+    else if (!strcmp(name, "slots")) h->slots = value >= 2 ? 2 : (value == 1 ? 1 : 0);
     else if (!strcmp(name, "cddt_bins")) h->cddt_bins_kernel = value != 0;
     else if (!strcmp(name, "cddt_lds_sort")) { h->cddt_lds_sort = value < 128 ? 128 : (value > (int)CDDT_LDS_SORT ? (int)CDDT_LDS_SORT : value); h->cddt_epoch = ~0ull; }
     else return fail(RL_ERR_INVALID, "unknown option '%s'", name);
@@ -542,6 +547,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "wg_threads")) *value_out = h->wg_threads;
     else if (!strcmp(name, "last_grid")) *value_out = h->last_grid;
     else if (!strcmp(name, "xcd_bands")) *value_out = h->xcd_bands;
+    else if (!strcmp(name, "slots")) *value_out = h->slots;
     else if (!strcmp(name, "cddt_bins")) *value_out = h->cddt_bins_kernel;
     else if (!strcmp(name, "cddt_lds_sort")) *value_out = h->cddt_lds_sort;
     else if (!strcmp(name, "map_epoch")) *value_out = (int64_t)h->map->epoch;
@@ -1157,7 +1163,16 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         else if (nt == 512) LAUNCH_S(A, C, 512, false);     \
         else LAUNCH_S(A, C, 256, false);                    \
     } while (0)
-        if (crash) { if (aux) LAUNCH_S_N(true, true); else LAUNCH_S_N(false, true); }
+        const int slots = h->slots ? h->slots : ((long)n_poses * num_rays >= (1L << 23) ? 2 : 1);
+        if (slots == 2 && !crash && !aux && h->tiled && (inl || nt == 1024)) {
+            // two rays per lane: both slots' loads in flight (plain ranges on the tiled step map)
+            if (inl)
+                hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, true, true, 2>), dim3(grid), dim3(1024),
+                                   lds_q, stream, pm, f, sp, d_out, d_hits, d_steps, cp);
+            else
+                hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, false, true, 2>), dim3(grid), dim3(1024),
+                                   lds_q, stream, pm, f, sp, d_out, d_hits, d_steps, cp);
+        } else if (crash) { if (aux) LAUNCH_S_N(true, true); else LAUNCH_S_N(false, true); }
         else       { if (aux) LAUNCH_S_N(true, false); else LAUNCH_S_N(false, false); }
 #undef LAUNCH_S_N
 #undef LAUNCH_S

@@ -63,7 +63,8 @@ def one_case(seed):
                                  "tiled": int(r.integers(0, 2)), "low_water": int(r.choice([0, 5, 12, 24, 40])),
                                  "run_log2": int(r.choice([-1, 0, 2, 5])), "xcd_bands": int(r.choice([1, 3, 8])),
                                  "grid_mult": int(r.choice([1, 8])), "wg_threads": int(r.choice([256, 512, 1024])),
-                                 "bin_multi_min": int(r.choice([64, 8192])), "pinned_max_rays": int(r.choice([0, 262144]))}
+                                 "bin_multi_min": int(r.choice([64, 8192])), "pinned_max_rays": int(r.choice([0, 262144])),
+                                 "slots": int(r.choice([1, 2]))}
                         for k_, v_ in sched.items():
                             m.set_option(k_, v_)
                     out = np.empty(n, np.float32); hits = np.empty((n, 2), np.int32); st = np.empty(n, np.uint16)
@@ -79,6 +80,7 @@ def one_case(seed):
             if rows * cols <= 20000:
                 td = int(r.choice([2, 16, 112, 113, 360]))
                 m = range_libc.PyCDDTCast(omap, mrx, td)
+                m.set_option("cddt_bins", int(r.integers(0, 2))); m.set_option("cddt_lds_sort", int(r.choice([128, 16384])))
                 out = np.empty(n, np.float32); m.calc_range_fan(poses, out, fov, B)
                 assert np.array_equal(out, om.cddt_fan(td, poses, fov, B)), "CDDT td=%d" % td
                 m.close()
