@@ -1164,7 +1164,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         else LAUNCH_S(A, C, 256, false);                    \
     } while (0)
         const int slots = h->slots ? h->slots : ((long)n_poses * num_rays >= (1L << 23) ? 2 : 1);
-        if (slots == 2 && !crash && !aux && h->tiled && (inl || nt == 1024)) {
+        if (slots == 2 && !crash && !aux && h->tiled && !h->debug_stamps && (inl || nt == 1024)) {
             // two rays per lane: both slots' loads in flight (plain ranges on the tiled step map)
             if (inl)
                 hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, true, true, 2>), dim3(grid), dim3(1024),
