@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libscan_amd.so")
+#: SCANLIB_SO: an alternative build of the library (A/B runs of two builds on one box, tools/ab_so.sh)
+_SO = os.environ.get("SCANLIB_SO") or os.path.join(_HERE, "libscan_amd.so")
 _LIB = None
 
 RL_OK = 0
@@ -139,7 +140,12 @@ def lib():
         _share_torch_hip_runtime()
         L = C.CDLL(_SO)
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                if os.environ.get("SCANLIB_SO"):          # an older build in an A/B run: newer entry points absent
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _LIB = L

@@ -875,7 +875,7 @@ __device__ __forceinline__ uint32_t stripe_band_list(const MapParams &m, const f
 constexpr int STREAM_HDR = 66;
 
 template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED, int SLOTS = 1>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(96)))
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
 void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__restrict__ out,
                           int32_t *__restrict__ hits, uint16_t *__restrict__ steps, CrashParams cp)
 {
@@ -951,15 +951,17 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     if (sp.dbg) t_start = wall_clock64();
 
     if constexpr (SLOTS == 2) {
-        // ---------------- two rays per lane (ranges only: no diagnostics, no crash test; tiled step map)
-        static_assert(!(SLOTS == 2) || (!AUX && !CRASH && TILED), "two-slot form: plain ranges on the tiled step map");
+        // ---------------- two rays per lane (ranges, optionally the fused crash test; no diagnostics; tiled step map)
+        static_assert(!(SLOTS == 2) || (!AUX && TILED), "two-slot form: ranges (+ crash test) on the tiled step map");
         struct Slot {
             float gx, gy, dx, dy, t, d_last;
             int pc, pr;
             uint32_t oidx;
             bool has_ray;
+            uint32_t pose;         // CRASH only
+            int jbeam;             // CRASH only
         };
-        Slot sa{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, 0u, false}, sb = sa;
+        Slot sa{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, 0u, false, 0u, 0}, sb = sa;
         bool exhausted = total == 0;
         auto finish = [&](Slot &s) {
             float r = f.max_range;
@@ -970,6 +972,15 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             r *= pm.res;
             if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + s.oidx);
             if (out) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + (s.oidx << 2)) = r;
+            if (CRASH) {
+                if (((double)r - edge_l[s.jbeam]) < cp.thresh) {
+                    uint32_t *seen = &crash_seen[s.pose & (STREAM_HDR - 3)];
+                    if (*seen != s.pose) {            // (a race only costs a redundant atomic)
+                        *seen = s.pose;
+                        crash_note(cp, s.pose);
+                    }
+                }
+            }
             s.has_ray = false;
         };
         auto claim = [&](Slot &s, uint32_t q) {
@@ -992,6 +1003,10 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 s.dy = __builtin_fmaf(pr_.st, cs.x, pr_.ct * cs.y);
                 s.d_last = 1.0f;
                 s.oidx = (po & ~POSE_INVALID) * (uint32_t)f.num_rays + (uint32_t)j;
+                if (CRASH) {
+                    s.pose = po & ~POSE_INVALID;
+                    s.jbeam = j;
+                }
                 s.has_ray = true;
                 s.t = (po & POSE_INVALID) ? INF : 0.0f;
             }

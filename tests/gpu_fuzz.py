@@ -97,7 +97,7 @@ def one_case(seed):
             edge = r.uniform(0.05, 0.6, B)
             thr = 0.001
             rr = om.rm_fan(poses, fov, B, 1.0)[0]
-            m = range_libc.PyRayMarchingGPU(omap, mrx)
+            m = range_libc.PyRayMarchingGPU(omap, mrx); m.set_option("slots", int(r.choice([1, 2])))
             assert m.check_collision_many(poses, fov, B, edge, thr) == O.is_crashed(rr, B, P, edge, thr), "crash many"
             grp = next(k for k in (7, 5, 4, 3, 2, 1) if P % k == 0)
             want = [O.is_crashed(rr[k * grp * B:(k + 1) * grp * B], B, grp, edge, thr) for k in range(P // grp)]

@@ -24,6 +24,7 @@ def _gpu(need_gpu):
     {"inline_map_kb": 0, "order_inline": 0, "stripe_max": 0},   # binning launch writes records
     {"inline_map_kb": 0, "bin_multi_min": 64},     # grid-wide binning kernels (hist / keys scratch)
     {"grid_mult": 4},                              # half-machine grids: two launches co-resident
+    {"grid_mult": 3, "slots": 2},                  # bench.py's pipelined configuration: two rays per lane
 ])
 def test_interleaved_batches_on_concurrent_streams_are_bit_exact(oracle_mod, opts):
     """Batches enqueued round robin on 3 concurrent streams through ONE handle: each stream's

@@ -1099,8 +1099,9 @@ def test_two_player_front_end_rebuilds_in_place(oracle_mod):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("slots", [1, 2])              # 2: two rays per lane, crash test fused into that form too
 @pytest.mark.parametrize("n", [200, 513, 3000])
-def test_fused_crash_marks_poses_then_reduces(oracle_mod, n):
+def test_fused_crash_marks_poses_then_reduces(oracle_mod, n, slots):
     """Whole-batch and grouped crash index for batches on both sides of the direct / per-pose-mark
     switch (512 poses), many poses crashing at once; equal to isCrashed on the oracle's ranges."""
     from pyracecarsimulator_amd import racecar as RC
@@ -1112,8 +1113,11 @@ def test_fused_crash_marks_poses_then_reduces(oracle_mod, n):
     edge = RC.edge_distances(B, -fov / 2, fov / B, 0.275, 0.2032, 0.3302) + 0.25      # wide car: many crashes
     r0, _, _ = om.rm_fan(poses, fov, B, step_coeff=1.0, nthreads=4)
     m = range_libc.PyRayMarchingGPU(omap, 300)
+    m.set_option("slots", slots)
     want = oracle_mod.is_crashed(r0, B, n, edge, 0.001)
     assert m.check_collision_many(poses, fov, B, edge, 0.001) == want
+    kept = np.empty(n * B, np.float32)                     # ... with the ranges kept: identical to the oracle
+    assert m.check_collision_many(poses, fov, B, edge, 0.001, ranges=kept) == want and np.array_equal(kept, r0)
     far = np.full(B, -100.0)                                                          # nothing crashes
     assert m.check_collision_many(poses, fov, B, far, 0.001) == -(n + 1)
     grp = next(k for k in (40, 27, 25, 19, 8, 3, 1) if n % k == 0)

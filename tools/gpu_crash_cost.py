@@ -12,8 +12,13 @@ for P, group in ((4096, 128), (4096, 4096), (4096, 1), (32768, 128)):
     omap = range_libc.PyOMap(w.gmap); dt = omap.distance_transform()
     poses = workloads.make_poses(w, dt=dt); B = w.num_rays
     m = range_libc.PyRayMarchingGPU(omap, 300)
+    if os.environ.get("SCAN_SLOTS"):
+        m.set_option("slots", int(os.environ["SCAN_SLOTS"]))
     d_poses = torch.from_numpy(poses).cuda(); d_out = torch.empty(P * B, dtype=torch.float32, device="cuda")
-    edge = RC.edge_distances(B, -w.fov / 2, w.fov / B, 0.275, 0.2032, 0.3302)
+    try:
+        edge = RC.edge_distances(B, -w.fov / 2, w.fov / B, 0.275, 0.2032, 0.3302)
+    except AttributeError:                                   # an older build under SCANLIB_SO (A/B run)
+        edge = np.full(B, 0.15)
     d_edge = torch.from_numpy(edge).cuda(); d_first = torch.empty(P // group, dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
 
