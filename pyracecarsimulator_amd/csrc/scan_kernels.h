@@ -2206,9 +2206,15 @@ __device__ __forceinline__ float cddt_query_bin(const CddtParams &cp, float max_
 // are parked in LDS and the beams only look their bin up — the kernel turns from a latency-bound
 // search per ray into a stream of range stores.  Bit-identical to the per-ray statement (same bin
 // index arithmetic, same query).
+// `order` (optional): the poses in map-tile order (the keys-only binning launch of the ray-marching
+// path); the sorted list is cut into n_bands bands, band x walked by the workgroups with
+// blockIdx % n_bands == x — one XCD under round-robin dispatch —, so the workgroups of an XCD query
+// neighbouring origins at the same time: for every theta bin they land in neighbouring buckets, and the
+// table lines one pose fetched are L2 hits for the next (the table is ~10x an XCD's L2).
 __global__ __launch_bounds__(1024) void cddt_fan_bins_kernel(MapParams m, FanParams f, CddtParams cp,
                                                              const float *__restrict__ poses,
-                                                             float *__restrict__ out)
+                                                             float *__restrict__ out,
+                                                             const uint32_t *__restrict__ order, int n_bands)
 {
     extern __shared__ float bin_range[];                 // theta_disc floats (this workgroup's pose)
     const int nt = (int)blockDim.x;
@@ -2216,7 +2222,11 @@ __global__ __launch_bounds__(1024) void cddt_fan_bins_kernel(MapParams m, FanPar
     lp.theta_disc = cp.theta_disc;
     lp.bins_per_rad = cp.bins_per_rad;
     const float td_f = (float)cp.theta_disc, inv_td = 1.0f / (float)cp.theta_disc;
-    for (int pose = blockIdx.x; pose < f.n_poses; pose += gridDim.x) {
+    const int band = (int)(blockIdx.x % (unsigned)n_bands), g = (int)(blockIdx.x / (unsigned)n_bands);
+    const int G = ((int)gridDim.x - band + n_bands - 1) / n_bands;
+    const int lo = (int)(((long)f.n_poses * band) / n_bands), hi = (int)(((long)f.n_poses * (band + 1)) / n_bands);
+    for (int slot = lo + g; slot < hi; slot += G) {
+        const int pose = order ? (int)(order[slot] & ~POSE_INVALID) : slot;
         float gx, gy, thg;
         world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
                       poses[3 * (size_t)pose + 2], gx, gy, thg);

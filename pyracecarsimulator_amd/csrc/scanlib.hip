@@ -182,6 +182,9 @@ struct rl_method {
                                  // loads in flight per lane; 0 = auto (2 from 2^23 rays per launch up: +3..5 % there, while a
                                  // lone small launch ends 8 % later with its tail on half as many waves; callers that keep
                                  // several launches in flight set 2: +15..20 %)
+    int cddt_sort = 0;                                     // per-bin fan kernel walks the poses in map-tile order, XCD bands
+                                                           // (measured: -13 % at 4096 poses - the binning launch and no
+                                                           // reuse at that density -, +3 % at 32768: off by default)
     int cddt_lds_sort = (int)CDDT_LDS_SORT;                // buckets up to this size are sorted in LDS (diagnostics: lower it)
     int cddt_bins_kernel = 1;                              // 1: one query per (pose, theta bin); 0: per ray
     DevBuf pdt;                  // EDT with a border of `pad` cells of -1 (stream kernel)
@@ -517,6 +520,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
     else if (!strcmp(name, "slots")) h->slots = value >= 2 ? 2 : (value == 1 ? 1 : 0);
     else if (!strcmp(name, "cddt_bins")) h->cddt_bins_kernel = value != 0;
+    else if (!strcmp(name, "cddt_sort")) h->cddt_sort = value != 0;
     else if (!strcmp(name, "cddt_lds_sort")) { h->cddt_lds_sort = value < 128 ? 128 : (value > (int)CDDT_LDS_SORT ? (int)CDDT_LDS_SORT : value); h->cddt_epoch = ~0ull; }
     else return fail(RL_ERR_INVALID, "unknown option '%s'", name);
     return RL_OK;
@@ -549,6 +553,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "xcd_bands")) *value_out = h->xcd_bands;
     else if (!strcmp(name, "slots")) *value_out = h->slots;
     else if (!strcmp(name, "cddt_bins")) *value_out = h->cddt_bins_kernel;
+    else if (!strcmp(name, "cddt_sort")) *value_out = h->cddt_sort;
     else if (!strcmp(name, "cddt_lds_sort")) *value_out = h->cddt_lds_sort;
     else if (!strcmp(name, "map_epoch")) *value_out = (int64_t)h->map->epoch;
     else return fail(RL_ERR_INVALID, "unknown info '%s'", name);
@@ -941,8 +946,16 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
                 // one lane per theta bin, up to 1024; the grid keeps every CU's 2048 lanes occupied
                 const int bnt = std::min(1024, ((h->theta_disc + 63) / 64) * 64);
                 const int bgrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * (2048 / bnt)));
+                // tile-ordered poses in XCD bands: neighbouring origins hit neighbouring buckets (L2 reuse)
+                const uint32_t *d_order = nullptr;
+                int cbands = 1;
+                if (h->sort_poses && h->cddt_sort && n_poses >= 512 && bgrid >= h->xcd_bands) {
+                    if ((rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, bin_keys_only_ok(h, n_poses)))) return rc;
+                    d_order = (const uint32_t *)cx->order.p;
+                    cbands = h->xcd_bands;
+                }
                 hipLaunchKernelGGL(cddt_fan_bins_kernel, dim3(bgrid), dim3(bnt), (size_t)h->theta_disc * sizeof(float),
-                                   stream, m->mp, f, h->cdp, d_poses, d_out);
+                                   stream, m->mp, f, h->cdp, d_poses, d_out, d_order, cbands);
             } else {
                 hipLaunchKernelGGL(cddt_fan_kernel, dim3(pgrid), dim3(256), 0, stream, m->mp, f, h->cdp,
                                    d_poses, d_out);
