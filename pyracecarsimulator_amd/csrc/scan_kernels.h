@@ -894,6 +894,9 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     // INLINE: per owned chunk {gx, gy, cos, sin} and pose id | invalid flag, filled below
     PoseRec *lrec = reinterpret_cast<PoseRec *>(lds_f + ((tables + 3) & ~(size_t)3));   // 16-B aligned
     uint32_t *lord = reinterpret_cast<uint32_t *>(lrec + (INLINE ? sp.k_max : 0));
+    // INLINE: per owned block, first beam of the block (low 16 bits) and number of valid rays in it
+    // (a ray slot then finds its record and beam with an LDS read instead of two integer divisions)
+    uint32_t *lblk = lord + (INLINE ? sp.k_max : 0);
     if (threadIdx.x == 0) *q_next = 0;
     if (CRASH && threadIdx.x < STREAM_HDR - 2) crash_seen[threadIdx.x] = 0xffffffffu;
     for (int j = threadIdx.x; j < f.num_rays; j += NT) {
@@ -926,10 +929,16 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         // of its own chunks into records (a few hundred, one per lane) and keeps them in LDS
         const MapParams mp = *sp.map;
         // stripe mode: this band's poses (a row stripe of the map) compacted here, in LDS
-        uint32_t *list = lord + sp.k_max;
+        uint32_t *list = lblk + (sp.k_max >> 1);
         if (sp.stripe == 1 && seg_hi > seg_lo)
             stripe_band_list<NT>(mp, sp.raw_poses, f.n_poses, seg_lo, seg_hi, list,
                                  reinterpret_cast<int *>(list + (seg_hi - seg_lo) + 1));
+        for (uint32_t i = threadIdx.x; i < K; i += NT) {
+            const uint32_t blk = blk_of(i);
+            const uint32_t j0 = blk - fast_div(blk, sp.div_B) * (uint32_t)f.num_rays;
+            const uint32_t nvalid = blk < seg_rays ? min(64u, seg_rays - blk) : 0u;
+            lblk[i] = j0 | (nvalid << 16);
+        }
         // (num_rays >= 64 here, so a block of 64 rays touches at most two poses: slots 2k, 2k+1)
         for (uint32_t k2 = threadIdx.x; k2 < 2 * K; k2 += NT) {
             const uint32_t p0 = fast_div(blk_of(k2 >> 1), sp.div_B) + (k2 & 1);
@@ -984,14 +993,25 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             s.has_ray = false;
         };
         auto claim = [&](Slot &s, uint32_t q) {
-            const uint32_t blk = blk_of(q >> 6);
-            const uint32_t ray = blk + (q & 63);
-            if (ray < seg_rays) {
+            bool valid;
+            int j;
+            uint32_t li = 0, si = 0;
+            if (INLINE) {
+                const uint32_t bw = lblk[q >> 6];
+                valid = (q & 63) < (bw >> 16);
+                uint32_t jj = (bw & 0xffffu) + (q & 63);
+                const bool next_pose = jj >= (uint32_t)f.num_rays;
+                jj -= next_pose ? (uint32_t)f.num_rays : 0u;
+                j = (int)jj;
+                li = 2 * (q >> 6) + (next_pose ? 1u : 0u);
+            } else {
+                const uint32_t ray = blk_of(q >> 6) + (q & 63);
+                valid = ray < seg_rays;
                 const uint32_t spose = fast_div(ray, sp.div_B);
-                const int j = (int)(ray - spose * (uint32_t)f.num_rays);
-                uint32_t li = 0;
-                if (INLINE) li = 2 * (q >> 6) + (spose - fast_div(blk, sp.div_B));
-                const uint32_t si = seg_lo + spose;
+                j = (int)(ray - spose * (uint32_t)f.num_rays);
+                si = seg_lo + spose;
+            }
+            if (valid) {
                 const uint32_t po = INLINE ? lord[li]
                     : *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sp.order) + (si << 2));
                 const PoseRec pr_ = INLINE ? lrec[li]
@@ -1100,16 +1120,27 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 exhausted = qb + cnt >= total;
                 const uint32_t q = qb + rank;
                 if (mine && q < total) {
-                    const uint32_t blk = blk_of(q >> 6);
-                    const uint32_t ray = blk + (q & 63);
-                    if (ray < seg_rays) {
+                    bool valid;
+                    int j;
+                    uint32_t li = 0, si = 0;
+                    if (INLINE) {
+                        const uint32_t bw = lblk[q >> 6];
+                        valid = (q & 63) < (bw >> 16);
+                        uint32_t jj = (bw & 0xffffu) + (q & 63);
+                        const bool next_pose = jj >= (uint32_t)f.num_rays;
+                        jj -= next_pose ? (uint32_t)f.num_rays : 0u;
+                        j = (int)jj;
+                        li = 2 * (q >> 6) + (next_pose ? 1u : 0u);
+                    } else {
+                        const uint32_t ray = blk_of(q >> 6) + (q & 63);
+                        valid = ray < seg_rays;
                         const uint32_t spose = fast_div(ray, sp.div_B);
-                        const int j = (int)(ray - spose * (uint32_t)f.num_rays);
-                        uint32_t li = 0;
-                        if (INLINE) li = 2 * (q >> 6) + (spose - fast_div(blk, sp.div_B));
+                        j = (int)(ray - spose * (uint32_t)f.num_rays);
                         // SGPR base + 32-bit lane offset (global_load ... s[base]) instead of 64-bit
                         // per-lane pointers
-                        const uint32_t si = seg_lo + spose;
+                        si = seg_lo + spose;
+                    }
+                    if (valid) {
                         const uint32_t po = INLINE ? lord[li]
                             : *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sp.order) + (si << 2));
                         const PoseRec pr_ = INLINE ? lrec[li]

@@ -1110,7 +1110,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             k_max = 2 * ((int)k_blocks + 1);                                 // two records per block
             if (stripe)                                   // band list + histogram / wave counts / cuts
                 lds_extra = ((size_t)(n_poses + bands - 1) / bands + 2 + STRIPE_BINS + 3 * (nt / 64) + 4) * 4;
-            if ((size_t)k_max * 20 + lds * (crash ? 2 : 1) + lds_extra + 32 + STREAM_HDR * 4 > 56 * 1024) inl = false;
+            if ((size_t)k_max * 22 + lds * (crash ? 2 : 1) + lds_extra + 32 + STREAM_HDR * 4 > 56 * 1024) inl = false;
         }
         if (!inl) {
             nt = h->wg_threads;
@@ -1157,7 +1157,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.run_log2 = inl ? inl_rl : rl2;          // (the inline LDS record table was sized for inl_rl)
         h->last_grid = grid * waves_per_wg / WAVES_PER_WG;
         const size_t tab_floats = STREAM_HDR + (crash ? 4 : 2) * (size_t)num_rays;   // fan table (+ edge table, f64)
-        const size_t lds_q = inl ? (((tab_floats + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 20 + lds_extra)
+        const size_t lds_q = inl ? (((tab_floats + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 22 + lds_extra)   // records 16 B + ids 4 B per slot, block words 4 B per two slots
                                  : tab_floats * sizeof(float);
         if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel alone
 #define LAUNCH_S(A, C, N, I)                                                                          \
