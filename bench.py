@@ -300,33 +300,41 @@ def main():
     def timed(step_fn, drain_fn, steps, warmup):
         for _ in range(warmup):
             step_fn()
-        drain_fn()
+        drain_fn(None)
         barrier()
-        # one pair of HIP events around the K timed steps (an event per step would put two extra
-        # barrier packets between consecutive launches); with several streams the first event is
-        # recorded before any step is enqueued and the last after every stream has been joined
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # HIP events around the K timed steps, none between them (an event per step would put two extra
+        # barrier packets between consecutive launches): one before the first step is enqueued — every
+        # stream is idle, the barrier has just synchronised the device — and one per stream behind its
+        # last step; the region ends with the latest of those
+        e0 = torch.cuda.Event(enable_timing=True)
+        ends = [torch.cuda.Event(enable_timing=True) for _ in streams]
         t0 = time.perf_counter()
         e0.record()
-        for s in streams:
-            s.wait_event(e0)
         for _ in range(steps):
             step_fn()
-        drain_fn()
-        e1.record()
+        drain_fn(ends)
         barrier()
         el = time.perf_counter() - t0
-        dev_ms = e0.elapsed_time(e1) / steps
+        dev_ms = max(e0.elapsed_time(e) for e in ends) / steps
         if multi:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, dev_ms
 
+    def scan_drain(ends):
+        scan.finish(ends)
+
+    def crash_drain(ends):
+        crash_gather.flush()
+        if ends is not None:
+            for e in ends:
+                e.record()                        # (the crash loop runs on the current stream)
+
     if mode == "crash":
-        elapsed, step_ms = timed(crash_step, crash_gather.flush, a.steps, a.warmup)
+        elapsed, step_ms = timed(crash_step, crash_drain, a.steps, a.warmup)
     else:
-        elapsed, step_ms = timed(lambda: scan.step(compute), scan.finish, a.steps, a.warmup)
+        elapsed, step_ms = timed(lambda: scan.step(compute), scan_drain, a.steps, a.warmup)
 
     if a.dist_single and world == 1 and mode == "ranges":
         torch.cuda.synchronize()
@@ -369,7 +377,7 @@ def main():
             k2 = max(10, a.steps // 4)
             meth.set_option("grid_mult", default_gm)
             meth.set_option("slots", 0)
-            el2, _ = timed(crash_step, crash_gather.flush, k2, min(a.warmup, 5))
+            el2, _ = timed(crash_step, crash_drain, k2, min(a.warmup, 5))
             out["crash_mode"] = {"value": round(rays_per_step * k2 / el2 / 1e6, 2), "unit": "Mrays/s",
                                  "ms_per_step": round(el2 / k2 * 1e3, 4), "steps": k2,
                                  "gather_bytes_per_step": 4 * n_groups * world,

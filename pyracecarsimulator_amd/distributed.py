@@ -114,8 +114,11 @@ class ShardedScan:
         return self.last.gathered
 
     def _on(self, sl):
+        # the current stream only matters to the collectives (they order themselves against it); a
+        # step without gathers hands the slot's stream to `compute` explicitly and skips the switch
         import contextlib
-        return self.torch.cuda.stream(sl.stream) if sl.stream is not None else contextlib.nullcontext()
+        return (self.torch.cuda.stream(sl.stream) if (sl.stream is not None and self.gather)
+                else contextlib.nullcontext())
 
     def step(self, compute):
         B = self.num_rays
@@ -136,18 +139,18 @@ class ShardedScan:
         self.last = sl
         return sl
 
-    def finish(self):
-        """Every enqueued march and gather of every slot is complete (device-side order; follow
-        with a device synchronisation before reading on the host)."""
-        for sl in self.slots:
+    def finish(self, end_events=None):
+        """Every enqueued march and gather of every slot is ordered before what follows on the slot
+        streams (device-side order; follow with a device synchronisation before reading on the host).
+        ``end_events``: optional list of torch events, one per slot — event k is recorded on slot k's
+        stream behind its last work (a caller timing a region takes the latest of them)."""
+        for k, sl in enumerate(self.slots):
             with self._on(sl):
                 for h in sl.handles:
                     h.wait()
                 sl.handles = []
-        if self.slots[0].stream is not None:
-            cur = self.torch.cuda.current_stream()
-            for sl in self.slots:
-                cur.wait_stream(sl.stream)
+            if end_events is not None and sl.stream is not None:
+                end_events[k].record(sl.stream)
 
     def global_order(self, slot=None):
         """Gathered ranges re-ordered to global pose order: rank-major blocks, i.e. exactly what
