@@ -127,3 +127,58 @@ def test_bucketed_index_gather_world2(every, n_steps):
         for r in range(world):
             for step in range(n_steps):
                 assert np.array_equal(got[r, step], np.arange(n_items) + 1000 * step + 100000 * r)
+
+
+def _depth_worker(rank, world, port, n_total, B, depth, n_steps, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = maps.make_maze(64, cell=16, wall=2, seed=3)
+        lo, hi = shard_range(n_total, rank, world)
+        scan = ShardedScan(hi - lo, B, "cpu", n_chunks=2, depth=depth)
+        got = []
+        slots = []
+        for k in range(n_steps):
+            poses = maps.sample_free_poses(g, n_total, 100 + k)[lo:hi]
+
+            def compute(clo, chi, view, stream=0, poses=poses):
+                view.copy_(torch.from_numpy(_fake_ranges(poses[clo:chi], B)))
+
+            slots.append(scan.step(compute))
+            if len(slots) == depth:                     # read the oldest slot before it is reused
+                scan.finish()
+                for sl in slots:
+                    got.append(scan.global_order(sl).numpy().copy())
+                slots = []
+        scan.finish()
+        for sl in slots:
+            got.append(scan.global_order(sl).numpy().copy())
+        q.put((rank, got))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("depth,n_steps", [(2, 4), (3, 5)])
+def test_sharded_scan_keeps_several_steps_in_flight(depth, n_steps):
+    """bench.py's N>1 schedule: `depth` steps in flight, each on its own slot (own local and gathered
+    buffers); a slot only waits for the gathers issued from it `depth` steps earlier.  Every step's
+    gathered ranges equal the single-process scan of that step's poses, in global pose order."""
+    world, n_total, B = 2, 20, 33
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_depth_worker, args=(r, world, port, n_total, B, depth, n_steps, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = maps.make_maze(64, cell=16, wall=2, seed=3)
+    for rank, got in res:
+        assert len(got) == n_steps
+        for k in range(n_steps):
+            want = _fake_ranges(maps.sample_free_poses(g, n_total, 100 + k), B)
+            assert np.array_equal(got[k], want), (rank, k)
