@@ -1177,13 +1177,20 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         else LAUNCH_S(A, C, 256, false);                    \
     } while (0)
         const int slots = h->slots ? h->slots : ((long)n_poses * num_rays >= (1L << 23) ? 2 : 1);
-        if (slots == 2 && !aux && h->tiled && !h->debug_stamps && (inl || nt == 1024)) {
+        if (slots == 2 && !aux && h->tiled && !h->debug_stamps) {
             // two rays per lane: both slots' loads in flight (ranges / fused crash test on the tiled step map)
-#define LAUNCH_S2(C, I)                                                                                        \
-    hipLaunchKernelGGL((rm_fan_stream_kernel<false, C, 1024, I, true, 2>), dim3(grid), dim3(1024), lds_q, stream, \
+#define LAUNCH_S2(C, N, I)                                                                                  \
+    hipLaunchKernelGGL((rm_fan_stream_kernel<false, C, N, I, true, 2>), dim3(grid), dim3(N), lds_q, stream, \
                        pm, f, sp, d_out, d_hits, d_steps, cp)
-            if (crash) { if (inl) LAUNCH_S2(true, true); else LAUNCH_S2(true, false); }
-            else       { if (inl) LAUNCH_S2(false, true); else LAUNCH_S2(false, false); }
+#define LAUNCH_S2_N(C)                                   \
+    do {                                                 \
+        if (inl) LAUNCH_S2(C, 1024, true);               \
+        else if (nt == 1024) LAUNCH_S2(C, 1024, false);  \
+        else if (nt == 512) LAUNCH_S2(C, 512, false);    \
+        else LAUNCH_S2(C, 256, false);                   \
+    } while (0)
+            if (crash) LAUNCH_S2_N(true); else LAUNCH_S2_N(false);
+#undef LAUNCH_S2_N
 #undef LAUNCH_S2
         } else if (crash) { if (aux) LAUNCH_S_N(true, true); else LAUNCH_S_N(false, true); }
         else       { if (aux) LAUNCH_S_N(true, false); else LAUNCH_S_N(false, false); }
