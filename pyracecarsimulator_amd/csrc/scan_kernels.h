@@ -1660,12 +1660,113 @@ __global__ __launch_bounds__(256) void occ_fan_lds_kernel(MapParams m, FanParams
 }
 
 // K2b: the same walk on the K1b schedule (tile-ordered poses, XCD bands, a workgroup's waves
-// sharing one ray stream with lane refill), reading the bit-packed map straight through L1/L2
+// sharing one ray stream with lane refill), reading a bit-packed map straight through L1/L2
 // (2049^2 cells = 0.5 MB: the whole map is cache resident).  Staging a per-pose LDS window
 // (bl_fan_kernel above) ties 1081 rays to one workgroup and makes every pose end with its
 // slowest ray (up to 303 steps against a mean of 46); the stream form has no such join.
+//
+// Round 2: the walk itself is a hand-scheduled loop (bl_march_loop), made possible by two padded
+// copies of the bit map (bl_pad_bits_kernel):
+//  * a border of free cells as wide as a walk can get away from the map, so the four in-bounds
+//    tests of every step disappear (cells out there ARE free, and floor-conversion of a negative
+//    coordinate lands in the border exactly where the statement's `_x >= 0` test says "outside");
+//  * a TRANSPOSED copy for steep rays (major axis = rows): the walk's (major, minor) pair addresses
+//    either copy with the same formula — bit `major & 31` of word `minor * stride + (major >> 5)` —
+//    so the per-step "steep ? .. : .." selects disappear; base offset and stride are per-lane values.
+// 19 VALU + 1 load per step (EXEC = lanes still walking), against ~40 compiler-scheduled before.
+// Origins so far outside that the padded copies do not cover their walk never reach the map: they
+// run the stepping arithmetic without map reads when they are claimed (their step count is still
+// the statement's).  Bit-identical to the CPU statement (ranges, hit cells, step counts).
+struct BlPad {
+    const uint32_t *bits;       // both padded copies in one buffer
+    uint32_t k_n, k_t;          // byte offset of the word holding cell (0, 0): normal / transposed copy
+    int stride_n, stride_t;     // words per padded row
+    float near;                 // origins with -near < g < dim + near are covered by the padding
+};
+
+// out[(pr) * stride + w]: 32 cells of the padded view; view(rr, cc) = occ[rr][cc] or, transposed, occ[cc][rr]
+__global__ __launch_bounds__(256) void bl_pad_bits_kernel(const uint8_t *__restrict__ occ, int rows, int cols,
+                                                          int transposed, int pad_minor, int pad_major32,
+                                                          int stride, int prow_count, uint32_t *__restrict__ out)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x, pr = blockIdx.y;
+    if (w >= stride || pr >= prow_count) return;
+    const int vrows = transposed ? cols : rows, vcols = transposed ? rows : cols;
+    const int rr = pr - pad_minor;
+    uint32_t word = 0;
+    if (rr >= 0 && rr < vrows) {
+        const int c0 = (w - pad_major32) * 32;
+#pragma unroll 4
+        for (int k = 0; k < 32; ++k) {
+            const int cc = c0 + k;
+            if (cc >= 0 && cc < vcols) {
+                const uint8_t v = transposed ? occ[(size_t)cc * cols + rr] : occ[(size_t)rr * cols + cc];
+                if (v) word |= 1u << k;
+            }
+        }
+    }
+    out[(size_t)pr * stride + w] = word;
+}
+
+// The walk: x is the major coordinate (advances by xstep = +-1 every step), y the minor one.
+//   top:    leave when (int)x == end or the step budget is used up        (the statement's while test)
+//   step:   x += xstep; err += deltay; if (2 err >= deltax) { y += ystep; err -= deltax }
+//           (the conditional pair as m = 0/1 and two fmas: y + m*ystep and err - m*deltax round once,
+//            exactly like the add / subtract they stand for)
+//   probe:  bit (floor x & 31) of word [floor y][floor x >> 5] of the lane's padded copy; a set bit ends the walk
+__device__ __forceinline__ void bl_march_loop(float &x, float &y, float &err, uint32_t &n, int &ix, int &iy,
+                                              uint32_t &bit, uint32_t &live, float xstep, float ystep,
+                                              float deltax, float deltay, int end, int stride, uint32_t basek,
+                                              const uint32_t *bits, uint32_t cap0, uint32_t low)
+{
+    unsigned long long save, tmp;
+    uint32_t cnt;
+    float e2, m;
+    int it, a;
+    uint32_t word;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_cmpx_ne_u32_e32 0, %[live]\n"
+        "L_blwalk_%=:\n\t"
+        "v_cvt_i32_f32_e32 %[it], %[x]\n\t"
+        "v_cmpx_ne_i32_e32 %[it], %[end]\n\t"
+        "v_cmpx_gt_u32_e32 %[cap0], %[n]\n\t"
+        "v_add_f32_e32 %[x], %[x], %[xstep]\n\t"
+        "v_add_f32_e32 %[err], %[err], %[deltay]\n\t"
+        "v_add_f32_e32 %[e2], %[err], %[err]\n\t"
+        "v_cmp_ge_f32_e32 vcc, %[e2], %[deltax]\n\t"
+        "v_cndmask_b32_e64 %[m], 0, 1.0, vcc\n\t"
+        "v_fma_f32 %[y], %[m], %[ystep], %[y]\n\t"
+        "v_fma_f32 %[err], %[m], -%[deltax], %[err]\n\t"
+        "v_add_u32_e32 %[n], 1, %[n]\n\t"
+        "v_cvt_flr_i32_f32_e32 %[ix], %[x]\n\t"
+        "v_cvt_flr_i32_f32_e32 %[iy], %[y]\n\t"
+        "v_ashrrev_i32_e32 %[a], 5, %[ix]\n\t"
+        "v_mad_i32_i24 %[a], %[iy], %[stride], %[a]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 2, %[basek]\n\t"
+        "global_load_dword %[word], %[a], %[bits]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_bfe_u32 %[bit], %[word], %[ix], 1\n\t"
+        "v_cmpx_eq_u32_e32 0, %[bit]\n\t"
+        "s_bcnt1_i32_b64 %[cnt], exec\n\t"
+        "s_cmp_gt_u32 %[cnt], %[low]\n\t"
+        "s_cbranch_scc1 L_blwalk_%=\n\t"
+        "s_mov_b64 %[tmp], exec\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        "v_mov_b32_e32 %[live], 0\n\t"
+        "s_mov_b64 exec, %[tmp]\n\t"
+        "v_mov_b32_e32 %[live], 1\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        : [x] "+v"(x), [y] "+v"(y), [err] "+v"(err), [n] "+v"(n), [ix] "+v"(ix), [iy] "+v"(iy), [bit] "+v"(bit),
+          [live] "+v"(live), [e2] "=&v"(e2), [m] "=&v"(m), [it] "=&v"(it), [a] "=&v"(a), [word] "=&v"(word),
+          [save] "=&s"(save), [tmp] "=&s"(tmp), [cnt] "=&s"(cnt)
+        : [xstep] "v"(xstep), [ystep] "v"(ystep), [deltax] "v"(deltax), [deltay] "v"(deltay), [end] "v"(end),
+          [stride] "v"(stride), [basek] "v"(basek), [bits] "s"(bits), [cap0] "s"(cap0), [low] "s"(low)
+        : "vcc", "scc", "memory");
+}
+
 template <bool AUX, int NT>
-__global__ __launch_bounds__(NT) void bl_fan_stream_kernel(MapParams m, FanParams f, StreamParams sp,
+__global__ __launch_bounds__(NT) void bl_fan_stream_kernel(MapParams m, FanParams f, StreamParams sp, BlPad bp,
                                                           float *__restrict__ out,
                                                           int32_t *__restrict__ hits,
                                                           uint16_t *__restrict__ steps)
@@ -1698,20 +1799,34 @@ __global__ __launch_bounds__(NT) void bl_fan_stream_kernel(MapParams m, FanParam
     auto occupied = [&](int col, int row) -> bool {
         return (m.bits[(size_t)row * m.bits_stride + (col >> 5)] >> (col & 31)) & 1u;
     };
+    const uint32_t cap0 = (uint32_t)((int)f.max_range + 3);
 
     bool exhausted = total == 0;
-    bool has_ray = false, active = false, steep = false;
+    bool has_ray = false, steep = false;
+    uint32_t live = 0, bit = 0, nstep = 0, oidx = 0, basek = 0;
     float x0 = 0, y0 = 0, _x = 0, _y = 0, error = 0, deltax = 0, deltay = 0, xstep = 0, ystep = 0;
-    float range = 0;
-    int end = 0, cap = 0, hc = -1, hr = -1;
-    uint32_t oidx = 0, nstep = 0;
+    float range0 = 0;                 // range of a ray that never walks (start cell occupied: 0)
+    int end = 0, ix = -1, iy = -1, stride = 0;
+    bool start_hit = false;
 
     for (;;) {
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = __ballot(live == 0);
         if (idle) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
                                       __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            if (!active && has_ray) {
+            if (live == 0 && has_ray) {
+                float range = f.max_range;
+                int hc = -1, hr = -1;
+                if (start_hit) {
+                    range = range0;
+                    hc = ix;
+                    hr = iy;
+                } else if (bit) {
+                    const float xd = _x - x0, yd = _y - y0;
+                    range = __builtin_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+                    hc = steep ? iy : ix;
+                    hr = steep ? ix : iy;
+                }
                 float r = range * m.res;
                 if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + oidx);
                 out[oidx] = r;
@@ -1729,7 +1844,7 @@ __global__ __launch_bounds__(NT) void bl_fan_stream_kernel(MapParams m, FanParam
                 exhausted = qb + cnt >= total;
                 const uint32_t q = qb + rank;
                 const uint32_t ray = blk_of(q >> 6) + (q & 63);
-                if (!active && q < total && ray < seg_rays) {
+                if (live == 0 && q < total && ray < seg_rays) {
                     const uint32_t spose = fast_div(ray, sp.div_B);
                     const int j = (int)(ray - spose * (uint32_t)f.num_rays);
                     const uint32_t po = sp.order[seg_lo + spose];
@@ -1741,15 +1856,15 @@ __global__ __launch_bounds__(NT) void bl_fan_stream_kernel(MapParams m, FanParam
                     oidx = (po & ~POSE_INVALID) * (uint32_t)f.num_rays + (uint32_t)j;
                     has_ray = true;
                     nstep = 0;
-                    range = f.max_range;
-                    hc = -1;
-                    hr = -1;
+                    bit = 0;
+                    start_hit = false;
                     if (!(po & POSE_INVALID)) {
                         if (gx > -1.0f && gx < m.fcols && gy > -1.0f && gy < m.frows &&
                             occupied((int)gx, (int)gy)) {
-                            range = 0.0f;                       // start cell occupied
-                            hc = (int)gx;
-                            hr = (int)gy;
+                            start_hit = true;                   // start cell occupied: range 0
+                            range0 = 0.0f;
+                            ix = (int)gx;
+                            iy = (int)gy;
                         } else {
                             x0 = gx;
                             y0 = gy;
@@ -1768,48 +1883,29 @@ __global__ __launch_bounds__(NT) void bl_fan_stream_kernel(MapParams m, FanParam
                             xstep = x0 < x1 ? 1.0f : -1.0f;
                             ystep = y0 < y1 ? 1.0f : -1.0f;
                             end = (int)(x1 + xstep);
-                            cap = (int)f.max_range + 3;
-                            active = true;
+                            stride = steep ? bp.stride_t : bp.stride_n;
+                            basek = steep ? bp.k_t : bp.k_n;
+                            const bool near = gx > -bp.near && gx < m.fcols + bp.near && gy > -bp.near &&
+                                              gy < m.frows + bp.near;
+                            if (near) {
+                                live = 1;
+                            } else {
+                                // too far outside for the padded copies: this walk never meets the map; only
+                                // its step count is left to find (same arithmetic, no map reads)
+                                uint32_t cap = cap0;
+                                while ((int)_x != end && cap-- > 0) {
+                                    _x += xstep;
+                                    ++nstep;
+                                }
+                            }
                         }
                     }
                 }
             }
         }
-        unsigned long long act = __ballot(active);
-        if (!act) {
-            if (exhausted && !__ballot(has_ray)) break;
-            continue;
-        }
-        const int low = exhausted ? 0 : sp.low_water;
-        do {
-            if (active) {
-                if ((int)_x != end && cap-- > 0) {
-                    _x += xstep;
-                    error += deltay;
-                    if (error * 2.0f >= deltax) {
-                        _y += ystep;
-                        error -= deltax;
-                    }
-                    ++nstep;
-                    const float lim_major = steep ? m.frows : m.fcols;
-                    const float lim_minor = steep ? m.fcols : m.frows;
-                    if (_x >= 0.0f && _x < lim_major && _y >= 0.0f && _y < lim_minor) {
-                        const int col = steep ? (int)_y : (int)_x;
-                        const int row = steep ? (int)_x : (int)_y;
-                        if (occupied(col, row)) {
-                            const float xd = _x - x0, yd = _y - y0;
-                            range = __builtin_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
-                            hc = col;
-                            hr = row;
-                            active = false;
-                        }
-                    }
-                } else {
-                    active = false;
-                }
-            }
-            act = __ballot(active);
-        } while (__popcll(act) > low);
+        if (exhausted && !__ballot(live != 0) && !__ballot(has_ray)) break;
+        bl_march_loop(_x, _y, error, nstep, ix, iy, bit, live, xstep, ystep, deltax, deltay, end, stride, basek,
+                      bp.bits, cap0, exhausted ? 0u : (uint32_t)sp.low_water);
     }
 }
 

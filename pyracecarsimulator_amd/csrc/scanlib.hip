@@ -187,6 +187,10 @@ struct rl_method {
                                                            // reuse at that density -, +3 % at 32768: off by default)
     int cddt_lds_sort = (int)CDDT_LDS_SORT;                // buckets up to this size are sorted in LDS (diagnostics: lower it)
     int cddt_bins_kernel = 1;                              // 1: one query per (pose, theta bin); 0: per ray
+    DevBuf blpad;                // K2b: padded normal + transposed bit maps (bl_pad_bits_kernel)
+    BlPad blp{};
+    uint64_t blpad_epoch = ~0ull;
+    TableDep blpad_dep;
     DevBuf pdt;                  // EDT with a border of `pad` cells of -1 (stream kernel)
     int pad = 0, pstride = 0;
     uint64_t pdt_epoch = ~0ull;  // map epoch the padded copy was built from
@@ -468,9 +472,10 @@ extern "C" void rl_method_destroy(rl_method *h)
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->pin_flag) (void)hipHostFree(h->pin_flag);
     for (LaunchCtx &c : h->ctx) c.release();
-    for (TableDep *d : {&h->pdt_dep, &h->lut_dep, &h->cddt_dep})
+    for (TableDep *d : {&h->pdt_dep, &h->lut_dep, &h->cddt_dep, &h->blpad_dep})
         if (d->ev) (void)hipEventDestroy(d->ev);
     h->pdt.release();
+    h->blpad.release();
     h->lut.release();
     for (DevBuf *b : {&h->cd_cos, &h->cd_sin, &h->cd_trans, &h->cd_width, &h->cd_boff, &h->cd_offsets,
                       &h->cd_xs, &h->cd_xs2, &h->cd_cursor, &h->cd_tmp})
@@ -779,6 +784,39 @@ static int ensure_cddt(rl_method *h, hipStream_t stream)
     return table_built(h->cddt_dep, stream);
 }
 
+// K2b's padded bit maps (normal + transposed), rebuilt when the map changed
+static int ensure_blpad(rl_method *h, hipStream_t stream)
+{
+    rl_map *m = h->map;
+    if (h->blpad_epoch == m->epoch && h->blpad.p) return table_wait(h->blpad_dep, stream);
+    if (h->blpad.p) HIPCHK(hipDeviceSynchronize());     // launches of other streams may still read the old copy
+    const int reach = (int)h->max_range + 3 + 2;        // cells a walk can get away from its origin (cap + margin)
+    const int near = reach;                             // origins up to here outside the map are still covered
+    const int pad = near + reach + 2;
+    const int pad32 = (pad + 31) / 32;                  // major-axis padding in words
+    const int stride_n = (m->cols + 31) / 32 + 2 * pad32, prow_n = m->rows + 2 * pad;
+    const int stride_t = (m->rows + 31) / 32 + 2 * pad32, prow_t = m->cols + 2 * pad;
+    const size_t words_n = (size_t)stride_n * prow_n, words_t = (size_t)stride_t * prow_t;
+    if ((words_n + words_t) * 4 > (size_t)1 << 31) return fail(RL_ERR_UNSUPPORTED, "map too large for the padded bit maps");
+    int rc = h->blpad.ensure((words_n + words_t) * 4);
+    if (rc) return rc;
+    uint32_t *out_n = (uint32_t *)h->blpad.p, *out_t = out_n + words_n;
+    hipLaunchKernelGGL(bl_pad_bits_kernel, dim3((stride_n + 255) / 256, prow_n), dim3(256), 0, stream, m->d_occ,
+                       m->rows, m->cols, 0, pad, pad32, stride_n, prow_n, out_n);
+    hipLaunchKernelGGL(bl_pad_bits_kernel, dim3((stride_t + 255) / 256, prow_t), dim3(256), 0, stream, m->d_occ,
+                       m->rows, m->cols, 1, pad, pad32, stride_t, prow_t, out_t);
+    HIPCHK(hipGetLastError());
+    BlPad &bp = h->blp;
+    bp.bits = out_n;
+    bp.stride_n = stride_n;
+    bp.stride_t = stride_t;
+    bp.k_n = (uint32_t)(((size_t)pad * stride_n + pad32) * 4);
+    bp.k_t = (uint32_t)((words_n + (size_t)pad * stride_t + pad32) * 4);
+    bp.near = (float)near;
+    h->blpad_epoch = m->epoch;
+    return table_built(h->blpad_dep, stream);
+}
+
 static BlParams make_bl(const rl_method *h, int num_rays, size_t &lds_bytes)
 {
     BlParams bp{};
@@ -963,6 +1001,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         } else {
             if (h->variant >= 1 && (long)n_poses * num_rays < (1L << 30)) {
                 // K2b: stream schedule on the cache-resident bit map
+                if ((rc = ensure_blpad(h, stream))) return rc;
                 if ((rc = bin_poses(h, *cx, d_poses, n_poses, 1, stream))) return rc;
                 StreamParams sp{};
                 sp.rec = (const PoseRec *)cx->rec_sorted.p;
@@ -976,10 +1015,10 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
                 const size_t lds_s = (size_t)num_rays * sizeof(float2) + 2 * sizeof(float);
                 if (d_hits || d_steps)
                     hipLaunchKernelGGL((bl_fan_stream_kernel<true, 1024>), dim3(bg), dim3(1024), lds_s,
-                                       stream, m->mp, f, sp, d_out, d_hits, d_steps);
+                                       stream, m->mp, f, sp, h->blp, d_out, d_hits, d_steps);
                 else
                     hipLaunchKernelGGL((bl_fan_stream_kernel<false, 1024>), dim3(bg), dim3(1024), lds_s,
-                                       stream, m->mp, f, sp, d_out, d_hits, d_steps);
+                                       stream, m->mp, f, sp, h->blp, d_out, d_hits, d_steps);
             } else {
                 size_t lds_bl = 0;
                 BlParams bp = make_bl(h, num_rays, lds_bl);
