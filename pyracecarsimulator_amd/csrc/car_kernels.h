@@ -51,8 +51,10 @@ __device__ inline void car_step(const CarParams &P, CarState &cs, double input_s
     const double switch_at = cs.st_dyn ? ST_THRESH : K_THRESH;
     if (cs.velocity < switch_at) {
         // updateNormal (:171-194): kinematic single track
-        const double vx = cs.velocity * cos(cs.theta);
-        const double vy = cs.velocity * sin(cs.theta);
+        double sin_h, cos_h;                       // one argument reduction for both (the chain of 200
+        sincos(cs.theta, &sin_h, &cos_h);          //  dependent steps of a lone roll-out is latency, all of it)
+        const double vx = cs.velocity * cos_h;
+        const double vy = cs.velocity * sin_h;
         const double yaw_rate = cs.velocity / P.WB * tan(cs.steer_angle);
         cs.x += vx * dt;
         cs.y += vy * dt;
@@ -65,8 +67,10 @@ __device__ inline void car_step(const CarParams &P, CarState &cs, double input_s
     } else {
         // updateSingle (:196-237): dynamic single track.  The operation order of every expression is
         // the reference's (parity with its compiled Car is <= 1e-9, tests/golden/car_rollouts_ref.npz).
-        const double vx = cs.velocity * cos(cs.theta + cs.slip_angle);
-        const double vy = cs.velocity * sin(cs.theta + cs.slip_angle);
+        double sin_h, cos_h;
+        sincos(cs.theta + cs.slip_angle, &sin_h, &cos_h);
+        const double vx = cs.velocity * cos_h;
+        const double vy = cs.velocity * sin_h;
         const double yaw_rate = cs.angular_velocity;
         const double load_rear = G * P.L_R - accel * P.H_CG;        // axle loads under longitudinal acceleration
         const double load_front = G * P.L_F + accel * P.H_CG;
