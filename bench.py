@@ -240,7 +240,8 @@ def main():
     gm = a.grid_mult or (3 if P > 1 else default_gm)
     meth.set_option("grid_mult", gm)
     if P > 1 and method in ("RM", "RMGPU"):
-        meth.set_option("slots", 2)               # two rays per lane: what several launches in flight want
+        meth.set_option("slots", 3)               # several rays per lane (three where the kernel has that form,
+        #                                           else two): what several launches in flight want
     for kv in a.opt:
         k, v = kv.split("=")
         meth.set_option(k, int(v))
@@ -357,7 +358,7 @@ def main():
                    "max_range_px": w.max_range_px, "map": "%dx%d" % (gmap.rows, gmap.cols),
                    "parallelism": "pose-batch dp%d" % world,
                    "pipeline": "%d steps in flight on %d concurrent streams, grid_mult %d%s" % (
-                       P, P, gm, ", two rays per lane" if method in ("RM", "RMGPU") else "")
+                       P, P, gm, ", two or three rays per lane" if method in ("RM", "RMGPU") else "")
                                if P > 1 else "serial (one stream), grid_mult %d" % gm,
                    "gather": {"none": "none",
                               "ranges": "all-gather ranges (4 B/ray), %d chunks per step, overlapped with "
@@ -405,7 +406,7 @@ def main():
         meth.set_option("timing", 0)
         meth.set_option("grid_mult", gm)
         if P > 1 and method in ("RM", "RMGPU"):
-            meth.set_option("slots", 2)
+            meth.set_option("slots", 3)
         k_ms = float(np.mean(ks))
         serial_ach = bpr * n * B / (k_ms * 1e-3) / 1e9
         out["kernel_ms_avg"] = round(eff_ms, 4)

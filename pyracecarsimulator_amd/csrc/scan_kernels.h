@@ -733,6 +733,88 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
 }
 
 
+// Three rays per lane: the same alternation over three live masks (slot C: t v36 / dir v[38:39] /
+// origin v[40:41] / scratch v[42:43]).
+__device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, float gyA, float &tA, int &cA, int &rA,
+                                            float &dA, float dxB, float dyB, float gxB, float gyB, float &tB,
+                                            int &cB, int &rB, float &dB, float dxC, float dyC, float gxC, float gyC,
+                                            float &tC, int &cC, int &rC, float &dC, const float *pdt, int stride,
+                                            int nstride, uint32_t k4, float max_range, uint32_t low)
+{
+    unsigned long long save, mA, mB, mC;
+    uint32_t n, n2;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_mov_b64 %[mA], exec\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
+        "s_mov_b64 %[mB], exec\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v36\n\t"
+        "s_mov_b64 %[mC], exec\n"
+        "L_march3_%=:\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[cA], v26\n\t"
+        "v_cvt_i32_f32_e32 %[rA], v27\n\t"
+        "v_lshl_add_u32 v26, %[cA], 4, %[k4]\n\t"
+        "v_and_b32_e32 v27, 3, %[rA]\n\t"
+        "v_mad_i32_i24 v26, %[rA], %[stride], v26\n\t"
+        "v_mad_i32_i24 v26, v27, %[nstride], v26\n\t"
+        "global_load_dword %[dA], v26, %[base]\n\t"
+        "s_mov_b64 exec, %[mB]\n\t"
+        "v_pk_fma_f32 v[34:35], v[30:31], v[28:29], v[32:33] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[cB], v34\n\t"
+        "v_cvt_i32_f32_e32 %[rB], v35\n\t"
+        "v_lshl_add_u32 v34, %[cB], 4, %[k4]\n\t"
+        "v_and_b32_e32 v35, 3, %[rB]\n\t"
+        "v_mad_i32_i24 v34, %[rB], %[stride], v34\n\t"
+        "v_mad_i32_i24 v34, v35, %[nstride], v34\n\t"
+        "global_load_dword %[dB], v34, %[base]\n\t"
+        "s_mov_b64 exec, %[mC]\n\t"
+        "v_pk_fma_f32 v[42:43], v[38:39], v[36:37], v[40:41] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[cC], v42\n\t"
+        "v_cvt_i32_f32_e32 %[rC], v43\n\t"
+        "v_lshl_add_u32 v42, %[cC], 4, %[k4]\n\t"
+        "v_and_b32_e32 v43, 3, %[rC]\n\t"
+        "v_mad_i32_i24 v42, %[rC], %[stride], v42\n\t"
+        "v_mad_i32_i24 v42, v43, %[nstride], v42\n\t"
+        "global_load_dword %[dC], v42, %[base]\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_add_f32_e32 v20, v20, %[dA]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_mov_b64 %[mA], exec\n\t"
+        "s_mov_b64 exec, %[mB]\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_add_f32_e32 v28, v28, %[dB]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
+        "s_mov_b64 %[mB], exec\n\t"
+        "s_mov_b64 exec, %[mC]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_add_f32_e32 v36, v36, %[dC]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v36\n\t"
+        "s_mov_b64 %[mC], exec\n\t"
+        "s_bcnt1_i32_b64 %[n], %[mA]\n\t"
+        "s_bcnt1_i32_b64 %[n2], %[mB]\n\t"
+        "s_add_u32 %[n], %[n], %[n2]\n\t"
+        "s_bcnt1_i32_b64 %[n2], exec\n\t"
+        "s_add_u32 %[n], %[n], %[n2]\n\t"
+        "s_cmp_gt_u32 %[n], %[low]\n\t"
+        "s_cbranch_scc1 L_march3_%=\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        : [tA] "+{v20}"(tA), [cA] "+v"(cA), [rA] "+v"(rA), [dA] "+v"(dA), [tB] "+{v28}"(tB), [cB] "+v"(cB),
+          [rB] "+v"(rB), [dB] "+v"(dB), [tC] "+{v36}"(tC), [cC] "+v"(cC), [rC] "+v"(rC), [dC] "+v"(dC),
+          [save] "=&s"(save), [mA] "=&s"(mA), [mB] "=&s"(mB), [mC] "=&s"(mC), [n] "=&s"(n), [n2] "=&s"(n2)
+        : [dyA] "{v22}"(dyA), [dxA] "{v23}"(dxA), [gxA] "{v24}"(gxA), [gyA] "{v25}"(gyA), [dyB] "{v30}"(dyB),
+          [dxB] "{v31}"(dxB), [gxB] "{v32}"(gxB), [gyB] "{v33}"(gyB), [dyC] "{v38}"(dyC), [dxC] "{v39}"(dxC),
+          [gxC] "{v40}"(gxC), [gyC] "{v41}"(gyC), [mx] "s"(max_range), [stride] "s"(stride),
+          [nstride] "s"(nstride), [k4] "s"(k4), [base] "s"(pdt), [low] "s"(low)
+        : "v26", "v27", "v34", "v35", "v42", "v43", "vcc", "scc", "memory");
+}
+
+
 struct PadMap {
     const float *pdt;        // padded step map (pad_dt_kernel / pad_dt_tiled_kernel)
     int stride, nstride, pad; // row-major: elements per row, 0; tiled: S4 = 4*pcol bytes, -(S4-4)
@@ -959,9 +1041,9 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     uint32_t n_serv = 0, ns_drain = 0, drain_samples = 0;
     if (sp.dbg) t_start = wall_clock64();
 
-    if constexpr (SLOTS == 2) {
-        // ---------------- two rays per lane (ranges, optionally the fused crash test; no diagnostics; tiled step map)
-        static_assert(!(SLOTS == 2) || (!AUX && TILED), "two-slot form: ranges (+ crash test) on the tiled step map");
+    if constexpr (SLOTS >= 2) {
+        // ---------------- two (three) rays per lane (ranges, optionally the fused crash test; no diagnostics; tiled step map)
+        static_assert(!(SLOTS >= 2) || (!AUX && TILED), "multi-slot form: ranges (+ crash test) on the tiled step map");
         struct Slot {
             float gx, gy, dx, dy, t, d_last;
             int pc, pr;
@@ -970,7 +1052,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             uint32_t pose;         // CRASH only
             int jbeam;             // CRASH only
         };
-        Slot sa{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, 0u, false, 0u, 0}, sb = sa;
+        Slot sa{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, 0u, false, 0u, 0}, sb = sa, sc = sa;
         bool exhausted = total == 0;
         auto finish = [&](Slot &s) {
             float r = f.max_range;
@@ -1034,31 +1116,47 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         for (;;) {
             const unsigned long long idle_a = __ballot(!(sa.t < f.max_range));
             const unsigned long long idle_b = __ballot(!(sb.t < f.max_range));
-            if (idle_a | idle_b) {
+            const unsigned long long idle_c = SLOTS == 3 ? __ballot(!(sc.t < f.max_range)) : 0ull;
+            if (idle_a | idle_b | idle_c) {
                 const bool mine_a = !(sa.t < f.max_range), mine_b = !(sb.t < f.max_range);
+                const bool mine_c = SLOTS == 3 && !(sc.t < f.max_range);
                 if (mine_a && sa.has_ray) finish(sa);
                 if (mine_b && sb.has_ray) finish(sb);
+                if (SLOTS == 3 && mine_c && sc.has_ray) finish(sc);
                 if (!exhausted) {                     // wave-uniform
-                    const uint32_t cnt_a = (uint32_t)__popcll(idle_a), cnt = cnt_a + (uint32_t)__popcll(idle_b);
+                    const uint32_t cnt_a = (uint32_t)__popcll(idle_a), cnt_b = (uint32_t)__popcll(idle_b);
+                    const uint32_t cnt = cnt_a + cnt_b + (uint32_t)__popcll(idle_c);
                     uint32_t qb = 0;
                     if (lane == 0) qb = atomicAdd(q_next, cnt);
                     qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
                     exhausted = qb + cnt >= total;
-                    // slot-A lanes take the first cnt_a slots in lane order, slot-B lanes the rest
+                    // slot-A lanes take the first cnt_a slots in lane order, then slot B's, then slot C's
                     const uint32_t qa = qb + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_a >> 32),
                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)idle_a, 0u));
                     const uint32_t qbb = qb + cnt_a + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_b >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)idle_b, 0u));
                     if (mine_a && qa < total) claim(sa, qa);
                     if (mine_b && qbb < total) claim(sb, qbb);
+                    if (SLOTS == 3) {
+                        const uint32_t qc = qb + cnt_a + cnt_b + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_c >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)idle_c, 0u));
+                        if (mine_c && qc < total) claim(sc, qc);
+                    }
                 }
             }
             if (exhausted && !__ballot(sa.t < f.max_range) && !__ballot(sb.t < f.max_range) &&
-                !__ballot(sa.has_ray) && !__ballot(sb.has_ray))
+                !__ballot(sa.has_ray) && !__ballot(sb.has_ray) &&
+                (SLOTS < 3 || (!__ballot(sc.t < f.max_range) && !__ballot(sc.has_ray))))
                 break;
-            march_loop2(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
-                        sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
-                        exhausted ? 0u : 2u * (uint32_t)sp.low_water);
+            if (SLOTS == 3)
+                march_loop3(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
+                            sb.t, sb.pc, sb.pr, sb.d_last, sc.dx, sc.dy, sc.gx, sc.gy, sc.t, sc.pc, sc.pr, sc.d_last,
+                            pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
+                            exhausted ? 0u : 3u * (uint32_t)sp.low_water);
+            else
+                march_loop2(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
+                            sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
+                            exhausted ? 0u : 2u * (uint32_t)sp.low_water);
         }
         return;
     }

@@ -178,7 +178,7 @@ struct rl_method {
     int cd_geom_rows = -1, cd_geom_cols = -1;              // map shape the constants were made for
     bool cd_sort_attr = false;
     bool cd_counts_clean = false;                          // bucket counters are all zero (see ensure_cddt)
-    int slots = 0;               // stream kernel: rays per lane; 2 = plain-range launches on the tiled step map keep two
+    int slots = 0;               // stream kernel: rays per lane; 2 (3: inline form only, +4 % with four launches in flight) = plain-range launches on the tiled step map keep two
                                  // loads in flight per lane; 0 = auto (2 from 2^23 rays per launch up: +3..5 % there, while a
                                  // lone small launch ends 8 % later with its tail on half as many waves; callers that keep
                                  // several launches in flight set 2: +15..20 %)
@@ -523,7 +523,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
     else if (!strcmp(name, "wg_threads")) h->wg_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256);
     else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
-    else if (!strcmp(name, "slots")) h->slots = value >= 2 ? 2 : (value == 1 ? 1 : 0);
+    else if (!strcmp(name, "slots")) h->slots = value >= 3 ? 3 : (value == 2 ? 2 : (value == 1 ? 1 : 0));
     else if (!strcmp(name, "cddt_bins")) h->cddt_bins_kernel = value != 0;
     else if (!strcmp(name, "cddt_sort")) h->cddt_sort = value != 0;
     else if (!strcmp(name, "cddt_lds_sort")) { h->cddt_lds_sort = value < 128 ? 128 : (value > (int)CDDT_LDS_SORT ? (int)CDDT_LDS_SORT : value); h->cddt_epoch = ~0ull; }
@@ -1216,7 +1216,11 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         else LAUNCH_S(A, C, 256, false);                    \
     } while (0)
         const int slots = h->slots ? h->slots : ((long)n_poses * num_rays >= (1L << 23) ? 2 : 1);
-        if (slots == 2 && !aux && h->tiled && !h->debug_stamps) {
+        if (slots == 3 && !aux && !crash && h->tiled && !h->debug_stamps && inl) {
+            // three rays per lane (experiment: plain ranges, records derived in the kernel)
+            hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, true, true, 3>), dim3(grid), dim3(1024), lds_q,
+                               stream, pm, f, sp, d_out, d_hits, d_steps, cp);
+        } else if (slots >= 2 && !aux && h->tiled && !h->debug_stamps) {
             // two rays per lane: both slots' loads in flight (ranges / fused crash test on the tiled step map)
 #define LAUNCH_S2(C, N, I)                                                                                  \
     hipLaunchKernelGGL((rm_fan_stream_kernel<false, C, N, I, true, 2>), dim3(grid), dim3(N), lds_q, stream, \

@@ -69,6 +69,7 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "inline_map_kb": 0, "stripe_max": 0, "xcd_bands": 3, "grid_mult": 1},
     {"variant": 1, "inline_map_kb": 0, "stripe_max": 0, "order_inline": 0},   # classic: binning launch writes the records
     {"variant": 1, "slots": 2},                                 # two rays per lane (ranges-only launches)
+    {"variant": 1, "slots": 3},                                 # three rays per lane
     {"variant": 1, "slots": 2, "inline_map_kb": 0, "stripe_max": 0},          # ... behind the keys-only binning launch
     {"variant": 1, "slots": 2, "inline_prep": 0, "low_water": 0},             # ... records from the binning launch
     {"variant": 1, "slots": 2, "inline_prep": 0, "bin_multi_min": 64, "xcd_bands": 3, "grid_mult": 2},
