@@ -674,6 +674,7 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
 // siblings on its SIMD.  (Round 1 tried two slots with per-slot predication on the row-major layout:
 // the extra VALU per sample made it 6 % slower.)  Registers are fixed as in march_loop: slot A
 // t v20 / dir v[22:23] / origin v[24:25] / scratch v[26:27], slot B t v28 / v[30:31] / v[32:33] / v[34:35].
+template <bool TILED>
 __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, float gyA, float &tA, int &cA, int &rA,
                                             float &dA, float dxB, float dyB, float gxB, float gyB, float &tB,
                                             int &cB, int &rB, float &dB, const float *pdt, int stride, int nstride,
@@ -693,19 +694,29 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
         "v_cvt_i32_f32_e32 %[rA], v27\n\t"
+        ".if %[tiled]\n\t"
         "v_lshl_add_u32 v26, %[cA], 4, %[k4]\n\t"
         "v_and_b32_e32 v27, 3, %[rA]\n\t"
         "v_mad_i32_i24 v26, %[rA], %[stride], v26\n\t"
         "v_mad_i32_i24 v26, v27, %[nstride], v26\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v26, %[rA], %[stride], %[cA]\n\t"
+        "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
+        ".endif\n\t"
         "global_load_dword %[dA], v26, %[base]\n\t"
         "s_mov_b64 exec, %[mB]\n\t"
         "v_pk_fma_f32 v[34:35], v[30:31], v[28:29], v[32:33] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
         "v_cvt_i32_f32_e32 %[cB], v34\n\t"
         "v_cvt_i32_f32_e32 %[rB], v35\n\t"
+        ".if %[tiled]\n\t"
         "v_lshl_add_u32 v34, %[cB], 4, %[k4]\n\t"
         "v_and_b32_e32 v35, 3, %[rB]\n\t"
         "v_mad_i32_i24 v34, %[rB], %[stride], v34\n\t"
         "v_mad_i32_i24 v34, v35, %[nstride], v34\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v34, %[rB], %[stride], %[cB]\n\t"
+        "v_lshl_add_u32 v34, v34, 2, %[k4]\n\t"
+        ".endif\n\t"
         "global_load_dword %[dB], v34, %[base]\n\t"
         "s_mov_b64 exec, %[mA]\n\t"
         "s_waitcnt vmcnt(1)\n\t"
@@ -728,13 +739,14 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
           [n2] "=&s"(n2)
         : [dyA] "{v22}"(dyA), [dxA] "{v23}"(dxA), [gxA] "{v24}"(gxA), [gyA] "{v25}"(gyA), [dyB] "{v30}"(dyB),
           [dxB] "{v31}"(dxB), [gxB] "{v32}"(gxB), [gyB] "{v33}"(gyB), [mx] "s"(max_range), [stride] "s"(stride),
-          [nstride] "s"(nstride), [k4] "s"(k4), [base] "s"(pdt), [low] "s"(low)
+          [nstride] "s"(nstride), [k4] "s"(k4), [base] "s"(pdt), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "v34", "v35", "vcc", "scc", "memory");
 }
 
 
 // Three rays per lane: the same alternation over three live masks (slot C: t v36 / dir v[38:39] /
 // origin v[40:41] / scratch v[42:43]).
+template <bool TILED>
 __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, float gyA, float &tA, int &cA, int &rA,
                                             float &dA, float dxB, float dyB, float gxB, float gyB, float &tB,
                                             int &cB, int &rB, float &dB, float dxC, float dyC, float gxC, float gyC,
@@ -758,28 +770,43 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
         "v_cvt_i32_f32_e32 %[rA], v27\n\t"
+        ".if %[tiled]\n\t"
         "v_lshl_add_u32 v26, %[cA], 4, %[k4]\n\t"
         "v_and_b32_e32 v27, 3, %[rA]\n\t"
         "v_mad_i32_i24 v26, %[rA], %[stride], v26\n\t"
         "v_mad_i32_i24 v26, v27, %[nstride], v26\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v26, %[rA], %[stride], %[cA]\n\t"
+        "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
+        ".endif\n\t"
         "global_load_dword %[dA], v26, %[base]\n\t"
         "s_mov_b64 exec, %[mB]\n\t"
         "v_pk_fma_f32 v[34:35], v[30:31], v[28:29], v[32:33] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
         "v_cvt_i32_f32_e32 %[cB], v34\n\t"
         "v_cvt_i32_f32_e32 %[rB], v35\n\t"
+        ".if %[tiled]\n\t"
         "v_lshl_add_u32 v34, %[cB], 4, %[k4]\n\t"
         "v_and_b32_e32 v35, 3, %[rB]\n\t"
         "v_mad_i32_i24 v34, %[rB], %[stride], v34\n\t"
         "v_mad_i32_i24 v34, v35, %[nstride], v34\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v34, %[rB], %[stride], %[cB]\n\t"
+        "v_lshl_add_u32 v34, v34, 2, %[k4]\n\t"
+        ".endif\n\t"
         "global_load_dword %[dB], v34, %[base]\n\t"
         "s_mov_b64 exec, %[mC]\n\t"
         "v_pk_fma_f32 v[42:43], v[38:39], v[36:37], v[40:41] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
         "v_cvt_i32_f32_e32 %[cC], v42\n\t"
         "v_cvt_i32_f32_e32 %[rC], v43\n\t"
+        ".if %[tiled]\n\t"
         "v_lshl_add_u32 v42, %[cC], 4, %[k4]\n\t"
         "v_and_b32_e32 v43, 3, %[rC]\n\t"
         "v_mad_i32_i24 v42, %[rC], %[stride], v42\n\t"
         "v_mad_i32_i24 v42, v43, %[nstride], v42\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v42, %[rC], %[stride], %[cC]\n\t"
+        "v_lshl_add_u32 v42, v42, 2, %[k4]\n\t"
+        ".endif\n\t"
         "global_load_dword %[dC], v42, %[base]\n\t"
         "s_mov_b64 exec, %[mA]\n\t"
         "s_waitcnt vmcnt(2)\n\t"
@@ -810,7 +837,7 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         : [dyA] "{v22}"(dyA), [dxA] "{v23}"(dxA), [gxA] "{v24}"(gxA), [gyA] "{v25}"(gyA), [dyB] "{v30}"(dyB),
           [dxB] "{v31}"(dxB), [gxB] "{v32}"(gxB), [gyB] "{v33}"(gyB), [dyC] "{v38}"(dyC), [dxC] "{v39}"(dxC),
           [gxC] "{v40}"(gxC), [gyC] "{v41}"(gyC), [mx] "s"(max_range), [stride] "s"(stride),
-          [nstride] "s"(nstride), [k4] "s"(k4), [base] "s"(pdt), [low] "s"(low)
+          [nstride] "s"(nstride), [k4] "s"(k4), [base] "s"(pdt), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "v34", "v35", "v42", "v43", "vcc", "scc", "memory");
 }
 
@@ -1043,7 +1070,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
 
     if constexpr (SLOTS >= 2) {
         // ---------------- two (three) rays per lane (ranges, optionally the fused crash test; no diagnostics; tiled step map)
-        static_assert(!(SLOTS >= 2) || (!AUX && TILED), "multi-slot form: ranges (+ crash test) on the tiled step map");
+        static_assert(!(SLOTS >= 2) || !AUX, "multi-slot form: ranges (+ crash test), no diagnostics");
         struct Slot {
             float gx, gy, dx, dy, t, d_last;
             int pc, pr;
@@ -1149,12 +1176,12 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 (SLOTS < 3 || (!__ballot(sc.t < f.max_range) && !__ballot(sc.has_ray))))
                 break;
             if (SLOTS == 3)
-                march_loop3(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
+                march_loop3<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
                             sb.t, sb.pc, sb.pr, sb.d_last, sc.dx, sc.dy, sc.gx, sc.gy, sc.t, sc.pc, sc.pr, sc.d_last,
                             pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
                             exhausted ? 0u : 3u * (uint32_t)sp.low_water);
             else
-                march_loop2(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
+                march_loop2<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
                             sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
                             exhausted ? 0u : 2u * (uint32_t)sp.low_water);
         }

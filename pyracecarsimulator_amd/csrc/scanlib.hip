@@ -1216,10 +1216,14 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         else LAUNCH_S(A, C, 256, false);                    \
     } while (0)
         const int slots = h->slots ? h->slots : ((long)n_poses * num_rays >= (1L << 23) ? 2 : 1);
-        if (slots == 3 && !aux && !crash && h->tiled && !h->debug_stamps && inl) {
-            // three rays per lane (experiment: plain ranges, records derived in the kernel)
-            hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, true, true, 3>), dim3(grid), dim3(1024), lds_q,
-                               stream, pm, f, sp, d_out, d_hits, d_steps, cp);
+        if (slots == 3 && !aux && !crash && !h->debug_stamps && inl) {
+            // three rays per lane (plain ranges, records derived in the kernel)
+            if (h->tiled)
+                hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, true, true, 3>), dim3(grid), dim3(1024),
+                                   lds_q, stream, pm, f, sp, d_out, d_hits, d_steps, cp);
+            else
+                hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, true, false, 3>), dim3(grid), dim3(1024),
+                                   lds_q, stream, pm, f, sp, d_out, d_hits, d_steps, cp);
         } else if (slots >= 2 && !aux && h->tiled && !h->debug_stamps) {
             // two rays per lane: both slots' loads in flight (ranges / fused crash test on the tiled step map)
 #define LAUNCH_S2(C, N, I)                                                                                  \
