@@ -218,6 +218,41 @@ def test_canonical_fan_vs_upstream_literal_fan(oracle_mod):
     assert worst <= 2e-4
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_other_casters_c_oracle_equals_numpy_statements(oracle_mod, seed):
+    """Rows a12-a14: BresenhamsLine, GiantLUTCast queries and CDDTCast (table + queries) of the C
+    oracle against independently structured NumPy statements (oracle/np_statement.py: all rays stepped
+    together, edge map by array shifts, buckets as np.unique arrays searched with searchsorted) —
+    ranges, hit cells and step counts bit for bit, on seeded mazes with rotated origins, poses outside
+    the map and in the (-1, 0) truncation strip, several fans and theta discretisations."""
+    from oracle import np_statement as N
+    rng = np.random.default_rng(seed)
+    g = maps.make_maze(64 + 9 * seed, cell=10 + 3 * seed, wall=1 + seed % 3, p=0.5, seed=seed,
+                       resolution=[0.05, 0.1, 1.0, 0.013][seed],
+                       origin=(-1.0 + seed, 0.7 - seed, [0.0, 0.4, -2.5, 3.1][seed]))
+    mrx = [40, 60, 25, 120][seed]
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    poses = maps.sample_free_poses(g, 14, seed)
+    poses[0] = [-50.0, 0.0, 0.0]                                   # far outside
+    c, s_ = np.cos(g.origin[2]), np.sin(g.origin[2])
+    poses[1, 0] = g.origin[0] + (c * -0.3 - s_ * 5.5) * g.resolution      # -1 < gx < 0
+    poses[1, 1] = g.origin[1] + (s_ * -0.3 + c * 5.5) * g.resolution
+    poses[2, 2] = 1e4
+    for B, fov in ((97, 4.71), (33, 6.283), (64, -2.0)):
+        r, h, st = N.bl_fan(g.occ, g.resolution, g.origin, mrx, poses, fov, B)
+        r0, h0, s0 = om.bl_fan(poses, fov, B)
+        assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(st, s0), ("BL", B, fov)
+        td = int(rng.choice([30, 90, 181]))
+        lut = om.lut_build(td, nthreads=oracle_mod.max_threads())
+        assert np.array_equal(N.lut_fan(lut, g.occ.shape, g.resolution, g.origin, mrx, poses, fov, B),
+                              om.lut_fan(lut, poses, fov, B)), ("LUT", td, B, fov)
+    for td in (16, 37, 112):
+        tab = N.CddtTable(g.occ, td)
+        for B, fov in ((97, 4.71), (40, 6.283)):
+            assert np.array_equal(N.cddt_fan(tab, g.resolution, g.origin, mrx, poses, fov, B),
+                                  om.cddt_fan(td, poses, fov, B)), ("CDDT", td, B, fov)
+
+
 def test_bresenham_close_to_ray_marching(oracle_mod):
     g, z = load_golden("rm_maze256")
     diff = np.abs(z["ranges_bl"] - z["ranges_cpu"])
