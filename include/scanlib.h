@@ -37,6 +37,7 @@
 #ifndef SCANLIB_H
 #define SCANLIB_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -115,6 +116,13 @@ int rl_calc_range_many_fan(rl_method *h, const float *ins_rows3, float *outs, in
  * optional diagnostics for RL_RM / RL_RM_GPU / RL_BRESENHAM; pass NULL otherwise. */
 int rl_calc_range_fan(rl_method *h, const float *poses_p3, int n_poses, float fov, int num_rays,
                       float *outs, int32_t *hit_cells_or_null, uint16_t *steps_or_null);
+
+/* Optional: pinned host memory for result buffers.  A host-pointer scan whose `outs` lies inside a
+ * block from rl_host_alloc is written by the kernel directly (no staging copy on the way back:
+ * scanMany(200) 63 -> ~40 us).  ScanSimulator2D keeps its cached output vectors
+ * (scripts/scan_simulator.py:32-40) in such blocks.  rl_host_free waits for the device first.      */
+int rl_host_alloc(size_t bytes, void **out);
+int rl_host_free(void *p);
 
 /* device-resident, asynchronous forms (pointers are device memory on the map's
  * device, stream is a hipStream_t or NULL for the default stream).               */

@@ -71,6 +71,8 @@ SYMBOLS = {
     "rl_car_rollout_check": (C.c_int, [C.c_void_p, C.c_void_p, f64p, f64p, C.c_int, C.c_int, C.c_int,
                                        C.c_double, C.c_float, C.c_int, f64p, C.c_double,
                                        C.POINTER(C.c_int), f64p, f64p]),
+    "rl_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rl_host_free": (C.c_int, [C.c_void_p]),
     "rl_car_edge_distances": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                         f64p]),
     "rl_car_is_crashed": (C.c_int, [f32p, C.c_int, C.c_int, f64p, C.c_double, C.POINTER(C.c_int)]),
@@ -171,3 +173,41 @@ def raw(name):
 def check(code: int) -> None:
     if code != RL_OK:
         raise ScanLibError(code, lib().rl_last_error().decode("utf-8", "replace"))
+
+
+class _PinnedOwner:
+    """Keeps one rl_host_alloc block alive for the NumPy array built on it."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr and _LIB is not None:
+                _LIB.rl_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_zeros(shape, dtype):
+    """A zeroed NumPy array in pinned host memory of the library (rl_host_alloc): host-pointer scans
+    write their ranges straight into it.  Falls back to ordinary memory when no device is usable (the
+    array is then just an array; scans would fail earlier anyway)."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape))
+    p = C.c_void_p()
+    try:
+        rc = lib().rl_host_alloc(max(n, 1) * dt.itemsize, C.byref(p))
+    except Exception:
+        rc = -1
+    if rc != RL_OK or not p.value:
+        return np.zeros(shape, dtype=dt)
+    nbytes = max(n, 1) * dt.itemsize
+
+    class _Block(C.c_char * nbytes):              # (a Python subclass: instances can carry the owner)
+        pass
+
+    buf = _Block.from_address(p.value)
+    buf._owner = _PinnedOwner(p.value)            # freed when the last array on the block is gone
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)

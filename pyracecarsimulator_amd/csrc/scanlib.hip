@@ -52,13 +52,59 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *rl_last_error(void) { return g_err.c_str(); }
-extern "C" const char *rl_version(void) { return "scanlib-amd 0.1 (gfx950)"; }
+extern "C" const char *rl_version(void) { return "scanlib-amd 0.2 (gfx950)"; }
 
 extern "C" int rl_device_count(void)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// ------------------------------------------------------------------------------
+// pinned host blocks handed to callers (rl_host_alloc): a scan whose output buffer lies in one of
+// them is written by the kernel directly — no staging copy on the way back
+// ------------------------------------------------------------------------------
+static std::mutex g_host_mu;
+static std::vector<std::pair<char *, size_t>> g_host_blocks;
+
+static bool in_host_block(const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    for (const auto &b : g_host_blocks)
+        if ((const char *)p >= b.first && (const char *)p + bytes <= b.first + b.second) return true;
+    return false;
+}
+
+extern "C" int rl_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0) return fail(RL_ERR_INVALID, "rl_host_alloc: bad arguments");
+    if (rl_device_count() <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available");
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess)
+        return fail(RL_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+    memset(p, 0, bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        g_host_blocks.emplace_back((char *)p, bytes);
+    }
+    *out = p;
+    return RL_OK;
+}
+
+extern "C" int rl_host_free(void *p)
+{
+    if (!p) return RL_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        auto it = std::find_if(g_host_blocks.begin(), g_host_blocks.end(),
+                               [&](const std::pair<char *, size_t> &b) { return b.first == (char *)p; });
+        if (it == g_host_blocks.end()) return fail(RL_ERR_INVALID, "rl_host_free: not a block of rl_host_alloc");
+        g_host_blocks.erase(it);
+    }
+    (void)hipDeviceSynchronize();                      // a kernel may still be writing into it
+    HIPCHK(hipHostFree(p));
+    return RL_OK;
 }
 
 // ------------------------------------------------------------------------------
@@ -820,7 +866,11 @@ static int ensure_blpad(rl_method *h, hipStream_t stream)
 static BlParams make_bl(const rl_method *h, int num_rays, size_t &lds_bytes)
 {
     BlParams bp{};
-    bp.R = (int)std::ceil(h->max_range) + 3;
+    // window radius: a walk takes at most (int)max_range + 3 unit steps, but its float coordinate can gain
+    // one more cell on the way — x0 + 1 + 1 + ... rounds UP when it crosses a power of two with a
+    // fraction just below 1 (127.99999 + 1 -> 129.0) — found by the 30-minute fuzz of round 2 as a stale
+    // LDS read one row outside a window sized with no margin; two cells of margin now
+    bp.R = (int)std::ceil(h->max_range) + 5;
     bp.ww = ((2 * bp.R + 32 + 31) / 32) | 1;
     const size_t win = (size_t)(2 * bp.R + 1) * bp.ww * sizeof(uint32_t);
     const size_t fan = (size_t)num_rays * sizeof(float2);
@@ -1381,9 +1431,11 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
         return RL_OK;
     }
     // small calls: zero-copy through pinned host memory (scan() 45 -> ~25 us host-visible)
-    const bool zc = !hits && !steps && n_rays <= (size_t)h->pinned_max_rays;
+    // output buffer inside a pinned block of rl_host_alloc: the kernel writes the ranges straight into it
+    const bool direct_out = outs && !hits && !steps && in_host_block(outs, n_rays * sizeof(float));
+    const bool zc = !hits && !steps && (direct_out || n_rays <= (size_t)h->pinned_max_rays);
     const size_t off_out = ((size_t)n_poses * 3 * sizeof(float) + 255) & ~(size_t)255;
-    const size_t off_end = off_out + ((n_rays * sizeof(float) + 255) & ~(size_t)255);
+    const size_t off_end = off_out + (direct_out ? 0 : ((n_rays * sizeof(float) + 255) & ~(size_t)255));
     if (zc) {
         if ((rc = pin_ensure(h, off_end))) return rc;
         memcpy(h->pin, poses, (size_t)n_poses * 3 * sizeof(float));
@@ -1418,7 +1470,9 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
             cp.group = 0;
         }
     }
-    float *d_out = (outs || !first_crashed) ? (zc ? (float *)((char *)h->pin + off_out) : (float *)h->outs.p) : nullptr;
+    float *d_out = (outs || !first_crashed)
+                       ? (direct_out ? outs : zc ? (float *)((char *)h->pin + off_out) : (float *)h->outs.p)
+                       : nullptr;
     rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_out,
                     hits ? (int32_t *)h->hits.p : nullptr, steps ? (uint16_t *)h->steps.p : nullptr,
                     first_crashed ? &cp : nullptr, h->stream);
@@ -1441,7 +1495,7 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     HIPCHK(hipStreamSynchronize(h->stream));
     int flag = first_crashed ? *h->pin_flag : 0;
     if (crash_direct && flag == INT_MAX) flag = -(n_poses + 1);
-    if (zc) {
+    if (zc && !direct_out) {
         if (outs) memcpy(outs, (char *)h->pin + off_out, n_rays * sizeof(float));
     }
     if (first_crashed) *first_crashed = flag;      // first crashed pose, or -(n_poses + 1)

@@ -20,7 +20,7 @@ import sys
 
 import numpy as np
 
-from . import range_libc
+from . import _lib, range_libc
 
 
 class ScanSimulator2D:
@@ -33,11 +33,13 @@ class ScanSimulator2D:
         self.twopi = math.pi * 2
 
         # cached vectors (scan_simulator.py:32-40)
-        self.output_vector = np.zeros(self.num_rays, dtype=np.float32)
+        # (the two result vectors live in pinned host memory of the library: the kernels write the
+        #  ranges straight into them, no staging copy on the way back)
+        self.output_vector = _lib.pinned_zeros(self.num_rays, np.float32)
         self.noise = np.zeros(self.num_rays, dtype=np.float32)
         self.input_vector = np.zeros((self.num_rays, 3), dtype=np.float32)
         self._addr_of = (None, None, 0, 0)       # (input_vector, output_vector, their addresses)
-        self.output_vector_many = np.zeros(batch_size * self.num_rays, dtype=np.float32)
+        self.output_vector_many = _lib.pinned_zeros(batch_size * self.num_rays, np.float32)
         self.input_vector_many = np.zeros((batch_size * self.num_rays, 3), dtype=np.float32)
         self._poses_many = np.zeros((batch_size, 3), dtype=np.float32)
 

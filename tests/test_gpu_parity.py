@@ -335,6 +335,28 @@ def test_device_resident_api_with_torch_streams(oracle_mod):
 
 
 # ---------------------------------------------------------------- full BASELINE size: properties
+def test_cfg1_one_pose_through_scan_simulator(oracle_mod):
+    """configs[0]: the map of maps/map.yaml (2049^2; the .pgm is missing from the mount, so the seeded maze
+    stands in), ONE pose, 1081 beams, "RM" (range_libc's CPU RayMarching, step coefficient 0.999)
+    through ScanSimulator2D.scan — the reference's own plumbing case (scripts/scan_simulator.py:88-111) —
+    bit for bit against the oracle, for a handful of poses one at a time."""
+    w = workloads.cfg1()
+    assert (w.n_poses, w.num_rays, w.method) == (1, 1081, "RM")
+    g = w.gmap
+    omap = range_libc.PyOMap(g)
+    om = oracle_mod.OracleMap.from_gridmap(g, w.max_range_px)
+    om._dt = omap.distance_transform()
+    sim = ScanSimulator2D(w.num_rays, w.fov, 0.01, batch_size=1)
+    sim.setMap(omap, w.max_range_px, g.resolution, g.origin)
+    sim.setRaytracingMethod(w.method)
+    poses = np.concatenate([workloads.make_poses(w, dt=om.dt), maps.sample_free_poses(g, 7, 99, dt=om.dt)])
+    for p in poses:
+        got = sim.scan(float(p[0]), float(p[1]), float(p[2]))
+        assert got is sim.output_vector
+        want = om.rm_fan(p[None, :], w.fov, w.num_rays, step_coeff=0.999)[0]
+        assert np.array_equal(got, want)
+
+
 def test_cfg2_full_size_properties(oracle_mod):
     """configs[1]: 2049^2 map, 4096 poses x 1081 beams (4.4 M rays) — checked through properties
     that do not need the oracle on every ray, plus an oracle spot check on a pose subsample."""
@@ -452,6 +474,35 @@ def test_occ_fan_lds_north_star_shape_within_one_cell_of_ray_marching(oracle_mod
         rb = np.empty(2 * 1081, np.float32)
         m.calc_range_fan(bad, rb, 4.71, 1081)
         assert np.array_equal(rb, np.full(2 * 1081, np.float32(300.0) * np.float32(g.resolution)))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_bresenham_coordinate_rounds_up_across_a_power_of_two(oracle_mod, variant):
+    """The walk's float coordinate x0 + 1 + 1 + ... can gain a cell: 127.99999237 + 1 lies exactly half
+    way between two float32 values above 128 and rounds to 129.0.  When the skipped integer (128) is the
+    walk's end cell, the end test never fires, the walk runs to its step budget and stands budget + 1
+    cells from its start cell — an occupied cell exactly there must be hit.  (Found by the 30-minute fuzz
+    of round 2: K2's LDS window had no margin for that cell and read stale LDS one row outside.)"""
+    occ = np.zeros((160, 96), np.uint8)
+    occ[132, :] = 1                                    # 11 rows above the start row 121
+    occ[:100, 68] = 1                                  # 11 columns right of the start column 57
+    g = maps.GridMap(occ, 1.0, (0.0, 0.0, 0.0), "binade")
+    mrx = 7                                            # budget: 10 steps
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    y0 = np.float32(122.0) - np.float32(2.0 ** -17)    # 121.99999237: reaches 127.99999237 after 6 steps
+    x0 = np.float32(58.0) - np.float32(2.0 ** -18)     # 57.99999619: reaches 63.99999619 after 6 steps
+    poses = np.array([[50.5, y0, 0.9], [20.25, y0, 0.9], [x0, 20.5, 0.67], [x0, 60.25, 0.67],
+                      [50.5, np.float32(122.25), 0.9]], np.float32)
+    r0, h0, s0 = om.bl_fan(poses, 0.15, 64)
+    assert (h0[:128, 1] == 132).all() and (s0[:128] == 10).all()          # the statement: 11 rows in 10 steps
+    assert (h0[128:256, 0] == 68).all() and (h0[256:] == -1).all()
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyBresenhamsLine(omap, mrx)
+    m.set_option("variant", variant)
+    for B, fov in ((64, 0.15), (1, 0.0), (100, 6.283)):
+        r, h, s = _fan(m, poses, fov, B)
+        r1, h1, s1 = om.bl_fan(poses, fov, B)
+        assert np.array_equal(r, r1) and np.array_equal(h, h1) and np.array_equal(s, s1), (variant, B)
 
 
 # ---------------------------------------------------------------- K3: GiantLUT
@@ -1038,6 +1089,45 @@ def test_small_host_calls_zero_copy_equals_staged_path(oracle_mod):
         if cls is range_libc.PyRayMarchingGPU:
             r0, _, _ = om.rm_fan(poses, 4.71, 1081, step_coeff=1.0)
             assert np.array_equal(outs[(65536, 50)], r0)
+
+
+@pytest.mark.gpu
+def test_pinned_result_vectors_are_written_directly(oracle_mod):
+    """ScanSimulator2D keeps its cached result vectors in pinned blocks of the library (rl_host_alloc):
+    the kernel writes the ranges straight into them.  Same results as the staged path, for calls below
+    and above the zero-copy threshold, and the block outlives the simulator while an array refers to it."""
+    import gc
+    g = maps.load_colombia()
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    omap = range_libc.PyOMap(g)
+    sim = ScanSimulator2D(1081, 4.71, 0.01, batch_size=300)
+    assert sim.output_vector_many.base is not None and sim.output_vector.base is not None   # pinned blocks
+    sim.setMap(omap, 300, g.resolution, g.origin)
+    sim.setRaytracingMethod("RMGPU")
+    poses = maps.sample_free_poses(g, 300, 12, dt=om.dt)
+    want = om.rm_fan(poses, 4.71, 1081, step_coeff=1.0, nthreads=4)[0]
+    out = sim.scanMany(poses)
+    assert out is sim.output_vector_many and np.array_equal(out, want)        # 324 300 rays: above 262 144
+    one = sim.scan(*poses[5])
+    assert np.array_equal(one, want[5 * 1081:6 * 1081])
+    # an ordinary array takes the staged path: same bits
+    plain = np.empty_like(want)
+    sim.scan_method.calc_range_fan(poses, plain, 4.71, 1081)
+    assert np.array_equal(plain, want)
+    # a larger pinned buffer used directly through the dense API, with the crash test riding along
+    big = _lib.pinned_zeros(2000 * 1081, np.float32)
+    p2 = maps.sample_free_poses(g, 2000, 13, dt=om.dt)
+    w2 = om.rm_fan(p2, 4.71, 1081, step_coeff=1.0, nthreads=oracle_mod.max_threads())[0]
+    sim.scan_method.calc_range_fan(p2, big, 4.71, 1081)
+    assert np.array_equal(big, w2)
+    edge = oracle_mod.edge_distances(1081, -4.71 / 2, 4.71 / 1081, 0.275, 0.2032, 0.3302)
+    big[:] = 0
+    code = sim.scan_method.check_collision_many(p2, 4.71, 1081, edge, 0.001, ranges=big)
+    assert code == oracle_mod.is_crashed(w2, 1081, 2000, edge, 0.001) and np.array_equal(big, w2)
+    keep = sim.output_vector_many
+    del sim
+    gc.collect()
+    assert np.array_equal(keep, want)                      # the block lives as long as the array does
 
 
 @pytest.mark.gpu
