@@ -240,8 +240,8 @@ def main():
     gm = a.grid_mult or (3 if P > 1 else default_gm)
     meth.set_option("grid_mult", gm)
     if P > 1 and method in ("RM", "RMGPU"):
-        meth.set_option("slots", 3)               # several rays per lane (three where the kernel has that form,
-        #                                           else two): what several launches in flight want
+        meth.set_option("slots", 3 if n <= 8192 else 2)   # several rays per lane: what launches in flight want
+        #                                           (three pay for small batches only, measured)
     for kv in a.opt:
         k, v = kv.split("=")
         meth.set_option(k, int(v))
@@ -358,7 +358,7 @@ def main():
                    "max_range_px": w.max_range_px, "map": "%dx%d" % (gmap.rows, gmap.cols),
                    "parallelism": "pose-batch dp%d" % world,
                    "pipeline": "%d steps in flight on %d concurrent streams, grid_mult %d%s" % (
-                       P, P, gm, ", two or three rays per lane" if method in ("RM", "RMGPU") else "")
+                       P, P, gm, ", %d rays per lane" % (3 if n <= 8192 else 2) if method in ("RM", "RMGPU") else "")
                                if P > 1 else "serial (one stream), grid_mult %d" % gm,
                    "gather": {"none": "none",
                               "ranges": "all-gather ranges (4 B/ray), %d chunks per step, overlapped with "
@@ -406,7 +406,7 @@ def main():
         meth.set_option("timing", 0)
         meth.set_option("grid_mult", gm)
         if P > 1 and method in ("RM", "RMGPU"):
-            meth.set_option("slots", 3)
+            meth.set_option("slots", 3 if n <= 8192 else 2)
         k_ms = float(np.mean(ks))
         serial_ach = bpr * n * B / (k_ms * 1e-3) / 1e9
         out["kernel_ms_avg"] = round(eff_ms, 4)

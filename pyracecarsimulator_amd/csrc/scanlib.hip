@@ -1266,9 +1266,12 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         else LAUNCH_S(A, C, 256, false);                    \
     } while (0)
         const int slots = h->slots ? h->slots : ((long)n_poses * num_rays >= (1L << 23) ? 2 : 1);
-        if (slots == 3 && !aux && !crash && !h->debug_stamps && inl) {
-            // three rays per lane (plain ranges, records derived in the kernel)
-            if (h->tiled)
+        if (slots == 3 && !aux && !crash && !h->debug_stamps && (inl || (nt == 1024 && h->tiled))) {
+            // three rays per lane (plain ranges)
+            if (!inl)
+                hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, false, true, 3>), dim3(grid), dim3(1024),
+                                   lds_q, stream, pm, f, sp, d_out, d_hits, d_steps, cp);
+            else if (h->tiled)
                 hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, true, true, 3>), dim3(grid), dim3(1024),
                                    lds_q, stream, pm, f, sp, d_out, d_hits, d_steps, cp);
             else

@@ -42,6 +42,15 @@ def one_case(seed):
         g = maps.GridMap(occ, res, origin, "fuzz")
         # poses: inside, near edges, outside
         gx = r.uniform(-3, cols + 3, P); gy = r.uniform(-3, rows + 3, P); th = r.uniform(-7, 7, P)
+        if r.random() < 0.25:
+            # coordinates a hair below an integer on an identity grid: float accumulation (x0 + 1 + 1 ...) then
+            # rounds up across powers of two and walks gain a cell (the round-2 K2 window bug lived there)
+            res, origin = 1.0, (0.0, 0.0, 0.0)
+            snap = r.random(P) < 0.5
+            eps = 2.0 ** -r.integers(14, 21, P)
+            gx = np.where(snap, np.floor(r.uniform(1, cols + 1, P)) - eps, gx)
+            gy = np.where(snap, np.floor(r.uniform(1, rows + 1, P)) - eps, gy)
+            g = maps.GridMap(occ, res, origin, "fuzz")
         c, s = np.cos(origin[2]), np.sin(origin[2])
         poses = np.stack([origin[0] + (c * gx - s * gy) * res, origin[1] + (s * gx + c * gy) * res, th + origin[2]], 1).astype(np.float32)
         try:
