@@ -102,7 +102,13 @@ extern "C" int rl_host_free(void *p)
         if (it == g_host_blocks.end()) return fail(RL_ERR_INVALID, "rl_host_free: not a block of rl_host_alloc");
         g_host_blocks.erase(it);
     }
-    (void)hipDeviceSynchronize();                      // a kernel may still be writing into it
+    // a kernel (on any device) may still be writing into it
+    int ndev = 0, cur = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && hipGetDevice(&cur) == hipSuccess) {
+        for (int d = 0; d < ndev; ++d)
+            if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+        (void)hipSetDevice(cur);
+    }
     HIPCHK(hipHostFree(p));
     return RL_OK;
 }
@@ -572,7 +578,12 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "slots")) h->slots = value >= 3 ? 3 : (value == 2 ? 2 : (value == 1 ? 1 : 0));
     else if (!strcmp(name, "cddt_bins")) h->cddt_bins_kernel = value != 0;
     else if (!strcmp(name, "cddt_sort")) h->cddt_sort = value != 0;
-    else if (!strcmp(name, "cddt_lds_sort")) { h->cddt_lds_sort = value < 128 ? 128 : (value > (int)CDDT_LDS_SORT ? (int)CDDT_LDS_SORT : value); h->cddt_epoch = ~0ull; }
+    else if (!strcmp(name, "cddt_lds_sort")) {
+        int v = 128;                                   // a power of two in [128, CDDT_LDS_SORT]: the bitonic network pads to one
+        while (v * 2 <= value && v * 2 <= (int)CDDT_LDS_SORT) v *= 2;
+        h->cddt_lds_sort = v;
+        h->cddt_epoch = ~0ull;
+    }
     else return fail(RL_ERR_INVALID, "unknown option '%s'", name);
     return RL_OK;
 }
