@@ -421,7 +421,9 @@ def main():
                                       "frac": round(serial_ach / HBM_PEAK_GBS, 5),
                                       "what": "the march kernel alone on an idle machine (grid_mult %d)" % default_gm}}
         if method in ("RM", "RMGPU") and mean_steps > 0:
-            # the kernel's real limiter: the CU's scattered-gather rate, probed in this run
+            # the kernel's real limiters, next to the contractual HBM object.  (1) the CU's scattered-gather
+            # rate, probed in this run; (2) VALU issue: wave-level VALU instructions per launch (rocprofv3
+            # SQ_INSTS_VALU of the several-rays-per-lane kernel, committed) x 4 clocks each on 4 SIMDs per CU
             lanes, clk, ncu = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int(0)
             _lib.check(_lib.lib().rl_probe_gather_rate(local_rank, 46, ctypes.byref(lanes), ctypes.byref(clk),
                                                         ctypes.byref(ncu)))
@@ -432,6 +434,13 @@ def main():
                                       "serial_frac": round(samples / (k_ms * 1e-3) / peak, 5),
                                       "probe": "%.2f active lanes/clk/CU x %d CUs x %.2f GHz (rl_probe_gather_rate, "
                                                "46 random lanes, this run)" % (lanes.value, ncu.value, clk.value / 1e9)}
+            valu = _pmc_traffic(a.workload, method + "/valu_insts")
+            if valu and P > 1 and n == workloads.CONFIGS[a.workload]().n_poses:
+                floor_ms = valu * 4.0 / (4 * ncu.value * clk.value) * 1e3
+                out["roofline_valu"] = {"wave_valu_insts_per_launch": valu, "floor_ms": round(floor_ms, 5),
+                                        "frac": round(floor_ms / eff_ms, 5),
+                                        "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, profiles/r02/"
+                                                  "r2_pmc_cfg2_slots3; not measured in this run)"}
         if rank == 0 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, gmap, poses_all, method, a.cpu_seconds)
     if rank == 0:
