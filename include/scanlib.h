@@ -226,10 +226,10 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  * measured optima on MI355X.
  *   schedule   variant (1 stream kernel | 0 chunk-per-wave | 2 occ_fan_lds: unit steps on an LDS occupancy
  *              window, approximate), grid_mult, wg_threads, low_water, run_log2 (-1 auto), xcd_bands,
- *              sort_poses, tiled (step-map layout), slots (rays per lane: 1 | 2 | 0 auto),
+ *              sort_poses, tiled (step-map layout), slots (rays per lane: 1 | 2 | 3 | 0 auto),
  *              cddt_bins (one search per pose and theta bin), cddt_lds_sort
  *   binning    inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min,
- *              bin_generic
+ *              bin_generic, bin_ppw (poses per workgroup of the grid-wide binning kernels)
  *   launches   slice_log2 (pose slices below 2^n rays), pinned_max_rays (zero-copy host calls)
  *   diagnosis  timing (1 launch sequence | 2 march kernel only), debug_stamps, drain_prio, lut_debug */
 int rl_method_set_option(rl_method *h, const char *name, int value);

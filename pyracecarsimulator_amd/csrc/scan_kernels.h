@@ -511,7 +511,8 @@ __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const
 // global atomics — clustered roll-out poses would serialise on a few words), written tile-major
 // as hist_all[tile * n_wg + w]; one scan over that array then gives every (tile, workgroup) pair
 // its base slot, and the scatter pass hands out slots from LDS cursors.
-constexpr int POSES_PER_WG = 2048;
+constexpr int POSES_PER_WG = 512;      // (2048 while one workgroup scanned all the counters; with the per-tile
+                                       //  scan 256..1024 are equally good and 4..13 % ahead of that)
 
 __global__ __launch_bounds__(256) void pose_prep_kernel(MapParams m, const float *__restrict__ poses,
                                                         int n, PoseRec *__restrict__ rec,
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(MapParams m, const float
                                                         uint32_t *__restrict__ hist_all, int n_wg,
                                                         int tile_shift, int tiles_x, int n_tiles,
                                                         uint32_t *__restrict__ order_if_unsorted,
-                                                        int walk_outside)
+                                                        int walk_outside, int poses_per_wg)
 {
     extern __shared__ uint32_t lhist[];            // n_tiles
     const int w = blockIdx.x;
@@ -527,8 +528,8 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(MapParams m, const float
         for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) lhist[i] = 0;
         __syncthreads();
     }
-    const int p_end = min(n, (w + 1) * POSES_PER_WG);
-    for (int p = w * POSES_PER_WG + threadIdx.x; p < p_end; p += blockDim.x) {
+    const int p_end = min(n, (w + 1) * poses_per_wg);
+    for (int p = w * poses_per_wg + threadIdx.x; p < p_end; p += blockDim.x) {
         PoseRec r;
         const uint32_t kf = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r, walk_outside != 0);
         rec[p] = r;
@@ -544,34 +545,58 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(MapParams m, const float
     for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) hist_all[(size_t)i * n_wg + w] = lhist[i];
 }
 
-// in-place exclusive scan of n counters by one workgroup
-__global__ __launch_bounds__(1024) void tile_scan_kernel(uint32_t *__restrict__ hist, int n)
+// exclusive scan of the 256 values a workgroup of 256 holds (one per lane) + their total
+__device__ __forceinline__ uint32_t wg256_excl_scan(uint32_t v, uint32_t *part /* 4 */, uint32_t &total)
 {
-    __shared__ uint32_t part[1024];
-    const int tid = threadIdx.x;
-    const int E = (n + 1023) / 1024;
-    uint32_t local = 0;
-    for (int e = 0; e < E; ++e) {
-        int i = tid * E + e;
-        if (i < n) local += hist[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += o;
     }
-    part[tid] = local;
+    __syncthreads();                                   // (part[] of the previous tile has been read)
+    if (lane == 63) part[wave] = incl;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += part[w];
+    total = part[0] + part[1] + part[2] + part[3];
+    return before + incl - v;
+}
+
+// The (tile, workgroup) counters of the grid-wide binning, hist_all[tile * n_wg + w], scanned by one
+// workgroup PER TILE in two small launches — (a) inside the tile's own run of n_wg counters (coalesced
+// 256-wide pieces, running carry) + the tile's total, (b) add the totals of the tiles in front — instead
+// of one workgroup walking all tiles x workgroups counters with a lane-strided pattern (131 072 counters at
+// 262 144 poses: the single-workgroup scan was the longest of the three binning kernels).
+__global__ __launch_bounds__(256) void tile_scan_a_kernel(uint32_t *__restrict__ hist_all, int n_wg,
+                                                          uint32_t *__restrict__ tile_total)
+{
+    __shared__ uint32_t part[4];
+    uint32_t *row = hist_all + (size_t)blockIdx.x * n_wg;
+    uint32_t carry = 0;
+    for (int i0 = 0; i0 < n_wg; i0 += 256) {
+        const int i = i0 + (int)threadIdx.x;
+        const uint32_t v = i < n_wg ? row[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = wg256_excl_scan(v, part, tot);
+        if (i < n_wg) row[i] = carry + ex;
+        carry += tot;
     }
-    uint32_t base = part[tid] - local;
-    for (int e = 0; e < E; ++e) {
-        int i = tid * E + e;
-        if (i < n) {
-            uint32_t c = hist[i];
-            hist[i] = base;
-            base += c;
-        }
-    }
+    if (threadIdx.x == 0) tile_total[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void tile_scan_b_kernel(uint32_t *__restrict__ hist_all, int n_wg,
+                                                          const uint32_t *__restrict__ tile_total)
+{
+    __shared__ uint32_t part[4];
+    const int t = blockIdx.x;
+    uint32_t mine = 0;
+    for (int k = threadIdx.x; k < t; k += 256) mine += tile_total[k];
+    uint32_t base;
+    (void)wg256_excl_scan(mine, part, base);           // base = poses in the tiles in front of this one
+    uint32_t *row = hist_all + (size_t)t * n_wg;
+    for (int i = threadIdx.x; i < n_wg; i += 256) row[i] += base;
 }
 
 __global__ __launch_bounds__(256) void pose_scatter_kernel(int n, const PoseRec *__restrict__ rec,
@@ -579,14 +604,14 @@ __global__ __launch_bounds__(256) void pose_scatter_kernel(int n, const PoseRec 
                                                            const uint32_t *__restrict__ base_all,
                                                            int n_wg, int n_tiles,
                                                            PoseRec *__restrict__ rec_sorted,
-                                                           uint32_t *__restrict__ order)
+                                                           uint32_t *__restrict__ order, int poses_per_wg)
 {
     extern __shared__ uint32_t cursor[];           // n_tiles
     const int w = blockIdx.x;
     for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) cursor[i] = base_all[(size_t)i * n_wg + w];
     __syncthreads();
-    const int p_end = min(n, (w + 1) * POSES_PER_WG);
-    for (int p = w * POSES_PER_WG + threadIdx.x; p < p_end; p += blockDim.x) {
+    const int p_end = min(n, (w + 1) * poses_per_wg);
+    for (int p = w * poses_per_wg + threadIdx.x; p < p_end; p += blockDim.x) {
         const uint32_t kf = keys[p];
         const uint32_t slot = atomicAdd(&cursor[kf & ~POSE_INVALID], 1u);
         order[slot] = (uint32_t)p | (kf & POSE_INVALID);
@@ -2237,24 +2262,6 @@ __global__ __launch_bounds__(256) void cddt_project_kernel(CddtParams cp, const 
 // buckets (coalesced 256-wide tiles, running carry) and publish the bin's total, (2) add the totals
 // of the bins in front.  (One workgroup walking all ~30 000 counters with a lane-strided pattern
 // took 42 us on colombia.)  Pass 2 also queues the buckets too large for the one-wave sort.
-__device__ __forceinline__ uint32_t wg256_excl_scan(uint32_t v, uint32_t *part /* 4 */, uint32_t &total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
-        if (lane >= off) incl += o;
-    }
-    __syncthreads();                                   // (part[] of the previous tile has been read)
-    if (lane == 63) part[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (int w = 0; w < wave; ++w) before += part[w];
-    total = part[0] + part[1] + part[2] + part[3];
-    return before + incl - v;
-}
-
 __global__ __launch_bounds__(256) void cddt_scan_bins_kernel(CddtParams cp, const uint32_t *__restrict__ counts,
                                                              uint32_t *__restrict__ bin_total)
 {

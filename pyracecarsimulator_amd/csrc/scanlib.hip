@@ -261,6 +261,7 @@ struct rl_method {
     std::vector<double> edge_host; // the car-outline table last uploaded to `edge` (re-sent only when it changes)
     int *pin_flag = nullptr;       // pinned landing slot for the crash index
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
+    int bin_ppw = POSES_PER_WG;  // ... poses per workgroup of those kernels
     int order_inline = 1;        // big maps, stripe_max..8192 poses: keys-only binning launch + INLINE march
     int stripe_max = 2560;       // big maps, inline_max..stripe_max poses: no binning launch, workgroups compact
                                  // their own row-stripe band of the pose list (0 = off)
@@ -562,6 +563,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "drain_prio")) h->drain_prio = value != 0;
     else if (!strcmp(name, "timing")) h->timing = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
+    else if (!strcmp(name, "bin_ppw")) h->bin_ppw = value < 256 ? 256 : (value > 8192 ? 8192 : value);
     else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
     else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
     else if (!strcmp(name, "tiled")) h->tiled = value != 0;
@@ -600,6 +602,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "drain_prio")) *value_out = h->drain_prio;
     else if (!strcmp(name, "timing")) *value_out = h->timing;
     else if (!strcmp(name, "bin_multi_min")) *value_out = h->bin_multi_min;
+    else if (!strcmp(name, "bin_ppw")) *value_out = h->bin_ppw;
     else if (!strcmp(name, "inline_prep")) *value_out = h->inline_prep;
     else if (!strcmp(name, "bin_generic")) *value_out = h->bin_generic;
     else if (!strcmp(name, "tiled")) *value_out = h->tiled;
@@ -912,7 +915,8 @@ static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_po
     const int tiles_x = (m->cols >> shift) + 1;
     const int n_tiles = tiles_x * ((m->rows >> shift) + 1);
     if (n_poses >= h->bin_multi_min) {
-        const int n_wg = (n_poses + POSES_PER_WG - 1) / POSES_PER_WG;
+        const int ppw = h->bin_ppw;
+        const int n_wg = (n_poses + ppw - 1) / ppw;
         if (do_sort) {
             // grid-wide binning on coarse tiles (<= 1024): per-workgroup LDS histograms ->
             // one scan over (tile, workgroup) -> scatter from LDS cursors
@@ -921,23 +925,26 @@ static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_po
             const int ctx = (m->cols >> cshift) + 1;
             const int cnt = ctx * ((m->rows >> cshift) + 1);
             const size_t n_ctr = (size_t)cnt * n_wg;
-            if ((rc = cx.hist.ensure(n_ctr * sizeof(uint32_t)))) return rc;
+            if ((rc = cx.hist.ensure((n_ctr + cnt) * sizeof(uint32_t)))) return rc;     // counters, then tile totals
             hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
                                m->mp, d_poses, n_poses, (PoseRec *)cx.rec.p,
                                (uint32_t *)cx.keys.p, (uint32_t *)cx.hist.p, n_wg, cshift, ctx,
-                               cnt, (uint32_t *)nullptr, walk_outside);
-            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream,
-                               (uint32_t *)cx.hist.p, (int)n_ctr);
+                               cnt, (uint32_t *)nullptr, walk_outside, ppw);
+            uint32_t *tile_total = (uint32_t *)cx.hist.p + n_ctr;
+            hipLaunchKernelGGL(tile_scan_a_kernel, dim3(cnt), dim3(256), 0, stream, (uint32_t *)cx.hist.p, n_wg,
+                               tile_total);
+            hipLaunchKernelGGL(tile_scan_b_kernel, dim3(cnt), dim3(256), 0, stream, (uint32_t *)cx.hist.p, n_wg,
+                               (const uint32_t *)tile_total);
             hipLaunchKernelGGL(pose_scatter_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
                                n_poses, (const PoseRec *)cx.rec.p, (const uint32_t *)cx.keys.p,
                                (const uint32_t *)cx.hist.p, n_wg, cnt, (PoseRec *)cx.rec_sorted.p,
-                               (uint32_t *)cx.order.p);
+                               (uint32_t *)cx.order.p, ppw);
         } else {
             // caller's order kept: one fully parallel pass, records land in place
             hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), 0, stream, m->mp, d_poses,
                                n_poses, (PoseRec *)cx.rec_sorted.p, (uint32_t *)nullptr,
                                (uint32_t *)nullptr, n_wg, shift, tiles_x, n_tiles,
-                               (uint32_t *)cx.order.p, walk_outside);
+                               (uint32_t *)cx.order.p, walk_outside, ppw);
         }
     } else if (do_sort && n_poses <= 8192 && !h->bin_generic) {
         if (keys_only)
