@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WG) void rm_rays_kernel(MapParams m, FanParams f,
 //      misses before the first sample — decided once per pose.)  Rows are interleaved in
 //      groups of 4 so that a 128-B line is a 4x8 block of cells (see pdt_tiled_index).
 //  (1) pose binning — pose_bin_small_kernel (one 1024-lane workgroup, < 8192 poses) or
-//      pose_prep/tile_scan/pose_scatter (grid-wide): per-pose records (gx, gy, cos th, sin th)
+//      pose_prep/tile_scan_a,b/pose_scatter (grid-wide): per-pose records (gx, gy, cos th, sin th)
 //      ordered by the map tile the pose stands in (LDS histogram -> scan -> scatter).  Small
 //      batches and maps that fit every XCD's L2 skip it: the march kernel derives the records
 //      of its own ray blocks into LDS (INLINE).
@@ -268,8 +268,9 @@ __global__ __launch_bounds__(WG) void rm_rays_kernel(MapParams m, FanParams f,
 //      MI355X, which made the launch atomic-bound.)
 //      The first version was instruction-issue bound (~60 VALU+SALU per sample); the march
 //      loop is now hand-scheduled assembly with EXEC as the live mask:
-//      10 VALU + 1 load + 4 SALU per sample (march_loop below).  What bounds it today —
-//      the CU's gather rate (~3.85 lanes/clk) and load latency — is in DESIGN.md section 4.
+//      9 VALU + 1 load + 4 SALU per sample (march_loop below), two or three rays per lane
+//      (march_loop2/3).  What bounds it today — VALU issue and the CU's gather rate, both at
+//      ~65 % (cfg2) to ~85 % (32 k poses) — is in DESIGN.md section 4.
 // Results are bit-identical to K1 (same arithmetic; only the schedule differs).
 // ==============================================================================
 struct PoseRec {
@@ -771,6 +772,9 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
 
 // Three rays per lane: the same alternation over three live masks (slot C: t v36 / dir v[38:39] /
 // origin v[40:41] / scratch v[42:43]).
+// (Tried and dropped, no measurable change at cfg2 / 32 k poses: a drain-phase form that branches over
+//  a slot whose rays have all finished instead of issuing its 9 VALU with EXEC = 0, and a 24-bit
+//  multiply for the output index in the claim.)
 template <bool TILED>
 __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, float gyA, float &tA, int &cA, int &rA,
                                             float &dA, float dxB, float dyB, float gxB, float gyB, float &tB,

@@ -207,7 +207,7 @@ struct rl_method {
     uint64_t noise_seed = 0, ray_offset = 0;
     int variant = 1;             // 0: chunk kernel (K1); 1: binned + banded + lane-refill stream kernel (K1b)
     int grid_mult = 8;           // workgroups per CU for the persistent launches (8 resident: <= 80 SGPRs, <= 64 VGPRs)
-    int low_water = 12;          // stream kernel: refill when <= this many lanes still march (re-tuned for the 10-VALU loop)
+    int low_water = 12;          // stream kernel: refill when <= this many lanes still march (re-tuned for the hand-scheduled loop)
     int sort_poses = 1;          // stream kernel: order poses by map tile
     int xcd_bands = 8;           // stream kernel: bands of the sorted list, one per XCD
     int timing = 0;              // 1: HIP events around every launch sequence (rl_last_kernel_ms);
