@@ -16,6 +16,7 @@ PASSES=(
  "GRBM_GUI_ACTIVE"
  "FETCH_SIZE"
  "WRITE_SIZE"
+ "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_VMEM"
 )
 i=0
 for P in "${PASSES[@]}"; do
