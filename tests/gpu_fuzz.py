@@ -102,7 +102,6 @@ def one_case(seed):
                 assert np.array_equal(out, om.lut_fan(lut, poses, fov, B)), "LUT fan td=%d" % td
                 m.close()
             # fused / generic crash tests, whole batch and grouped
-            from pyracecarsimulator_amd import racecar as RC
             edge = r.uniform(0.05, 0.6, B)
             thr = 0.001
             rr = om.rm_fan(poses, fov, B, 1.0)[0]

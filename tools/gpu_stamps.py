@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-wave start/end stamps of the stream kernel (where does a launch's time go?)."""
-import argparse, os, sys, json
+import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
