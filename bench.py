@@ -428,7 +428,9 @@ def main():
             _lib.check(_lib.lib().rl_probe_gather_rate(local_rank, 46, ctypes.byref(lanes), ctypes.byref(clk),
                                                         ctypes.byref(ncu)))
             peak = lanes.value * ncu.value * clk.value
-            samples = mean_steps * n * B
+            # gathered samples: the statement's count less the t = 0 sample of every ray, which the kernel
+            # reads once per pose with the pose record (pose_first_step)
+            samples = max(mean_steps - 1.0, 0.0) * n * B
             out["roofline_gather"] = {"achieved_samples_per_s": round(samples / (eff_ms * 1e-3), 1),
                                       "peak": round(peak, 1), "frac": round(samples / (eff_ms * 1e-3) / peak, 5),
                                       "serial_frac": round(samples / (k_ms * 1e-3) / peak, 5),

@@ -332,6 +332,21 @@ __global__ __launch_bounds__(256) void pad_dt_kernel(const float *__restrict__ d
     }
 }
 
+// The FIRST sample of a ray is taken at t = 0, i.e. at the pose's own cell, whatever the beam: it is
+// read once per pose (with the record) instead of once per ray, and the ray starts at t = first step.
+//   free origin cell   -> its step max(d*coeff, 1): the ray starts there with one sample counted
+//   occupied origin    -> 0: the ray starts at t = 0 and finds the hit itself (KAT-2: its range is
+//                         the distance to the cell corner, computed from the sampled cell)
+//   no ray (origin outside the map / non-finite pose) -> PDT_NO_RAY: born finished, a miss
+#define PDT_NO_RAY 2.5e38f
+__device__ __forceinline__ float pose_first_step(const MapParams &m, float gx, float gy, uint32_t flags,
+                                                 float coeff)
+{
+    if (flags & POSE_INVALID) return PDT_NO_RAY;
+    const float v = m.dt[(size_t)(int)gy * m.cols + (int)gx];
+    return v <= 0.0f ? 0.0f : __builtin_fmaxf(v * coeff, 1.0f);
+}
+
 __device__ __forceinline__ uint32_t pose_record(const MapParams &m, const float *__restrict__ poses,
                                                 int p, int tile_shift, int tiles_x, int n_tiles,
                                                 PoseRec &r, bool walk_outside = false)
@@ -363,7 +378,8 @@ __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float
                                                         PoseRec *__restrict__ rec_sorted,
                                                         uint32_t *__restrict__ order,
                                                         uint32_t *__restrict__ keys, int tile_shift,
-                                                        int tiles_x, int n_tiles, int do_sort, int walk_outside)
+                                                        int tiles_x, int n_tiles, int do_sort, int walk_outside,
+                                                        float *__restrict__ d0, float coeff)
 {
     extern __shared__ uint32_t hist[];          // n_tiles counters, then 1024 scan partials
     uint32_t *part = hist + n_tiles;
@@ -381,6 +397,7 @@ __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float
         } else {
             rec_sorted[p] = r;
             order[p] = (uint32_t)p | flag;
+            if (d0) d0[p] = pose_first_step(m, r.gx, r.gy, flag, coeff);
         }
     }
     if (!do_sort) return;
@@ -414,7 +431,9 @@ __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float
         const uint32_t kf = keys[p];
         const uint32_t slot = atomicAdd(&hist[kf & ~POSE_INVALID], 1u);
         order[slot] = (uint32_t)p | (kf & POSE_INVALID);
-        rec_sorted[slot] = rec[p];
+        const PoseRec r = rec[p];
+        rec_sorted[slot] = r;
+        if (d0) d0[slot] = pose_first_step(m, r.gx, r.gy, kf, coeff);
     }
 }
 
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const
                                                               int n, PoseRec *__restrict__ rec_sorted,
                                                               uint32_t *__restrict__ order,
                                                               int tile_shift, int tiles_x, int n_tiles,
-                                                              int walk_outside)
+                                                              int walk_outside, float *__restrict__ d0, float coeff)
 {
     extern __shared__ uint32_t hist[];          // n_tiles counters, then 1024 scan partials
     uint32_t *part = hist + n_tiles;
@@ -500,7 +519,10 @@ __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const
         if (p < n) {
             const uint32_t slot = atomicAdd(&hist[kf[u] & ~POSE_INVALID], 1u);
             order[slot] = (uint32_t)p | (kf[u] & POSE_INVALID);
-            if (!KEYS_ONLY) rec_sorted[slot] = r[u];
+            if (!KEYS_ONLY) {
+                rec_sorted[slot] = r[u];
+                if (d0) d0[slot] = pose_first_step(m, r[u].gx, r[u].gy, kf[u], coeff);
+            }
         }
     }
 }
@@ -521,7 +543,8 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(MapParams m, const float
                                                         uint32_t *__restrict__ hist_all, int n_wg,
                                                         int tile_shift, int tiles_x, int n_tiles,
                                                         uint32_t *__restrict__ order_if_unsorted,
-                                                        int walk_outside, int poses_per_wg)
+                                                        int walk_outside, int poses_per_wg,
+                                                        float *__restrict__ d0_if_unsorted, float coeff)
 {
     extern __shared__ uint32_t lhist[];            // n_tiles
     const int w = blockIdx.x;
@@ -536,6 +559,7 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(MapParams m, const float
         rec[p] = r;
         if (order_if_unsorted) {                   // keep the caller's pose order
             order_if_unsorted[p] = (uint32_t)p | (kf & POSE_INVALID);
+            if (d0_if_unsorted) d0_if_unsorted[p] = pose_first_step(m, r.gx, r.gy, kf, coeff);
         } else {
             keys[p] = kf;
             atomicAdd(&lhist[kf & ~POSE_INVALID], 1u);
@@ -605,7 +629,8 @@ __global__ __launch_bounds__(256) void pose_scatter_kernel(int n, const PoseRec 
                                                            const uint32_t *__restrict__ base_all,
                                                            int n_wg, int n_tiles,
                                                            PoseRec *__restrict__ rec_sorted,
-                                                           uint32_t *__restrict__ order, int poses_per_wg)
+                                                           uint32_t *__restrict__ order, int poses_per_wg,
+                                                           MapParams m, float *__restrict__ d0, float coeff)
 {
     extern __shared__ uint32_t cursor[];           // n_tiles
     const int w = blockIdx.x;
@@ -616,7 +641,9 @@ __global__ __launch_bounds__(256) void pose_scatter_kernel(int n, const PoseRec 
         const uint32_t kf = keys[p];
         const uint32_t slot = atomicAdd(&cursor[kf & ~POSE_INVALID], 1u);
         order[slot] = (uint32_t)p | (kf & POSE_INVALID);
-        rec_sorted[slot] = rec[p];
+        const PoseRec r = rec[p];
+        rec_sorted[slot] = r;
+        if (d0) d0[slot] = pose_first_step(m, r.gx, r.gy, kf, coeff);
     }
 }
 
@@ -882,6 +909,7 @@ struct PadMap {
 struct StreamParams {
     const PoseRec *rec;      // sorted order
     const uint32_t *order;   // sorted slot -> pose index | POSE_INVALID
+    const float *d0;         // sorted slot -> first step of the pose's rays (pose_first_step)
     FastDiv div_B;           // division by num_rays
     int low_water;           // refill when <= low_water lanes are still marching
     int n_bands;
@@ -1034,7 +1062,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     uint32_t *lord = reinterpret_cast<uint32_t *>(lrec + (INLINE ? sp.k_max : 0));
     // INLINE: per owned block, first beam of the block (low 16 bits) and number of valid rays in it
     // (a ray slot then finds its record and beam with an LDS read instead of two integer divisions)
-    uint32_t *lblk = lord + (INLINE ? sp.k_max : 0);
+    float *ld0 = reinterpret_cast<float *>(lord + (INLINE ? sp.k_max : 0));   // first step per record
+    uint32_t *lblk = reinterpret_cast<uint32_t *>(ld0 + (INLINE ? sp.k_max : 0));
     if (threadIdx.x == 0) *q_next = 0;
     if (CRASH && threadIdx.x < STREAM_HDR - 2) crash_seen[threadIdx.x] = 0xffffffffu;
     for (int j = threadIdx.x; j < f.num_rays; j += NT) {
@@ -1087,6 +1116,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 const uint32_t kf = pose_record(mp, sp.raw_poses, (int)pid, 0, 1, 1, r);
                 lrec[k2] = r;
                 lord[k2] = pid | (kf & POSE_INVALID);
+                ld0[k2] = pose_first_step(mp, r.gx, r.gy, kf, f.step_coeff);
             }
         }
     }
@@ -1159,14 +1189,15 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 s.gy = pr_.gy;
                 s.dx = __builtin_fmaf(pr_.ct, cs.x, -(pr_.st * cs.y));
                 s.dy = __builtin_fmaf(pr_.st, cs.x, pr_.ct * cs.y);
-                s.d_last = 1.0f;
                 s.oidx = (po & ~POSE_INVALID) * (uint32_t)f.num_rays + (uint32_t)j;
                 if (CRASH) {
                     s.pose = po & ~POSE_INVALID;
                     s.jbeam = j;
                 }
                 s.has_ray = true;
-                s.t = (po & POSE_INVALID) ? INF : 0.0f;
+                // the sample at t = 0 was taken with the pose record (pose_first_step)
+                s.t = s.d_last = INLINE ? ld0[li]
+                    : *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sp.d0) + (si << 2));
             }
         };
         for (;;) {
@@ -1305,12 +1336,13 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                         gy = pr_.gy;
                         dx = __builtin_fmaf(pr_.ct, cs.x, -(pr_.st * cs.y));
                         dy = __builtin_fmaf(pr_.st, cs.x, pr_.ct * cs.y);
-                        d_last = 1.0f;
-                        nstep = 0;
                         jbeam = j;
                         oidx = pose * (uint32_t)f.num_rays + (uint32_t)j;
                         has_ray = true;
-                        t = (po & POSE_INVALID) ? INF : 0.0f;
+                        // the sample at t = 0 was taken with the pose record (pose_first_step)
+                        t = d_last = INLINE ? ld0[li]
+                            : *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sp.d0) + (si << 2));
+                        nstep = (t > 0.0f && t < PDT_NO_RAY) ? 1u : 0u;
                     }
                 }
             }

@@ -180,11 +180,11 @@ struct LaunchCtx {
     hipStream_t stream = nullptr;
     bool bound = false;
     uint64_t last_use = 0;
-    DevBuf rec, rec_sorted, order, keys, hist, pose_first, dbg;
+    DevBuf rec, rec_sorted, order, keys, hist, pose_first, dbg, d0;
     int crash_epoch = 0;           // mark value of the last per-pose crash launch (pose_marks)
     void release()
     {
-        for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg}) b->release();
+        for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg, &d0}) b->release();
     }
 };
 constexpr int N_LAUNCH_CTX = 4;
@@ -905,6 +905,14 @@ static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_po
 {
     const rl_map *m = h->map;
     int rc;
+    // ray marching: the sample every ray of a pose takes at t = 0, read once per pose with the record
+    // (pose_first_step); the Bresenham walk (walk_outside) has no use for it
+    float *d0 = nullptr;
+    if (!walk_outside && !keys_only) {
+        if ((rc = cx.d0.ensure((size_t)n_poses * sizeof(float)))) return rc;
+        d0 = (float *)cx.d0.p;
+    }
+    const float coeff = h->step_coeff;
     if ((rc = cx.rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
     if ((rc = cx.order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
     if ((rc = cx.keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
@@ -929,7 +937,7 @@ static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_po
             hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
                                m->mp, d_poses, n_poses, (PoseRec *)cx.rec.p,
                                (uint32_t *)cx.keys.p, (uint32_t *)cx.hist.p, n_wg, cshift, ctx,
-                               cnt, (uint32_t *)nullptr, walk_outside, ppw);
+                               cnt, (uint32_t *)nullptr, walk_outside, ppw, (float *)nullptr, coeff);
             uint32_t *tile_total = (uint32_t *)cx.hist.p + n_ctr;
             hipLaunchKernelGGL(tile_scan_a_kernel, dim3(cnt), dim3(256), 0, stream, (uint32_t *)cx.hist.p, n_wg,
                                tile_total);
@@ -938,31 +946,31 @@ static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_po
             hipLaunchKernelGGL(pose_scatter_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
                                n_poses, (const PoseRec *)cx.rec.p, (const uint32_t *)cx.keys.p,
                                (const uint32_t *)cx.hist.p, n_wg, cnt, (PoseRec *)cx.rec_sorted.p,
-                               (uint32_t *)cx.order.p, ppw);
+                               (uint32_t *)cx.order.p, ppw, m->mp, d0, coeff);
         } else {
             // caller's order kept: one fully parallel pass, records land in place
             hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), 0, stream, m->mp, d_poses,
                                n_poses, (PoseRec *)cx.rec_sorted.p, (uint32_t *)nullptr,
                                (uint32_t *)nullptr, n_wg, shift, tiles_x, n_tiles,
-                               (uint32_t *)cx.order.p, walk_outside, ppw);
+                               (uint32_t *)cx.order.p, walk_outside, ppw, d0, coeff);
         }
     } else if (do_sort && n_poses <= 8192 && !h->bin_generic) {
         if (keys_only)
             hipLaunchKernelGGL(pose_bin_small_kernel<true>, dim3(1), dim3(1024),
                                (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
                                n_poses, (PoseRec *)cx.rec_sorted.p, (uint32_t *)cx.order.p, shift,
-                               tiles_x, n_tiles, walk_outside);
+                               tiles_x, n_tiles, walk_outside, (float *)nullptr, coeff);
         else
             hipLaunchKernelGGL(pose_bin_small_kernel<false>, dim3(1), dim3(1024),
                                (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
                                n_poses, (PoseRec *)cx.rec_sorted.p, (uint32_t *)cx.order.p, shift,
-                               tiles_x, n_tiles, walk_outside);
+                               tiles_x, n_tiles, walk_outside, d0, coeff);
     } else {
         hipLaunchKernelGGL(pose_bin_kernel, dim3(1), dim3(1024),
                            (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
                            n_poses, (PoseRec *)cx.rec.p, (PoseRec *)cx.rec_sorted.p,
                            (uint32_t *)cx.order.p, (uint32_t *)cx.keys.p, shift, tiles_x,
-                           n_tiles, do_sort, walk_outside);
+                           n_tiles, do_sort, walk_outside, d0, coeff);
     }
     return RL_OK;
 }
@@ -1217,7 +1225,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             k_max = 2 * ((int)k_blocks + 1);                                 // two records per block
             if (stripe)                                   // band list + histogram / wave counts / cuts
                 lds_extra = ((size_t)(n_poses + bands - 1) / bands + 2 + STRIPE_BINS + 3 * (nt / 64) + 4) * 4;
-            if ((size_t)k_max * 22 + lds * (crash ? 2 : 1) + lds_extra + 32 + STREAM_HDR * 4 > 56 * 1024) inl = false;
+            if ((size_t)k_max * 26 + lds * (crash ? 2 : 1) + lds_extra + 32 + STREAM_HDR * 4 > 56 * 1024) inl = false;
         }
         if (!inl) {
             nt = h->wg_threads;
@@ -1236,6 +1244,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         StreamParams sp{};
         sp.rec = (const PoseRec *)cx->rec_sorted.p;
         sp.order = (const uint32_t *)cx->order.p;
+        sp.d0 = (const float *)cx->d0.p;
         sp.div_B = make_fastdiv((uint32_t)num_rays);
         sp.low_water = h->low_water;
         sp.n_bands = bands;
@@ -1264,7 +1273,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.run_log2 = inl ? inl_rl : rl2;          // (the inline LDS record table was sized for inl_rl)
         h->last_grid = grid * waves_per_wg / WAVES_PER_WG;
         const size_t tab_floats = STREAM_HDR + (crash ? 4 : 2) * (size_t)num_rays;   // fan table (+ edge table, f64)
-        const size_t lds_q = inl ? (((tab_floats + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 22 + lds_extra)   // records 16 B + ids 4 B per slot, block words 4 B per two slots
+        const size_t lds_q = inl ? (((tab_floats + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 26 + lds_extra)   // records 16 B + ids 4 B + first steps 4 B per slot, block words 4 B per two slots
                                  : tab_floats * sizeof(float);
         if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel alone
 #define LAUNCH_S(A, C, N, I)                                                                          \
