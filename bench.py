@@ -442,7 +442,7 @@ def main():
                 out["roofline_valu"] = {"wave_valu_insts_per_launch": valu, "floor_ms": round(floor_ms, 5),
                                         "frac": round(floor_ms / eff_ms, 5),
                                         "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, profiles/r02/"
-                                                  "r2_pmc_cfg2_slots3; not measured in this run)"}
+                                                  "r2_pmc_cfg2_slots3_final; not measured in this run)"}
         if rank == 0 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, gmap, poses_all, method, a.cpu_seconds)
     if rank == 0:
