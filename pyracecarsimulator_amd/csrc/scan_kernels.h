@@ -647,6 +647,17 @@ __global__ __launch_bounds__(256) void pose_scatter_kernel(int n, const PoseRec 
     }
 }
 
+// (cos, sin) of every beam angle of a fan: the table the stream kernels stage into LDS
+__global__ __launch_bounds__(256) void fan_table_kernel(FanParams f, float2 *__restrict__ tab)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < f.num_rays) {
+        float s, c;
+        det_sincosf(fan_alpha(f, j), s, c);
+        tab[j] = make_float2(c, s);
+    }
+}
+
 // unsigned division by a launch-time constant (round-up method, any 32-bit dividend)
 struct FastDiv {
     uint32_t mul, sh1, sh2, d;
@@ -910,6 +921,7 @@ struct StreamParams {
     const PoseRec *rec;      // sorted order
     const uint32_t *order;   // sorted slot -> pose index | POSE_INVALID
     const float *d0;         // sorted slot -> first step of the pose's rays (pose_first_step)
+    const float2 *fan_tab;   // (cos, sin) of the num_rays beam angles, built once per (fov, num_rays)
     FastDiv div_B;           // division by num_rays
     int low_water;           // refill when <= low_water lanes are still marching
     int n_bands;
@@ -1066,10 +1078,11 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     uint32_t *lblk = reinterpret_cast<uint32_t *>(ld0 + (INLINE ? sp.k_max : 0));
     if (threadIdx.x == 0) *q_next = 0;
     if (CRASH && threadIdx.x < STREAM_HDR - 2) crash_seen[threadIdx.x] = 0xffffffffu;
+    // (the beam directions are the same for every workgroup of every launch with this fan: a table
+    //  of the handle, fan_table_kernel — 1081 sincos per workgroup were 3 % of a cfg2 launch's VALU
+    //  work and the first microsecond of every workgroup's life)
     for (int j = threadIdx.x; j < f.num_rays; j += NT) {
-        float s, c;
-        det_sincosf(fan_alpha(f, j), s, c);
-        fan_cs[j] = make_float2(c, s);
+        fan_cs[j] = sp.fan_tab[j];
         if (CRASH) edge_l[j] = cp.edge[j];
     }
 

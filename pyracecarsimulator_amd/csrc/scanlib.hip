@@ -253,6 +253,15 @@ struct rl_method {
     LaunchCtx ctx[N_LAUNCH_CTX];
     uint64_t use_clock = 0;
     TableDep pdt_dep, lut_dep, cddt_dep;
+    // beam-direction tables (cos, sin per beam) of the fans this handle has been called with
+    struct FanTab {
+        uint32_t fov_bits = 0;
+        int num_rays = 0;
+        uint64_t last_use = 0;
+        DevBuf tab;
+        TableDep dep;
+    } fan_tabs[4];
+    uint64_t fan_clock = 0;
     // small host calls (scan(): one pose, scanMany(): a roll-out): poses and ranges go through ONE
     // pinned, device-mapped host buffer the kernels read / write directly — no staging copies
     void *pin = nullptr;
@@ -527,6 +536,10 @@ extern "C" void rl_method_destroy(rl_method *h)
     for (LaunchCtx &c : h->ctx) c.release();
     for (TableDep *d : {&h->pdt_dep, &h->lut_dep, &h->cddt_dep, &h->blpad_dep})
         if (d->ev) (void)hipEventDestroy(d->ev);
+    for (auto &ft : h->fan_tabs) {
+        if (ft.dep.ev) (void)hipEventDestroy(ft.dep.ev);
+        ft.tab.release();
+    }
     h->pdt.release();
     h->blpad.release();
     h->lut.release();
@@ -704,6 +717,39 @@ static int table_wait(TableDep &d, hipStream_t stream)
 // ------------------------------------------------------------------------------
 // derived tables (built lazily on the launch stream, rebuilt when the map changed)
 // ------------------------------------------------------------------------------
+// (cos, sin) of the beam angles of fan f: one small table per (fov, num_rays) the handle is called
+// with — four are kept, the least recently used one is rebuilt (after a device synchronisation:
+// launches of other streams may still read it) when a fifth fan shows up
+static int ensure_fan_table(rl_method *h, const FanParams &f, float fov, hipStream_t stream, const float2 **out)
+{
+    uint32_t bits;
+    memcpy(&bits, &fov, sizeof bits);
+    rl_method::FanTab *slot = nullptr;
+    for (auto &ft : h->fan_tabs)
+        if (ft.tab.p && ft.fov_bits == bits && ft.num_rays == f.num_rays) slot = &ft;
+    if (slot) {
+        slot->last_use = ++h->fan_clock;
+        *out = (const float2 *)slot->tab.p;
+        return table_wait(slot->dep, stream);
+    }
+    for (auto &ft : h->fan_tabs)
+        if (!ft.tab.p) { slot = &ft; break; }
+    if (!slot) {
+        slot = &h->fan_tabs[0];
+        for (auto &ft : h->fan_tabs)
+            if (ft.last_use < slot->last_use) slot = &ft;
+        HIPCHK(hipDeviceSynchronize());
+    }
+    int rc = slot->tab.ensure((size_t)f.num_rays * sizeof(float2));
+    if (rc) return rc;
+    hipLaunchKernelGGL(fan_table_kernel, dim3((f.num_rays + 255) / 256), dim3(256), 0, stream, f, (float2 *)slot->tab.p);
+    slot->fov_bits = bits;
+    slot->num_rays = f.num_rays;
+    slot->last_use = ++h->fan_clock;
+    *out = (const float2 *)slot->tab.p;
+    return table_built(slot->dep, stream);
+}
+
 static int ensure_lut(rl_method *h, hipStream_t stream)
 {
     rl_map *m = h->map;
@@ -1245,6 +1291,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.rec = (const PoseRec *)cx->rec_sorted.p;
         sp.order = (const uint32_t *)cx->order.p;
         sp.d0 = (const float *)cx->d0.p;
+        if ((rc = ensure_fan_table(h, f, fov, stream, &sp.fan_tab))) return rc;
         sp.div_B = make_fastdiv((uint32_t)num_rays);
         sp.low_water = h->low_water;
         sp.n_bands = bands;

@@ -150,6 +150,24 @@ def test_rm_fan_vs_oracle_beam_counts(oracle_mod, B, fov):
         assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0)
 
 
+def test_one_handle_called_with_many_fans_keeps_its_direction_tables_straight(oracle_mod):
+    """The beam-direction table is cached per (fov, num_rays) on the handle, four fans deep: seven
+    fans alternating on one handle go through hits, fills and evictions, ranges / hit cells / sample
+    counts of every call equal the oracle's."""
+    g = maps.make_maze(256, cell=32, wall=3, p=0.5, seed=77, origin=(1.0, -2.0, 0.4))
+    mrx = 120
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    poses = maps.sample_free_poses(g, 70, 5, dt=om.dt)
+    fans = [(1081, 4.71), (720, 4.71), (1081, 3.0), (64, 6.283), (271, 4.71), (1081, -4.71), (100, 0.5)]
+    want = {fan: om.rm_fan(poses, fan[1], fan[0], step_coeff=1.0) for fan in fans}
+    m = range_libc.PyRayMarchingGPU(omap, mrx)
+    for fan in fans + fans[::-1] + fans[::2] + fans:
+        r, h, s = _fan(m, poses, fan[1], fan[0])
+        r0, h0, s0 = want[fan]
+        assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0), fan
+
+
 def test_edge_cases(oracle_mod):
     g = maps.make_room(128, wall=2)
     om = oracle_mod.OracleMap.from_gridmap(g, 300)
