@@ -87,9 +87,10 @@ __device__ __forceinline__ float gauss_noise(uint64_t seed, uint64_t ray_id)
     uint32_t k = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const uint32_t hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
-        c0 = hi ^ k ^ c1;
-        c1 = lo;
+        // (the 64-bit product in one v_mad_u64_u32 instead of v_mul_hi_u32 + v_mul_lo_u32)
+        const uint64_t prod = (uint64_t)0xD256D193u * c0;
+        c0 = (uint32_t)(prod >> 32) ^ k ^ c1;
+        c1 = (uint32_t)prod;
         k += 0x9E3779B9u;
     }
     // two uniforms, u1 in (0,1], u2 in [0,1): Box-Muller with the hardware log / cos / sqrt estimates
