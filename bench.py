@@ -189,6 +189,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     if a.same_device:
         local_rank = 0
+        if a.backend == "nccl":      # RCCL refuses two ranks on one device ("Duplicate GPU detected")
+            print("bench.py: --same-device runs over gloo (RCCL needs one GPU per rank)", file=sys.stderr)
+            a.backend = "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or a.dist_single:
