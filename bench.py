@@ -252,9 +252,8 @@ def main():
     scan = ShardedScan(n, B, dev, n_chunks=n_chunks, gather=(mode == "ranges"), streams=streams,
                        gather_single_rank=a.dist_single)
 
-    def compute(clo, chi, view, sptr):
-        meth.calc_range_fan_device(d_poses.data_ptr() + clo * 12, chi - clo, w.fov, B,
-                                   view.data_ptr(), stream=sptr)
+    # a step = meth.calc_range_fan_device(local poses -> the slot's buffer) per chunk, prepared once
+    scan.bind(meth, d_poses.data_ptr(), w.fov)
 
     # 'crash': the reference's consumer of a scanned batch is Car::isCrashed per roll-out
     # (scripts/racecar_simulator_v2.py:146-167); group = roll-out length (params.yaml:126 uses 200)
@@ -305,13 +304,16 @@ def main():
         for _ in range(warmup):
             step_fn()
         drain_fn(None)
-        barrier()
         # HIP events around the K timed steps, none between them (an event per step would put two extra
         # barrier packets between consecutive launches): one before the first step is enqueued — every
         # stream is idle, the barrier has just synchronised the device — and one per stream behind its
-        # last step; the region ends with the latest of those
+        # last step; the region ends with the latest of those.  (torch creates the HIP event at the
+        # first record(): done here, outside the timed region.)
         e0 = torch.cuda.Event(enable_timing=True)
         ends = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        for e in [e0] + ends:
+            e.record()
+        barrier()
         t0 = time.perf_counter()
         e0.record()
         for _ in range(steps):
@@ -338,7 +340,7 @@ def main():
     if mode == "crash":
         elapsed, step_ms = timed(crash_step, crash_drain, a.steps, a.warmup)
     else:
-        elapsed, step_ms = timed(lambda: scan.step(compute), scan_drain, a.steps, a.warmup)
+        elapsed, step_ms = timed(scan.step, scan_drain, a.steps, a.warmup)
 
     if a.dist_single and world == 1 and mode == "ranges":
         torch.cuda.synchronize()

@@ -58,7 +58,7 @@ def chunk_bounds(n_local: int, n_chunks: int):
 
 
 class _Slot:
-    __slots__ = ("local", "gathered", "stream", "handles")
+    __slots__ = ("local", "gathered", "stream", "handles", "views", "dsts", "calls", "sptr")
 
 
 class ShardedScan:
@@ -100,9 +100,31 @@ class ShardedScan:
                                        device=device) if self.gather else None)
             sl.stream = streams[k % len(streams)] if streams else None
             sl.handles = []
+            # per chunk: the slice of `local` a march fills and, when gathering, where its all-gather
+            # lands — built once, a step only walks them
+            sl.views = [sl.local[lo * num_rays:hi * num_rays] for lo, hi in self.chunks]
+            sl.dsts = ([sl.gathered[ci * self.world * (hi - lo) * num_rays:(ci + 1) * self.world * (hi - lo) * num_rays]
+                        for ci, (lo, hi) in enumerate(self.chunks)] if self.gather else None)
+            sl.calls = None
+            sl.sptr = sl.stream.cuda_stream if sl.stream is not None else 0
             self.slots.append(sl)
         self.tick = 0
         self.last = self.slots[0]
+        self._bound = None
+
+    def bind(self, method, d_poses_ptr: int, fov: float):
+        """Fix the scan a step performs — ``method.calc_range_fan_device`` of the local poses at
+        device address ``d_poses_ptr`` into the slot's buffer — so that ``step()`` without a
+        ``compute`` callback is one prepared C call per chunk (no per-step tensor slicing, pointer
+        look-ups or ctypes argument objects: a step costs the host ~7 us instead of ~10, which is what
+        a short burst of steps sees between its first and its last launch)."""
+        from . import _lib
+        raw = _lib.raw("rl_calc_range_fan_device")
+        B = self.num_rays
+        for sl in self.slots:
+            base = sl.local.data_ptr()
+            sl.calls = [(d_poses_ptr + lo * 12, hi - lo, base + lo * B * 4) for lo, hi in self.chunks]
+        self._bound = (raw, method._h, float(fov), _lib.check)
 
     # the first slot's buffers (depth 1: the only ones)
     @property
@@ -120,22 +142,33 @@ class ShardedScan:
         return (self.torch.cuda.stream(sl.stream) if (sl.stream is not None and self.gather)
                 else contextlib.nullcontext())
 
-    def step(self, compute):
-        B = self.num_rays
+    def step(self, compute=None):
         sl = self.slots[self.tick % self.depth]
         self.tick += 1
+        if compute is None and not self.gather:      # bound scan, nothing to exchange: the lean path
+            raw, h, fov, check = self._bound
+            for pp, cnt, op in sl.calls:
+                rc = raw(h, pp, cnt, fov, self.num_rays, op, None, None, sl.sptr)
+                if rc:
+                    check(rc)
+            self.last = sl
+            return sl
         with self._on(sl):
             for h in sl.handles:          # gathers of the step that used this slot `depth` steps ago
                 h.wait()
             sl.handles = []
-            sptr = sl.stream.cuda_stream if sl.stream is not None else 0
             for ci, (lo, hi) in enumerate(self.chunks):
-                view = sl.local[lo * B:hi * B]
-                compute(lo, hi, view, sptr)
+                view = sl.views[ci]
+                if compute is None:
+                    raw, hm, fov, check = self._bound
+                    pp, cnt, op = sl.calls[ci]
+                    rc = raw(hm, pp, cnt, fov, self.num_rays, op, None, None, sl.sptr)
+                    if rc:
+                        check(rc)
+                else:
+                    compute(lo, hi, view, sl.sptr)
                 if self.gather:
-                    per = (hi - lo) * B
-                    dst = sl.gathered[ci * self.world * per:(ci + 1) * self.world * per]
-                    sl.handles.append(self.dist.all_gather_into_tensor(dst, view, async_op=True))
+                    sl.handles.append(self.dist.all_gather_into_tensor(sl.dsts[ci], view, async_op=True))
         self.last = sl
         return sl
 
