@@ -1,8 +1,8 @@
 #!/bin/bash
 # the driver's command is `bench.py --gpus 1 --steps 20 --warmup 5`: a 20-step burst, where the fill
-# and the drain of the launch pipeline are a fifth of the timed region.  Pipeline depth x grid x rays
+# and the drain of the launch pipeline are a seventh of the timed region.  Pipeline depth x grid x rays
 # per lane at that length (each point 3 runs).
-for cfg in "4 3 3" "4 3 2" "3 3 3" "3 4 3" "4 4 3" "2 4 3" "2 5 2" "3 5 2" "4 2 3" "1 8 1"; do
+for cfg in "4 3 3" "4 4 3" "4 2 3" "3 3 3" "3 4 3" "4 3 2" "2 4 3" "1 8 1"; do
   set -- $cfg
   for rep in 1 2 3; do
     python bench.py --no-cpu-baseline --steps 20 --warmup 5 --pipeline $1 --grid-mult $2 --opt slots=$3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('pipeline $1 grid_mult $2 slots $3', d['value'], d['ms_per_step'])"
