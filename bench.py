@@ -203,6 +203,12 @@ def main():
             s_.close()
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints a version banner with C stdio on stdout, which a pipe delivers at process exit —
+        # AFTER the JSON line.  While the process group lives, C-level stdout goes to stderr; it comes
+        # back (flushed) for the one line this program owes its caller.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -450,10 +456,15 @@ def main():
                                                   "r2_pmc_cfg2_slots3_final; not measured in this run)"}
         if rank == 0 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, gmap, poses_all, method, a.cpu_seconds)
+    if world > 1 or a.dist_single:
+        dist.barrier()
+        dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1 or a.dist_single:
-        dist.destroy_process_group()
 
 
 def _pmc_traffic(workload, method):
