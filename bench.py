@@ -37,7 +37,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 
 KERNEL_OF = {"RM": "rm_fan_stream_kernel", "RMGPU": "rm_fan_stream_kernel", "BL": "bl_fan_stream_kernel",
-             "GLT": "lut_fan_lds_kernel", "CDDT": "cddt_fan_kernel"}
+             "GLT": "lut_fan_lds_kernel", "CDDT": "cddt_fan_bins_kernel"}
 
 
 def parse_args():
