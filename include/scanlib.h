@@ -234,6 +234,70 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *   diagnosis  timing (1 launch sequence | 2 march kernel only), debug_stamps, drain_prio, lut_debug */
 int rl_method_set_option(rl_method *h, const char *name, int value);
 int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
+/* ---- launch planning -------------------------------------------------------------------------
+ * Which kernel, grid, LDS size and pose-binning pass a fan call of (n_poses x num_rays) takes is
+ * decided by ONE pure function of the map shape, the device's CU count and the options above —
+ * no device, no handle state: rl_plan_fan can be called (and is tested) on a box without a GPU.
+ * rl_method_plan_fan applies it with a handle's current options; every launch goes through the
+ * same function and rl_method_last_plan returns the plan the last launch of the handle used
+ * (`name` is the kernel as a rocprofv3 kernel trace prints it, template arguments included).     */
+typedef struct rl_plan_opts {
+    int variant, grid_mult, wg_threads, low_water, sort_poses, xcd_bands, slots, tiled;
+    int inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min, bin_generic;
+    int run_log2, cddt_bins, cddt_sort, lut_debug, debug_stamps, slice_log2, reserved[3];
+} rl_plan_opts;
+
+typedef enum rl_kernel_id {
+    RL_K_NONE = 0,
+    RL_K_RM_CHUNK = 1,      /* rm_fan_kernel<AUX, CRASH>: one 64-beam chunk per wave (variant 0)          */
+    RL_K_RM_STREAM = 2,     /* rm_fan_stream_kernel<AUX, CRASH, NT, INLINE, TILED, SLOTS> (default)       */
+    RL_K_OCC_LDS = 3,       /* occ_fan_lds_kernel<AUX> (variant 2)                                        */
+    RL_K_BL_STREAM = 4,     /* bl_fan_stream_kernel<AUX, 1024>                                            */
+    RL_K_BL_LDS = 5,        /* bl_fan_kernel<AUX> (variant 0)                                             */
+    RL_K_LUT_LDS = 6,       /* lut_fan_lds_kernel<NL, CH>                                                 */
+    RL_K_LUT_FAN = 7,       /* lut_fan_kernel<CH>                                                         */
+    RL_K_CDDT_BINS = 8,     /* cddt_fan_bins_kernel                                                       */
+    RL_K_CDDT_RAYS = 9      /* cddt_fan_kernel                                                            */
+} rl_kernel_id;
+
+typedef enum rl_binning {
+    RL_BIN_NONE = 0,          /* the march kernel derives the pose records of its own blocks (LDS)        */
+    RL_BIN_SMALL_KEYS = 1,    /* pose_bin_small_kernel<true>: tile order only, one workgroup              */
+    RL_BIN_SMALL_RECORDS = 2, /* pose_bin_small_kernel<false>: records in tile order, one workgroup       */
+    RL_BIN_GRID_SORT = 3,     /* pose_prep -> tile_scan_a -> tile_scan_b -> pose_scatter (grid-wide)      */
+    RL_BIN_GRID_UNSORTED = 4, /* pose_prep only (caller's order kept)                                     */
+    RL_BIN_GENERIC = 5        /* pose_bin_kernel: one workgroup, any size                                 */
+} rl_binning;
+
+typedef struct rl_launch_plan {
+    int kernel;          /* rl_kernel_id                                                                  */
+    int grid, block;     /* workgroups, threads per workgroup                                             */
+    int lds_bytes;       /* dynamic LDS per workgroup                                                     */
+    int binning;         /* rl_binning pass in front of the march (0 = none)                              */
+    int record_source;   /* RL_K_RM_STREAM: 0 records binned in HBM | 1 derived in LDS, caller's order |
+                            2 derived in LDS, row-stripe bands compacted by every workgroup |
+                            3 derived in LDS, tile order from the keys-only binning pass                  */
+    int slots;           /* rays per lane                                                                 */
+    int bands, run_log2, k_max, tiled, aux, crash;
+    int nl, ch;          /* GiantLUT: 16-B loads per lane and row, 64-beam chunks per pose                */
+    int slices;          /* > 1: the batch goes through in this many pose slices of slice_poses poses,    */
+    int slice_poses;     /*      each its own launch sequence planned like this one (for its own size)    */
+    char name[192];
+} rl_launch_plan;
+
+int rl_plan_default_opts(rl_plan_opts *out);
+/* kind: rl_kind; want_aux: hit cells / step counts requested; want_crash: fused crash test.
+ * opts_or_null = defaults.  Pure host arithmetic.                                                 */
+int rl_plan_fan(int kind, int n_cu, int rows, int cols, float max_range_px, int theta_disc,
+                const rl_plan_opts *opts_or_null, int n_poses, int num_rays, int want_aux,
+                int want_crash, rl_launch_plan *out);
+int rl_method_plan_fan(rl_method *h, int n_poses, int num_rays, int want_aux, int want_crash,
+                       rl_launch_plan *out);
+int rl_method_last_plan(rl_method *h, rl_launch_plan *out);
+/* launch contexts (per-stream scratch sets) a handle keeps: streams beyond this count are served
+ * after a device synchronisation (callers that pipeline batches stay at or below it).            */
+int rl_launch_contexts(void);
+
 /* test hook (RL_GIANT_LUT): builds the table if needed and copies rows [row0,row1) of
  * uint16 lut[row][col][theta_bin] (entry = rint(min(range_px,max_range)*65535/max_range)). */
 int rl_method_read_lut(rl_method *h, int row0, int row1, uint16_t *out);

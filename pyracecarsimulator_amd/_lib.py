@@ -24,6 +24,35 @@ i32p = C.POINTER(C.c_int32)
 u16p = C.POINTER(C.c_uint16)
 u8p = C.POINTER(C.c_uint8)
 
+
+
+class PlanOpts(C.Structure):
+    """rl_plan_opts (include/scanlib.h): the options that shape a launch."""
+    _fields_ = [(n, C.c_int) for n in (
+        "variant", "grid_mult", "wg_threads", "low_water", "sort_poses", "xcd_bands", "slots", "tiled",
+        "inline_prep", "inline_max", "inline_map_kb", "stripe_max", "order_inline", "bin_multi_min",
+        "bin_generic", "run_log2", "cddt_bins", "cddt_sort", "lut_debug", "debug_stamps", "slice_log2")] + [
+        ("reserved", C.c_int * 3)]
+
+
+class LaunchPlan(C.Structure):
+    """rl_launch_plan (include/scanlib.h)."""
+    _fields_ = [(n, C.c_int) for n in (
+        "kernel", "grid", "block", "lds_bytes", "binning", "record_source", "slots", "bands", "run_log2",
+        "k_max", "tiled", "aux", "crash", "nl", "ch", "slices", "slice_poses")] + [("name", C.c_char * 192)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "name"}
+        d["name"] = self.name.decode()
+        d["kernel"] = KERNEL_IDS.get(self.kernel, str(self.kernel))
+        d["binning"] = BINNINGS.get(self.binning, str(self.binning))
+        return d
+
+
+KERNEL_IDS = {0: "none", 1: "rm_chunk", 2: "rm_stream", 3: "occ_lds", 4: "bl_stream", 5: "bl_lds", 6: "lut_lds",
+              7: "lut_fan", 8: "cddt_bins", 9: "cddt_rays"}
+BINNINGS = {0: "none", 1: "small_keys", 2: "small_records", 3: "grid_sort", 4: "grid_unsorted", 5: "generic"}
+
 #: every symbol include/scanlib.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rl_version": (C.c_char_p, []),
@@ -82,7 +111,29 @@ SYMBOLS = {
     "rl_method_read_lut": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u16p]),
     "rl_debug_read_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "rl_probe_gather_rate": (C.c_int, [C.c_int, C.c_int, f64p, f64p, C.POINTER(C.c_int)]),
+    "rl_plan_default_opts": (C.c_int, [C.POINTER(PlanOpts)]),
+    "rl_plan_fan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(PlanOpts), C.c_int,
+                              C.c_int, C.c_int, C.c_int, C.POINTER(LaunchPlan)]),
+    "rl_method_plan_fan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LaunchPlan)]),
+    "rl_method_last_plan": (C.c_int, [C.c_void_p, C.POINTER(LaunchPlan)]),
+    "rl_launch_contexts": (C.c_int, []),
 }
+
+
+def plan_fan(kind, rows, cols, n_poses, num_rays, max_range_px=300.0, theta_disc=0, n_cu=256, aux=False,
+             crash=False, **opts):
+    """The launch plan of a fan call (rl_plan_fan: pure host arithmetic, no device needed) as a dict.
+    ``opts`` override fields of the default rl_plan_opts."""
+    o = PlanOpts()
+    check(lib().rl_plan_default_opts(C.byref(o)))
+    for k, v in opts.items():
+        if not hasattr(o, k):
+            raise KeyError("unknown plan option %r" % k)
+        setattr(o, k, int(v))
+    pl = LaunchPlan()
+    check(lib().rl_plan_fan(int(kind), int(n_cu), int(rows), int(cols), float(max_range_px), int(theta_disc),
+                            C.byref(o), int(n_poses), int(num_rays), int(bool(aux)), int(bool(crash)), C.byref(pl)))
+    return pl.as_dict()
 
 
 class ScanLibError(RuntimeError):

@@ -1,0 +1,297 @@
+// launch_plan.h — which kernel, grid, LDS size and pose-binning pass a fan call takes.
+//
+// ONE pure function of (range method, CU count, map shape, options, batch shape): no HIP call, no
+// handle state, so it is tested on a box without a GPU (tests/test_host.py, through rl_plan_fan)
+// for every BASELINE.json configuration and for the reference's own 200-pose roll-out batch
+// (/root/reference/params.yaml:126, scripts/mcts.py:214-237).  launch_fan (scanlib.hip) executes
+// exactly the plan this returns; the thresholds in here are measured optima (profiles/r03/
+// plan_sweep*.txt), not derived constants.
+#pragma once
+#include "../../include/scanlib.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace plan {
+
+// layout constants shared with scan_kernels.h (static_asserts in scanlib.hip tie them together)
+constexpr int WG = 256;                  // threads of the unit workgroup grid_mult counts in
+constexpr int STREAM_HDR = 66;           // LDS header words of the stream kernels
+constexpr int STRIPE_BINS = 64;
+constexpr int STRIPE_MAX_PER_LANE = 8;
+constexpr int INLINE_LDS_BUDGET = 56 * 1024;   // LDS an INLINE workgroup may use (two 1024-lane workgroups per CU)
+constexpr int INLINE_REC_BYTES = 26;     // per record slot: record 16 B + pose id 4 B + first step 4 B + half a block word
+
+struct In {
+    int kind = RL_RM_GPU, n_cu = 256, rows = 0, cols = 0, theta_disc = 0;
+    float max_range = 300.0f;
+    rl_plan_opts o{};
+    int n_poses = 0, num_rays = 0;
+    bool aux = false, crash = false;
+};
+
+inline void default_opts(rl_plan_opts &o)
+{
+    std::memset(&o, 0, sizeof o);
+    o.variant = 1;
+    o.grid_mult = 8;          // workgroups (x256 threads) per CU of a persistent launch
+    o.wg_threads = 1024;
+    o.low_water = 12;
+    o.sort_poses = 1;
+    o.xcd_bands = 8;
+    o.slots = 0;              // auto
+    o.tiled = 1;
+    o.inline_prep = 1;
+    o.inline_max = 512;
+    o.inline_map_kb = 2048;
+    o.stripe_max = 2560;
+    o.order_inline = 1;
+    o.bin_multi_min = 8192;
+    o.bin_generic = 0;
+    o.run_log2 = -1;
+    o.cddt_bins = 1;
+    o.cddt_sort = 0;
+    o.lut_debug = 0;
+    o.debug_stamps = 0;
+    o.slice_log2 = 30;
+}
+
+// the binning pass a batch of n_poses takes when one is needed (bin_poses in scanlib.hip)
+inline bool keys_only_ok(const rl_plan_opts &o, int n_poses)
+{
+    return o.sort_poses && n_poses >= 64 && n_poses < o.bin_multi_min && n_poses <= 8192 && !o.bin_generic;
+}
+
+inline int binning_for(const rl_plan_opts &o, int n_poses, bool keys_only)
+{
+    const bool do_sort = o.sort_poses && n_poses >= 64;
+    if (n_poses >= o.bin_multi_min) return do_sort ? RL_BIN_GRID_SORT : RL_BIN_GRID_UNSORTED;
+    if (do_sort && n_poses <= 8192 && !o.bin_generic) return keys_only ? RL_BIN_SMALL_KEYS : RL_BIN_SMALL_RECORDS;
+    return RL_BIN_GENERIC;
+}
+
+// Bresenham / occupancy window in LDS (make_bl in scanlib.hip)
+inline void bl_window(float max_range, int num_rays, int &R, int &ww, bool &use_lds, size_t &lds_bytes)
+{
+    R = (int)std::ceil(max_range) + 5;
+    ww = ((2 * R + 32 + 31) / 32) | 1;
+    const size_t win = (size_t)(2 * R + 1) * ww * sizeof(uint32_t);
+    const size_t fan = (size_t)num_rays * 8;
+    use_lds = (win + fan) <= 150 * 1024;
+    lds_bytes = fan + (use_lds ? win : 0);
+}
+
+inline const char *tf(bool b) { return b ? "true" : "false"; }
+
+inline int plan_one(const In &in, rl_launch_plan *p)
+{
+    const rl_plan_opts &o = in.o;
+    const int n_poses = in.n_poses, num_rays = in.num_rays, n_cu = in.n_cu;
+    const long rays = (long)n_poses * num_rays;
+    p->aux = in.aux;
+    p->crash = in.crash;
+    p->slots = 1;
+    p->bands = 1;
+    p->slices = 1;
+    p->slice_poses = n_poses;
+    p->tiled = o.tiled;
+    if (in.kind == RL_GIANT_LUT) {
+        p->grid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4, (long)n_cu * o.grid_mult));
+        p->block = 256;
+        const int td = in.theta_disc;
+        const int nl = (td / 2 + 255) / 256;                 // 16-B loads per lane for one row
+        const bool lds_ok = (td % 2 == 0) && nl <= 3 && num_rays <= 17 * 64 && !(o.lut_debug & 4);
+        p->ch = num_rays <= 12 * 64 ? 12 : 17;
+        if (lds_ok) {
+            p->kernel = RL_K_LUT_LDS;
+            p->nl = nl;
+            p->lds_bytes = 4 * nl * 256 * (int)sizeof(uint32_t);
+            std::snprintf(p->name, sizeof p->name, "scan::lut_fan_lds_kernel<%d, %d>", nl, p->ch);
+        } else {
+            p->kernel = RL_K_LUT_FAN;
+            std::snprintf(p->name, sizeof p->name, "scan::lut_fan_kernel<%d>", p->ch);
+        }
+        return RL_OK;
+    }
+    if (in.kind == RL_CDDT) {
+        if (o.cddt_bins && in.theta_disc <= num_rays && in.theta_disc <= 8192) {
+            // one lane per theta bin, up to 1024; the grid keeps every CU's 2048 lanes occupied
+            const int bnt = std::min(1024, ((in.theta_disc + 63) / 64) * 64);
+            p->kernel = RL_K_CDDT_BINS;
+            p->block = bnt;
+            p->grid = (int)std::max(1L, std::min((long)n_poses, (long)n_cu * (2048 / bnt)));
+            p->lds_bytes = in.theta_disc * (int)sizeof(float);
+            if (o.sort_poses && o.cddt_sort && n_poses >= 512 && p->grid >= o.xcd_bands) {
+                p->binning = binning_for(o, n_poses, keys_only_ok(o, n_poses));
+                p->bands = o.xcd_bands;
+            }
+            std::snprintf(p->name, sizeof p->name, "scan::cddt_fan_bins_kernel");
+        } else {
+            p->kernel = RL_K_CDDT_RAYS;
+            p->block = 256;
+            p->grid = (int)std::max(1L, std::min((long)n_poses, (long)n_cu * o.grid_mult));
+            std::snprintf(p->name, sizeof p->name, "scan::cddt_fan_kernel");
+        }
+        return RL_OK;
+    }
+    if (in.kind == RL_BRESENHAM) {
+        if (o.variant >= 1 && rays < (1L << 30)) {
+            // K2b: stream schedule on the cache-resident padded bit maps
+            p->kernel = RL_K_BL_STREAM;
+            p->binning = binning_for(o, n_poses, false);
+            p->bands = n_poses >= 64 ? o.xcd_bands : 1;
+            const long n_blocks = (rays + 63) / 64;
+            p->grid = (int)std::max((long)p->bands, std::min((n_blocks + 15) / 16, (long)n_cu * o.grid_mult / 4));
+            p->block = 1024;
+            p->lds_bytes = num_rays * 8 + 8;
+            std::snprintf(p->name, sizeof p->name, "scan::bl_fan_stream_kernel<%s, 1024>", tf(in.aux));
+        } else {
+            int R, ww;
+            bool use_lds;
+            size_t lds;
+            bl_window(in.max_range, num_rays, R, ww, use_lds, lds);
+            p->kernel = RL_K_BL_LDS;
+            p->grid = (int)std::max(1L, std::min((long)n_poses, (long)n_cu * 2));
+            p->block = 256;
+            p->lds_bytes = (int)lds;
+            std::snprintf(p->name, sizeof p->name, "scan::bl_fan_kernel<%s>", tf(in.aux));
+        }
+        return RL_OK;
+    }
+    // ---- ray marching (RL_RM / RL_RM_GPU)
+    const long cpp = (num_rays + 63) / 64;
+    const long n_chunks = (o.variant >= 1) ? (rays + 63) / 64 : (long)n_poses * cpp;
+    const bool stream_ok = rays < (1L << 30);
+    if (o.variant == 2) {
+        int R, ww;
+        bool use_lds;
+        size_t lds;
+        bl_window(in.max_range, num_rays, R, ww, use_lds, lds);
+        if (in.crash || !use_lds) return RL_ERR_UNSUPPORTED;
+        p->kernel = RL_K_OCC_LDS;
+        p->grid = (int)std::max(1L, std::min((long)n_poses, (long)n_cu * 2));
+        p->block = 256;
+        p->lds_bytes = (int)lds;
+        std::snprintf(p->name, sizeof p->name, "scan::occ_fan_lds_kernel<%s>", tf(in.aux));
+        return RL_OK;
+    }
+    if (!(o.variant >= 1 && stream_ok)) {
+        p->kernel = RL_K_RM_CHUNK;
+        p->grid = (int)std::max(1L, std::min((n_chunks + 3) / 4, (long)n_cu * o.grid_mult));
+        p->block = WG;
+        p->lds_bytes = num_rays * 8;
+        std::snprintf(p->name, sizeof p->name, "scan::rm_fan_kernel<%s, %s>", tf(in.aux), tf(in.crash));
+        return RL_OK;
+    }
+    // K1b.  (1) where the pose records come from, (2) the persistent grid, (3) rays per lane
+    const int bands = n_poses >= 64 ? o.xcd_bands : 1;
+    int nt = o.wg_threads;
+    const size_t fan_bytes = (size_t)num_rays * 8;
+    // small batches: no binning launch, workgroups derive the records of their own blocks ... and
+    // whenever the map sits in every XCD's L2: tile order buys nothing there
+    const bool small_map = (size_t)in.rows * in.cols * sizeof(float) <= (size_t)o.inline_map_kb * 1024;
+    bool inl = o.inline_prep && num_rays >= 64 && (small_map || (n_poses < o.inline_max && n_poses < o.bin_multi_min));
+    // big maps, mid-size batches: every workgroup compacts the poses of its own band (a row stripe
+    // of the map) from the caller's list
+    const bool stripe = o.inline_prep && num_rays >= 64 && !inl && bands > 1 && o.sort_poses && n_poses >= 64 &&
+                        n_poses <= std::min(o.stripe_max, 1024 * STRIPE_MAX_PER_LANE);
+    if (stripe) inl = true;
+    // big maps, up to 8192 poses: keys-only binning launch + INLINE march that takes its pose ids
+    // from the tile order
+    const bool order_inl = o.inline_prep && o.order_inline && num_rays >= 64 && !inl && bands > 1 &&
+                           keys_only_ok(o, n_poses);
+    if (order_inl) inl = true;
+    int k_max = 0, inl_rl = 0;
+    size_t lds_extra = 0;
+    if (inl) {
+        nt = 1024;
+        const long g_min = std::max(1L, std::min((n_chunks + 15) / 16, (long)n_cu * o.grid_mult * WG / nt) / bands);
+        const long seg_chunks_max = ((((long)n_poses + bands - 1) / bands) * num_rays + 63) / 64;
+        const long grid_i = std::max((long)bands, std::min((n_chunks + 15) / 16, std::max((long)n_cu * o.grid_mult * WG / nt, 1L)));
+        inl_rl = o.run_log2;
+        if (inl_rl < 0) {
+            inl_rl = 0;                               // (stripe batches are small: single blocks)
+            if (!stripe)
+                for (; inl_rl < 5 && ((n_chunks / grid_i) >> (inl_rl + 1)) >= 16; ++inl_rl) {}
+        }
+        const long seg_runs_max = (seg_chunks_max + (1L << inl_rl) - 1) >> inl_rl;
+        const long k_blocks = ((seg_runs_max + g_min - 1) / g_min) << inl_rl;
+        k_max = 2 * ((int)k_blocks + 1);                                 // two records per block
+        if (stripe)                                   // band list + histogram / wave counts / cuts
+            lds_extra = ((size_t)(n_poses + bands - 1) / bands + 2 + STRIPE_BINS + 3 * (nt / 64) + 4) * 4;
+        if ((size_t)k_max * INLINE_REC_BYTES + fan_bytes * (in.crash ? 2 : 1) + lds_extra + 32 + STREAM_HDR * 4 >
+            (size_t)INLINE_LDS_BUDGET)
+            inl = false;
+    }
+    if (!inl) {
+        nt = o.wg_threads;
+        p->binning = binning_for(o, n_poses, false);
+        p->record_source = 0;
+    } else if (order_inl) {
+        p->binning = binning_for(o, n_poses, true);
+        p->record_source = 3;
+    } else {
+        p->binning = RL_BIN_NONE;
+        p->record_source = stripe ? 2 : 1;
+    }
+    const int waves_per_wg = nt / 64;
+    const long want_q = (n_chunks + waves_per_wg - 1) / waves_per_wg;
+    const long cap_q = (long)n_cu * o.grid_mult * WG / nt;
+    p->grid = (int)std::max((long)bands, std::min(want_q, std::max(cap_q, 1L)));
+    p->block = nt;
+    int rl2 = o.run_log2;
+    if (rl2 < 0) {
+        const long per_wg = n_chunks / std::max(p->grid, 1);
+        for (rl2 = 0; rl2 < 5 && (per_wg >> (rl2 + 1)) >= 16; ++rl2) {}
+    }
+    p->run_log2 = inl ? inl_rl : rl2;          // (the inline LDS record table was sized for inl_rl)
+    p->bands = bands;
+    p->k_max = inl ? k_max : 0;
+    const size_t tab_floats = STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays;   // fan table (+ edge table, f64)
+    p->lds_bytes = (int)(inl ? (((tab_floats + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * INLINE_REC_BYTES + lds_extra)
+                             : tab_floats * sizeof(float));
+    const int slots = o.slots ? o.slots : (rays >= (1L << 23) ? 2 : 1);
+    bool a = in.aux, c = in.crash, t = o.tiled != 0;
+    int s = 1;
+    if (slots == 3 && !in.aux && !in.crash && !o.debug_stamps && (inl || (nt == 1024 && o.tiled))) {
+        s = 3;
+        nt = 1024;
+        if (!inl) t = true;
+    } else if (slots >= 2 && !in.aux && o.tiled && !o.debug_stamps) {
+        s = 2;
+        t = true;
+    }
+    p->kernel = RL_K_RM_STREAM;
+    p->slots = s;
+    p->tiled = t;
+    p->block = inl ? 1024 : nt;
+    std::snprintf(p->name, sizeof p->name, "scan::rm_fan_stream_kernel<%s, %s, %d, %s, %s, %d>", tf(a), tf(c),
+                  p->block, tf(inl), tf(t), s);
+    return RL_OK;
+}
+
+inline int plan_fan(const In &in, rl_launch_plan *p)
+{
+    std::memset(p, 0, sizeof *p);
+    if (in.n_poses <= 0 || in.num_rays <= 0) {
+        std::snprintf(p->name, sizeof p->name, "(nothing to launch)");
+        return RL_OK;
+    }
+    // the stream kernels index rays with 32-bit byte offsets: batches of 2^30 rays or more go
+    // through in pose slices, each its own launch sequence
+    const long slice_rays = 1L << in.o.slice_log2;
+    if ((long)in.n_poses * in.num_rays >= slice_rays && in.o.variant >= 1 && !in.crash && in.n_poses > 1) {
+        const int per = (int)std::max(1L, (slice_rays - 1) / in.num_rays);
+        In first = in;
+        first.n_poses = std::min(per, in.n_poses);
+        const int rc = plan_one(first, p);
+        p->slices = (in.n_poses + per - 1) / per;
+        p->slice_poses = per;
+        return rc;
+    }
+    return plan_one(in, p);
+}
+
+}  // namespace plan

@@ -9,6 +9,7 @@
 #include "car_kernels.h"
 #include "consumer_kernels.h"
 #include "probe_kernels.h"
+#include "launch_plan.h"
 
 #include <hip/hip_runtime.h>
 
@@ -26,6 +27,10 @@
 #include <vector>
 
 using namespace scan;
+
+static_assert(plan::WG == scan::WG && plan::STREAM_HDR == scan::STREAM_HDR && plan::STRIPE_BINS == scan::STRIPE_BINS &&
+                  plan::STRIPE_MAX_PER_LANE == scan::STRIPE_MAX_PER_LANE,
+              "launch_plan.h and scan_kernels.h disagree about the stream kernels' LDS layout");
 
 // ------------------------------------------------------------------------------
 // errors
@@ -187,7 +192,7 @@ struct LaunchCtx {
         for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg, &d0}) b->release();
     }
 };
-constexpr int N_LAUNCH_CTX = 4;
+constexpr int N_LAUNCH_CTX = 8;      // (HIP's default 4 hardware queues carry 4 concurrent streams; GPU_MAX_HW_QUEUES=8 carries 8)
 
 // A derived table (step map, GiantLUT, CDDT) is built lazily on the stream of the call that needs
 // it first; launches on OTHER streams must not start before the build has finished.
@@ -286,6 +291,7 @@ struct rl_method {
     int debug_stamps = 0;        // diagnostics: per-wave start/end stamps of the stream kernel
     int last_grid = 0;
     void *last_dbg = nullptr;    // stamps buffer of the last launch (in its context)
+    rl_launch_plan last_plan{};  // what the last fan launch of this handle was planned as (plan::plan_fan)
     std::vector<float> h_poses;
     std::mutex mu;
 };
@@ -939,16 +945,12 @@ static BlParams make_bl(const rl_method *h, int num_rays, size_t &lds_bytes)
     return bp;
 }
 
-// pose records in map-tile order (rec_sorted / order), by the binning kernel set that fits the
-// batch size; walk_outside = Bresenham semantics (origins outside the map still walk)
-static bool bin_keys_only_ok(const rl_method *h, int n_poses)
-{
-    return h->sort_poses && n_poses >= 64 && n_poses < h->bin_multi_min && n_poses <= 8192 && !h->bin_generic;
-}
-
+// pose records in map-tile order (rec_sorted / order) by the binning pass the launch plan names
+// (rl_binning, plan::binning_for); walk_outside = Bresenham semantics (origins outside the map still walk)
 static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_poses, int walk_outside,
-                     hipStream_t stream, bool keys_only = false)
+                     hipStream_t stream, int binning)
 {
+    const bool keys_only = binning == RL_BIN_SMALL_KEYS;
     const rl_map *m = h->map;
     int rc;
     // ray marching: the sample every ray of a pose takes at t = 0, read once per pose with the record
@@ -963,12 +965,12 @@ static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_po
     if ((rc = cx.order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
     if ((rc = cx.keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
     if ((rc = cx.rec_sorted.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
-    const int do_sort = (h->sort_poses && n_poses >= 64) ? 1 : 0;
+    const int do_sort = (binning == RL_BIN_GRID_UNSORTED || (binning == RL_BIN_GENERIC && !(h->sort_poses && n_poses >= 64))) ? 0 : 1;
     int shift = 6;
     while ((long)((m->cols >> shift) + 1) * ((m->rows >> shift) + 1) > 8192) ++shift;
     const int tiles_x = (m->cols >> shift) + 1;
     const int n_tiles = tiles_x * ((m->rows >> shift) + 1);
-    if (n_poses >= h->bin_multi_min) {
+    if (binning == RL_BIN_GRID_SORT || binning == RL_BIN_GRID_UNSORTED) {
         const int ppw = h->bin_ppw;
         const int n_wg = (n_poses + ppw - 1) / ppw;
         if (do_sort) {
@@ -1000,7 +1002,7 @@ static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_po
                                (uint32_t *)nullptr, n_wg, shift, tiles_x, n_tiles,
                                (uint32_t *)cx.order.p, walk_outside, ppw, d0, coeff);
         }
-    } else if (do_sort && n_poses <= 8192 && !h->bin_generic) {
+    } else if (binning == RL_BIN_SMALL_KEYS || binning == RL_BIN_SMALL_RECORDS) {
         if (keys_only)
             hipLaunchKernelGGL(pose_bin_small_kernel<true>, dim3(1), dim3(1024),
                                (size_t)(n_tiles + 1024) * sizeof(uint32_t), stream, m->mp, d_poses,
@@ -1033,30 +1035,165 @@ static FastDiv make_fastdiv(uint32_t d)
     return f;
 }
 
-// enqueue the fan kernels on `stream`; all pointers are device pointers
+// the options of a handle that shape a launch, as the planner takes them
+static rl_plan_opts opts_of(const rl_method *h)
+{
+    rl_plan_opts o;
+    plan::default_opts(o);
+    o.variant = h->variant;
+    o.grid_mult = h->grid_mult;
+    o.wg_threads = h->wg_threads;
+    o.low_water = h->low_water;
+    o.sort_poses = h->sort_poses;
+    o.xcd_bands = h->xcd_bands;
+    o.slots = h->slots;
+    o.tiled = h->tiled;
+    o.inline_prep = h->inline_prep;
+    o.inline_max = h->inline_max;
+    o.inline_map_kb = h->inline_map_kb;
+    o.stripe_max = h->stripe_max;
+    o.order_inline = h->order_inline;
+    o.bin_multi_min = h->bin_multi_min;
+    o.bin_generic = h->bin_generic;
+    o.run_log2 = h->run_log2;
+    o.cddt_bins = h->cddt_bins_kernel;
+    o.cddt_sort = h->cddt_sort;
+    o.lut_debug = h->lut_debug;
+    o.debug_stamps = h->debug_stamps;
+    o.slice_log2 = h->slice_log2;
+    return o;
+}
+
+static int plan_for(const rl_method *h, int n_poses, int num_rays, bool aux, bool crash, rl_launch_plan *out)
+{
+    plan::In in;
+    in.kind = h->kind;
+    in.n_cu = h->map->n_cu;
+    in.rows = h->map->rows;
+    in.cols = h->map->cols;
+    in.theta_disc = h->theta_disc;
+    in.max_range = h->max_range;
+    in.o = opts_of(h);
+    in.n_poses = n_poses;
+    in.num_rays = num_rays;
+    in.aux = aux;
+    in.crash = crash;
+    return plan::plan_fan(in, out);
+}
+
+// step map of a ray-marching method (the EDT padded, holding the march's step), rebuilt when the map
+// or the layout option changed
+static int ensure_step_map(rl_method *h, hipStream_t stream)
+{
+    const rl_map *m = h->map;
+    int rc;
+    if (h->pdt_epoch == m->epoch && h->pdt.p && h->pdt_tiled == h->tiled) return table_wait(h->pdt_dep, stream);
+    if (h->pdt.p) HIPCHK(hipDeviceSynchronize());   // launches of other streams may still read the old copy
+    h->pad = (int)std::ceil(h->max_range) + 2;
+    if (h->tiled) {
+        h->pad = (h->pad + 7) & ~7;                       // 128-B lines line up with the border
+        const int prow = (m->rows + 2 * h->pad + 3) & ~3;
+        const int pcol = (m->cols + 2 * h->pad + 7) & ~7;
+        h->pstride = 4 * pcol;                            // S4: bytes between rows of a 4-row group
+        const long k_elems = (long)h->pad * pcol + 4L * h->pad;
+        if ((rc = h->pdt.ensure((size_t)prow * pcol * sizeof(float)))) return rc;
+        hipLaunchKernelGGL(pad_dt_tiled_kernel, dim3((pcol + 255) / 256, prow), dim3(256), 0, stream,
+                           m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad, pcol, k_elems,
+                           h->step_coeff);
+        h->pdt_k4 = (uint32_t)(k_elems * 4);
+    } else {
+        h->pstride = (m->cols + 2 * h->pad + 31) & ~31;
+        const int prow = m->rows + 2 * h->pad;
+        if ((rc = h->pdt.ensure((size_t)prow * h->pstride * sizeof(float)))) return rc;
+        hipLaunchKernelGGL(pad_dt_kernel, dim3((h->pstride + 255) / 256, prow), dim3(256), 0,
+                           stream, m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad,
+                           h->pstride, h->step_coeff);
+        h->pdt_k4 = (uint32_t)(((size_t)h->pad * h->pstride + h->pad) * 4);
+    }
+    h->pdt_epoch = m->epoch;
+    h->pdt_tiled = h->tiled;
+    return table_built(h->pdt_dep, stream);
+}
+
+// the stream-kernel instantiation a plan names
+template <bool A, bool C, int N, bool I, bool T, int S>
+static void launch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, const PadMap &pm, const FanParams &f,
+                             const StreamParams &sp, float *d_out, int32_t *d_hits, uint16_t *d_steps,
+                             const CrashParams &cp)
+{
+    hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, N, I, T, S>), dim3(pl.grid), dim3(N), (size_t)pl.lds_bytes, stream,
+                       pm, f, sp, d_out, d_hits, d_steps, cp);
+}
+
+static int dispatch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, const PadMap &pm, const FanParams &f,
+                              const StreamParams &sp, float *d_out, int32_t *d_hits, uint16_t *d_steps,
+                              const CrashParams &cp)
+{
+    const bool inl = pl.record_source != 0, tiled = pl.tiled != 0, aux = pl.aux != 0, crash = pl.crash != 0;
+    const int nt = pl.block;
+#define RM_ARGS pl, stream, pm, f, sp, d_out, d_hits, d_steps, cp
+    if (pl.slots == 3) {                       // three rays per lane: plain ranges, 1024 lanes
+        if (!inl) launch_rm_stream<false, false, 1024, false, true, 3>(RM_ARGS);
+        else if (tiled) launch_rm_stream<false, false, 1024, true, true, 3>(RM_ARGS);
+        else launch_rm_stream<false, false, 1024, true, false, 3>(RM_ARGS);
+    } else if (pl.slots == 2) {                // two rays per lane: ranges / fused crash test, tiled step map
+#define RM_S2(C)                                                                     \
+    do {                                                                             \
+        if (inl) launch_rm_stream<false, C, 1024, true, true, 2>(RM_ARGS);           \
+        else if (nt == 1024) launch_rm_stream<false, C, 1024, false, true, 2>(RM_ARGS); \
+        else if (nt == 512) launch_rm_stream<false, C, 512, false, true, 2>(RM_ARGS);   \
+        else launch_rm_stream<false, C, 256, false, true, 2>(RM_ARGS);               \
+    } while (0)
+        if (crash) RM_S2(true); else RM_S2(false);
+#undef RM_S2
+    } else {
+#define RM_S1(A, C, T)                                                               \
+    do {                                                                             \
+        if (inl) launch_rm_stream<A, C, 1024, true, T, 1>(RM_ARGS);                  \
+        else if (nt == 1024) launch_rm_stream<A, C, 1024, false, T, 1>(RM_ARGS);     \
+        else if (nt == 512) launch_rm_stream<A, C, 512, false, T, 1>(RM_ARGS);       \
+        else launch_rm_stream<A, C, 256, false, T, 1>(RM_ARGS);                      \
+    } while (0)
+#define RM_S1_T(A, C) do { if (tiled) RM_S1(A, C, true); else RM_S1(A, C, false); } while (0)
+        if (crash) { if (aux) RM_S1_T(true, true); else RM_S1_T(false, true); }
+        else       { if (aux) RM_S1_T(true, false); else RM_S1_T(false, false); }
+#undef RM_S1_T
+#undef RM_S1
+    }
+#undef RM_ARGS
+    return RL_OK;
+}
+
+// enqueue the fan kernels on `stream`; all pointers are device pointers.  What is launched is decided by
+// plan::plan_fan (launch_plan.h); this function only executes the plan.
 static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov, int num_rays,
                       float *d_out, int32_t *d_hits, uint16_t *d_steps, const CrashParams *crash,
                       hipStream_t stream)
 {
     if (n_poses == 0) return RL_OK;
     const rl_map *m = h->map;
-    LaunchCtx *cx = nullptr;
-    {
-        int rc_ = acquire_ctx(h, stream, &cx);
-        if (rc_) return rc_;
+    const bool aux = d_hits || d_steps;
+    if (h->kind != RL_RM && h->kind != RL_RM_GPU) {
+        if (crash) return fail(RL_ERR_UNSUPPORTED, "fused crash test needs a ray-marching method");
+        if (aux && h->kind != RL_BRESENHAM)
+            return fail(RL_ERR_UNSUPPORTED, "hit cells / step counts exist only for RM and Bresenham");
     }
-    // the stream kernels index rays with 32-bit byte offsets: batches of 2^30 rays or more
-    // (4 GiB of ranges) go through in pose slices, each its own launch sequence
-    const long slice_rays = 1L << h->slice_log2;
-    if ((long)n_poses * num_rays >= slice_rays && h->variant >= 1 && !crash && n_poses > 1) {
-        const int per = (int)std::max(1L, (slice_rays - 1) / num_rays);
+    rl_launch_plan pl;
+    int rc = plan_for(h, n_poses, num_rays, aux, crash != nullptr, &pl);
+    if (rc == RL_ERR_UNSUPPORTED)
+        return fail(rc, crash ? "the fused crash test needs variant 0 or 1"
+                              : "occupancy window of max_range %g does not fit LDS", h->max_range);
+    if (rc) return fail(rc, "launch planning failed");
+    if (pl.slices > 1) {
+        // pose slices below 2^slice_log2 rays, each its own launch sequence
+        const int per = pl.slice_poses;
         const uint64_t base_off = h->ray_offset;
-        int rc = RL_OK;
         // one event pair around the whole sliced sequence (the per-slice pairs would leave the
         // last slice only)
         const int timing = h->timing;
         h->timing = 0;
         if (timing) HIPCHK(hipEventRecord(h->ev0, stream));
+        rc = RL_OK;
         for (int p0 = 0; p0 < n_poses && rc == RL_OK; p0 += per) {
             const int np = std::min(per, n_poses - p0);
             const size_t r0 = (size_t)p0 * num_rays;
@@ -1070,215 +1207,110 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         if (timing && rc == RL_OK) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
         return rc;
     }
+    LaunchCtx *cx = nullptr;
+    if ((rc = acquire_ctx(h, stream, &cx))) return rc;
+    h->last_plan = pl;
     FanParams f = make_fan(h, n_poses, fov, num_rays);
-    if (h->kind != RL_RM && h->kind != RL_RM_GPU) {
-        if (crash) return fail(RL_ERR_UNSUPPORTED, "fused crash test needs a ray-marching method");
-        if ((d_hits || d_steps) && h->kind != RL_BRESENHAM)
-            return fail(RL_ERR_UNSUPPORTED, "hit cells / step counts exist only for RM and Bresenham");
-        int rc;
-        const int pgrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * h->grid_mult));
-        if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
-        if (h->kind == RL_GIANT_LUT) {
-            if ((rc = ensure_lut(h, stream))) return rc;
-            const int lgrid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4,
-                                                         (long)m->n_cu * h->grid_mult));
-            const int td = h->theta_disc;
-            const int nl = (td / 2 + 255) / 256;                 // 16-B loads per lane for one row
-            const bool lds_ok = (td % 2 == 0) && nl <= 3 && num_rays <= 17 * 64 && !(h->lut_debug & 4);
-            if (lds_ok) {
-                const size_t lds_b = (size_t)4 * nl * 256 * sizeof(uint32_t);
-#define LAUNCH_LL(N, C)                                                                           \
-    hipLaunchKernelGGL((lut_fan_lds_kernel<N, C>), dim3(lgrid), dim3(256), lds_b, stream, m->mp, f, \
-                       h->lp, d_poses, d_out)
-                if (num_rays <= 12 * 64) { if (nl == 1) LAUNCH_LL(1, 12); else if (nl == 2) LAUNCH_LL(2, 12); else LAUNCH_LL(3, 12); }
-                else                     { if (nl == 1) LAUNCH_LL(1, 17); else if (nl == 2) LAUNCH_LL(2, 17); else LAUNCH_LL(3, 17); }
-#undef LAUNCH_LL
-            } else if (num_rays <= 12 * 64)
-                hipLaunchKernelGGL((lut_fan_kernel<12>), dim3(lgrid), dim3(256), 0, stream, m->mp, f,
-                                   h->lp, d_poses, d_out);
-            else
-                hipLaunchKernelGGL((lut_fan_kernel<17>), dim3(lgrid), dim3(256), 0, stream, m->mp, f,
-                                   h->lp, d_poses, d_out);
-        } else if (h->kind == RL_CDDT) {
-            if ((rc = ensure_cddt(h, stream))) return rc;
-            // one bucket search per (pose, theta bin) when that is fewer than one per ray
-            if (h->cddt_bins_kernel && h->theta_disc <= num_rays && h->theta_disc <= 8192) {
-                // one lane per theta bin, up to 1024; the grid keeps every CU's 2048 lanes occupied
-                const int bnt = std::min(1024, ((h->theta_disc + 63) / 64) * 64);
-                const int bgrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * (2048 / bnt)));
-                // tile-ordered poses in XCD bands: neighbouring origins hit neighbouring buckets (L2 reuse)
-                const uint32_t *d_order = nullptr;
-                int cbands = 1;
-                if (h->sort_poses && h->cddt_sort && n_poses >= 512 && bgrid >= h->xcd_bands) {
-                    if ((rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, bin_keys_only_ok(h, n_poses)))) return rc;
-                    d_order = (const uint32_t *)cx->order.p;
-                    cbands = h->xcd_bands;
-                }
-                hipLaunchKernelGGL(cddt_fan_bins_kernel, dim3(bgrid), dim3(bnt), (size_t)h->theta_disc * sizeof(float),
-                                   stream, m->mp, f, h->cdp, d_poses, d_out, d_order, cbands);
-            } else {
-                hipLaunchKernelGGL(cddt_fan_kernel, dim3(pgrid), dim3(256), 0, stream, m->mp, f, h->cdp,
-                                   d_poses, d_out);
-            }
-        } else {
-            if (h->variant >= 1 && (long)n_poses * num_rays < (1L << 30)) {
-                // K2b: stream schedule on the cache-resident bit map
-                if ((rc = ensure_blpad(h, stream))) return rc;
-                if ((rc = bin_poses(h, *cx, d_poses, n_poses, 1, stream))) return rc;
-                StreamParams sp{};
-                sp.rec = (const PoseRec *)cx->rec_sorted.p;
-                sp.order = (const uint32_t *)cx->order.p;
-                sp.div_B = make_fastdiv((uint32_t)num_rays);
-                sp.low_water = h->low_water;
-                sp.n_bands = n_poses >= 64 ? h->xcd_bands : 1;
-                const long n_blocks = ((long)n_poses * num_rays + 63) / 64;
-                const int bg = (int)std::max((long)sp.n_bands,
-                                             std::min((n_blocks + 15) / 16, (long)m->n_cu * h->grid_mult / 4));
-                const size_t lds_s = (size_t)num_rays * sizeof(float2) + 2 * sizeof(float);
-                if (d_hits || d_steps)
-                    hipLaunchKernelGGL((bl_fan_stream_kernel<true, 1024>), dim3(bg), dim3(1024), lds_s,
-                                       stream, m->mp, f, sp, h->blp, d_out, d_hits, d_steps);
-                else
-                    hipLaunchKernelGGL((bl_fan_stream_kernel<false, 1024>), dim3(bg), dim3(1024), lds_s,
-                                       stream, m->mp, f, sp, h->blp, d_out, d_hits, d_steps);
-            } else {
-                size_t lds_bl = 0;
-                BlParams bp = make_bl(h, num_rays, lds_bl);
-                if (lds_bl > 48 * 1024) {          // more dynamic LDS than the default cap: opt in
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl_fan_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl_fan_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
-                }
-                const int bgrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * 2));
-                if (d_hits || d_steps)
-                    hipLaunchKernelGGL((bl_fan_kernel<true>), dim3(bgrid), dim3(256), lds_bl, stream,
-                                       m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
-                else
-                    hipLaunchKernelGGL((bl_fan_kernel<false>), dim3(bgrid), dim3(256), lds_bl, stream,
-                                       m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
-            }
-        }
-        HIPCHK(hipGetLastError());
-        if (h->timing) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
-        return RL_OK;
-    }
-    const long cpp = (num_rays + 63) / 64;
-    const long n_chunks = (h->variant >= 1) ? ((long)n_poses * num_rays + 63) / 64   // 64-ray blocks
-                                            : (long)n_poses * cpp;                   // K1: chunks
-    long want = (n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG;
-    long cap = (long)m->n_cu * h->grid_mult;
-    int grid = (int)std::max(1L, std::min(want, cap));
-    size_t lds = (size_t)num_rays * sizeof(float2);
-    CrashParams cp{nullptr, 0.0, nullptr, 1};
-    if (crash) cp = *crash;
-    const bool aux = d_hits || d_steps;
-    const bool stream_ok = (long)n_poses * num_rays < (1L << 30);
-    if (h->timing) HIPCHK(hipEventRecord(h->ev0, stream));
-    if (h->variant == 2) {
-        // occ_fan_lds: unit-step march on an LDS-resident occupancy window (A/B partner, approximate)
-        if (crash) return fail(RL_ERR_UNSUPPORTED, "the fused crash test needs variant 0 or 1");
-        size_t lds_occ = 0;
-        BlParams bp = make_bl(h, num_rays, lds_occ);
-        if (!bp.use_lds) return fail(RL_ERR_UNSUPPORTED, "occupancy window of max_range %g does not fit LDS", h->max_range);
-        if (lds_occ > 48 * 1024) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&occ_fan_lds_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_occ));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&occ_fan_lds_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_occ));
-        }
-        const int ogrid = (int)std::max(1L, std::min((long)n_poses, (long)m->n_cu * 2));
-        if (aux)
-            hipLaunchKernelGGL((occ_fan_lds_kernel<true>), dim3(ogrid), dim3(256), lds_occ, stream, m->mp, f, bp,
-                               d_poses, d_out, d_hits, d_steps);
+    const dim3 grid(pl.grid), block(pl.block);
+    const size_t lds = (size_t)pl.lds_bytes;
+    if (h->timing == 1) HIPCHK(hipEventRecord(h->ev0, stream));
+    switch (pl.kernel) {
+    case RL_K_LUT_LDS:
+    case RL_K_LUT_FAN: {
+        if ((rc = ensure_lut(h, stream))) return rc;
+        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+#define LAUNCH_LL(N, C) hipLaunchKernelGGL((lut_fan_lds_kernel<N, C>), grid, block, lds, stream, m->mp, f, h->lp, d_poses, d_out)
+        if (pl.kernel == RL_K_LUT_LDS) {
+            if (pl.ch == 12) { if (pl.nl == 1) LAUNCH_LL(1, 12); else if (pl.nl == 2) LAUNCH_LL(2, 12); else LAUNCH_LL(3, 12); }
+            else             { if (pl.nl == 1) LAUNCH_LL(1, 17); else if (pl.nl == 2) LAUNCH_LL(2, 17); else LAUNCH_LL(3, 17); }
+        } else if (pl.ch == 12)
+            hipLaunchKernelGGL((lut_fan_kernel<12>), grid, block, 0, stream, m->mp, f, h->lp, d_poses, d_out);
         else
-            hipLaunchKernelGGL((occ_fan_lds_kernel<false>), dim3(ogrid), dim3(256), lds_occ, stream, m->mp, f, bp,
-                               d_poses, d_out, d_hits, d_steps);
-    } else if (h->variant >= 1 && stream_ok) {
+            hipLaunchKernelGGL((lut_fan_kernel<17>), grid, block, 0, stream, m->mp, f, h->lp, d_poses, d_out);
+#undef LAUNCH_LL
+        break;
+    }
+    case RL_K_CDDT_BINS: {
+        if ((rc = ensure_cddt(h, stream))) return rc;
+        // tile-ordered poses in XCD bands: neighbouring origins hit neighbouring buckets (L2 reuse)
+        const uint32_t *d_order = nullptr;
+        if (pl.binning != RL_BIN_NONE) {
+            if ((rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, pl.binning))) return rc;
+            d_order = (const uint32_t *)cx->order.p;
+        }
+        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+        hipLaunchKernelGGL(cddt_fan_bins_kernel, grid, block, lds, stream, m->mp, f, h->cdp, d_poses, d_out, d_order,
+                           pl.bands);
+        break;
+    }
+    case RL_K_CDDT_RAYS:
+        if ((rc = ensure_cddt(h, stream))) return rc;
+        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+        hipLaunchKernelGGL(cddt_fan_kernel, grid, block, 0, stream, m->mp, f, h->cdp, d_poses, d_out);
+        break;
+    case RL_K_BL_STREAM: {
+        // K2b: stream schedule on the cache-resident bit map
+        if ((rc = ensure_blpad(h, stream))) return rc;
+        if ((rc = bin_poses(h, *cx, d_poses, n_poses, 1, stream, pl.binning))) return rc;
+        StreamParams sp{};
+        sp.rec = (const PoseRec *)cx->rec_sorted.p;
+        sp.order = (const uint32_t *)cx->order.p;
+        sp.div_B = make_fastdiv((uint32_t)num_rays);
+        sp.low_water = h->low_water;
+        sp.n_bands = pl.bands;
+        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+        if (aux)
+            hipLaunchKernelGGL((bl_fan_stream_kernel<true, 1024>), grid, block, lds, stream, m->mp, f, sp, h->blp, d_out,
+                               d_hits, d_steps);
+        else
+            hipLaunchKernelGGL((bl_fan_stream_kernel<false, 1024>), grid, block, lds, stream, m->mp, f, sp, h->blp, d_out,
+                               d_hits, d_steps);
+        break;
+    }
+    case RL_K_BL_LDS:
+    case RL_K_OCC_LDS: {
+        size_t lds_bl = 0;
+        BlParams bp = make_bl(h, num_rays, lds_bl);
+        if (lds_bl > 48 * 1024) {          // more dynamic LDS than the default cap: opt in
+            const void *fa = pl.kernel == RL_K_BL_LDS ? reinterpret_cast<const void *>(&bl_fan_kernel<true>)
+                                                      : reinterpret_cast<const void *>(&occ_fan_lds_kernel<true>);
+            const void *fb = pl.kernel == RL_K_BL_LDS ? reinterpret_cast<const void *>(&bl_fan_kernel<false>)
+                                                      : reinterpret_cast<const void *>(&occ_fan_lds_kernel<false>);
+            HIPCHK(hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
+            HIPCHK(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
+        }
+        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+        if (pl.kernel == RL_K_BL_LDS) {
+            if (aux) hipLaunchKernelGGL((bl_fan_kernel<true>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+            else     hipLaunchKernelGGL((bl_fan_kernel<false>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+        } else {
+            // occ_fan_lds: unit-step march on an LDS-resident occupancy window (A/B partner, approximate)
+            if (aux) hipLaunchKernelGGL((occ_fan_lds_kernel<true>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+            else     hipLaunchKernelGGL((occ_fan_lds_kernel<false>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+        }
+        break;
+    }
+    case RL_K_RM_CHUNK: {
+        CrashParams cp{nullptr, 0.0, nullptr, 1};
+        if (crash) cp = *crash;
+        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+#define LAUNCH_CHUNK(A, C) hipLaunchKernelGGL((rm_fan_kernel<A, C>), grid, block, lds, stream, m->mp, f, d_poses, d_out, d_hits, d_steps, cp)
+        if (crash) { if (aux) LAUNCH_CHUNK(true, true); else LAUNCH_CHUNK(false, true); }
+        else       { if (aux) LAUNCH_CHUNK(true, false); else LAUNCH_CHUNK(false, false); }
+#undef LAUNCH_CHUNK
+        break;
+    }
+    case RL_K_RM_STREAM: {
         // (1) per-pose records + tile-ordered permutation, (2) banded lane-refill march
-        int rc;
+        CrashParams cp{nullptr, 0.0, nullptr, 1};
+        if (crash) cp = *crash;
         if ((rc = cx->rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
         if ((rc = cx->order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
         if ((rc = cx->keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
-        // step map of this method, rebuilt when the map (or the layout option) changed
-        if (h->pdt_epoch != m->epoch || !h->pdt.p || h->pdt_tiled != h->tiled) {
-            if (h->pdt.p) HIPCHK(hipDeviceSynchronize());   // launches of other streams may still read the old copy
-            h->pad = (int)std::ceil(h->max_range) + 2;
-            if (h->tiled) {
-                h->pad = (h->pad + 7) & ~7;                       // 128-B lines line up with the border
-                const int prow = (m->rows + 2 * h->pad + 3) & ~3;
-                const int pcol = (m->cols + 2 * h->pad + 7) & ~7;
-                h->pstride = 4 * pcol;                            // S4: bytes between rows of a 4-row group
-                const long k_elems = (long)h->pad * pcol + 4L * h->pad;
-                if ((rc = h->pdt.ensure((size_t)prow * pcol * sizeof(float)))) return rc;
-                hipLaunchKernelGGL(pad_dt_tiled_kernel, dim3((pcol + 255) / 256, prow), dim3(256), 0, stream,
-                                   m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad, pcol, k_elems,
-                                   h->step_coeff);
-                h->pdt_k4 = (uint32_t)(k_elems * 4);
-            } else {
-                h->pstride = (m->cols + 2 * h->pad + 31) & ~31;
-                const int prow = m->rows + 2 * h->pad;
-                if ((rc = h->pdt.ensure((size_t)prow * h->pstride * sizeof(float)))) return rc;
-                hipLaunchKernelGGL(pad_dt_kernel, dim3((h->pstride + 255) / 256, prow), dim3(256), 0,
-                                   stream, m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad,
-                                   h->pstride, h->step_coeff);
-                h->pdt_k4 = (uint32_t)(((size_t)h->pad * h->pstride + h->pad) * 4);
-            }
-            h->pdt_epoch = m->epoch;
-            h->pdt_tiled = h->tiled;
-            if ((rc = table_built(h->pdt_dep, stream))) return rc;
-        } else if ((rc = table_wait(h->pdt_dep, stream))) {
+        if ((rc = ensure_step_map(h, stream))) return rc;
+        if (pl.binning != RL_BIN_NONE &&
+            (rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, pl.binning)))
             return rc;
-        }
-        const int bands = n_poses >= 64 ? h->xcd_bands : 1;
-        // persistent grid: grid_mult x 256 threads per CU, whatever the workgroup size
-        int nt = h->wg_threads;
-        // small batches: skip the binning launch, workgroups derive the records of their own chunks
-        // ... and whenever the map is small enough to sit in every XCD's L2: tile order buys nothing
-        // there, so the binning launch (~9 us) is pure overhead (colombia, 4096 poses: +15 %)
-        const bool small_map = (size_t)m->rows * m->cols * sizeof(float) <= (size_t)h->inline_map_kb * 1024;
-        bool inl = h->inline_prep && num_rays >= 64 &&
-                   (small_map || (n_poses < h->inline_max && n_poses < h->bin_multi_min));
-        // (small maps: up to the ~40k poses whose records fit a workgroup's LDS, checked below)
-        // big maps, mid-size batches: still no binning launch — every workgroup compacts the poses of
-        // its own band (a row stripe of the map) from the caller's list, see stripe_band_list
-        const bool stripe = h->inline_prep && num_rays >= 64 && !inl && bands > 1 && h->sort_poses &&
-                            n_poses >= 64 && n_poses <= std::min(h->stripe_max, 1024 * STRIPE_MAX_PER_LANE);
-        if (stripe) inl = true;
-        // big maps, up to 8192 poses: a keys-only binning launch (tile order, no records) in front of
-        // an INLINE march that takes its pose ids from `order` — the per-pose sincos leaves the
-        // one-workgroup binning kernel
-        // (above 8192 poses the grid-wide binning is off the critical path and INLINE loses 2-3 %)
-        const bool order_inl = h->inline_prep && h->order_inline && num_rays >= 64 && !inl && bands > 1 &&
-                               bin_keys_only_ok(h, n_poses);
-        if (order_inl) inl = true;
-        int k_max = 0, inl_rl = 0;
-        size_t lds_extra = 0;
-        if (inl) {
-            nt = 1024;
-            const long g_min = std::max(1L, std::min((n_chunks + 15) / 16, (long)m->n_cu * h->grid_mult * WG / nt) / bands);
-            const long seg_chunks_max = ((((long)n_poses + bands - 1) / bands) * num_rays + 63) / 64;
-            // runs of 2^rl blocks (same rule as below, for the grid an INLINE launch gets)
-            const long grid_i = std::max((long)bands, std::min((n_chunks + 15) / 16, std::max((long)m->n_cu * h->grid_mult * WG / nt, 1L)));
-            inl_rl = h->run_log2;
-            if (inl_rl < 0) {
-                inl_rl = 0;                               // (stripe batches are small: single blocks)
-                if (!stripe)
-                    for (; inl_rl < 5 && ((n_chunks / grid_i) >> (inl_rl + 1)) >= 16; ++inl_rl) {}
-            }
-            const long seg_runs_max = (seg_chunks_max + (1L << inl_rl) - 1) >> inl_rl;
-            const long k_blocks = ((seg_runs_max + g_min - 1) / g_min) << inl_rl;
-            k_max = 2 * ((int)k_blocks + 1);                                 // two records per block
-            if (stripe)                                   // band list + histogram / wave counts / cuts
-                lds_extra = ((size_t)(n_poses + bands - 1) / bands + 2 + STRIPE_BINS + 3 * (nt / 64) + 4) * 4;
-            if ((size_t)k_max * 26 + lds * (crash ? 2 : 1) + lds_extra + 32 + STREAM_HDR * 4 > 56 * 1024) inl = false;
-        }
-        if (!inl) {
-            nt = h->wg_threads;
-            if ((rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream))) return rc;
-        } else if (order_inl) {
-            if ((rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, true))) return rc;
-        }
         PadMap pm{};
         pm.pdt = (const float *)h->pdt.p;
         pm.stride = h->pstride;
@@ -1294,89 +1326,27 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         if ((rc = ensure_fan_table(h, f, fov, stream, &sp.fan_tab))) return rc;
         sp.div_B = make_fastdiv((uint32_t)num_rays);
         sp.low_water = h->low_water;
-        sp.n_bands = bands;
+        sp.n_bands = pl.bands;
         sp.raw_poses = d_poses;
         sp.map = m->d_mp;
-        sp.k_max = k_max;
+        sp.k_max = pl.k_max;
         sp.drain_prio = h->drain_prio;
         sp.dbg = nullptr;
-        const int waves_per_wg = nt / 64;
-        long want_q = (n_chunks + waves_per_wg - 1) / waves_per_wg;
-        long cap_q = (long)m->n_cu * h->grid_mult * WG / nt;
-        grid = (int)std::max((long)bands, std::min(want_q, std::max(cap_q, 1L)));
+        const int waves_per_wg = pl.block / 64;
         if (h->debug_stamps) {
-            if ((rc = cx->dbg.ensure((size_t)grid * waves_per_wg * 4 * sizeof(uint64_t)))) return rc;
+            if ((rc = cx->dbg.ensure((size_t)pl.grid * waves_per_wg * 4 * sizeof(uint64_t)))) return rc;
             sp.dbg = (unsigned long long *)cx->dbg.p;
             h->last_dbg = cx->dbg.p;
         }
-        // runs of consecutive blocks keep a workgroup on one pose for a while (L1/TA locality) but
-        // coarsen the static balance: 16+ runs per workgroup, at most 32 blocks per run
-        int rl2 = h->run_log2;
-        if (rl2 < 0) {
-            const long per_wg = n_chunks / std::max(grid, 1);
-            for (rl2 = 0; rl2 < 5 && (per_wg >> (rl2 + 1)) >= 16; ++rl2) {}
-        }
-        sp.stripe = (inl && stripe) ? 1 : (inl && order_inl) ? 2 : 0;
-        sp.run_log2 = inl ? inl_rl : rl2;          // (the inline LDS record table was sized for inl_rl)
-        h->last_grid = grid * waves_per_wg / WAVES_PER_WG;
-        const size_t tab_floats = STREAM_HDR + (crash ? 4 : 2) * (size_t)num_rays;   // fan table (+ edge table, f64)
-        const size_t lds_q = inl ? (((tab_floats + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * 26 + lds_extra)   // records 16 B + ids 4 B + first steps 4 B per slot, block words 4 B per two slots
-                                 : tab_floats * sizeof(float);
+        sp.stripe = pl.record_source == 2 ? 1 : pl.record_source == 3 ? 2 : 0;
+        sp.run_log2 = pl.run_log2;
+        h->last_grid = pl.grid * waves_per_wg / WAVES_PER_WG;
         if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel alone
-#define LAUNCH_S(A, C, N, I)                                                                          \
-    do {                                                                                              \
-        if (h->tiled)                                                                                 \
-            hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, N, I, true>), dim3(grid), dim3(N), lds_q,  \
-                               stream, pm, f, sp, d_out, d_hits, d_steps, cp);                        \
-        else                                                                                          \
-            hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, N, I, false>), dim3(grid), dim3(N), lds_q, \
-                               stream, pm, f, sp, d_out, d_hits, d_steps, cp);                        \
-    } while (0)
-#define LAUNCH_S_N(A, C)                                    \
-    do {                                                    \
-        if (inl) LAUNCH_S(A, C, 1024, true);                \
-        else if (nt == 1024) LAUNCH_S(A, C, 1024, false);   \
-        else if (nt == 512) LAUNCH_S(A, C, 512, false);     \
-        else LAUNCH_S(A, C, 256, false);                    \
-    } while (0)
-        const int slots = h->slots ? h->slots : ((long)n_poses * num_rays >= (1L << 23) ? 2 : 1);
-        if (slots == 3 && !aux && !crash && !h->debug_stamps && (inl || (nt == 1024 && h->tiled))) {
-            // three rays per lane (plain ranges)
-            if (!inl)
-                hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, false, true, 3>), dim3(grid), dim3(1024),
-                                   lds_q, stream, pm, f, sp, d_out, d_hits, d_steps, cp);
-            else if (h->tiled)
-                hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, true, true, 3>), dim3(grid), dim3(1024),
-                                   lds_q, stream, pm, f, sp, d_out, d_hits, d_steps, cp);
-            else
-                hipLaunchKernelGGL((rm_fan_stream_kernel<false, false, 1024, true, false, 3>), dim3(grid), dim3(1024),
-                                   lds_q, stream, pm, f, sp, d_out, d_hits, d_steps, cp);
-        } else if (slots >= 2 && !aux && h->tiled && !h->debug_stamps) {
-            // two rays per lane: both slots' loads in flight (ranges / fused crash test on the tiled step map)
-#define LAUNCH_S2(C, N, I)                                                                                  \
-    hipLaunchKernelGGL((rm_fan_stream_kernel<false, C, N, I, true, 2>), dim3(grid), dim3(N), lds_q, stream, \
-                       pm, f, sp, d_out, d_hits, d_steps, cp)
-#define LAUNCH_S2_N(C)                                   \
-    do {                                                 \
-        if (inl) LAUNCH_S2(C, 1024, true);               \
-        else if (nt == 1024) LAUNCH_S2(C, 1024, false);  \
-        else if (nt == 512) LAUNCH_S2(C, 512, false);    \
-        else LAUNCH_S2(C, 256, false);                   \
-    } while (0)
-            if (crash) LAUNCH_S2_N(true); else LAUNCH_S2_N(false);
-#undef LAUNCH_S2_N
-#undef LAUNCH_S2
-        } else if (crash) { if (aux) LAUNCH_S_N(true, true); else LAUNCH_S_N(false, true); }
-        else       { if (aux) LAUNCH_S_N(true, false); else LAUNCH_S_N(false, false); }
-#undef LAUNCH_S_N
-#undef LAUNCH_S
-    } else {
-#define LAUNCH_CHUNK(A, C)                                                                  \
-    hipLaunchKernelGGL((rm_fan_kernel<A, C>), dim3(grid), dim3(WG), lds, stream, m->mp, f,  \
-                       d_poses, d_out, d_hits, d_steps, cp)
-        if (crash) { if (aux) LAUNCH_CHUNK(true, true); else LAUNCH_CHUNK(false, true); }
-        else       { if (aux) LAUNCH_CHUNK(true, false); else LAUNCH_CHUNK(false, false); }
-#undef LAUNCH_CHUNK
+        if ((rc = dispatch_rm_stream(pl, stream, pm, f, sp, d_out, d_hits, d_steps, cp))) return rc;
+        break;
+    }
+    default:
+        return fail(RL_ERR_INVALID, "launch plan names no kernel");
     }
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
@@ -1417,6 +1387,64 @@ static int launch_rays(rl_method *h, const float *d_ins, long n, float *d_out, i
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
     return RL_OK;
 }
+
+// ------------------------------------------------------------------------------
+// launch planning through the C ABI (pure host arithmetic: works without a device)
+// ------------------------------------------------------------------------------
+extern "C" int rl_plan_default_opts(rl_plan_opts *out)
+{
+    if (!out) return fail(RL_ERR_INVALID, "rl_plan_default_opts: null pointer");
+    plan::default_opts(*out);
+    return RL_OK;
+}
+
+extern "C" int rl_plan_fan(int kind, int n_cu, int rows, int cols, float max_range_px, int theta_disc,
+                           const rl_plan_opts *opts_or_null, int n_poses, int num_rays, int want_aux,
+                           int want_crash, rl_launch_plan *out)
+{
+    if (!out) return fail(RL_ERR_INVALID, "rl_plan_fan: null pointer");
+    if (kind < RL_BRESENHAM || kind > RL_GIANT_LUT) return fail(RL_ERR_INVALID, "unknown range method kind %d", kind);
+    if (n_cu <= 0 || rows <= 0 || cols <= 0 || n_poses < 0 || num_rays <= 0 || !(max_range_px > 0.0f))
+        return fail(RL_ERR_INVALID, "rl_plan_fan: bad shape arguments");
+    plan::In in;
+    in.kind = kind;
+    in.n_cu = n_cu;
+    in.rows = rows;
+    in.cols = cols;
+    in.max_range = max_range_px;
+    in.theta_disc = theta_disc;
+    if (opts_or_null) in.o = *opts_or_null; else plan::default_opts(in.o);
+    in.n_poses = n_poses;
+    in.num_rays = num_rays;
+    in.aux = want_aux != 0;
+    in.crash = want_crash != 0;
+    if (in.crash && kind != RL_RM && kind != RL_RM_GPU)
+        return fail(RL_ERR_UNSUPPORTED, "fused crash test needs a ray-marching method");
+    const int rc = plan::plan_fan(in, out);
+    if (rc) return fail(rc, "no kernel of this variant serves the request");
+    return RL_OK;
+}
+
+extern "C" int rl_method_plan_fan(rl_method *h, int n_poses, int num_rays, int want_aux, int want_crash,
+                                  rl_launch_plan *out)
+{
+    if (!h || !out) return fail(RL_ERR_INVALID, "rl_method_plan_fan: null pointer");
+    if (n_poses < 0 || num_rays <= 0) return fail(RL_ERR_INVALID, "rl_method_plan_fan: bad shape arguments");
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int rc = plan_for(h, n_poses, num_rays, want_aux != 0, want_crash != 0, out);
+    if (rc) return fail(rc, "no kernel of this variant serves the request");
+    return RL_OK;
+}
+
+extern "C" int rl_method_last_plan(rl_method *h, rl_launch_plan *out)
+{
+    if (!h || !out) return fail(RL_ERR_INVALID, "rl_method_last_plan: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    *out = h->last_plan;
+    return RL_OK;
+}
+
+extern "C" int rl_launch_contexts(void) { return N_LAUNCH_CTX; }
 
 extern "C" int rl_calc_range_fan_device(rl_method *h, const float *d_poses, int n_poses, float fov,
                                         int num_rays, float *d_outs, int32_t *d_hits,

@@ -276,6 +276,20 @@ class _RangeMethod:
         _lib.check(_lib.lib().rl_method_get_info(self._h, name.encode(), C.byref(v)))
         return int(v.value)
 
+    def plan_fan(self, n_poses, num_rays, aux=False, crash=False):
+        """What a fan call of this shape would launch with the handle's current options
+        (kernel with template arguments, grid, LDS, binning pass): rl_method_plan_fan."""
+        pl = _lib.LaunchPlan()
+        _lib.check(_lib.lib().rl_method_plan_fan(self._h, int(n_poses), int(num_rays), int(bool(aux)),
+                                                 int(bool(crash)), C.byref(pl)))
+        return pl.as_dict()
+
+    def last_plan(self):
+        """The plan the last fan launch of this handle executed (rl_method_last_plan)."""
+        pl = _lib.LaunchPlan()
+        _lib.check(_lib.lib().rl_method_last_plan(self._h, C.byref(pl)))
+        return pl.as_dict()
+
     def debug_stamps(self):
         """(n_waves, 4) uint64 diagnostics of the last stream-kernel launch (option debug_stamps)."""
         n = self.get_info("last_grid") * 4 * 4

@@ -213,3 +213,89 @@ def test_pyomap_ingests_an_occupancy_grid_message_like_the_reference():
     for yaw in (2.5, -3.0, -0.4, 0.0):
         g2 = maps.GridMap(g.occ, g.resolution, (0.0, 0.0, yaw), "yaw")
         assert abs(range_libc.PyOMap._ingest(occupancy_grid_msg(g2), None, None, None)[2][2] - yaw) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# launch planning (rl_plan_fan: pure host arithmetic, include/scanlib.h "launch planning")
+# ---------------------------------------------------------------------------------------------
+def _plan(kind, rows, cols, n, B, **kw):
+    return _lib.plan_fan(kind, rows, cols, n, B, **kw)
+
+
+def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch():
+    """Which kernel every BASELINE.json configuration launches, decided without a device."""
+    RM, RMGPU, CDDT, GLT, BL = _lib.RL_RM, _lib.RL_RM_GPU, _lib.RL_CDDT, _lib.RL_GIANT_LUT, _lib.RL_BRESENHAM
+    # cfg1: one pose — no binning pass, the two workgroups derive their records in LDS
+    p = _plan(RM, 2049, 2049, 1, 1081)
+    assert (p["kernel"], p["binning"], p["record_source"], p["grid"], p["bands"]) == ("rm_stream", "none", 1, 2, 1)
+    # cfg2 through the library's defaults (a lone launch): keys-only binning + INLINE march, whole machine
+    p = _plan(RMGPU, 2049, 2049, 4096, 1081)
+    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 1>"
+    assert (p["binning"], p["record_source"], p["grid"], p["block"], p["bands"]) == ("small_keys", 3, 512, 1024, 8)
+    # cfg2 the way bench.py pipelines it: three rays per lane, 0.75 workgroups per CU
+    p = _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, grid_mult=3)
+    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 3>"
+    assert (p["grid"], p["slots"], p["binning"]) == (192, 3, "small_keys")
+    assert p["lds_bytes"] <= 56 * 1024
+    # diagnostics and the fused crash test keep one or two rays per lane
+    assert _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, aux=True)["slots"] == 1
+    assert _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, crash=True)["name"] == \
+        "scan::rm_fan_stream_kernel<false, true, 1024, true, true, 2>"
+    # cfg3: GiantLUT rows of 1442 bins = 3 x 16-B loads per lane, 17 chunks of 64 beams; and the CDDT variant
+    p = _plan(GLT, 2000, 2000, 65536, 1081, theta_disc=1442)
+    assert (p["name"], p["grid"], p["block"], p["lds_bytes"]) == ("scan::lut_fan_lds_kernel<3, 17>", 2048, 256, 12288)
+    p = _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=108)
+    assert (p["kernel"], p["block"], p["grid"], p["lds_bytes"]) == ("cddt_bins", 128, 4096, 432)
+    assert _plan(CDDT, 2000, 2000, 65536, 64, theta_disc=108)["kernel"] == "cddt_rays"   # fewer beams than bins
+    # cfg4: the whole 2^20-pose batch goes through in two pose slices (32-bit ray offsets); a rank's
+    # shard in one; colombia sits in every XCD's L2, so big batches take grid-wide binning + two rays per lane
+    p = _plan(RMGPU, 350, 435, 1 << 20, 1081)
+    assert p["slices"] == 2 and p["slice_poses"] * 1081 < 1 << 30
+    p = _plan(RMGPU, 350, 435, 131072, 1081)
+    assert (p["slices"], p["binning"], p["record_source"], p["slots"], p["grid"]) == (1, "grid_sort", 0, 2, 512)
+    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, false, true, 2>"
+    # ... while a 4096-pose batch on it needs no binning at all
+    assert _plan(RMGPU, 350, 435, 4096, 1081)["binning"] == "none"
+    # cfg5: 720 beams, 4096^2
+    p = _plan(RMGPU, 4096, 4096, 262144, 720)
+    assert (p["binning"], p["slots"], p["slices"]) == ("grid_sort", 2, 1)
+    assert _plan(RMGPU, 4096, 4096, 32768, 720)["binning"] == "grid_sort"
+    # the reference's own batch: 200 roll-out poses x 1080 beams (params.yaml:126,28) — one launch, no binning
+    p = _plan(RMGPU, 350, 435, 200, 1080)
+    assert (p["kernel"], p["binning"], p["record_source"], p["slices"]) == ("rm_stream", "none", 1, 1)
+    assert p["grid"] * 16 >= 200 * 1080 // 64            # a wave per 64-ray block: nothing queues
+    # Bresenham: stream schedule with records binned; 2-arg per-ray API = fan of one beam
+    assert _plan(BL, 2049, 2049, 4096, 1081)["name"] == "scan::bl_fan_stream_kernel<false, 1024>"
+    assert _plan(RMGPU, 2049, 2049, 100000, 1)["kernel"] == "rm_stream"
+
+
+def test_launch_plan_thresholds_and_lds_budget():
+    """The planner's case boundaries on a big map, and that no plan asks for more LDS than two
+    1024-lane workgroups per CU can have."""
+    RMGPU = _lib.RL_RM_GPU
+    src = {n: _plan(RMGPU, 2049, 2049, n, 1081)["record_source"] for n in (64, 511, 512, 2560, 2561, 8191, 8192, 65536)}
+    assert src == {64: 1, 511: 1, 512: 2, 2560: 2, 2561: 3, 8191: 3, 8192: 0, 65536: 0}
+    bins = {n: _plan(RMGPU, 2049, 2049, n, 1081)["binning"] for n in (511, 2560, 2561, 8192)}
+    assert bins == {511: "none", 2560: "none", 2561: "small_keys", 8192: "grid_sort"}
+    for rows, cols in ((350, 435), (2049, 2049), (4096, 4096)):
+        for n in (1, 63, 64, 200, 512, 1000, 2560, 4096, 8191, 8192, 40000, 65536, 1 << 20):
+            for B in (64, 271, 720, 1081, 7680):
+                for kw in ({}, {"slots": 3, "grid_mult": 3}, {"slots": 2, "grid_mult": 4}, {"crash": True}, {"aux": True}):
+                    p = _plan(RMGPU, rows, cols, n, B, **kw)
+                    # (the fused crash test cannot be cut into pose slices: 2^30 rays and more keep the chunk kernel)
+                    assert p["kernel"] == ("rm_chunk" if kw.get("crash") and n * B >= 1 << 30 else "rm_stream")
+                    assert p["grid"] >= 1
+                    assert p["lds_bytes"] <= (56 if p["record_source"] else 150) * 1024, (rows, n, B, kw, p)
+                    if p["record_source"] in (2, 3):
+                        assert p["bands"] == 8
+                    if p["slots"] > 1:
+                        assert not p["aux"]
+    # options reach the plan
+    assert _plan(RMGPU, 2049, 2049, 4096, 1081, variant=0)["name"] == "scan::rm_fan_kernel<false, false>"
+    assert _plan(RMGPU, 2049, 2049, 4096, 1081, inline_prep=0)["binning"] == "small_records"
+    assert _plan(RMGPU, 2049, 2049, 4096, 1081, tiled=0, slots=2)["slots"] == 1
+    with pytest.raises(_lib.ScanLibError):
+        _plan(_lib.RL_GIANT_LUT, 100, 100, 10, 1081, theta_disc=100, crash=True)
+    with pytest.raises(KeyError):
+        _plan(RMGPU, 100, 100, 10, 1081, no_such_option=1)
+    assert _lib.lib().rl_launch_contexts() >= 4
