@@ -10,12 +10,24 @@ A "step" is one pass of the hot path over one synthetic pose batch: the fan-expa
 ``n_poses x num_rays`` rays (ScanSimulator2D.scanMany -> calc_range_many,
 /root/reference/scripts/scan_simulator.py:113-135) with poses and ranges resident in HBM.
 Consecutive steps are enqueued round robin on ``--pipeline`` streams (default: 4 for batches up to
-32768 poses) so that step k+1 fills the CUs step k's last long rays leave idle; every step is complete (and, for N>1, every
-all-gather) before the clock stops.  ``--pipeline 1`` is the strictly serial schedule.
-For N>1 every rank scans its own ``n_poses`` block (weak scaling) and the ranges are all-gathered
-over xGMI, chunk by chunk, overlapped with the marches of the following steps (BASELINE.json
-north_star); the figure for the reduced exchange (fused crash test, all-gather of the int32 crash
-indices) rides along as ``crash_mode``.
+32768 poses) so that step k+1 fills the CUs step k's last long rays leave idle — and every step in
+flight scans its OWN seeded pose batch (P distinct batches, as consecutive MCTS roll-out batches
+are); every step is complete (and, for N>1, every exchange) before the clock stops.
+``--pipeline 1`` is the strictly serial schedule.
+
+Timing: W warm-up steps, then ``--bursts`` (25) bursts of EXACTLY K steps, each bracketed by a barrier +
+device synchronisation on both sides, maximum over ranks; ``value`` is the MEDIAN burst (min / max ride
+along), so one line is not one sample of a 0.7-ms region.
+
+Verification (untimed, after the bursts): every slot's range buffer must be bit-equal to a serial,
+one-ray-per-lane launch of the same poses, and (in the cpu_baseline leg) a 64-pose subsample bit-equal
+to the CPU oracle; the line carries ``"verified": true`` and the process exits non-zero otherwise.
+
+N>1: cfg2 / cfg3 fix the poses per GPU (weak scaling); cfg4 / cfg5 shard BASELINE.json's GLOBAL batch
+(2^20 / 262144 poses / N: strong scaling); ``--poses`` always means poses per GPU.  Exchange per step
+(``--gather``): ``ranges`` = all-gather of every range over xGMI (BASELINE.json north_star, default),
+``ranges_u16`` = the same on 16-bit ranges (lossy, labelled), ``root`` = gather to rank 0 only,
+``crash`` = fused crash test + all-gather of the int32 crash indices, ``none``.
 """
 from __future__ import annotations
 
@@ -34,10 +46,9 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
-
-KERNEL_OF = {"RM": "rm_fan_stream_kernel", "RMGPU": "rm_fan_stream_kernel", "BL": "bl_fan_stream_kernel",
-             "GLT": "lut_fan_lds_kernel", "CDDT": "cddt_fan_bins_kernel"}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+XGMI_LINKS = 7               # fully connected 8-GPU node: one link per peer
+XGMI_LINK_GBS = 153.0 / 2    # ~153 GB/s per link both directions together -> per direction
 
 
 def parse_args():
@@ -45,6 +56,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=15)
+    ap.add_argument("--bursts", type=int, default=25,
+                    help="timed bursts of --steps steps; value = the median burst (fewer when one burst "
+                         "takes more than ~0.2 s)")
     ap.add_argument("--workload", default="cfg2",
                     help="cfg2 (default: 2049^2 maze, 4096x1081, RMGPU) | cfg3 | cfg4 | cfg5")
     ap.add_argument("--poses", type=int, default=0, help="poses per GPU (0 = workload default)")
@@ -59,12 +73,14 @@ def parse_args():
                          "0.75 workgroups of 1024 per CU, two rays per lane: several launches co-resident on "
                          "every CU), the library default 8 when serial")
     ap.add_argument("--chunks", type=int, default=0,
-                    help="all-gather chunks per step (N>1); 0 = auto: 1 when steps are pipelined (the gather of "
+                    help="exchange chunks per step (N>1); 0 = auto: 1 when steps are pipelined (the gather of "
                          "step k overlaps the marches of the following steps; every extra collective costs "
                          "~29 us of host time), 4 on the serial schedule (gather of chunk k overlaps march k+1)")
-    ap.add_argument("--gather", default="ranges", choices=["ranges", "crash", "none"],
+    ap.add_argument("--gather", default="ranges", choices=["ranges", "ranges_u16", "root", "crash", "none"],
                     help="N>1 exchange per step: 'ranges' (default) = all-gather of every range, 4 B/ray "
-                         "(BASELINE.json north_star); 'crash' = fused per-roll-out crash test, all-gather "
+                         "(BASELINE.json north_star); 'ranges_u16' = the same on 16-bit fixed-point ranges "
+                         "(2 B/ray, LOSSY: <= 0.11 mm at 15 m); 'root' = gather to rank 0 only (the reference's "
+                         "consumer is one MCTS process); 'crash' = fused per-roll-out crash test, all-gather "
                          "of the int32 crash indices (what MCTS.rollout consumes); 'none' = shards stay put")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--gather-every", type=int, default=8,
@@ -72,7 +88,10 @@ def parse_args():
     ap.add_argument("--no-crash-line", action="store_true",
                     help="N>1: skip the extra timed loop that measures the 'crash' exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed output verification (tuning sweeps)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the same-batch figure, the end-to-end host latencies and the gather-rate probe")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
     ap.add_argument("--opt", action="append", default=[], help="kernel option name=int (tuning)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -107,10 +126,18 @@ def make_method(range_libc, omap, w, method):
     if method == "BL":
         return range_libc.PyBresenhamsLine(omap, w.max_range_px)
     if method == "CDDT":
-        return range_libc.PyCDDTCast(omap, w.max_range_px, w.theta_disc or 108)
+        return range_libc.PyCDDTCast(omap, w.max_range_px, theta_disc_of(w, method))
     if method == "GLT":
-        return range_libc.PyGiantLUTCast(omap, w.max_range_px, w.theta_disc or 1442)
+        return range_libc.PyGiantLUTCast(omap, w.max_range_px, theta_disc_of(w, method))
     raise SystemExit("unknown method %r" % method)
+
+
+def theta_disc_of(w, method):
+    # CDDT: 108 ~ the two-player game's 112 (scripts/two_player/rcs_two_player.py:121) on an even bin count
+    # per quadrant; GiantLUT: bin spacing = beam spacing
+    if method == "CDDT":
+        return w.theta_disc if (w.theta_disc and w.method == "CDDT") else 108
+    return w.theta_disc or 1442
 
 
 def algorithmic_bytes_per_ray(method, mean_steps, num_rays, w):
@@ -128,9 +155,31 @@ def algorithmic_bytes_per_ray(method, mean_steps, num_rays, w):
     return 4.0 + pose
 
 
-def cpu_baseline(w, gmap, poses_all, method, seconds):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def oracle_flags():
+    try:
+        for line in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if line.startswith("CFLAGS"):
+                return "gcc " + line.split(":=", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(w, gmap, poses_all, method, seconds, check=None):
     """Oracle (kind "port": range_libc's CPU classes are absent from the reference mount) timed
-    on this host's cores over a bounded sample of the same poses."""
+    on this host's cores over a bounded sample of the same poses — RayMarching AND BresenhamsLine,
+    the two CPU classes BASELINE.json's north_star names.  ``check(om, O)`` (optional) runs the
+    oracle-side output verification with the oracle map this leg has loaded anyway."""
     from oracle import oracle as O
     om = O.OracleMap.from_gridmap(gmap, w.max_range_px)
     _ = om.dt
@@ -138,35 +187,60 @@ def cpu_baseline(w, gmap, poses_all, method, seconds):
     step = 1.0 if method == "RMGPU" else 0.999
     B = w.num_rays
 
-    def run(poses, nt):
+    def run(kind, poses, nt):
         t = time.perf_counter()
-        if method == "BL":
+        if kind == "BL":
             om.bl_fan(poses, w.fov, B, nthreads=nt)
         else:
-            om.rm_fan(poses, w.fov, B, step_coeff=step, nthreads=nt, want_hits=False,
-                      want_steps=False)
+            om.rm_fan(poses, w.fov, B, step_coeff=step, nthreads=nt, want_hits=False, want_steps=False)
         return time.perf_counter() - t
 
-    # 1 thread: faithful to range_libc's serial loop; bounded sample
-    n1 = min(len(poses_all), 512)
-    run(poses_all[:64], 1)
-    t1 = run(poses_all[:n1], 1)
-    rate1 = n1 * B / t1
-    # all cores: repeat the whole batch until ~seconds elapsed (threads ramp up slowly in VMs)
-    batch = poses_all[:min(len(poses_all), 16384)]
-    reps, tot, t_all = 0, 0, 0.0
-    run(batch, nthr)
-    while t_all < seconds and reps < 200:
-        t_all += run(batch, nthr)
-        tot += len(batch) * B
-        reps += 1
-    rate = tot / t_all
-    name = "BresenhamsLine" if method == "BL" else "RayMarching"
-    return {"value": round(rate / 1e6, 3), "unit": "Mrays/s", "cores": nthr, "kind": "port",
-            "sample": "%s oracle (oracle/rangelib_oracle.c, OpenMP over poses), %d x (%d poses x %d "
-                      "beams) of the same workload in %.1f s" % (name, reps, len(batch), B, t_all),
-            "single_thread_Mrays_s": round(rate1 / 1e6, 3),
-            "single_thread_sample": "%d poses x %d beams" % (n1, B)}
+    def measure(kind, secs, n1):
+        # 1 thread: faithful to range_libc's serial loop; bounded sample
+        run(kind, poses_all[:32], 1)
+        n1 = min(len(poses_all), n1)
+        t1 = run(kind, poses_all[:n1], 1)
+        # all cores: repeat a batch until ~secs elapsed (threads ramp up slowly in VMs)
+        batch = poses_all[:min(len(poses_all), 16384 if kind != "BL" else 2048)]
+        reps, tot, t_all = 0, 0, 0.0
+        run(kind, batch, nthr)
+        while t_all < secs and reps < 200:
+            t_all += run(kind, batch, nthr)
+            tot += len(batch) * B
+            reps += 1
+        return (tot / t_all / 1e6, n1 * B / t1 / 1e6,
+                "%d x (%d poses x %d beams) in %.1f s; 1 thread: %d poses" % (reps, len(batch), B, t_all, n1))
+
+    primary = "BL" if method == "BL" else "RM"
+    rate, rate1, sample = measure(primary, seconds, 512 if primary == "RM" else 64)
+    name = {"RM": "RayMarching", "BL": "BresenhamsLine"}
+    out = {"value": round(rate, 3), "unit": "Mrays/s", "cores": nthr, "kind": "port",
+           "sample": "%s oracle (oracle/rangelib_oracle.c, OpenMP over poses), %s of the same workload"
+                     % (name[primary], sample),
+           "single_thread_Mrays_s": round(rate1, 3), "cpu_model": cpu_model(), "flags": oracle_flags()}
+    other = "RM" if primary == "BL" else "BL"
+    r2, r21, s2 = measure(other, max(2.0, seconds / 3.0), 64 if other == "BL" else 512)
+    out["bresenham" if other == "BL" else "raymarching"] = {
+        "value": round(r2, 3), "unit": "Mrays/s", "cores": nthr, "single_thread": round(r21, 3),
+        "sample": "%s oracle, %s" % (name[other], s2)}
+    if check is not None:
+        out["_verification"] = check(om, O)
+    return out
+
+
+def pmc_entry(workload, method, n, plan):
+    """The committed rocprofv3 PMC pass of EXACTLY this launch shape (profiles/pmc_traffic.json), or None:
+    workload, method, poses per launch, kernel (template arguments included) and grid must all match."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            entries = json.load(f).get("entries", [])
+    except (OSError, ValueError):
+        return None
+    for e in entries:
+        if (e.get("workload") == workload and e.get("method") == method and e.get("poses") == n and
+                e.get("kernel") == plan["name"] and e.get("grid") == plan["grid"]):
+            return e
+    return None
 
 
 def main():
@@ -194,7 +268,9 @@ def main():
             a.backend = "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or a.dist_single:
+    multi = world > 1 or a.dist_single            # a process group exists
+    saved_stdout = None
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.dist_single and world == 1:
             s_ = socket.socket()
@@ -215,13 +291,13 @@ def main():
             dist.init_process_group(a.backend)
 
     w = workloads.CONFIGS[a.workload]()
-    if a.poses:
-        w.n_poses = a.poses
+    n, n_global, scaling = workloads.batch_layout(w, world, a.poses)
+    w.n_poses = n
     method = a.method or w.method
     B = w.num_rays
+    lo, _hi = workloads.shard_range(n_global, rank, world)
 
     # map: built on rank 0, broadcast over RCCL (north_star), tables built per GPU
-    multi = world > 1 or a.dist_single            # a process group exists
     gmap = w.gmap
     if multi:
         gmap = broadcast_map(w.gmap if rank == 0 else None, 0, dev)
@@ -230,43 +306,61 @@ def main():
     if a.variant >= 0:
         meth.set_option("variant", a.variant)
     if w.noise_std > 0:
-        meth.set_noise(w.noise_std, w.noise_seed, rank * w.n_poses * B)
+        meth.set_noise(w.noise_std, w.noise_seed, lo * B)    # keyed by the GLOBAL ray id: shard-invariant
+    max_range_m = w.max_range_px * gmap.resolution
 
-    # poses: one seeded global batch of world*n_poses, rank r takes block r (weak scaling)
-    dt = omap.distance_transform()
-    poses_all = workloads.make_global_poses(w, world, dt=dt)
-    lo, hi = workloads.shard_range(len(poses_all), rank, world)
-    poses = np.ascontiguousarray(poses_all[lo:hi])
-    d_poses = torch.from_numpy(poses).to(dev)
-    n = len(poses)
-
-    mode = "none" if (a.no_gather or (world == 1 and not a.dist_single)) else a.gather
-    # streams that really run concurrently (HIP maps streams onto a few hardware queues)
+    mode = "none" if (a.no_gather or not multi) else a.gather
+    crash_capable = method in ("RM", "RMGPU")
+    if mode == "crash" and not crash_capable:
+        mode = "ranges"
+    # streams that really run concurrently (HIP maps streams onto a few hardware queues); a handle keeps
+    # rl_launch_contexts() per-stream scratch sets — more streams than that would silently serialise
+    n_ctx = int(_lib.lib().rl_launch_contexts())
     P = a.pipeline if a.pipeline > 0 else (1 if (method in ("RM", "RMGPU", "BL") and n > 32768) else 4)
+    if mode == "crash":
+        P = 1                                     # the crash loop runs serially on the current stream
+    if P > n_ctx:
+        print("bench.py: --pipeline %d clamped to the library's %d launch contexts" % (P, n_ctx), file=sys.stderr)
+        P = n_ctx
     streams = concurrent_streams(P) if P > 1 else [torch.cuda.current_stream()]
     P = len(streams)
     default_gm = meth.get_info("grid_mult")
     gm = a.grid_mult or (3 if P > 1 else default_gm)
-    meth.set_option("grid_mult", gm)
-    if P > 1 and method in ("RM", "RMGPU"):
-        meth.set_option("slots", 3 if n <= 8192 else 2)   # several rays per lane: what launches in flight want
-        #                                           (three pay for small batches only, measured)
-    for kv in a.opt:
-        k, v = kv.split("=")
-        meth.set_option(k, int(v))
-    n_chunks = a.chunks or (1 if P > 1 else 4)
-    scan = ShardedScan(n, B, dev, n_chunks=n_chunks, gather=(mode == "ranges"), streams=streams,
-                       gather_single_rank=a.dist_single)
+    pipe_slots = (3 if n <= 8192 else 2) if (P > 1 and method in ("RM", "RMGPU")) else 0
 
-    # a step = meth.calc_range_fan_device(local poses -> the slot's buffer) per chunk, prepared once
-    scan.bind(meth, d_poses.data_ptr(), w.fov)
+    def apply_schedule(pipelined: bool):
+        meth.set_option("grid_mult", gm if pipelined else default_gm)
+        if method in ("RM", "RMGPU"):
+            meth.set_option("slots", pipe_slots if pipelined else 0)
+        if pipelined:
+            for kv in a.opt:
+                k, v = kv.split("=")
+                meth.set_option(k, int(v))
+
+    apply_schedule(True)
+
+    # poses: P seeded batches — every step in flight scans its own (slot k always batch k); rank r takes
+    # block r of each global batch, generated on its own GPU
+    dt = omap.distance_transform()
+    batches = [workloads.rank_poses(w, n_global, rank, world, dt=dt, seed=w.pose_seed + 7919 * k, device=local_rank)
+               for k in range(P)]
+    d_poses = [torch.from_numpy(b).to(dev) for b in batches]
+    del dt
+
+    n_chunks = a.chunks or (1 if P > 1 else 4)
+    scan = ShardedScan(n, B, dev, n_chunks=n_chunks, gather=mode in ("ranges", "ranges_u16", "root"),
+                       streams=streams, gather_single_rank=a.dist_single,
+                       mode=mode if mode in ("ranges", "ranges_u16", "root") else "ranges", root=0,
+                       max_range_m=max_range_m)
+    scan.bind(meth, [t.data_ptr() for t in d_poses], w.fov)
+    plan = meth.plan_fan(n, B)                     # what a step launches (kernel with template arguments, grid)
 
     # 'crash': the reference's consumer of a scanned batch is Car::isCrashed per roll-out
     # (scripts/racecar_simulator_v2.py:146-167); group = roll-out length (params.yaml:126 uses 200)
     group = next(gsz for gsz in range(min(200, n), 0, -1) if n % gsz == 0)
     n_groups = n // group
     crash_gather = d_edge = None
-    if multi and method in ("RM", "RMGPU"):
+    if multi and crash_capable:
         from pyracecarsimulator_amd import racecar as RC
         from pyracecarsimulator_amd.distributed import BucketedIndexGather
         edge = RC.edge_distances(B, -w.fov / 2.0, w.fov / B, 0.275, RC.DEFAULT_CAR["width"],
@@ -275,16 +369,13 @@ def main():
         # buckets of M steps, double-buffered: the (latency-bound, M x ~100 B) all-gather of bucket b
         # overlaps the marches of bucket b+1 on RCCL's stream
         crash_gather = BucketedIndexGather(n_groups, a.gather_every, dev)
-    elif mode == "crash":
-        mode = "ranges" if (world > 1 or a.dist_single) else "none"
     cur_stream = torch.cuda.current_stream().cuda_stream
 
     # untimed diagnostics launch: mean samples per ray (feeds the algorithmic-bytes figure)
-    mean_steps = 0.0
-    p99_steps = max_steps = 0.0
+    mean_steps = p99_steps = max_steps = 0.0
     if method in ("RM", "RMGPU", "BL"):
         d_steps = torch.empty(n * B, dtype=torch.int16, device=dev)
-        meth.calc_range_fan_device(d_poses.data_ptr(), n, w.fov, B, scan.local.data_ptr(),
+        meth.calc_range_fan_device(d_poses[0].data_ptr(), n, w.fov, B, scan.slots[0].local.data_ptr(),
                                    d_steps_ptr=d_steps.data_ptr(), stream=cur_stream)
         torch.cuda.synchronize()
         st = d_steps.to(torch.int32).bitwise_and(0xFFFF).float()
@@ -295,7 +386,7 @@ def main():
         del d_steps, st, sub
 
     def crash_step():
-        meth.check_collision_groups_device(d_poses.data_ptr(), n_groups, group, w.fov, B,
+        meth.check_collision_groups_device(d_poses[0].data_ptr(), n_groups, group, w.fov, B,
                                            d_edge.data_ptr(), 0.001,
                                            crash_gather.slot_view().data_ptr(),
                                            scan.slots[0].local.data_ptr(), stream=cur_stream)
@@ -306,10 +397,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step_fn, drain_fn, steps, warmup):
-        for _ in range(warmup):
-            step_fn()
-        drain_fn(None)
+    def burst(step_fn, drain_fn, steps):
+        """EXACTLY ``steps`` steps between two barrier + synchronise brackets: (wall seconds, maximum
+        over ranks; device ms per step from HIP events on the slot streams)."""
         # HIP events around the K timed steps, none between them (an event per step would put two extra
         # barrier packets between consecutive launches): one before the first step is enqueued — every
         # stream is idle, the barrier has just synchronised the device — and one per stream behind its
@@ -334,6 +424,15 @@ def main():
             el = float(t.item())
         return el, dev_ms
 
+    def timed(step_fn, drain_fn, steps, warmup, bursts):
+        """W warm-up steps, then bursts of K steps; returns the per-burst (seconds, device ms per step)."""
+        for _ in range(max(warmup, P)):             # (at least one step per slot: verification reads them all)
+            step_fn()
+        drain_fn(None)
+        first = burst(step_fn, drain_fn, steps)
+        n_b = bursts if first[0] < 0.2 else max(3, min(bursts, int(2.0 / first[0])))
+        return [first] + [burst(step_fn, drain_fn, steps) for _ in range(n_b - 1)]
+
     def scan_drain(ends):
         scan.finish(ends)
 
@@ -343,98 +442,230 @@ def main():
             for e in ends:
                 e.record()                        # (the crash loop runs on the current stream)
 
-    if mode == "crash":
-        elapsed, step_ms = timed(crash_step, crash_drain, a.steps, a.warmup)
-    else:
-        elapsed, step_ms = timed(scan.step, scan_drain, a.steps, a.warmup)
+    def summarise(runs, steps, rays_per_step):
+        els = sorted(r[0] for r in runs)
+        med = els[len(els) // 2] if len(els) % 2 else 0.5 * (els[len(els) // 2 - 1] + els[len(els) // 2])
+        devs = sorted(r[1] for r in runs)
+        dev_med = devs[len(devs) // 2]
+        v = lambda el: rays_per_step * steps / el / 1e6      # noqa: E731
+        return {"value": v(med), "min": v(els[-1]), "max": v(els[0]), "ms_per_step": med / steps * 1e3,
+                "dev_ms": dev_med, "bursts": len(els)}
 
-    if a.dist_single and world == 1 and mode == "ranges":
-        torch.cuda.synchronize()
-        if not torch.equal(scan.global_order(), scan.local):
-            raise SystemExit("dist-single: gathered ranges differ from the local ranges")
     rays_per_step = n * B * world
-    value = rays_per_step * a.steps / elapsed / 1e6
-    bpr = algorithmic_bytes_per_ray(method, mean_steps, B, w)
+    if mode == "crash":
+        apply_schedule(False)
+        runs = timed(crash_step, crash_drain, a.steps, a.warmup, a.bursts)
+        plan = meth.plan_fan(n, B, crash=True)
+    else:
+        runs = timed(scan.step, scan_drain, a.steps, a.warmup, a.bursts)
+    res = summarise(runs, a.steps, rays_per_step)
+    step_ms = res["dev_ms"]
 
+    # ---------------------------------------------------------------- verification (untimed)
+    # (1) every slot's buffer == a serial, one-ray-per-lane, whole-machine launch of the same poses;
+    # (2) N>1: what was gathered == what the ranks hold; (3) with the CPU baseline: oracle subsample.
+    verification = {}
+    ok = True
+    d_ref = None
+    if not a.no_verify and mode != "crash":
+        torch.cuda.synchronize()
+        apply_schedule(False)
+        if method in ("RM", "RMGPU"):
+            meth.set_option("slots", 1)             # (auto would take two rays per lane from 2^23 rays up)
+        d_ref = torch.empty(n * B, dtype=torch.float32, device=dev)
+        bad = []
+        for k, sl in enumerate(scan.slots):
+            meth.calc_range_fan_device(d_poses[k].data_ptr(), n, w.fov, B, d_ref.data_ptr(), stream=cur_stream)
+            torch.cuda.synchronize()
+            if not torch.equal(sl.local, d_ref):
+                bad.append((k, int((sl.local != d_ref).sum().item())))
+        ref_plan = meth.last_plan()
+        verification["slots_equal_serial_launch"] = not bad
+        verification["serial_launch"] = ref_plan["name"] + " grid %d" % ref_plan["grid"]
+        if bad:
+            ok = False
+            verification["slots_differing"] = bad
+        if scan.gather:
+            # every rank's block of what this rank gathered against the owner's local buffer: exact for
+            # 'ranges' / 'root', within the quantisation step for 'ranges_u16'
+            g_ok = True
+            for sl in scan.slots:
+                mine = sl.local.view(torch.int32).to(torch.int64).sum().reshape(1)
+                sums = torch.zeros(world, dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(sums, mine)
+                if sl.gathered is None:
+                    continue
+                g = scan.global_order(sl).view(world, -1)
+                if mode == "ranges_u16":
+                    own = g[rank]
+                    g_ok &= bool(((own - sl.local.clamp(0.0, max_range_m)).abs().max() <= max_range_m / 131070 * 1.001).item())
+                else:
+                    got = g.view(torch.int32).to(torch.int64).sum(dim=1)
+                    g_ok &= bool(torch.equal(got, sums))
+            flag = torch.tensor([1 if g_ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            verification["gathered_equals_local"] = bool(flag.item())
+            ok &= bool(flag.item())
+        apply_schedule(True)
+
+    def oracle_check(om, O):
+        """64 poses of slot 0's batch: the device ranges (noise off) bit-equal to the CPU oracle."""
+        sub = np.unique(np.linspace(0, n - 1, 64 if method != "GLT" else 16).astype(np.int64))
+        poses = np.ascontiguousarray(batches[0][sub])
+        nthr = O.max_threads()
+        got = np.empty(len(sub) * B, np.float32)
+        if w.noise_std > 0:
+            meth.set_noise(0.0, 0, 0)
+        try:
+            for pipelined in (True, False):
+                apply_schedule(pipelined)
+                meth.calc_range_fan(poses, got, w.fov, B)
+                if method in ("RM", "RMGPU"):
+                    want = om.rm_fan(poses, w.fov, B, step_coeff=1.0 if method == "RMGPU" else 0.999, nthreads=nthr,
+                                     want_hits=False, want_steps=False)[0]
+                elif method == "BL":
+                    want = om.bl_fan(poses, w.fov, B, nthreads=nthr)[0]
+                elif method == "CDDT":
+                    want = om.cddt_fan(theta_disc_of(w, method), poses, w.fov, B, nthreads=nthr)
+                else:
+                    # GiantLUT: the table (11.5 GB at cfg3) does not fit the host — the oracle's fan query reads the
+                    # DEVICE table rows of the sampled poses' cells (the table itself is pinned by tests/)
+                    td = theta_disc_of(w, method)
+                    rr, cc = om.lut_pose_cells(poses)
+                    rows = np.empty((len(sub), td), np.uint16)
+                    cache = {}
+                    for i, (r_, c_) in enumerate(zip(rr, cc)):
+                        if int(r_) not in cache:
+                            cache[int(r_)] = meth.table(int(r_), int(r_) + 1)[0]
+                        rows[i] = cache[int(r_)][int(c_)]
+                    want = om.lut_fan_rows(rows, poses, w.fov, B)
+                if not np.array_equal(got, want):
+                    return {"oracle_subsample": False, "differing_rays": int((got != want).sum())}
+            if d_ref is not None and w.noise_std <= 0:
+                # the serial full-batch launch above (== every slot's buffer) at the same poses
+                apply_schedule(False)
+                meth.calc_range_fan_device(d_poses[0].data_ptr(), n, w.fov, B, d_ref.data_ptr(), stream=cur_stream)
+                torch.cuda.synchronize()
+                rows_ = d_ref.view(n, B)[torch.from_numpy(sub).to(dev)].reshape(-1).cpu().numpy()
+                if not np.array_equal(rows_, want):
+                    return {"oracle_subsample": False, "differing_rays_full_batch": int((rows_ != want).sum())}
+        finally:
+            if w.noise_std > 0:
+                meth.set_noise(w.noise_std, w.noise_seed, lo * B)
+            apply_schedule(True)
+        return {"oracle_subsample": True,
+                "oracle_sample": "%d poses x %d beams of batch 0, bit-equal (noise off)" % (len(sub), B)}
+
+    bpr = algorithmic_bytes_per_ray(method, mean_steps, B, w)
+    slots_now = meth.get_info("slots") if method in ("RM", "RMGPU") else 0
     out = {
         "metric": "million rays/sec, 1081-beam scans" if B == 1081 else
                   "million rays/sec, %d-beam scans" % B,
-        "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "value": round(res["value"], 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(res["ms_per_step"], 4),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (seeded maze + seeded free-space poses; maps/map.pgm is missing from "
                 "the reference mount)" if "maze" in gmap.name else "reference map fixture + " + w.pose_note,
         "config": {"workload": w.describe(), "method": method, "poses_per_gpu": n,
-                   "global_poses": n * world, "num_rays": B, "fov": w.fov,
+                   "global_poses": n_global, "num_rays": B, "fov": w.fov,
                    "max_range_px": w.max_range_px, "map": "%dx%d" % (gmap.rows, gmap.cols),
                    "parallelism": "pose-batch dp%d" % world,
-                   "pipeline": "%d steps in flight on %d concurrent streams, grid_mult %d%s" % (
-                       P, P, gm, ", %d rays per lane" % (3 if n <= 8192 else 2) if method in ("RM", "RMGPU") else "")
-                               if P > 1 else "serial (one stream), grid_mult %d" % gm,
+                   "pose_batches": "%d distinct seeded batches, one per step in flight" % P,
+                   "pipeline": ("%d steps in flight on %d concurrent streams, grid_mult %d%s" % (
+                       P, P, meth.get_info("grid_mult"), ", %d rays per lane" % plan["slots"] if method in ("RM", "RMGPU") else "")
+                                if P > 1 else "serial (one stream), grid_mult %d" % meth.get_info("grid_mult")),
+                   "kernel": plan["name"], "grid": plan["grid"], "block": plan["block"], "binning": plan["binning"],
                    "gather": {"none": "none",
                               "ranges": "all-gather ranges (4 B/ray), %d chunks per step, overlapped with "
                                         "the following steps' marches" % len(scan.chunks),
+                              "ranges_u16": "all-gather of 16-bit fixed-point ranges (2 B/ray, LOSSY: <= %.3g mm), "
+                                            "%d chunks per step" % (max_range_m / 131070 * 1e3, len(scan.chunks)),
+                              "root": "gather of the ranges (4 B/ray) to rank 0 only, %d chunks per step" % len(scan.chunks),
                               "crash": "fused crash test per %d-pose roll-out, all-gather of int32 "
                                        "crash indices in buckets of %d steps" % (group, max(1, a.gather_every))}[mode]},
+        "bursts": res["bursts"], "value_min": round(res["min"], 2), "value_max": round(res["max"], 2),
+        "value_is": "median of %d bursts of %d steps, each bracketed by barrier + device synchronisation" % (
+            res["bursts"], a.steps),
         "step_ms_avg": round(step_ms, 4),
         "mean_samples_per_ray": round(mean_steps, 3), "p99_samples_per_ray": round(p99_steps, 1),
         "max_samples_per_ray": round(max_steps, 1),
     }
+    del slots_now
     if multi:
         out["rccl_world"] = world
-        out["gather_bytes_per_step"] = {"ranges": 4 * n * B * world, "crash": 4 * n_groups * world,
-                                        "none": 0}[mode]
+        per_rank = n * B
+        gb = {"ranges": 4 * per_rank * world, "ranges_u16": 2 * per_rank * world, "root": 4 * per_rank * world,
+              "crash": 4 * n_groups * world, "none": 0}[mode]
+        out["gather_bytes_per_step"] = gb
+        # xGMI: what one GPU must RECEIVE per step (the busiest one: every GPU for an all-gather, rank 0 for
+        # 'root') against 7 links x per-direction link rate
+        ingress = {"ranges": 4 * per_rank * (world - 1), "ranges_u16": 2 * per_rank * (world - 1),
+                   "root": 4 * per_rank * (world - 1), "crash": 4 * n_groups * (world - 1), "none": 0}[mode]
+        links = min(XGMI_LINKS, max(world - 1, 1))
+        peak = links * XGMI_LINK_GBS
+        ach = ingress / (res["ms_per_step"] * 1e-3) / 1e9
+        out["roofline_xgmi"] = {"bound": "xgmi", "ingress_bytes_per_gpu_per_step": ingress,
+                                "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "GB/s",
+                                "frac": round(ach / peak, 5),
+                                "peak_is": "%d peer links x %.1f GB/s per direction (~153 GB/s per link both ways)" % (
+                                    links, XGMI_LINK_GBS),
+                                "floor_ms_per_step": round(ingress / (peak * 1e9) * 1e3, 4),
+                                "measured_on": "same-device dry run (no xGMI)" if a.same_device else (
+                                    "one rank (no peer)" if world == 1 else "%d GPUs" % world)}
         if crash_gather is not None and mode != "crash" and not a.no_crash_line:
-            # the reduced exchange on the same poses, serial schedule (its own timed loop)
+            # the reduced exchange on batch 0, serial schedule (its own timed loop)
             k2 = max(10, a.steps // 4)
-            meth.set_option("grid_mult", default_gm)
-            meth.set_option("slots", 0)
-            el2, _ = timed(crash_step, crash_drain, k2, min(a.warmup, 5))
-            out["crash_mode"] = {"value": round(rays_per_step * k2 / el2 / 1e6, 2), "unit": "Mrays/s",
-                                 "ms_per_step": round(el2 / k2 * 1e3, 4), "steps": k2,
+            apply_schedule(False)
+            runs2 = timed(crash_step, crash_drain, k2, min(a.warmup, 5), min(a.bursts, 7))
+            r2 = summarise(runs2, k2, rays_per_step)
+            apply_schedule(True)
+            out["crash_mode"] = {"value": round(r2["value"], 2), "unit": "Mrays/s",
+                                 "ms_per_step": round(r2["ms_per_step"], 4), "steps": k2, "bursts": r2["bursts"],
                                  "gather_bytes_per_step": 4 * n_groups * world,
+                                 "schedule": "serial (one stream), grid_mult %d" % default_gm,
                                  "what": "fused crash test per %d-pose roll-out, all-gather of the int32 crash "
                                          "indices in buckets of %d steps" % (group, max(1, a.gather_every))}
-    if world == 1:
+    if world == 1 and mode != "crash":
         # the dominant kernel.  `achieved` prices the ALGORITHMIC bytes of one launch against the time one
-        # launch takes out of the timed region (HIP events around the K steps / K): with P launches in
-        # flight that is the machine time a launch costs, not its begin-to-end span (a kernel trace shows
-        # each launch ~P x longer, P of them overlapping).  `serial` is the same kernel alone on an idle
-        # machine (library events around the march kernel on extra steps AFTER the timed region — a pair
-        # of event records per launch costs ~12 us, so it stays out of `value`): the duration a kernel
+        # launch takes out of the timed region (HIP events around the K steps / K, median burst): with P
+        # launches in flight that is the machine time a launch costs, not its begin-to-end span (a kernel
+        # trace shows each launch ~P x longer, P of them overlapping).  `serial` is the same kernel alone on
+        # an idle machine (library events around the march kernel on extra steps AFTER the timed region — a
+        # pair of event records per launch costs ~12 us, so it stays out of `value`): the duration a kernel
         # trace of `--pipeline 1` reports.
-        eff_ms = step_ms
-        achieved = bpr * n * B / (eff_ms * 1e-3) / 1e9
-        meth.set_option("grid_mult", default_gm)
-        if method in ("RM", "RMGPU"):
-            meth.set_option("slots", 0)
+        achieved = bpr * n * B / (step_ms * 1e-3) / 1e9
+        apply_schedule(False)
         meth.set_option("timing", 2)
         ks = []
-        solo_out = scan.slots[0].local
-        for _ in range(min(a.steps, 30)):
-            meth.calc_range_fan_device(d_poses.data_ptr(), n, w.fov, B, solo_out.data_ptr(), stream=cur_stream)
+        solo_out = d_ref if d_ref is not None else torch.empty(n * B, dtype=torch.float32, device=dev)
+        for _ in range(min(max(a.steps, 10), 30)):
+            meth.calc_range_fan_device(d_poses[0].data_ptr(), n, w.fov, B, solo_out.data_ptr(), stream=cur_stream)
             ks.append(meth.last_kernel_ms())
+        solo_plan = meth.last_plan()
         meth.set_option("timing", 0)
-        meth.set_option("grid_mult", gm)
-        if P > 1 and method in ("RM", "RMGPU"):
-            meth.set_option("slots", 3 if n <= 8192 else 2)
-        k_ms = float(np.mean(ks))
+        apply_schedule(True)
+        k_ms = float(np.median(ks))
         serial_ach = bpr * n * B / (k_ms * 1e-3) / 1e9
-        out["kernel_ms_avg"] = round(eff_ms, 4)
+        pe = pmc_entry(a.workload, method, n, plan)
+        traffic = pe["bytes"] if pe else None
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                           "traffic": _pmc_traffic(a.workload, method),
-                           "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes, committed; "
-                                             "not measured in this run)",
-                           "bytes_per_ray": round(bpr, 3), "kernel": KERNEL_OF[method],
-                           "launch_ms": round(eff_ms, 4), "launches_in_flight": P,
-                           "serial": {"kernel_ms": round(k_ms, 4), "achieved": round(serial_ach, 2),
+                           "traffic": traffic,
+                           "measured_hbm_gbs": round(traffic / (step_ms * 1e-3) / 1e9, 1) if traffic else None,
+                           "traffic_source": (pe["profile"] + " (rocprofv3 --pmc passes of this kernel, grid and batch "
+                                              "size, committed; not measured in this run)") if pe else
+                                             "no committed PMC pass matches this launch shape",
+                           "bytes_per_ray": round(bpr, 3), "kernel": plan["name"], "grid": plan["grid"],
+                           "launch_ms": round(step_ms, 4), "launches_in_flight": P,
+                           "serial": {"kernel": solo_plan["name"], "grid": solo_plan["grid"],
+                                      "kernel_ms": round(k_ms, 4), "achieved": round(serial_ach, 2),
                                       "frac": round(serial_ach / HBM_PEAK_GBS, 5),
-                                      "what": "the march kernel alone on an idle machine (grid_mult %d)" % default_gm}}
-        if method in ("RM", "RMGPU") and mean_steps > 0:
+                                      "what": "the march kernel alone on an idle machine (grid_mult %d), median of %d"
+                                              % (default_gm, len(ks))}}
+        if method in ("RM", "RMGPU") and mean_steps > 0 and not a.no_extras:
             # the kernel's real limiters, next to the contractual HBM object.  (1) the CU's scattered-gather
             # rate, probed in this run; (2) VALU issue: wave-level VALU instructions per launch (rocprofv3
-            # SQ_INSTS_VALU of the several-rays-per-lane kernel, committed) x 4 clocks each on 4 SIMDs per CU
+            # SQ_INSTS_VALU of exactly this launch shape, committed) x 4 clocks each on 4 SIMDs per CU
             lanes, clk, ncu = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int(0)
             _lib.check(_lib.lib().rl_probe_gather_rate(local_rank, 46, ctypes.byref(lanes), ctypes.byref(clk),
                                                         ctypes.byref(ncu)))
@@ -442,21 +673,63 @@ def main():
             # gathered samples: the statement's count less the t = 0 sample of every ray, which the kernel
             # reads once per pose with the pose record (pose_first_step)
             samples = max(mean_steps - 1.0, 0.0) * n * B
-            out["roofline_gather"] = {"achieved_samples_per_s": round(samples / (eff_ms * 1e-3), 1),
-                                      "peak": round(peak, 1), "frac": round(samples / (eff_ms * 1e-3) / peak, 5),
+            out["roofline_gather"] = {"achieved_samples_per_s": round(samples / (step_ms * 1e-3), 1),
+                                      "peak": round(peak, 1), "frac": round(samples / (step_ms * 1e-3) / peak, 5),
                                       "serial_frac": round(samples / (k_ms * 1e-3) / peak, 5),
                                       "probe": "%.2f active lanes/clk/CU x %d CUs x %.2f GHz (rl_probe_gather_rate, "
                                                "46 random lanes, this run)" % (lanes.value, ncu.value, clk.value / 1e9)}
-            valu = _pmc_traffic(a.workload, method + "/valu_insts")
-            if valu and P > 1 and n == workloads.CONFIGS[a.workload]().n_poses:
-                floor_ms = valu * 4.0 / (4 * ncu.value * clk.value) * 1e3
-                out["roofline_valu"] = {"wave_valu_insts_per_launch": valu, "floor_ms": round(floor_ms, 5),
-                                        "frac": round(floor_ms / eff_ms, 5),
-                                        "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU, profiles/r02/"
-                                                  "r2_pmc_cfg2_slots3_final; not measured in this run)"}
-        if rank == 0 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, gmap, poses_all, method, a.cpu_seconds)
-    if world > 1 or a.dist_single:
+            if pe and pe.get("valu_insts"):
+                floor_ms = pe["valu_insts"] * 4.0 / (4 * ncu.value * clk.value) * 1e3
+                out["roofline_valu"] = {"wave_valu_insts_per_launch": pe["valu_insts"], "floor_ms": round(floor_ms, 5),
+                                        "frac": round(floor_ms / step_ms, 5),
+                                        "lanes_per_valu_inst": pe.get("lanes_per_valu"),
+                                        "source": pe["profile"] + " (SQ_INSTS_VALU; not measured in this run)"}
+        if not a.no_extras and P > 1:
+            # the same schedule with every step in flight scanning the SAME batch (what round 2 measured):
+            # quantifies what identical cache lines in identical order are worth
+            scan.bind(meth, [d_poses[0].data_ptr()] * P, w.fov)
+            sb = summarise(timed(scan.step, scan_drain, a.steps, min(a.warmup, 5), min(a.bursts, 9)), a.steps,
+                           rays_per_step)
+            scan.bind(meth, [t.data_ptr() for t in d_poses], w.fov)
+            out["same_batch"] = {"value": round(sb["value"], 2), "ms_per_step": round(sb["ms_per_step"], 4),
+                                 "bursts": sb["bursts"],
+                                 "what": "all %d steps in flight scan batch 0 (not the reported configuration)" % P}
+        if not a.no_extras and method in ("RM", "RMGPU"):
+            # what the reference's callers see: numpy in -> numpy out through ScanSimulator2D
+            # (scripts/scan_simulator.py:88-135), scan() = the sim tick, scanMany(200) = one MCTS roll-out
+            from pyracecarsimulator_amd import ScanSimulator2D
+            sim = ScanSimulator2D(B, w.fov, 0.01, batch_size=min(200, n))
+            sim.setMap(omap, w.max_range_px, gmap.resolution, gmap.origin)
+            sim.setRaytracingMethod(method)
+            hp = batches[0][:sim.batch_size]
+            ts_one, ts_many = [], []
+            for i in range(60):
+                t0 = time.perf_counter()
+                sim.scan(float(hp[i % len(hp), 0]), float(hp[i % len(hp), 1]), float(hp[i % len(hp), 2]))
+                ts_one.append(time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                sim.scanMany(hp)
+                ts_many.append(time.perf_counter() - t0)
+            out["end_to_end"] = {"scan_us": round(float(np.median(ts_one[10:])) * 1e6, 1),
+                                 "scanMany_%d_us" % sim.batch_size: round(float(np.median(ts_many[10:])) * 1e6, 1),
+                                 "what": "host wall clock, numpy in -> numpy out through ScanSimulator2D "
+                                         "(PCIe and launch latency included), median of 50"}
+            sim.scan_method.close()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and mode != "crash":
+        cb = cpu_baseline(w, gmap, batches[0], method, a.cpu_seconds,
+                          check=None if a.no_verify else oracle_check)
+        v = cb.pop("_verification", None)
+        if v is not None:
+            verification.update(v)
+            ok &= bool(v.get("oracle_subsample"))
+        out["cpu_baseline"] = cb
+    elif not a.no_verify:
+        verification.setdefault("oracle_subsample", "not run (the oracle is loaded by the cpu_baseline leg only: "
+                                                    "rank 0 of a 1-GPU run without --no-cpu-baseline)")
+    if not a.no_verify and mode != "crash":
+        out["verified"] = bool(ok)
+        out["verification"] = verification
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
         ctypes.CDLL(None).fflush(None)
@@ -465,16 +738,9 @@ def main():
         os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
-
-
-def _pmc_traffic(workload, method):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*.json), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(p) as f:
-            return json.load(f).get("%s/%s" % (workload, method))
-    except (OSError, ValueError):
-        return None
+    if not a.no_verify and mode != "crash" and not ok:
+        print("bench.py: output verification FAILED: %s" % json.dumps(verification), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

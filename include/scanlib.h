@@ -307,6 +307,18 @@ int rl_method_read_lut(rl_method *h, int row0, int row1, uint16_t *out);
  * returns the number of words copied (>= 0) or a negative rl_status.                       */
 int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words);
 
+/* ---- 16-bit ranges for the multi-GPU exchange (opt-in, LOSSY) ---------------------------------
+ * The all-gather of ranges BASELINE.json's north_star names moves 4 B per ray over xGMI; these two
+ * streaming passes let a caller exchange 2 B per ray instead: q = rint(clamp(r, 0, max) * 65535 / max),
+ * r' = q * max / 65535.  Error <= max/131070 (0.11 mm at the reference's 15 m, params.yaml:39) —
+ * inside north_star's one-cell tolerance, but NOT bit-exact: only bench.py --gather ranges_u16 and
+ * distributed.ShardedScan(mode="ranges_u16") use them, and both label their results.
+ * Device pointers, 16-byte aligned; asynchronous on hip_stream.                                    */
+int rl_ranges_to_u16_device(int device, const float *d_ranges, size_t n, float max_range_m,
+                            uint16_t *d_out_u16, void *hip_stream);
+int rl_ranges_from_u16_device(int device, const uint16_t *d_in_u16, size_t n, float max_range_m,
+                              float *d_ranges, void *hip_stream);
+
 /* diagnostics: how fast a CU of this device retires a wave-wide global_load_dword whose
  * `active_lanes` live lanes read unrelated cells of a cache-resident table — the instruction the
  * ray-marching kernels are bound by (tools/probes/tcp_probe3.hip is the same

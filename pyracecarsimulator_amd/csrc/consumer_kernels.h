@@ -107,4 +107,53 @@ __global__ __launch_bounds__(64) void followgap_kernel(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------
+// Ranges as 16-bit fixed point for the multi-GPU exchange (opt-in, LOSSY, labelled wherever it is used):
+// q = rint(clamp(r, 0, max) * 65535 / max), r' = q * max / 65535 — half the bytes of the all-gather of
+// ranges over xGMI (BASELINE.json north_star) at max/65535/2 = 0.11 mm of error for the reference's 15 m
+// lidar (params.yaml:39), three orders of magnitude inside north_star's one-cell (50 mm) tolerance.
+// HBM-bound streaming passes: 8 ranges per lane and trip (two 16-B loads, one 16-B store).
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ranges_to_u16_kernel(const float *__restrict__ r, size_t n, float max_m,
+                                                            float scale, uint16_t *__restrict__ q)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            const float4 a = *reinterpret_cast<const float4 *>(r + i);
+            const float4 b = *reinterpret_cast<const float4 *>(r + i + 4);
+            auto cv = [&](float v) { return (uint32_t)__builtin_rintf(__builtin_fminf(__builtin_fmaxf(v, 0.0f), max_m) * scale); };
+            uint4 o;
+            o.x = cv(a.x) | (cv(a.y) << 16);
+            o.y = cv(a.z) | (cv(a.w) << 16);
+            o.z = cv(b.x) | (cv(b.y) << 16);
+            o.w = cv(b.z) | (cv(b.w) << 16);
+            *reinterpret_cast<uint4 *>(q + i) = o;
+        } else {
+            for (size_t k = i; k < n; ++k)
+                q[k] = (uint16_t)__builtin_rintf(__builtin_fminf(__builtin_fmaxf(r[k], 0.0f), max_m) * scale);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ranges_from_u16_kernel(const uint16_t *__restrict__ q, size_t n, float inv_scale,
+                                                              float *__restrict__ r)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(q + i);
+            float4 a, b;
+            a.x = (float)(v.x & 0xffffu) * inv_scale; a.y = (float)(v.x >> 16) * inv_scale;
+            a.z = (float)(v.y & 0xffffu) * inv_scale; a.w = (float)(v.y >> 16) * inv_scale;
+            b.x = (float)(v.z & 0xffffu) * inv_scale; b.y = (float)(v.z >> 16) * inv_scale;
+            b.z = (float)(v.w & 0xffffu) * inv_scale; b.w = (float)(v.w >> 16) * inv_scale;
+            *reinterpret_cast<float4 *>(r + i) = a;
+            *reinterpret_cast<float4 *>(r + i + 4) = b;
+        } else {
+            for (size_t k = i; k < n; ++k) r[k] = (float)q[k] * inv_scale;
+        }
+    }
+}
+
 }  // namespace scan

@@ -2033,6 +2033,44 @@ extern "C" int rl_followgap_eval_device(rl_followgap *g, const float *d_scans, i
     return followgap_launch(g, d_scans, n_scans, size, d_angles, (hipStream_t)hip_stream);
 }
 
+// ---------------------------------------------------------------- 16-bit ranges for the xGMI exchange (opt-in, lossy)
+static int u16_args(int device, size_t n, float max_range_m, const void *a, const void *b)
+{
+    if (!(max_range_m > 0.0f)) return fail(RL_ERR_INVALID, "max_range_m must be > 0");
+    if (n > 0 && (!a || !b)) return fail(RL_ERR_INVALID, "null device pointer");
+    if (n > 0 && (((uintptr_t)a | (uintptr_t)b) & 15)) return fail(RL_ERR_INVALID, "device buffers must be 16-byte aligned");
+    int ndev = rl_device_count();
+    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    return RL_OK;
+}
+
+extern "C" int rl_ranges_to_u16_device(int device, const float *d_ranges, size_t n, float max_range_m,
+                                       uint16_t *d_out, void *hip_stream)
+{
+    int rc = u16_args(device, n, max_range_m, d_ranges, d_out);
+    if (rc || n == 0) return rc;
+    HIPCHK(hipSetDevice(device));
+    const int grid = (int)std::min<size_t>((n / 8 + 255) / 256 + 1, 256 * 16);
+    hipLaunchKernelGGL(ranges_to_u16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_ranges, n,
+                       max_range_m, 65535.0f / max_range_m, d_out);
+    HIPCHK(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_ranges_from_u16_device(int device, const uint16_t *d_in, size_t n, float max_range_m,
+                                         float *d_ranges, void *hip_stream)
+{
+    int rc = u16_args(device, n, max_range_m, d_in, d_ranges);
+    if (rc || n == 0) return rc;
+    HIPCHK(hipSetDevice(device));
+    const int grid = (int)std::min<size_t>((n / 8 + 255) / 256 + 1, 256 * 16);
+    hipLaunchKernelGGL(ranges_from_u16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_in, n,
+                       max_range_m / 65535.0f, d_ranges);
+    HIPCHK(hipGetLastError());
+    return RL_OK;
+}
+
 // ---------------------------------------------------------------- diagnostics: gather-rate probe
 extern "C" int rl_probe_gather_rate(int device, int active_lanes, double *lanes_per_clk_per_cu,
                                     double *clock_hz, int *n_cu_out)

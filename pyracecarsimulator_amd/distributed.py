@@ -9,7 +9,11 @@ north_star names:
 * per batch: all-gather of the ranges, issued per CHUNK of the local pose block so that the
   gather of chunk k runs on RCCL's stream while the march kernel of chunk k+1 runs on the
   compute stream (xGMI is point-to-point: a ring all-gather is per-link bound, and for
-  4 B/ray it costs more than the kernel, so overlap is what matters).
+  4 B/ray it costs more than the kernel, so overlap is what matters).  Exchange modes
+  (``ShardedScan(mode=...)``): ``"ranges"`` the float32 all-gather north_star names;
+  ``"ranges_u16"`` the same collective on 16-bit fixed-point ranges (half the bytes, LOSSY:
+  <= 0.11 mm at 15 m, opt-in and labelled); ``"root"`` a gather to ONE consumer rank (the
+  reference's consumer is a single MCTS process: 7/8 of the GPUs then receive nothing).
 
 The reference has no collective anywhere (single process, single GPU: SURVEY §2.1).
 """
@@ -58,7 +62,8 @@ def chunk_bounds(n_local: int, n_chunks: int):
 
 
 class _Slot:
-    __slots__ = ("local", "gathered", "stream", "handles", "views", "dsts", "calls", "sptr")
+    __slots__ = ("local", "gathered", "stream", "handles", "views", "dsts", "calls", "sptr", "local_q",
+                 "gathered_q", "views_q", "dsts_q", "dst_lists", "decoded")
 
 
 class ShardedScan:
@@ -76,7 +81,8 @@ class ShardedScan:
     """
 
     def __init__(self, n_local: int, num_rays: int, device, n_chunks: int = 4, gather=True,
-                 depth: int = 1, streams=None, gather_single_rank: bool = False):
+                 depth: int = 1, streams=None, gather_single_rank: bool = False, mode: str = "ranges",
+                 root: int = 0, max_range_m: float = 15.0):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -84,6 +90,10 @@ class ShardedScan:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.n_local, self.num_rays = n_local, num_rays
+        if mode not in ("ranges", "ranges_u16", "root"):
+            raise ValueError("mode must be 'ranges', 'ranges_u16' or 'root'")
+        self.mode, self.root, self.max_range_m = mode, int(root), float(max_range_m)
+        self.device = device
         # (gather_single_rank: run the collectives even in a one-rank group — exercises the RCCL code
         #  path, stream ordering included, on a box with one GPU)
         self.gather = gather and (self.world > 1 or (gather_single_rank and dist.is_initialized()))
@@ -92,19 +102,36 @@ class ShardedScan:
             depth = max(depth, len(streams))
         self.depth = max(1, int(depth))
         self.slots = []
+        u16 = self.gather and mode == "ranges_u16"
+        holds_all = self.gather and (mode != "root" or self.rank == self.root)
+        self._dev_index = (device.index if getattr(device, "index", None) is not None else 0) \
+            if getattr(device, "type", "cpu") == "cuda" else -1
         for k in range(self.depth):
             sl = _Slot()
             sl.local = torch.empty(n_local * num_rays, dtype=torch.float32, device=device)
             # chunk-major gather buffer: [chunk][rank][poses_in_chunk * num_rays]
+            # (ranges_u16: the collective moves int16 bit patterns; `gathered` holds the decoded float32)
             sl.gathered = (torch.empty(self.world * n_local * num_rays, dtype=torch.float32,
-                                       device=device) if self.gather else None)
+                                       device=device) if holds_all else None)
+            sl.local_q = torch.empty(n_local * num_rays, dtype=torch.int16, device=device) if u16 else None
+            sl.gathered_q = (torch.empty(self.world * n_local * num_rays, dtype=torch.int16, device=device)
+                             if u16 else None)
             sl.stream = streams[k % len(streams)] if streams else None
             sl.handles = []
+            sl.decoded = True
             # per chunk: the slice of `local` a march fills and, when gathering, where its all-gather
             # lands — built once, a step only walks them
             sl.views = [sl.local[lo * num_rays:hi * num_rays] for lo, hi in self.chunks]
-            sl.dsts = ([sl.gathered[ci * self.world * (hi - lo) * num_rays:(ci + 1) * self.world * (hi - lo) * num_rays]
-                        for ci, (lo, hi) in enumerate(self.chunks)] if self.gather else None)
+
+            def _dsts(buf):
+                return [buf[ci * self.world * (hi - lo) * num_rays:(ci + 1) * self.world * (hi - lo) * num_rays]
+                        for ci, (lo, hi) in enumerate(self.chunks)]
+            sl.dsts = _dsts(sl.gathered) if holds_all else None
+            sl.views_q = [sl.local_q[lo * num_rays:hi * num_rays] for lo, hi in self.chunks] if u16 else None
+            sl.dsts_q = _dsts(sl.gathered_q) if u16 else None
+            # "root": the consumer rank's destination split per source rank (dist.gather wants a list)
+            sl.dst_lists = ([list(d.chunk(self.world)) for d in sl.dsts]
+                            if (self.gather and mode == "root" and self.rank == self.root) else None)
             sl.calls = None
             sl.sptr = sl.stream.cuda_stream if sl.stream is not None else 0
             self.slots.append(sl)
@@ -112,18 +139,23 @@ class ShardedScan:
         self.last = self.slots[0]
         self._bound = None
 
-    def bind(self, method, d_poses_ptr: int, fov: float):
+    def bind(self, method, d_poses_ptr, fov: float):
         """Fix the scan a step performs — ``method.calc_range_fan_device`` of the local poses at
         device address ``d_poses_ptr`` into the slot's buffer — so that ``step()`` without a
         ``compute`` callback is one prepared C call per chunk (no per-step tensor slicing, pointer
         look-ups or ctypes argument objects: a step costs the host ~7 us instead of ~10, which is what
-        a short burst of steps sees between its first and its last launch)."""
+        a short burst of steps sees between its first and its last launch).
+        ``d_poses_ptr``: one address, or one PER SLOT (``depth`` of them): every step in flight then
+        scans its own pose batch, as consecutive MCTS roll-out batches do."""
         from . import _lib
         raw = _lib.raw("rl_calc_range_fan_device")
         B = self.num_rays
-        for sl in self.slots:
+        ptrs = list(d_poses_ptr) if isinstance(d_poses_ptr, (list, tuple)) else [d_poses_ptr] * self.depth
+        if len(ptrs) != self.depth:
+            raise ValueError("one pose address per slot (%d) expected, got %d" % (self.depth, len(ptrs)))
+        for sl, pp in zip(self.slots, ptrs):
             base = sl.local.data_ptr()
-            sl.calls = [(d_poses_ptr + lo * 12, hi - lo, base + lo * B * 4) for lo, hi in self.chunks]
+            sl.calls = [(pp + lo * 12, hi - lo, base + lo * B * 4) for lo, hi in self.chunks]
         self._bound = (raw, method._h, float(fov), _lib.check)
 
     # the first slot's buffers (depth 1: the only ones)
@@ -157,6 +189,7 @@ class ShardedScan:
             for h in sl.handles:          # gathers of the step that used this slot `depth` steps ago
                 h.wait()
             sl.handles = []
+            self._decode(sl)              # (ranges_u16: what that step gathered becomes float32 now)
             for ci, (lo, hi) in enumerate(self.chunks):
                 view = sl.views[ci]
                 if compute is None:
@@ -168,9 +201,45 @@ class ShardedScan:
                 else:
                     compute(lo, hi, view, sl.sptr)
                 if self.gather:
-                    sl.handles.append(self.dist.all_gather_into_tensor(sl.dsts[ci], view, async_op=True))
+                    sl.handles.append(self._exchange(sl, ci, view))
         self.last = sl
         return sl
+
+    def _exchange(self, sl, ci, view):
+        """Issue the collective of chunk ``ci`` (asynchronous; ordered behind the march on the current
+        stream) and return its work handle."""
+        if self.mode == "ranges":
+            return self.dist.all_gather_into_tensor(sl.dsts[ci], view, async_op=True)
+        if self.mode == "root":
+            return self.dist.gather(view, sl.dst_lists[ci] if self.rank == self.root else None, dst=self.root,
+                                    async_op=True)
+        # ranges_u16: encode on the slot's stream, exchange 2 B per ray; decoded lazily (global_order / finish)
+        from . import _lib
+        vq = sl.views_q[ci]
+        if self._dev_index >= 0:
+            _lib.check(_lib.lib().rl_ranges_to_u16_device(self._dev_index, view.data_ptr(), view.numel(),
+                                                          self.max_range_m, vq.data_ptr(), sl.sptr or None))
+        else:                                   # CPU tests (gloo): the same arithmetic in torch
+            q = self.torch.round(view.clamp(0.0, self.max_range_m) * (65535.0 / self.max_range_m))
+            vq.copy_((q.to(self.torch.int32) - ((q >= 32768).to(self.torch.int32) << 16)).to(self.torch.int16))
+        sl.decoded = False
+        # (neither RCCL nor gloo has a 16-bit integer type: the collective moves the same bytes as uint8)
+        return self.dist.all_gather_into_tensor(sl.dsts_q[ci].view(self.torch.uint8), vq.view(self.torch.uint8),
+                                                async_op=True)
+
+    def _decode(self, sl):
+        """ranges_u16: gathered 16-bit values -> float32 ``gathered`` (after the gathers of the slot)."""
+        if self.mode != "ranges_u16" or sl.decoded or not self.gather:
+            return
+        if self._dev_index >= 0:
+            from . import _lib
+            _lib.check(_lib.lib().rl_ranges_from_u16_device(self._dev_index, sl.gathered_q.data_ptr(),
+                                                            sl.gathered_q.numel(), self.max_range_m,
+                                                            sl.gathered.data_ptr(), sl.sptr or None))
+        else:
+            q = sl.gathered_q.to(self.torch.int32) & 0xffff
+            sl.gathered.copy_(q.to(self.torch.float32) * (self.max_range_m / 65535.0))
+        sl.decoded = True
 
     def finish(self, end_events=None):
         """Every enqueued march and gather of every slot is ordered before what follows on the slot
@@ -182,6 +251,7 @@ class ShardedScan:
                 for h in sl.handles:
                     h.wait()
                 sl.handles = []
+                self._decode(sl)
             if end_events is not None and sl.stream is not None:
                 end_events[k].record(sl.stream)
 
@@ -191,6 +261,10 @@ class ShardedScan:
         sl = slot or self.last
         if not self.gather:
             return sl.local
+        if sl.gathered is None:
+            raise RuntimeError("mode 'root': only rank %d holds the gathered ranges" % self.root)
+        if not sl.decoded:
+            raise RuntimeError("call finish() before reading ranges_u16 results")
         B, W = self.num_rays, self.world
         per = (self.chunks[0][1] - self.chunks[0][0]) * B
         g = sl.gathered.view(len(self.chunks), W, per)

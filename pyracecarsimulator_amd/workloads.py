@@ -111,36 +111,72 @@ def rollout_inputs(w: "Workload", n_rollouts: int, seed: int, dt=None):
     return states, actions
 
 
-def rollout_poses(w: "Workload", n_poses: int, seed: int, dt=None, device: int = 0) -> np.ndarray:
+def rollout_poses(w: "Workload", n_poses: int, seed: int, dt=None, device: int = 0, lo: int = 0,
+                  hi=None) -> np.ndarray:
     """configs[3]'s pose batch as SURVEY.md §8(d) defines it: ceil(n/200) roll-outs x 200 steps
     integrated by the roll-out generator of this library (``rl_car_rollout``: Car::control +
     Car::updatePosition on the GPU, pinned to the reference's compiled Car by
-    tests/golden/car_rollouts_ref.npz), truncated to ``n_poses``.  Needs the MI355X."""
+    tests/golden/car_rollouts_ref.npz), truncated to ``n_poses``.  Needs the MI355X.
+
+    ``lo``/``hi`` select poses [lo, hi) of that batch: start states and actions are drawn for the
+    WHOLE batch (so the batch is the same whoever asks), but only the roll-outs that cover the block
+    are integrated, on ``device`` — a rank of an N-GPU job generates its own shard on its own GPU."""
     from .racecar import CarBatch
+    hi = n_poses if hi is None else hi
     R = -(-n_poses // ROLLOUT_STEPS)
     states, actions = rollout_inputs(w, R, seed, dt)
+    r_lo, r_hi = lo // ROLLOUT_STEPS, -(-hi // ROLLOUT_STEPS)
     cars = CarBatch(device=device)
-    poses, _, _ = cars.rollout(states, actions, ROLLOUT_STEPS, ROLLOUT_ACTION_EVERY, ROLLOUT_DT)
+    poses, _, _ = cars.rollout(states[r_lo:r_hi], actions[r_lo:r_hi], ROLLOUT_STEPS, ROLLOUT_ACTION_EVERY,
+                               ROLLOUT_DT)
     cars.close()
-    return np.ascontiguousarray(poses.reshape(-1, 3)[:n_poses])
+    off = lo - r_lo * ROLLOUT_STEPS
+    return np.ascontiguousarray(poses.reshape(-1, 3)[off:off + (hi - lo)])
 
 
 CONFIGS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}
 
 
-def make_poses(w: Workload, dt=None, n_poses=None, seed=None) -> np.ndarray:
+def make_poses(w: Workload, dt=None, n_poses=None, seed=None, lo: int = 0, hi=None, device: int = 0) -> np.ndarray:
     """Seeded free-space poses for a workload.  ``dt`` (cells) restricts the draw to cells
-    with >= 2 px clearance; without it any free cell qualifies."""
+    with >= 2 px clearance; without it any free cell qualifies.
+    ``lo``/``hi``: only poses [lo, hi) of the batch of ``n_poses`` (a rank's block)."""
     n = w.n_poses if n_poses is None else n_poses
     seed = w.pose_seed if seed is None else seed
+    hi = n if hi is None else hi
     if w.pose_kind == "rollout":
-        return rollout_poses(w, n, seed, dt)
-    return maps.sample_free_poses(w.gmap, n, seed, 2.0, dt)
+        return rollout_poses(w, n, seed, dt, device=device, lo=lo, hi=hi)
+    return np.ascontiguousarray(maps.sample_free_poses(w.gmap, n, seed, 2.0, dt)[lo:hi])
+
+
+#: BASELINE.json configs whose pose count is a GLOBAL batch to be sharded over the GPUs ("1M poses ...
+#: sharded over 8", "256k poses ... 8xMI355X"): strong scaling.  The others fix the poses per GPU (weak).
+GLOBAL_BATCH = ("cfg4", "cfg5")
+
+
+def batch_layout(w: Workload, world: int, poses_per_gpu: int = 0):
+    """(n_local, n_global, scaling) of a ``world``-GPU run: an explicit per-GPU pose count and the
+    per-GPU configs scale weakly (n_global = world * n_local); configs 4 and 5 shard their global batch
+    (n_local = n_global // world — every rank the same count, as the all-gather needs)."""
+    if poses_per_gpu:
+        return poses_per_gpu, poses_per_gpu * world, "weak"
+    if w.name in GLOBAL_BATCH and world > 1:
+        n_local = w.n_poses // world
+        return n_local, n_local * world, "strong"
+    return w.n_poses, w.n_poses * world, "weak"
 
 
 def make_global_poses(w: Workload, world: int = 1, dt=None) -> np.ndarray:
     """The seeded global batch of ``world * n_poses`` poses; rank r scans block ``shard_range(r)``."""
     return make_poses(w, dt=dt, n_poses=w.n_poses * world)
+
+
+def rank_poses(w: Workload, n_global: int, rank: int, world: int, dt=None, seed=None, device: int = 0):
+    """Rank ``rank``'s contiguous block of the seeded global batch of ``n_global`` poses — the same
+    poses ``make_poses(w, n_poses=n_global)[lo:hi]`` returns, generated without the other ranks'
+    roll-outs and on this rank's own device."""
+    lo, hi = shard_range(n_global, rank, world)
+    return make_poses(w, dt=dt, n_poses=n_global, seed=seed, lo=lo, hi=hi, device=device)
 
 
 def shard_range(n: int, rank: int, world: int):

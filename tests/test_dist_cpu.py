@@ -182,3 +182,82 @@ def test_sharded_scan_keeps_several_steps_in_flight(depth, n_steps):
         for k in range(n_steps):
             want = _fake_ranges(maps.sample_free_poses(g, n_total, 100 + k), B)
             assert np.array_equal(got[k], want), (rank, k)
+
+
+def _mode_worker(rank, world, port, n_total, B, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = maps.make_maze(64, cell=16, wall=2, seed=3)
+        lo, hi = shard_range(n_total, rank, world)
+        scan = ShardedScan(hi - lo, B, "cpu", n_chunks=2, depth=2, mode=mode, root=1, max_range_m=15.0)
+        out = []
+        for k in range(3):
+            poses = maps.sample_free_poses(g, n_total, 200 + k)[lo:hi]
+
+            def compute(clo, chi, view, stream=0, poses=poses, k=k):
+                # values in [0, 15] m like real ranges (plus one below 0 and one above the cap)
+                v = np.abs(_fake_ranges(poses[clo:chi], B)) % 15.0
+                v[0], v[-1] = -0.25, 15.5
+                view.copy_(torch.from_numpy(v.astype(np.float32)))
+
+            sl = scan.step(compute)
+            scan.finish()
+            out.append(None if sl.gathered is None else scan.global_order(sl).numpy().copy())
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["root", "ranges_u16"])
+def test_sharded_scan_exchange_modes_world2(mode):
+    """--gather root: only the consumer rank receives (bit-exact); --gather ranges_u16: every rank
+    receives 16-bit ranges, within max/131070 of the float32 values clamped to [0, max]."""
+    world, n_total, B = 2, 12, 40
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mode_worker, args=(r, world, port, n_total, B, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = maps.make_maze(64, cell=16, wall=2, seed=3)
+    for k in range(3):
+        poses_all = maps.sample_free_poses(g, n_total, 200 + k)
+        want = []
+        for r in range(world):
+            lo, hi = shard_range(n_total, r, world)
+            for clo, chi in ((0, (hi - lo) // 2), ((hi - lo) // 2, hi - lo)):
+                v = np.abs(_fake_ranges(poses_all[lo:hi][clo:chi], B)) % 15.0
+                v[0], v[-1] = -0.25, 15.5
+                want.append(v.astype(np.float32))
+        want = np.concatenate(want)
+        if mode == "root":
+            assert res[0][k] is None                      # rank 0 is not the consumer: holds nothing
+            assert np.array_equal(res[1][k], want)
+        else:
+            for r in range(world):
+                got = res[r][k]
+                assert np.abs(got - np.clip(want, 0.0, 15.0)).max() <= 15.0 / 131070 * 1.001
+                assert got.min() == 0.0 and got.max() == np.float32(15.0)
+
+
+def test_rank_blocks_of_a_seeded_batch_and_the_baseline_batch_layout():
+    """A rank generates only its own block, and the blocks tile the batch one GPU would draw;
+    cfg4 / cfg5 shard BASELINE.json's GLOBAL batch, the other configs fix the poses per GPU."""
+    from pyracecarsimulator_amd import workloads as W
+    w = W.cfg2()
+    whole = W.make_poses(w, n_poses=1000)
+    parts = [W.rank_poses(w, 1000, r, 8) for r in range(8)]
+    assert np.array_equal(np.concatenate(parts), whole)
+    assert not np.array_equal(W.rank_poses(w, 1000, 0, 8, seed=w.pose_seed + 1), parts[0])
+    assert W.batch_layout(W.cfg2(), 8) == (4096, 32768, "weak")
+    assert W.batch_layout(W.cfg3(), 4) == (65536, 262144, "weak")
+    assert W.batch_layout(W.cfg4(), 8) == (131072, 1 << 20, "strong")
+    assert W.batch_layout(W.cfg5(), 8) == (32768, 262144, "strong")
+    assert W.batch_layout(W.cfg5(), 8, poses_per_gpu=256) == (256, 2048, "weak")
+    assert W.batch_layout(W.cfg4(), 1) == (1 << 20, 1 << 20, "weak")
