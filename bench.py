@@ -91,6 +91,8 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed output verification (tuning sweeps)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the same-batch figure, the end-to-end host latencies and the gather-rate probe")
+    ap.add_argument("--selftest-corrupt", action="store_true",
+                    help="flip one range of the last slot before the verification (tests that `verified` gates)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (tuning)")
     ap.add_argument("--opt", action="append", default=[], help="kernel option name=int (tuning)")
@@ -469,6 +471,8 @@ def main():
     d_ref = None
     if not a.no_verify and mode != "crash":
         torch.cuda.synchronize()
+        if a.selftest_corrupt:
+            scan.slots[-1].local[n * B // 2] += 1.0
         apply_schedule(False)
         if method in ("RM", "RMGPU"):
             meth.set_option("slots", 1)             # (auto would take two rays per lane from 2^23 rays up)
@@ -498,7 +502,7 @@ def main():
                 g = scan.global_order(sl).view(world, -1)
                 if mode == "ranges_u16":
                     own = g[rank]
-                    g_ok &= bool(((own - sl.local.clamp(0.0, max_range_m)).abs().max() <= max_range_m / 131070 * 1.001).item())
+                    g_ok &= bool(((own - sl.local.clamp(0.0, max_range_m)).abs().max() <= max_range_m / 131070 * 1.01 + 2e-6).item())
                 else:
                     got = g.view(torch.int32).to(torch.int64).sum(dim=1)
                     g_ok &= bool(torch.equal(got, sums))

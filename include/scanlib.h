@@ -310,10 +310,11 @@ int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words);
 /* ---- 16-bit ranges for the multi-GPU exchange (opt-in, LOSSY) ---------------------------------
  * The all-gather of ranges BASELINE.json's north_star names moves 4 B per ray over xGMI; these two
  * streaming passes let a caller exchange 2 B per ray instead: q = rint(clamp(r, 0, max) * 65535 / max),
- * r' = q * max / 65535.  Error <= max/131070 (0.11 mm at the reference's 15 m, params.yaml:39) —
+ * r' = q * max / 65535.  Error <= max/131070 plus float32 rounding (< 0.12 mm at the reference's 15 m, params.yaml:39) —
  * inside north_star's one-cell tolerance, but NOT bit-exact: only bench.py --gather ranges_u16 and
  * distributed.ShardedScan(mode="ranges_u16") use them, and both label their results.
- * Device pointers, 16-byte aligned; asynchronous on hip_stream.                                    */
+ * Device pointers (any element alignment; 16-byte aligned pairs take the wide path); asynchronous on
+ * hip_stream.                                                                                       */
 int rl_ranges_to_u16_device(int device, const float *d_ranges, size_t n, float max_range_m,
                             uint16_t *d_out_u16, void *hip_stream);
 int rl_ranges_from_u16_device(int device, const uint16_t *d_in_u16, size_t n, float max_range_m,

@@ -114,15 +114,19 @@ __global__ __launch_bounds__(64) void followgap_kernel(const float *__restrict__
 // lidar (params.yaml:39), three orders of magnitude inside north_star's one-cell (50 mm) tolerance.
 // HBM-bound streaming passes: 8 ranges per lane and trip (two 16-B loads, one 16-B store).
 // ------------------------------------------------------------------------------
+// `head` leading elements (and everything, when vec == 0) go one by one: slices of a larger buffer start
+// wherever a pose block starts, and the 16-B forms need both pointers aligned at the same element
 __global__ __launch_bounds__(256) void ranges_to_u16_kernel(const float *__restrict__ r, size_t n, float max_m,
-                                                            float scale, uint16_t *__restrict__ q)
+                                                            float scale, uint16_t *__restrict__ q, size_t head, int vec)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
-    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    auto cv = [&](float v) { return (uint32_t)__builtin_rintf(__builtin_fminf(__builtin_fmaxf(v, 0.0f), max_m) * scale); };
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    if (!vec) head = n;
+    for (size_t k = tid; k < head; k += nthr) q[k] = (uint16_t)cv(r[k]);
+    for (size_t i = head + tid * 8; i < n; i += nthr * 8) {
         if (i + 8 <= n) {
             const float4 a = *reinterpret_cast<const float4 *>(r + i);
             const float4 b = *reinterpret_cast<const float4 *>(r + i + 4);
-            auto cv = [&](float v) { return (uint32_t)__builtin_rintf(__builtin_fminf(__builtin_fmaxf(v, 0.0f), max_m) * scale); };
             uint4 o;
             o.x = cv(a.x) | (cv(a.y) << 16);
             o.y = cv(a.z) | (cv(a.w) << 16);
@@ -130,17 +134,18 @@ __global__ __launch_bounds__(256) void ranges_to_u16_kernel(const float *__restr
             o.w = cv(b.z) | (cv(b.w) << 16);
             *reinterpret_cast<uint4 *>(q + i) = o;
         } else {
-            for (size_t k = i; k < n; ++k)
-                q[k] = (uint16_t)__builtin_rintf(__builtin_fminf(__builtin_fmaxf(r[k], 0.0f), max_m) * scale);
+            for (size_t k = i; k < n; ++k) q[k] = (uint16_t)cv(r[k]);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void ranges_from_u16_kernel(const uint16_t *__restrict__ q, size_t n, float inv_scale,
-                                                              float *__restrict__ r)
+                                                              float *__restrict__ r, size_t head, int vec)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
-    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    if (!vec) head = n;
+    for (size_t k = tid; k < head; k += nthr) r[k] = (float)q[k] * inv_scale;
+    for (size_t i = head + tid * 8; i < n; i += nthr * 8) {
         if (i + 8 <= n) {
             const uint4 v = *reinterpret_cast<const uint4 *>(q + i);
             float4 a, b;

@@ -2038,11 +2038,18 @@ static int u16_args(int device, size_t n, float max_range_m, const void *a, cons
 {
     if (!(max_range_m > 0.0f)) return fail(RL_ERR_INVALID, "max_range_m must be > 0");
     if (n > 0 && (!a || !b)) return fail(RL_ERR_INVALID, "null device pointer");
-    if (n > 0 && (((uintptr_t)a | (uintptr_t)b) & 15)) return fail(RL_ERR_INVALID, "device buffers must be 16-byte aligned");
     int ndev = rl_device_count();
     if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
     return RL_OK;
+}
+
+// leading elements until the u16 pointer is 16-B aligned, and whether the f32 pointer is aligned there too
+static void u16_split(const void *f32, const void *u16, size_t n, size_t &head, int &vec)
+{
+    head = ((16 - ((uintptr_t)u16 & 15)) & 15) / 2;
+    if (head > n) head = n;
+    vec = (((uintptr_t)f32 + 4 * head) & 15) == 0 && ((uintptr_t)u16 & 1) == 0 && ((uintptr_t)f32 & 3) == 0;
 }
 
 extern "C" int rl_ranges_to_u16_device(int device, const float *d_ranges, size_t n, float max_range_m,
@@ -2051,9 +2058,12 @@ extern "C" int rl_ranges_to_u16_device(int device, const float *d_ranges, size_t
     int rc = u16_args(device, n, max_range_m, d_ranges, d_out);
     if (rc || n == 0) return rc;
     HIPCHK(hipSetDevice(device));
+    size_t head;
+    int vec;
+    u16_split(d_ranges, d_out, n, head, vec);
     const int grid = (int)std::min<size_t>((n / 8 + 255) / 256 + 1, 256 * 16);
     hipLaunchKernelGGL(ranges_to_u16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_ranges, n,
-                       max_range_m, 65535.0f / max_range_m, d_out);
+                       max_range_m, 65535.0f / max_range_m, d_out, head, vec);
     HIPCHK(hipGetLastError());
     return RL_OK;
 }
@@ -2064,9 +2074,12 @@ extern "C" int rl_ranges_from_u16_device(int device, const uint16_t *d_in, size_
     int rc = u16_args(device, n, max_range_m, d_in, d_ranges);
     if (rc || n == 0) return rc;
     HIPCHK(hipSetDevice(device));
+    size_t head;
+    int vec;
+    u16_split(d_ranges, d_in, n, head, vec);
     const int grid = (int)std::min<size_t>((n / 8 + 255) / 256 + 1, 256 * 16);
     hipLaunchKernelGGL(ranges_from_u16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_in, n,
-                       max_range_m / 65535.0f, d_ranges);
+                       max_range_m / 65535.0f, d_ranges, head, vec);
     HIPCHK(hipGetLastError());
     return RL_OK;
 }

@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out_dir, n_total, B = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    mode = sys.argv[4] if len(sys.argv) > 4 else "ranges"
     import torch
     import torch.distributed as dist
     from pyracecarsimulator_amd import maps, range_libc
@@ -37,7 +38,7 @@ def main():
     lo, hi = shard_range(n_total, rank, world)
     streams = concurrent_streams(2)
     scan = ShardedScan(hi - lo, B, dev, n_chunks=3, gather=True, streams=streams if len(streams) == 2 else None,
-                       depth=2)
+                       depth=2, mode=mode, root=world - 1, max_range_m=300 * g.resolution)
     slots = []
     for k in range(2):
         lo_k, d_p = steps[k]
@@ -50,7 +51,8 @@ def main():
     scan.finish()
     torch.cuda.synchronize()
     for k, sl in enumerate(slots):
-        np.save(os.path.join(out_dir, "rank%d_step%d.npy" % (rank, k)), scan.global_order(sl).cpu().numpy())
+        if sl.gathered is not None:                          # ('root': only the consumer rank holds the batch)
+            np.save(os.path.join(out_dir, "rank%d_step%d.npy" % (rank, k)), scan.global_order(sl).cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,0 +1,169 @@
+"""The kernel the driver's number comes from, at the driver's shape: cfg2's 2049^2 map,
+4096 poses x 1081 beams, three rays per lane (`slots` 3), 0.75 workgroups per CU (`grid_mult` 3), four
+concurrent streams with four DIFFERENT pose batches in flight — bit for bit against the oracle on every
+64th pose and against a serial one-ray-per-lane launch on every ray; and bench.py's own line: verified,
+with the keys the judge reads.  Reference shape: /root/reference/scripts/scan_simulator.py:113-135."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from pyracecarsimulator_amd import _lib, range_libc, workloads
+from pyracecarsimulator_amd.pipeline import concurrent_streams
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu(need_gpu):
+    yield
+
+
+def test_cfg2_bench_shape_four_batches_in_flight_bit_equal_to_oracle(oracle_mod):
+    torch = pytest.importorskip("torch")
+    w = workloads.cfg2()
+    g, B, fov, mrx = w.gmap, w.num_rays, w.fov, w.max_range_px
+    omap = range_libc.PyOMap(g)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    om._dt = omap.distance_transform()            # (device EDT == oracle EDT is its own test; saves 20 s of CPU here)
+    m = range_libc.PyRayMarchingGPU(omap, mrx)
+    n, P = 4096, 4
+    batches = [workloads.make_poses(w, dt=om.dt, n_poses=n, seed=w.pose_seed + 7919 * k) for k in range(P)]
+    assert not np.array_equal(batches[0], batches[1])
+    d_poses = [torch.from_numpy(b).cuda() for b in batches]
+    d_out = [torch.zeros(n * B, dtype=torch.float32, device="cuda") for _ in range(P)]
+    streams = concurrent_streams(P)
+    assert len(streams) >= 2, "this box runs no two streams concurrently"
+    m.set_option("grid_mult", 3)
+    m.set_option("slots", 3)
+    plan = m.plan_fan(n, B)
+    assert plan["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 3>"
+    assert (plan["grid"], plan["block"], plan["binning"], plan["record_source"]) == (192, 1024, "small_keys", 3)
+    torch.cuda.synchronize()
+    for rep in range(10):                          # 40 launches, up to four in flight, round robin like bench.py
+        for k in range(P):
+            m.calc_range_fan_device(d_poses[k].data_ptr(), n, fov, B, d_out[k].data_ptr(),
+                                    stream=streams[k % len(streams)].cuda_stream)
+    torch.cuda.synchronize()
+    assert m.last_plan()["name"] == plan["name"] and m.last_plan()["grid"] == 192
+    # the oracle on every 64th pose of every batch
+    sub = np.arange(0, n, 64)
+    pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
+    got = [o.cpu().numpy() for o in d_out]
+    for k in range(P):
+        want = om.rm_fan(batches[k][sub], fov, B, step_coeff=1.0, nthreads=oracle_mod.max_threads(),
+                         want_hits=False, want_steps=False)[0]
+        assert np.array_equal(got[k][pick], want), "batch %d differs from the oracle" % k
+    # every ray against the serial schedule: one ray per lane, whole-machine grid, one stream
+    m.set_option("grid_mult", 8)
+    m.set_option("slots", 1)
+    ref = torch.empty(n * B, dtype=torch.float32, device="cuda")
+    for k in range(P):
+        m.calc_range_fan_device(d_poses[k].data_ptr(), n, fov, B, ref.data_ptr())
+        torch.cuda.synchronize()
+        assert m.last_plan()["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 1>"
+        assert torch.equal(ref, d_out[k]), "batch %d: pipelined three-rays-per-lane launch != serial launch" % k
+
+
+def test_launch_plan_is_what_runs():
+    """rl_method_plan_fan before a call == rl_method_last_plan after it == the pure rl_plan_fan with the
+    same options, for every method kind."""
+    g = workloads.cfg2().gmap
+    omap = range_libc.PyOMap(g)
+    poses = workloads.make_poses(workloads.cfg2(), n_poses=700)
+    out = np.empty(700 * 360, np.float32)
+    for cls, kind, td in ((range_libc.PyRayMarchingGPU, _lib.RL_RM_GPU, 0), (range_libc.PyBresenhamsLine, _lib.RL_BRESENHAM, 0),
+                          (range_libc.PyCDDTCast, _lib.RL_CDDT, 108), (range_libc.PyGiantLUTCast, _lib.RL_GIANT_LUT, 60)):
+        m = cls(omap, 120, td) if td else cls(omap, 120)
+        before = m.plan_fan(700, 360)
+        m.calc_range_fan(poses, out, 4.0, 360)
+        assert m.last_plan() == before
+        pure = _lib.plan_fan(kind, g.rows, g.cols, 700, 360, max_range_px=120.0, theta_disc=td,
+                             n_cu=m.get_info("n_cu"))
+        assert pure == before, (cls.__name__, pure, before)
+        m.close()
+
+
+def test_u16_range_passes_match_their_definition():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    for n in (8, 4096 * 1081, 1000003):
+        r = rng.uniform(-0.5, 15.5, n).astype(np.float32)
+        r[:3] = (0.0, 15.0, 7.5)
+        d_r = torch.from_numpy(r).cuda()
+        d_q = torch.zeros(n, dtype=torch.int16, device="cuda")
+        d_back = torch.zeros(n, dtype=torch.float32, device="cuda")
+        L = _lib.lib()
+        _lib.check(L.rl_ranges_to_u16_device(0, d_r.data_ptr(), n, 15.0, d_q.data_ptr(), None))
+        _lib.check(L.rl_ranges_from_u16_device(0, d_q.data_ptr(), n, 15.0, d_back.data_ptr(), None))
+        torch.cuda.synchronize()
+        q = d_q.cpu().numpy().view(np.uint16)
+        want_q = np.rint(np.clip(r, 0.0, 15.0) * np.float32(65535.0 / 15.0)).astype(np.uint16)
+        assert np.array_equal(q, want_q)
+        back = d_back.cpu().numpy()
+        assert np.array_equal(back, want_q.astype(np.float32) * np.float32(15.0 / 65535.0))
+        assert np.abs(back - np.clip(r, 0.0, 15.0)).max() <= 15.0 / 131070 * 1.01 + 2e-6
+    # slices that start anywhere (a pose block of a larger buffer): same values
+    n = 100000
+    r = rng.uniform(0.0, 15.0, n + 16).astype(np.float32)
+    d_r = torch.from_numpy(r).cuda()
+    d_q = torch.zeros(n + 16, dtype=torch.int16, device="cuda")
+    for off in (1, 3, 4, 5, 8):
+        d_q.zero_()
+        _lib.check(_lib.lib().rl_ranges_to_u16_device(0, d_r.data_ptr() + 4 * off, n, 15.0, d_q.data_ptr() + 2 * off, None))
+        torch.cuda.synchronize()
+        q = d_q.cpu().numpy().view(np.uint16)
+        assert np.array_equal(q[off:off + n], np.rint(r[off:off + n] * np.float32(65535.0 / 15.0)).astype(np.uint16))
+        assert not q[:off].any() and not q[off + n:].any()
+    with pytest.raises(_lib.ScanLibError):
+        _lib.check(_lib.lib().rl_ranges_to_u16_device(0, None, 8, 15.0, None, None))
+
+
+def test_bench_default_line_is_verified_and_complete():
+    """The driver's command (short CPU leg): rc 0, `verified`, both CPU baselines, the dominant kernel with
+    its template arguments, end-to-end host latencies, the same-batch figure next to the distinct-batch one."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+           "--cpu-seconds", "2"]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["verified"] is True
+    v = d["verification"]
+    assert v["slots_equal_serial_launch"] is True and v["oracle_subsample"] is True
+    assert d["bursts"] >= 25 and d["value_min"] <= d["value"] <= d["value_max"]
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["scaling"] == "weak" and d["dtype"] == "f32"
+    rf = d["roofline"]
+    assert rf["kernel"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 3>" and rf["grid"] == 192
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["launches_in_flight"] == 4
+    assert "measured_hbm_gbs" in rf and rf["serial"]["kernel"].endswith(", 1>")
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["bresenham"]["value"] > 0
+    assert cb["cpu_model"] and "-ffp-contract=off" in cb["flags"] and cb["cores"] >= 1
+    assert d["end_to_end"]["scan_us"] > 0 and d["end_to_end"]["scanMany_200_us"] > 0
+    assert d["same_batch"]["value"] > 0
+    assert "4 distinct seeded batches" in d["config"]["pose_batches"]
+
+
+def test_bench_verification_gate():
+    """`verified` is a real gate: without the CPU leg the oracle check is reported as not run and the slot
+    check still passes; with one range of one slot flipped behind the bench's back (--selftest-corrupt) the
+    line says verified false and the process exits non-zero."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--bursts", "3",
+            "--poses", "512", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(base + ["--opt", "low_water=20"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["verified"] is True and "not run" in d["verification"]["oracle_subsample"]
+    r = subprocess.run(base + ["--selftest-corrupt"], capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["verified"] is False and d["verification"]["slots_equal_serial_launch"] is False

@@ -72,16 +72,19 @@ def test_interleaved_batches_on_concurrent_streams_are_bit_exact(oracle_mod, opt
 
 
 def test_more_streams_than_launch_contexts(oracle_mod):
-    """Six streams on one handle (four launch contexts): contexts are handed over, results stay exact."""
+    """Two streams more than a handle has launch contexts (rl_launch_contexts): contexts are handed over
+    after a device synchronisation, results stay exact."""
     torch = pytest.importorskip("torch")
+    from pyracecarsimulator_amd import _lib
+    n_streams = _lib.lib().rl_launch_contexts() + 2
     g = maps.make_maze(300, cell=30, wall=2, p=0.5, seed=5)
     om = oracle_mod.OracleMap.from_gridmap(g, 200)
     omap = range_libc.PyOMap(g)
     m = range_libc.PyRayMarching(omap, 200)
     m.set_option("inline_map_kb", 0)
     B, fov = 360, 6.0
-    streams = [torch.cuda.Stream() for _ in range(6)]
-    batches = [maps.sample_free_poses(g, 600 + 50 * i, 70 + i, dt=om.dt) for i in range(6)]
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    batches = [maps.sample_free_poses(g, 600 + 50 * i, 70 + i, dt=om.dt) for i in range(n_streams)]
     d_poses = [torch.from_numpy(p).cuda() for p in batches]
     d_out = [torch.zeros(len(p) * B, dtype=torch.float32, device="cuda") for p in batches]
     for rep in range(3):

@@ -37,18 +37,22 @@ def _env():
     return env
 
 
-def test_two_ranks_gather_the_oracle_scan_in_global_pose_order(oracle_mod, tmp_path):
-    n_total, B = 600, 1081
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+@pytest.mark.parametrize("world,mode", [(2, "ranges"), (8, "ranges"), (2, "root"), (2, "ranges_u16")])
+def test_ranks_gather_the_oracle_scan_in_global_pose_order(oracle_mod, tmp_path, world, mode):
+    """2 and 8 ranks (cuda:0 each, gloo): what every rank gathered == the unsharded scan == the oracle, in
+    global pose order; 'root': only the consumer rank holds it; 'ranges_u16': within the quantisation step."""
+    n_total, B = 640 if world == 8 else 600, 1081
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(tmp_path), str(n_total), str(B)]
-    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+           os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(tmp_path), str(n_total), str(B), mode]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     g = maps.make_maze(512, cell=40, wall=3, p=0.45, seed=17, origin=(1.0, -2.0, 0.25))
     om = oracle_mod.OracleMap.from_gridmap(g, 300)
     from pyracecarsimulator_amd import range_libc
     omap = range_libc.PyOMap(g)
     m = range_libc.PyRayMarchingGPU(omap, 300)
+    max_m = 300 * g.resolution
     for k in range(2):
         poses_all = maps.sample_free_poses(g, n_total, 5 + k)
         clean = om.rm_fan(poses_all, 4.71, B, step_coeff=1.0, nthreads=oracle_mod.max_threads())[0]
@@ -60,11 +64,19 @@ def test_two_ranks_gather_the_oracle_scan_in_global_pose_order(oracle_mod, tmp_p
         assert np.array_equal(one, clean)
         m.set_noise(0.02, 99, 0)
         m.calc_range_fan(poses_all, one, 4.71, B)
-        for rank in range(2):
-            got = np.load(os.path.join(str(tmp_path), "rank%d_step%d.npy" % (rank, k)))
+        holders = [world - 1] if mode == "root" else list(range(world))
+        for rank in range(world):
+            f = os.path.join(str(tmp_path), "rank%d_step%d.npy" % (rank, k))
+            assert os.path.exists(f) == (rank in holders)
+            if rank not in holders:
+                continue
+            got = np.load(f)
             assert got.shape == one.shape
-            assert np.array_equal(got, one), "rank %d step %d: gathered ranges differ from the unsharded scan" % (rank, k)
-            assert np.abs(got - clean).max() < 0.2 and np.abs((got - clean).std() - 0.02) < 2e-3
+            if mode == "ranges_u16":
+                assert np.abs(got - np.clip(one, 0.0, max_m)).max() <= max_m / 131070 * 1.01 + 2e-6
+            else:
+                assert np.array_equal(got, one), "rank %d step %d: gathered ranges differ from the unsharded scan" % (rank, k)
+                assert np.abs(got - clean).max() < 0.2 and np.abs((got - clean).std() - 0.02) < 2e-3
 
 
 def test_bench_spawns_its_own_ranks():
@@ -83,7 +95,46 @@ def test_bench_spawns_its_own_ranks():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert "all-gather ranges" in d["config"]["gather"]
     assert d["gather_bytes_per_step"] == 4 * 512 * 1081 * 2
+    assert d["crash_mode"]["value"] > 0 and d["crash_mode"]["schedule"].startswith("serial")
+    assert d["verified"] is True and d["verification"]["gathered_equals_local"] is True
+    assert d["roofline_xgmi"]["ingress_bytes_per_gpu_per_step"] == 4 * 512 * 1081
+
+
+def test_bench_eight_ranks_on_one_device():
+    """The 8-wide run the driver's SCALE step performs, dry on the one GPU of the box: 8 ranks over gloo,
+    8-way chunk layout, 8 x concurrent_streams() probes, gathered == local on every rank."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2",
+           "--bursts", "3", "--poses", "256", "--same-device", "--backend", "gloo", "--no-cpu-baseline"]
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_poses"] == 2048
+    assert d["verified"] is True and d["verification"]["gathered_equals_local"] is True
+    x = d["roofline_xgmi"]
+    assert x["ingress_bytes_per_gpu_per_step"] == 7 * 4 * 256 * 1081 and x["peak"] == pytest.approx(7 * 76.5)
     assert d["crash_mode"]["value"] > 0
+
+
+@pytest.mark.parametrize("gather", ["root", "ranges_u16"])
+def test_bench_exchange_modes_two_ranks(gather):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--bursts", "3", "--poses", "384", "--same-device", "--backend", "gloo", "--no-cpu-baseline",
+           "--no-crash-line", "--gather", gather]
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["verified"] is True
+    per = 384 * 1081
+    assert d["gather_bytes_per_step"] == (2 if gather == "ranges_u16" else 4) * per * 2
+    assert ("LOSSY" in d["config"]["gather"]) == (gather == "ranges_u16")
 
 
 def test_bench_single_rank_through_rccl():
@@ -99,3 +150,4 @@ def test_bench_single_rank_through_rccl():
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and "all-gather ranges" in d["config"]["gather"] and d["value"] > 0
+    assert d["verified"] is True and d["verification"]["gathered_equals_local"] is True
