@@ -22,7 +22,7 @@ constexpr int STREAM_HDR = 66;           // LDS header words of the stream kerne
 constexpr int STRIPE_BINS = 64;
 constexpr int STRIPE_MAX_PER_LANE = 8;
 constexpr int INLINE_LDS_BUDGET = 56 * 1024;   // LDS an INLINE workgroup may use (two 1024-lane workgroups per CU)
-constexpr int INLINE_REC_BYTES = 26;     // per record slot: record 16 B + pose id 4 B + first step 4 B + half a block word
+constexpr int INLINE_REC_BYTES = 32;     // one BlockRec per owned 64-ray block (scan_kernels.h)
 
 struct In {
     int kind = RL_RM_GPU, n_cu = 256, rows = 0, cols = 0, theta_disc = 0;
@@ -188,7 +188,6 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     // K1b.  (1) where the pose records come from, (2) the persistent grid, (3) rays per lane
     const int bands = n_poses >= 64 ? o.xcd_bands : 1;
     int nt = o.wg_threads;
-    const size_t fan_bytes = (size_t)num_rays * 8;
     // small batches: no binning launch, workgroups derive the records of their own blocks ... and
     // whenever the map sits in every XCD's L2: tile order buys nothing there
     const bool small_map = (size_t)in.rows * in.cols * sizeof(float) <= (size_t)o.inline_map_kb * 1024;
@@ -205,25 +204,27 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     if (order_inl) inl = true;
     int k_max = 0, inl_rl = 0;
     size_t lds_extra = 0;
+    // INLINE launches cut every pose's fan into cpp blocks of 64 rays (the last one partly filled): a block
+    // never straddles two poses, so ONE record per block serves every ray slot of it
+    const long n_blocks_inl = (long)n_poses * cpp;
+    const size_t inl_tables = (((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays + 7) & ~(size_t)7) * sizeof(float);
     if (inl) {
         nt = 1024;
-        const long g_min = std::max(1L, std::min((n_chunks + 15) / 16, (long)n_cu * o.grid_mult * WG / nt) / bands);
-        const long seg_chunks_max = ((((long)n_poses + bands - 1) / bands) * num_rays + 63) / 64;
-        const long grid_i = std::max((long)bands, std::min((n_chunks + 15) / 16, std::max((long)n_cu * o.grid_mult * WG / nt, 1L)));
+        const long g_min = std::max(1L, std::min((n_blocks_inl + 15) / 16, (long)n_cu * o.grid_mult * WG / nt) / bands);
+        const long seg_chunks_max = (((long)n_poses + bands - 1) / bands) * cpp;
+        const long grid_i = std::max((long)bands, std::min((n_blocks_inl + 15) / 16, std::max((long)n_cu * o.grid_mult * WG / nt, 1L)));
         inl_rl = o.run_log2;
         if (inl_rl < 0) {
             inl_rl = 0;                               // (stripe batches are small: single blocks)
             if (!stripe)
-                for (; inl_rl < 5 && ((n_chunks / grid_i) >> (inl_rl + 1)) >= 16; ++inl_rl) {}
+                for (; inl_rl < 5 && ((n_blocks_inl / grid_i) >> (inl_rl + 1)) >= 16; ++inl_rl) {}
         }
         const long seg_runs_max = (seg_chunks_max + (1L << inl_rl) - 1) >> inl_rl;
         const long k_blocks = ((seg_runs_max + g_min - 1) / g_min) << inl_rl;
-        k_max = 2 * ((int)k_blocks + 1);                                 // two records per block
+        k_max = (int)k_blocks + 1;
         if (stripe)                                   // band list + histogram / wave counts / cuts
             lds_extra = ((size_t)(n_poses + bands - 1) / bands + 2 + STRIPE_BINS + 3 * (nt / 64) + 4) * 4;
-        if ((size_t)k_max * INLINE_REC_BYTES + fan_bytes * (in.crash ? 2 : 1) + lds_extra + 32 + STREAM_HDR * 4 >
-            (size_t)INLINE_LDS_BUDGET)
-            inl = false;
+        if (inl_tables + (size_t)k_max * INLINE_REC_BYTES + lds_extra + 32 > (size_t)INLINE_LDS_BUDGET) inl = false;
     }
     if (!inl) {
         nt = o.wg_threads;
@@ -237,21 +238,21 @@ inline int plan_one(const In &in, rl_launch_plan *p)
         p->record_source = stripe ? 2 : 1;
     }
     const int waves_per_wg = nt / 64;
-    const long want_q = (n_chunks + waves_per_wg - 1) / waves_per_wg;
+    const long n_blocks = inl ? n_blocks_inl : n_chunks;
+    const long want_q = (n_blocks + waves_per_wg - 1) / waves_per_wg;
     const long cap_q = (long)n_cu * o.grid_mult * WG / nt;
     p->grid = (int)std::max((long)bands, std::min(want_q, std::max(cap_q, 1L)));
     p->block = nt;
     int rl2 = o.run_log2;
     if (rl2 < 0) {
-        const long per_wg = n_chunks / std::max(p->grid, 1);
+        const long per_wg = n_blocks / std::max(p->grid, 1);
         for (rl2 = 0; rl2 < 5 && (per_wg >> (rl2 + 1)) >= 16; ++rl2) {}
     }
     p->run_log2 = inl ? inl_rl : rl2;          // (the inline LDS record table was sized for inl_rl)
     p->bands = bands;
     p->k_max = inl ? k_max : 0;
-    const size_t tab_floats = STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays;   // fan table (+ edge table, f64)
-    p->lds_bytes = (int)(inl ? (((tab_floats + 3) & ~(size_t)3) * sizeof(float) + (size_t)k_max * INLINE_REC_BYTES + lds_extra)
-                             : tab_floats * sizeof(float));
+    p->lds_bytes = (int)(inl ? inl_tables + (size_t)k_max * INLINE_REC_BYTES + lds_extra
+                             : ((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays) * sizeof(float));
     const int slots = o.slots ? o.slots : (rays >= (1L << 23) ? 2 : 1);
     bool a = in.aux, c = in.crash, t = o.tiled != 0;
     int s = 1;

@@ -284,34 +284,47 @@ constexpr uint32_t POSE_INVALID = 0x80000000u;   // order[] flag: origin outside
 #define PDT_HIT __builtin_inff()        /* occupied cell (EDT 0)          */
 #define PDT_OUTSIDE 3.0e38f             /* border: the ray left the map   */
 
-// tiled layout (TILED march): groups of 4 rows interleaved element-wise,
-//   element(r, c) = (r>>2)*4*pcol + 4*c + (r&3)          (r, c may be negative: border)
-// so one 128-B line holds a 4-row x 8-column block of cells (pcol and the border width are
-// multiples of 8).  In bytes ((r>>2)*4 == r - (r&3)), with S4 = 4*pcol:
-//   byte(r, c) = r*S4 - (r&3)*(S4-4) + 16*c + k4
-// which the march computes in 4 instructions (lshl_add, mad, and, mad).
-__device__ __forceinline__ long pdt_tiled_index(int r, int c, int pcol)
+// tiled layout (TILED march): groups of 4 rows interleaved element-wise, so that one 128-B line holds a
+// 4-row x 8-column block of cells, with a POWER-OF-TWO group pitch: in bytes, with r' = r + pad + 4 >= 0 and
+// c' = c + pad >= 0 (pad: border width, a multiple of 8; 4 more rows of slack in front),
+//   byte(r, c) = ((r' >> 2) << K) | (c' << 4) | ((r' & 3) << 2),     2^K = 16 * pcol2 >= 16 * max(padded cols, rows)
+// which the march computes in THREE instructions (round 2's pitch of 4*pcol bytes took four):
+//   a = r * M + padM          M = 4 + 2^(K-2): both copies of r' the address needs, (r'<<2) and (r'<<(K-2)),
+//                             from one 24-bit multiply-add (padM = (pad+4) * M sits in a VGPR: one SGPR
+//                             operand per VALU instruction on gfx9)
+//   a = a & MASK              MASK = 0xC | (~0 << K): keeps (r'&3)<<2 and (r'>>2)<<K — the copies do not overlap
+//                             because 2^(K-4) >= padded rows
+//   a = (c << 4) + a          the column bias pad<<4 is folded into the SGPR base; a >= 0 because the slack
+//                             group makes (r'>>2) >= 1 and 16*pad < 2^K
+// Columns [cols + 2*pad, pcol2) of a group are never written or read: the table is larger (2049^2: 44 MB
+// instead of 28 MB), the touched lines are the same.
+struct TiledGeom {
+    int K;                    // log2 of the group pitch in bytes
+    int pad, padr;            // column bias, row bias (pad + 4)
+    int pcols, prows;         // padded extent that holds data: cols + 2*pad, rows + 2*pad + 4 (multiple of 4)
+};
+
+__device__ __host__ __forceinline__ size_t pdt_tiled_byte(int rp, int cp, int K)
 {
-    return (long)(r >> 2) * 4 * pcol + 4 * (long)c + (r & 3);
+    return ((size_t)(rp >> 2) << K) | ((size_t)cp << 4) | ((size_t)(rp & 3) << 2);
 }
 
 // Both padded copies hold the march's STEP, not the distance: free cells max(d*coeff, 1) (the
 // two roundings of rm_march, done once per map instead of once per sample), occupied cells +inf,
 // border 3e38 — the stop codes survive because t + code >= max_range either way.
 __global__ __launch_bounds__(256) void pad_dt_tiled_kernel(const float *__restrict__ dt, int rows, int cols,
-                                                           float *__restrict__ pdt, int pad, int pcol,
-                                                           long k_elems, float coeff)
+                                                           float *__restrict__ pdt, TiledGeom tg, float coeff)
 {
-    const int pr = blockIdx.y;
-    const int r = pr - pad;
-    for (int pc = blockIdx.x * blockDim.x + threadIdx.x; pc < pcol; pc += gridDim.x * blockDim.x) {
-        const int c = pc - pad;
+    const int pr = blockIdx.y;                      // r' (biased row)
+    const int r = pr - tg.padr;
+    for (int pc = blockIdx.x * blockDim.x + threadIdx.x; pc < tg.pcols; pc += gridDim.x * blockDim.x) {
+        const int c = pc - tg.pad;
         float v = PDT_OUTSIDE;
         if (r >= 0 && r < rows && c >= 0 && c < cols) {
             v = dt[(size_t)r * cols + c];
             v = v <= 0.0f ? PDT_HIT : __builtin_fmaxf(v * coeff, 1.0f);
         }
-        pdt[k_elems + pdt_tiled_index(r, c, pcol)] = v;
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(pdt) + pdt_tiled_byte(pr, pc, tg.K)) = v;
     }
 }
 
@@ -685,8 +698,8 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
                                            int stride, int nstride, uint32_t k4, float max_range,
                                            uint32_t low)
 {
-    // TILED: stride = S4 (bytes), nstride = -(S4-4): 4 address instructions instead of 2, but the
-    // samples of a wave fall into fewer 128-B lines (4x8-cell blocks instead of 1x32-cell row pieces)
+    // TILED: stride = M, nstride = MASK, k4 = padM (see pdt_tiled_byte): 3 address instructions instead of
+    // 2, but the samples of a wave fall into fewer 128-B lines (4x8-cell blocks instead of 1x32-cell row pieces)
     // The two position fmas are ONE packed instruction (v_pk_fma_f32: both halves IEEE-fused, the same
     // bits as two v_fma_f32).  Packed operands are even-aligned register pairs, and inline asm cannot
     // name the halves of a 64-bit operand, so the pairs are fixed registers, in the order the refill
@@ -703,10 +716,9 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
         "v_cvt_i32_f32_e32 %[c], v26\n\t"
         "v_cvt_i32_f32_e32 %[r], v27\n\t"
         ".if %[tiled]\n\t"
-        "v_lshl_add_u32 v26, %[c], 4, %[k4]\n\t"
-        "v_and_b32_e32 v27, 3, %[r]\n\t"
-        "v_mad_i32_i24 v26, %[r], %[stride], v26\n\t"
-        "v_mad_i32_i24 v26, v27, %[nstride], v26\n\t"
+        "v_mad_i32_i24 v26, %[r], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v26, %[nstride], v26\n\t"
+        "v_lshl_add_u32 v26, %[c], 4, v26\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v26, %[r], %[stride], %[c]\n\t"
         "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
@@ -725,7 +737,7 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
         : [t] "+{v20}"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [ns] "+v"(nstep),
           [save] "=&s"(save), [n] "=&s"(n)
         : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy),
-          [mx] "s"(max_range), [stride] "s"(stride), [nstride] "s"(nstride), [k4] "s"(k4),
+          [mx] "s"(max_range), [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4),
           [base] "s"(pdt), [low] "s"(low), [aux] "n"(AUX ? 1 : 0), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "vcc", "scc", "memory");
 }
@@ -759,10 +771,9 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
         "v_cvt_i32_f32_e32 %[rA], v27\n\t"
         ".if %[tiled]\n\t"
-        "v_lshl_add_u32 v26, %[cA], 4, %[k4]\n\t"
-        "v_and_b32_e32 v27, 3, %[rA]\n\t"
-        "v_mad_i32_i24 v26, %[rA], %[stride], v26\n\t"
-        "v_mad_i32_i24 v26, v27, %[nstride], v26\n\t"
+        "v_mad_i32_i24 v26, %[rA], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v26, %[nstride], v26\n\t"
+        "v_lshl_add_u32 v26, %[cA], 4, v26\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v26, %[rA], %[stride], %[cA]\n\t"
         "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
@@ -773,10 +784,9 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "v_cvt_i32_f32_e32 %[cB], v34\n\t"
         "v_cvt_i32_f32_e32 %[rB], v35\n\t"
         ".if %[tiled]\n\t"
-        "v_lshl_add_u32 v34, %[cB], 4, %[k4]\n\t"
-        "v_and_b32_e32 v35, 3, %[rB]\n\t"
-        "v_mad_i32_i24 v34, %[rB], %[stride], v34\n\t"
-        "v_mad_i32_i24 v34, v35, %[nstride], v34\n\t"
+        "v_mad_i32_i24 v34, %[rB], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v34, %[nstride], v34\n\t"
+        "v_lshl_add_u32 v34, %[cB], 4, v34\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v34, %[rB], %[stride], %[cB]\n\t"
         "v_lshl_add_u32 v34, v34, 2, %[k4]\n\t"
@@ -803,7 +813,7 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
           [n2] "=&s"(n2)
         : [dyA] "{v22}"(dyA), [dxA] "{v23}"(dxA), [gxA] "{v24}"(gxA), [gyA] "{v25}"(gyA), [dyB] "{v30}"(dyB),
           [dxB] "{v31}"(dxB), [gxB] "{v32}"(gxB), [gyB] "{v33}"(gyB), [mx] "s"(max_range), [stride] "s"(stride),
-          [nstride] "s"(nstride), [k4] "s"(k4), [base] "s"(pdt), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
+          [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "v34", "v35", "vcc", "scc", "memory");
 }
 
@@ -838,10 +848,9 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
         "v_cvt_i32_f32_e32 %[rA], v27\n\t"
         ".if %[tiled]\n\t"
-        "v_lshl_add_u32 v26, %[cA], 4, %[k4]\n\t"
-        "v_and_b32_e32 v27, 3, %[rA]\n\t"
-        "v_mad_i32_i24 v26, %[rA], %[stride], v26\n\t"
-        "v_mad_i32_i24 v26, v27, %[nstride], v26\n\t"
+        "v_mad_i32_i24 v26, %[rA], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v26, %[nstride], v26\n\t"
+        "v_lshl_add_u32 v26, %[cA], 4, v26\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v26, %[rA], %[stride], %[cA]\n\t"
         "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
@@ -852,10 +861,9 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "v_cvt_i32_f32_e32 %[cB], v34\n\t"
         "v_cvt_i32_f32_e32 %[rB], v35\n\t"
         ".if %[tiled]\n\t"
-        "v_lshl_add_u32 v34, %[cB], 4, %[k4]\n\t"
-        "v_and_b32_e32 v35, 3, %[rB]\n\t"
-        "v_mad_i32_i24 v34, %[rB], %[stride], v34\n\t"
-        "v_mad_i32_i24 v34, v35, %[nstride], v34\n\t"
+        "v_mad_i32_i24 v34, %[rB], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v34, %[nstride], v34\n\t"
+        "v_lshl_add_u32 v34, %[cB], 4, v34\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v34, %[rB], %[stride], %[cB]\n\t"
         "v_lshl_add_u32 v34, v34, 2, %[k4]\n\t"
@@ -866,10 +874,9 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "v_cvt_i32_f32_e32 %[cC], v42\n\t"
         "v_cvt_i32_f32_e32 %[rC], v43\n\t"
         ".if %[tiled]\n\t"
-        "v_lshl_add_u32 v42, %[cC], 4, %[k4]\n\t"
-        "v_and_b32_e32 v43, 3, %[rC]\n\t"
-        "v_mad_i32_i24 v42, %[rC], %[stride], v42\n\t"
-        "v_mad_i32_i24 v42, v43, %[nstride], v42\n\t"
+        "v_mad_i32_i24 v42, %[rC], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v42, %[nstride], v42\n\t"
+        "v_lshl_add_u32 v42, %[cC], 4, v42\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v42, %[rC], %[stride], %[cC]\n\t"
         "v_lshl_add_u32 v42, v42, 2, %[k4]\n\t"
@@ -904,15 +911,16 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         : [dyA] "{v22}"(dyA), [dxA] "{v23}"(dxA), [gxA] "{v24}"(gxA), [gyA] "{v25}"(gyA), [dyB] "{v30}"(dyB),
           [dxB] "{v31}"(dxB), [gxB] "{v32}"(gxB), [gyB] "{v33}"(gyB), [dyC] "{v38}"(dyC), [dxC] "{v39}"(dxC),
           [gxC] "{v40}"(gxC), [gyC] "{v41}"(gyC), [mx] "s"(max_range), [stride] "s"(stride),
-          [nstride] "s"(nstride), [k4] "s"(k4), [base] "s"(pdt), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
+          [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "v34", "v35", "v42", "v43", "vcc", "scc", "memory");
 }
 
 
 struct PadMap {
-    const float *pdt;        // padded step map (pad_dt_kernel / pad_dt_tiled_kernel)
-    int stride, nstride, pad; // row-major: elements per row, 0; tiled: S4 = 4*pcol bytes, -(S4-4)
-    uint32_t k4;             // byte offset of map cell (0,0): (pad*stride + pad)*4
+    const float *pdt;        // padded step map (pad_dt_kernel / pad_dt_tiled_kernel); tiled: + (pad << 4) bytes,
+                             //   the column bias of the address
+    int stride, nstride, pad; // row-major: elements per row, 0; tiled: M = 4 + 2^(K-2), MASK = 0xC | (~0 << K)
+    uint32_t k4;             // row-major: byte offset of map cell (0,0): (pad*stride + pad)*4; tiled: padM = (pad+4)*M
     FastDiv div_stride;
     float res;
 };
@@ -927,7 +935,9 @@ struct StreamParams {
     int n_bands;
     const float *raw_poses;  // INLINE only: world poses (x, y, theta); every workgroup derives the
     const MapParams *map;    //   records of the chunks it owns itself (device copy of the map params)
-    int k_max;               // INLINE only: LDS capacity in chunk records
+    int k_max;               // INLINE only: LDS capacity in block records (BlockRec)
+    uint32_t cpp;            // INLINE only: 64-ray blocks per pose, ceil(num_rays / 64) — blocks never straddle a pose
+    FastDiv div_cpp;
     int drain_prio;          // raise wave priority once the workgroup's stream is exhausted
     int run_log2;            // a workgroup's stream interleaves RUNS of 2^run_log2 consecutive 64-ray blocks
     int stripe;              // INLINE only, where the band's pose ids come from: 0 = the caller's order
@@ -1052,12 +1062,27 @@ __device__ __forceinline__ uint32_t stripe_band_list(const MapParams &m, const f
 // LDS header of the stream kernels in floats: [0] slot counter, [1] spare, [2..66) crash_seen
 constexpr int STREAM_HDR = 66;
 
+// INLINE: everything a ray slot of a 64-ray block needs, in ONE 32-byte LDS record per owned block (two
+// ds_read_b128).  Blocks of an INLINE launch never straddle a pose — a pose's beams are padded to a
+// multiple of 64 (1081 beams: 7 idle slots in 1088, 0.65 %) — so block -> pose is one record, not the
+// "which of two poses" decode of a dense ray stream (round 2: two 16-B records + pose id + first step +
+// block word = 6 LDS reads and ~28 VALU per claim; now 3 reads and ~17).
+struct __attribute__((aligned(32))) BlockRec {
+    float gx, gy, ct, st;    // grid origin, cos / sin of the grid heading
+    float d0;                // first step of the pose's rays (pose_first_step)
+    uint32_t obase;          // BYTE offset of the block's first range in `out`: (pose * num_rays + j0) * 4
+    uint32_t j0nv;           // first beam of the block | valid rays in it << 16
+    uint32_t pose;           // pose id (fused crash test)
+};
+
+constexpr uint32_t NO_RAY = 0xffffffffu;       // output index of a slot that holds no ray
+
 template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED, int SLOTS = 1>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
 void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__restrict__ out,
                           int32_t *__restrict__ hits, uint16_t *__restrict__ steps, CrashParams cp)
 {
-    extern __shared__ float lds_f[];
+    extern __shared__ __attribute__((aligned(32))) float lds_f[];
     uint32_t *q_next = reinterpret_cast<uint32_t *>(lds_f);     // shared slot counter
     // [2 .. STREAM_HDR): CRASH only — poses this workgroup has already reported as crashed
     // (direct-mapped): a pose scraping a wall crashes on hundreds of beams, all marched by this
@@ -1069,13 +1094,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     // store's acknowledgement and the kernel 2.5x slower)
     double *edge_l = reinterpret_cast<double *>(lds_f + STREAM_HDR + 2 * (size_t)f.num_rays);
     const size_t tables = STREAM_HDR + (CRASH ? 4 : 2) * (size_t)f.num_rays;
-    // INLINE: per owned chunk {gx, gy, cos, sin} and pose id | invalid flag, filled below
-    PoseRec *lrec = reinterpret_cast<PoseRec *>(lds_f + ((tables + 3) & ~(size_t)3));   // 16-B aligned
-    uint32_t *lord = reinterpret_cast<uint32_t *>(lrec + (INLINE ? sp.k_max : 0));
-    // INLINE: per owned block, first beam of the block (low 16 bits) and number of valid rays in it
-    // (a ray slot then finds its record and beam with an LDS read instead of two integer divisions)
-    float *ld0 = reinterpret_cast<float *>(lord + (INLINE ? sp.k_max : 0));   // first step per record
-    uint32_t *lblk = reinterpret_cast<uint32_t *>(ld0 + (INLINE ? sp.k_max : 0));
+    // INLINE: one BlockRec per owned block, filled below
+    BlockRec *lrec = reinterpret_cast<BlockRec *>(lds_f + ((tables + 7) & ~(size_t)7));   // 32-B aligned
     if (threadIdx.x == 0) *q_next = 0;
     if (CRASH && threadIdx.x < STREAM_HDR - 2) crash_seen[threadIdx.x] = 0xffffffffu;
     // (the beam directions are the same for every workgroup of every launch with this fan: a table
@@ -1093,44 +1113,46 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     const uint32_t G = ((uint32_t)gridDim.x - (uint32_t)band + (uint32_t)nb - 1) / (uint32_t)nb;
     const uint32_t seg_lo = (uint32_t)(((long)f.n_poses * band) / nb);
     const uint32_t seg_hi = (uint32_t)(((long)f.n_poses * (band + 1)) / nb);
-    // the band's rays (pose-major, beam-minor) in blocks of 64: this workgroup owns blocks
-    // g, g+G, ... — K blocks, 64*K ray slots (any num_rays, no padding lanes)
+    // the band's rays in blocks of 64: this workgroup owns blocks g, g+G, ... (in runs) — K blocks, 64*K ray
+    // slots.  Binned records: the band's rays pose-major, beam-minor, cut every 64 (any num_rays, no
+    // padding lanes).  INLINE: cpp blocks per pose, the last one partly filled.
     const uint32_t seg_rays = (seg_hi - seg_lo) * (uint32_t)f.num_rays;
-    const uint32_t seg_chunks = (seg_rays + 63u) >> 6;
+    const uint32_t seg_chunks = INLINE ? (seg_hi - seg_lo) * sp.cpp : (seg_rays + 63u) >> 6;
     const uint32_t rl = (uint32_t)sp.run_log2, rmask = (1u << rl) - 1u;
     const uint32_t seg_runs = (seg_chunks + rmask) >> rl;
     const uint32_t K = (g < seg_runs ? (seg_runs - g + G - 1) / G : 0) << rl;
     const uint32_t total = K << 6;
-    // i-th block of this workgroup's stream -> first ray of the block
-    auto blk_of = [&](uint32_t i) { return (((g + (i >> rl) * G) << rl) + (i & rmask)) << 6; };
+    // i-th block of this workgroup's stream -> its index in the band / first ray of the block
+    auto blkidx_of = [&](uint32_t i) { return ((g + (i >> rl) * G) << rl) + (i & rmask); };
+    auto blk_of = [&](uint32_t i) { return blkidx_of(i) << 6; };
     const unsigned lane = threadIdx.x & 63;
     if (INLINE) {
-        // small batches: no binning launch in front of the march — each workgroup turns the poses
-        // of its own chunks into records (a few hundred, one per lane) and keeps them in LDS
+        // no binning launch (or a keys-only one) in front of the march — each workgroup turns the poses
+        // of its own blocks into records (a few hundred, one per lane) and keeps them in LDS
         const MapParams mp = *sp.map;
         // stripe mode: this band's poses (a row stripe of the map) compacted here, in LDS
-        uint32_t *list = lblk + (sp.k_max >> 1);
+        uint32_t *list = reinterpret_cast<uint32_t *>(lrec + sp.k_max);
         if (sp.stripe == 1 && seg_hi > seg_lo)
             stripe_band_list<NT>(mp, sp.raw_poses, f.n_poses, seg_lo, seg_hi, list,
                                  reinterpret_cast<int *>(list + (seg_hi - seg_lo) + 1));
         for (uint32_t i = threadIdx.x; i < K; i += NT) {
-            const uint32_t blk = blk_of(i);
-            const uint32_t j0 = blk - fast_div(blk, sp.div_B) * (uint32_t)f.num_rays;
-            const uint32_t nvalid = blk < seg_rays ? min(64u, seg_rays - blk) : 0u;
-            lblk[i] = j0 | (nvalid << 16);
-        }
-        // (num_rays >= 64 here, so a block of 64 rays touches at most two poses: slots 2k, 2k+1)
-        for (uint32_t k2 = threadIdx.x; k2 < 2 * K; k2 += NT) {
-            const uint32_t p0 = fast_div(blk_of(k2 >> 1), sp.div_B) + (k2 & 1);
-            if (seg_lo + p0 < seg_hi) {
+            const uint32_t b = blkidx_of(i);
+            BlockRec br{0.0f, 0.0f, 1.0f, 0.0f, PDT_NO_RAY, 0u, 0u, 0u};
+            if (b < seg_chunks) {
+                const uint32_t p0 = fast_div(b, sp.div_cpp);
+                const uint32_t j0 = (b - p0 * sp.cpp) << 6;
+                const uint32_t nvalid = min(64u, (uint32_t)f.num_rays - j0);
                 const uint32_t pid = sp.stripe == 1 ? list[p0]
                                    : sp.stripe == 2 ? (sp.order[seg_lo + p0] & ~POSE_INVALID) : seg_lo + p0;
                 PoseRec r;
                 const uint32_t kf = pose_record(mp, sp.raw_poses, (int)pid, 0, 1, 1, r);
-                lrec[k2] = r;
-                lord[k2] = pid | (kf & POSE_INVALID);
-                ld0[k2] = pose_first_step(mp, r.gx, r.gy, kf, f.step_coeff);
+                br.gx = r.gx; br.gy = r.gy; br.ct = r.ct; br.st = r.st;
+                br.d0 = pose_first_step(mp, r.gx, r.gy, kf, f.step_coeff);
+                br.obase = (pid * (uint32_t)f.num_rays + j0) << 2;
+                br.j0nv = j0 | (nvalid << 16);
+                br.pose = pid;
             }
+            lrec[i] = br;
         }
     }
     __syncthreads();
@@ -1140,18 +1162,78 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     uint32_t n_serv = 0, ns_drain = 0, drain_samples = 0;
     if (sp.dbg) t_start = wall_clock64();
 
+    // one ray slot of a lane.  oidx (byte offset of the range in `out`) == NO_RAY: the slot holds no ray
+    // (nothing to store when it is "finished")
+    struct Slot {
+        float gx, gy, dx, dy, t, d_last;
+        int pc, pr;
+        uint32_t oidx;
+        uint32_t pose;         // CRASH only
+        int jbeam;             // CRASH only
+    };
+    // ray slot q of this workgroup's stream -> the lane's slot state; false: a padding slot (no ray).
+    // s.oidx is the BYTE offset of the ray's range in `out` (the store needs no shift).
+    auto claim = [&](Slot &s, uint32_t q) -> bool {
+        if (INLINE) {
+            // everything is read before validity is known (one LDS round trip, not two): a padding slot of
+            // a pose's last block becomes a slot without a ray — t past max_range, oidx NO_RAY — whose other
+            // fields are never looked at (its beam index may point past the fan table: LDS reads are harmless)
+            const uint4 *rp = reinterpret_cast<const uint4 *>(lrec + (q >> 6));
+            const uint4 ra = rp[0], rb = rp[1];
+            const uint32_t l = q & 63u;
+            const bool valid = l < (rb.z >> 16);
+            const uint32_t j = (rb.z & 0xffffu) + l;
+            const float2 cs = fan_cs[j];
+            const float ct = __builtin_bit_cast(float, ra.z), st = __builtin_bit_cast(float, ra.w);
+            s.gx = __builtin_bit_cast(float, ra.x);
+            s.gy = __builtin_bit_cast(float, ra.y);
+            s.dx = __builtin_fmaf(ct, cs.x, -(st * cs.y));
+            s.dy = __builtin_fmaf(st, cs.x, ct * cs.y);
+            s.oidx = valid ? rb.y + (l << 2) : NO_RAY;
+            if (CRASH) {
+                s.pose = rb.w;
+                s.jbeam = (int)j;
+            }
+            // the sample at t = 0 was taken with the pose record (pose_first_step)
+            s.d_last = __builtin_bit_cast(float, rb.x);
+            s.t = valid ? s.d_last : __builtin_inff();
+            return valid;
+        }
+        const uint32_t ray = blk_of(q >> 6) + (q & 63);
+        if (ray >= seg_rays) return false;
+        const uint32_t spose = fast_div(ray, sp.div_B);
+        const int j = (int)(ray - spose * (uint32_t)f.num_rays);
+        // SGPR base + 32-bit lane offset (global_load ... s[base]) instead of 64-bit per-lane pointers
+        const uint32_t si = seg_lo + spose;
+        const uint32_t po = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sp.order) + (si << 2));
+        const PoseRec pr_ = *reinterpret_cast<const PoseRec *>(reinterpret_cast<const char *>(sp.rec) + (si << 4));
+        const float2 cs = fan_cs[j];
+        s.gx = pr_.gx;
+        s.gy = pr_.gy;
+        s.dx = __builtin_fmaf(pr_.ct, cs.x, -(pr_.st * cs.y));
+        s.dy = __builtin_fmaf(pr_.st, cs.x, pr_.ct * cs.y);
+        s.oidx = ((po & ~POSE_INVALID) * (uint32_t)f.num_rays + (uint32_t)j) << 2;
+        if (CRASH) {
+            s.pose = po & ~POSE_INVALID;
+            s.jbeam = j;
+        }
+        s.t = s.d_last = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sp.d0) + (si << 2));
+        return true;
+    };
+    auto crash_test = [&](const Slot &s, float r) {
+        if (((double)r - edge_l[s.jbeam]) < cp.thresh) {
+            uint32_t *seen = &crash_seen[s.pose & (STREAM_HDR - 3)];
+            if (*seen != s.pose) {            // (a race only costs a redundant atomic)
+                *seen = s.pose;
+                crash_note(cp, s.pose);
+            }
+        }
+    };
+
     if constexpr (SLOTS >= 2) {
         // ---------------- two (three) rays per lane (ranges, optionally the fused crash test; no diagnostics; tiled step map)
         static_assert(!(SLOTS >= 2) || !AUX, "multi-slot form: ranges (+ crash test), no diagnostics");
-        struct Slot {
-            float gx, gy, dx, dy, t, d_last;
-            int pc, pr;
-            uint32_t oidx;
-            bool has_ray;
-            uint32_t pose;         // CRASH only
-            int jbeam;             // CRASH only
-        };
-        Slot sa{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, 0u, false, 0u, 0}, sb = sa, sc = sa;
+        Slot sa{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, NO_RAY, 0u, 0}, sb = sa, sc = sa;
         bool exhausted = total == 0;
         auto finish = [&](Slot &s) {
             float r = f.max_range;
@@ -1160,58 +1242,10 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 r = hit_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
             }
             r *= pm.res;
-            if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + s.oidx);
-            if (out) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + (s.oidx << 2)) = r;
-            if (CRASH) {
-                if (((double)r - edge_l[s.jbeam]) < cp.thresh) {
-                    uint32_t *seen = &crash_seen[s.pose & (STREAM_HDR - 3)];
-                    if (*seen != s.pose) {            // (a race only costs a redundant atomic)
-                        *seen = s.pose;
-                        crash_note(cp, s.pose);
-                    }
-                }
-            }
-            s.has_ray = false;
-        };
-        auto claim = [&](Slot &s, uint32_t q) {
-            bool valid;
-            int j;
-            uint32_t li = 0, si = 0;
-            if (INLINE) {
-                const uint32_t bw = lblk[q >> 6];
-                valid = (q & 63) < (bw >> 16);
-                uint32_t jj = (bw & 0xffffu) + (q & 63);
-                const bool next_pose = jj >= (uint32_t)f.num_rays;
-                jj -= next_pose ? (uint32_t)f.num_rays : 0u;
-                j = (int)jj;
-                li = 2 * (q >> 6) + (next_pose ? 1u : 0u);
-            } else {
-                const uint32_t ray = blk_of(q >> 6) + (q & 63);
-                valid = ray < seg_rays;
-                const uint32_t spose = fast_div(ray, sp.div_B);
-                j = (int)(ray - spose * (uint32_t)f.num_rays);
-                si = seg_lo + spose;
-            }
-            if (valid) {
-                const uint32_t po = INLINE ? lord[li]
-                    : *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sp.order) + (si << 2));
-                const PoseRec pr_ = INLINE ? lrec[li]
-                    : *reinterpret_cast<const PoseRec *>(reinterpret_cast<const char *>(sp.rec) + (si << 4));
-                const float2 cs = fan_cs[j];
-                s.gx = pr_.gx;
-                s.gy = pr_.gy;
-                s.dx = __builtin_fmaf(pr_.ct, cs.x, -(pr_.st * cs.y));
-                s.dy = __builtin_fmaf(pr_.st, cs.x, pr_.ct * cs.y);
-                s.oidx = (po & ~POSE_INVALID) * (uint32_t)f.num_rays + (uint32_t)j;
-                if (CRASH) {
-                    s.pose = po & ~POSE_INVALID;
-                    s.jbeam = j;
-                }
-                s.has_ray = true;
-                // the sample at t = 0 was taken with the pose record (pose_first_step)
-                s.t = s.d_last = INLINE ? ld0[li]
-                    : *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sp.d0) + (si << 2));
-            }
+            if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (s.oidx >> 2));
+            if (out) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + s.oidx) = r;
+            if (CRASH) crash_test(s, r);
+            s.oidx = NO_RAY;
         };
         for (;;) {
             const unsigned long long idle_a = __ballot(!(sa.t < f.max_range));
@@ -1220,9 +1254,9 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             if (idle_a | idle_b | idle_c) {
                 const bool mine_a = !(sa.t < f.max_range), mine_b = !(sb.t < f.max_range);
                 const bool mine_c = SLOTS == 3 && !(sc.t < f.max_range);
-                if (mine_a && sa.has_ray) finish(sa);
-                if (mine_b && sb.has_ray) finish(sb);
-                if (SLOTS == 3 && mine_c && sc.has_ray) finish(sc);
+                if (mine_a && sa.oidx != NO_RAY) finish(sa);
+                if (mine_b && sb.oidx != NO_RAY) finish(sb);
+                if (SLOTS == 3 && mine_c && sc.oidx != NO_RAY) finish(sc);
                 if (!exhausted) {                     // wave-uniform
                     const uint32_t cnt_a = (uint32_t)__popcll(idle_a), cnt_b = (uint32_t)__popcll(idle_b);
                     const uint32_t cnt = cnt_a + cnt_b + (uint32_t)__popcll(idle_c);
@@ -1245,8 +1279,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 }
             }
             if (exhausted && !__ballot(sa.t < f.max_range) && !__ballot(sb.t < f.max_range) &&
-                !__ballot(sa.has_ray) && !__ballot(sb.has_ray) &&
-                (SLOTS < 3 || (!__ballot(sc.t < f.max_range) && !__ballot(sc.has_ray))))
+                !__ballot(sa.oidx != NO_RAY) && !__ballot(sb.oidx != NO_RAY) &&
+                (SLOTS < 3 || (!__ballot(sc.t < f.max_range) && !__ballot(sc.oidx != NO_RAY))))
                 break;
             if (SLOTS == 3)
                 march_loop3<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
@@ -1262,53 +1296,42 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     }
 
     bool exhausted = total == 0;
-    bool has_ray = false;
-    float gx = 0, gy = 0, dx = 0, dy = 0;
-    float t = INF;                 // t < max_range  <=>  the lane is marching
-    float d_last = 1.0f;           // last sample: PDT_HIT, PDT_OUTSIDE, or the free cell's step
-    int pc = 0, pr = 0;            // cell of the last sample
-    uint32_t oidx = 0, nstep = 0, pose = 0;
-    int jbeam = 0;
+    Slot s1{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, NO_RAY, 0u, 0};
+    // (s1.t < max_range  <=>  the lane is marching; d_last: PDT_HIT, PDT_OUTSIDE, or the free cell's step)
+    uint32_t nstep = 0;
 
     for (;;) {
         // ---------------- service: finish pending rays, claim new slots
-        const unsigned long long idle = __ballot(!(t < f.max_range));
+        const unsigned long long idle = __ballot(!(s1.t < f.max_range));
         if (idle) {
             if (sp.dbg) ++n_serv;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
                                       __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            const bool mine = !(t < f.max_range);
-            if (mine && has_ray) {
+            const bool mine = !(s1.t < f.max_range);
+            if (mine && s1.oidx != NO_RAY) {
+                const uint32_t oidx = s1.oidx >> 2;
                 float r = f.max_range;
                 int hc = -1, hr = -1;
-                if (d_last == PDT_HIT) {
-                    hc = pc;
-                    hr = pr;
-                    const float xd = (float)hc - gx, yd = (float)hr - gy;
+                if (s1.d_last == PDT_HIT) {
+                    hc = s1.pc;
+                    hr = s1.pr;
+                    const float xd = (float)hc - s1.gx, yd = (float)hr - s1.gy;
                     r = hit_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
                 }
                 r *= pm.res;
                 if (f.noise_std > 0.0f)
                     r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + oidx);
-                if (out) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + (oidx << 2)) = r;
+                if (out) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + s1.oidx) = r;
                 if (AUX) {
                     if (sp.dbg && t_drain && nstep - ns_drain > drain_samples) drain_samples = nstep - ns_drain;
                     if (hits) { hits[2 * (size_t)oidx] = hc; hits[2 * (size_t)oidx + 1] = hr; }
                     // the read that found the border is not a map sample (the CPU statement
                     // leaves the loop before reading)
-                    if (d_last == PDT_OUTSIDE) --nstep;
+                    if (s1.d_last == PDT_OUTSIDE) --nstep;
                     if (steps) steps[oidx] = (uint16_t)(nstep > 65535u ? 65535u : nstep);
                 }
-                if (CRASH) {
-                    if (((double)r - edge_l[jbeam]) < cp.thresh) {
-                        uint32_t *seen = &crash_seen[pose & (STREAM_HDR - 3)];
-                        if (*seen != pose) {            // (a race only costs a redundant atomic)
-                            *seen = pose;
-                            crash_note(cp, pose);
-                        }
-                    }
-                }
-                has_ray = false;
+                if (CRASH) crash_test(s1, r);
+                s1.oidx = NO_RAY;
             }
             if (!exhausted) {                         // wave-uniform
                 const uint32_t cnt = (uint32_t)__popcll(idle);
@@ -1318,45 +1341,9 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 exhausted = qb + cnt >= total;
                 const uint32_t q = qb + rank;
                 if (mine && q < total) {
-                    bool valid;
-                    int j;
-                    uint32_t li = 0, si = 0;
-                    if (INLINE) {
-                        const uint32_t bw = lblk[q >> 6];
-                        valid = (q & 63) < (bw >> 16);
-                        uint32_t jj = (bw & 0xffffu) + (q & 63);
-                        const bool next_pose = jj >= (uint32_t)f.num_rays;
-                        jj -= next_pose ? (uint32_t)f.num_rays : 0u;
-                        j = (int)jj;
-                        li = 2 * (q >> 6) + (next_pose ? 1u : 0u);
-                    } else {
-                        const uint32_t ray = blk_of(q >> 6) + (q & 63);
-                        valid = ray < seg_rays;
-                        const uint32_t spose = fast_div(ray, sp.div_B);
-                        j = (int)(ray - spose * (uint32_t)f.num_rays);
-                        // SGPR base + 32-bit lane offset (global_load ... s[base]) instead of 64-bit
-                        // per-lane pointers
-                        si = seg_lo + spose;
-                    }
-                    if (valid) {
-                        const uint32_t po = INLINE ? lord[li]
-                            : *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sp.order) + (si << 2));
-                        const PoseRec pr_ = INLINE ? lrec[li]
-                            : *reinterpret_cast<const PoseRec *>(reinterpret_cast<const char *>(sp.rec) + (si << 4));
-                        const float2 cs = fan_cs[j];
-                        pose = po & ~POSE_INVALID;
-                        gx = pr_.gx;
-                        gy = pr_.gy;
-                        dx = __builtin_fmaf(pr_.ct, cs.x, -(pr_.st * cs.y));
-                        dy = __builtin_fmaf(pr_.st, cs.x, pr_.ct * cs.y);
-                        jbeam = j;
-                        oidx = pose * (uint32_t)f.num_rays + (uint32_t)j;
-                        has_ray = true;
-                        // the sample at t = 0 was taken with the pose record (pose_first_step)
-                        t = d_last = INLINE ? ld0[li]
-                            : *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sp.d0) + (si << 2));
-                        nstep = (t > 0.0f && t < PDT_NO_RAY) ? 1u : 0u;
-                    }
+                    const bool got = claim(s1, q);
+                    // (branch-free: a branch on `got` would split the claim's LDS reads into dependent trips)
+                    if (AUX) nstep = got ? ((s1.t > 0.0f && s1.t < PDT_NO_RAY) ? 1u : 0u) : nstep;
                 }
             }
         }
@@ -1365,7 +1352,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         //  once when EXEC is empty, and keeping it unconditional keeps the ray state in place: a branch
         //  around the asm block made the compiler copy t / cell / step registers in and out of it,
         //  15 v_mov per service round)
-        if (exhausted && !__ballot(t < f.max_range) && !__ballot(has_ray)) break;
+        if (exhausted && !__ballot(s1.t < f.max_range) && !__ballot(s1.oidx != NO_RAY)) break;
         // ---------------- march while enough lanes are live (or nothing is left to claim)
         // a wave that can no longer refill is on the launch's critical path (its longest ray
         // decides when the kernel ends): let it win issue arbitration against refilling waves
@@ -1374,8 +1361,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             t_drain = wall_clock64();
             ns_drain = nstep;
         }
-        march_loop<AUX, TILED>(dx, dy, gx, gy, t, pc, pr, d_last, nstep, pm.pdt, pm.stride, pm.nstride,
-                               pm.k4, f.max_range, exhausted ? 0u : (uint32_t)sp.low_water);
+        march_loop<AUX, TILED>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, nstep, pm.pdt, pm.stride,
+                               pm.nstride, pm.k4, f.max_range, exhausted ? 0u : (uint32_t)sp.low_water);
     }
     uint32_t ds_max = 0;
     if (AUX && sp.dbg) {                                   // longest chain of samples marched after exhaustion

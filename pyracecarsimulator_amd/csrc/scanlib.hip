@@ -249,7 +249,7 @@ struct rl_method {
     uint64_t blpad_epoch = ~0ull;
     TableDep blpad_dep;
     DevBuf pdt;                  // EDT with a border of `pad` cells of -1 (stream kernel)
-    int pad = 0, pstride = 0;
+    int pad = 0, pstride = 0;    // pstride: elements per row (row-major) | M (tiled, see pdt_tiled_byte)
     uint64_t pdt_epoch = ~0ull;  // map epoch the padded copy was built from
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -283,7 +283,8 @@ struct rl_method {
     int run_log2 = -1;           // stream interleave granularity: runs of 2^run_log2 blocks; -1 = by batch size
     int tiled = 1;               // step map with 4 rows interleaved (a 128-B line = 4x8 cells); 0 = row-major
     int pdt_tiled = -1;          // layout the padded copy was built with
-    uint32_t pdt_k4 = 0;
+    uint32_t pdt_k4 = 0, pdt_mask = 0;
+    size_t pdt_base_off = 0;     // tiled: the column bias (pad << 4 bytes) folded into the base address
     int slice_log2 = 30;         // launches are cut into pose slices below 2^slice_log2 rays
     int bin_generic = 0;         // diagnostics: force the generic single-workgroup binning kernel
     int inline_prep = 1;         // tiny batches: no binning launch, workgroups derive their own records
@@ -1092,15 +1093,24 @@ static int ensure_step_map(rl_method *h, hipStream_t stream)
     h->pad = (int)std::ceil(h->max_range) + 2;
     if (h->tiled) {
         h->pad = (h->pad + 7) & ~7;                       // 128-B lines line up with the border
-        const int prow = (m->rows + 2 * h->pad + 3) & ~3;
-        const int pcol = (m->cols + 2 * h->pad + 7) & ~7;
-        h->pstride = 4 * pcol;                            // S4: bytes between rows of a 4-row group
-        const long k_elems = (long)h->pad * pcol + 4L * h->pad;
-        if ((rc = h->pdt.ensure((size_t)prow * pcol * sizeof(float)))) return rc;
-        hipLaunchKernelGGL(pad_dt_tiled_kernel, dim3((pcol + 255) / 256, prow), dim3(256), 0, stream,
-                           m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad, pcol, k_elems,
-                           h->step_coeff);
-        h->pdt_k4 = (uint32_t)(k_elems * 4);
+        TiledGeom tg{};
+        tg.pad = h->pad;
+        tg.padr = h->pad + 4;                             // one slack group in front: offsets stay positive
+        tg.pcols = m->cols + 2 * h->pad;
+        tg.prows = (m->rows + 2 * h->pad + 4 + 3) & ~3;
+        int lg = 3;                                       // power-of-two pitch >= padded cols and padded rows
+        while ((1 << lg) < std::max(tg.pcols, tg.prows)) ++lg;
+        tg.K = lg + 4;
+        const size_t bytes = ((size_t)(tg.prows >> 2)) << tg.K;
+        if (bytes > ((size_t)1 << 32)) return fail(RL_ERR_UNSUPPORTED, "map too large for the tiled step map");
+        const uint32_t M = 4u + (1u << (tg.K - 2));
+        h->pstride = (int)M;
+        h->pdt_mask = 0xCu | (~0u << tg.K);
+        h->pdt_k4 = (uint32_t)tg.padr * M;
+        h->pdt_base_off = (size_t)h->pad << 4;
+        if ((rc = h->pdt.ensure(bytes))) return rc;
+        hipLaunchKernelGGL(pad_dt_tiled_kernel, dim3((tg.pcols + 255) / 256, tg.prows), dim3(256), 0, stream,
+                           m->d_dt, m->rows, m->cols, (float *)h->pdt.p, tg, h->step_coeff);
     } else {
         h->pstride = (m->cols + 2 * h->pad + 31) & ~31;
         const int prow = m->rows + 2 * h->pad;
@@ -1109,6 +1119,8 @@ static int ensure_step_map(rl_method *h, hipStream_t stream)
                            stream, m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad,
                            h->pstride, h->step_coeff);
         h->pdt_k4 = (uint32_t)(((size_t)h->pad * h->pstride + h->pad) * 4);
+        h->pdt_mask = 0;
+        h->pdt_base_off = 0;
     }
     h->pdt_epoch = m->epoch;
     h->pdt_tiled = h->tiled;
@@ -1312,9 +1324,9 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             (rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, pl.binning)))
             return rc;
         PadMap pm{};
-        pm.pdt = (const float *)h->pdt.p;
+        pm.pdt = (const float *)((const char *)h->pdt.p + h->pdt_base_off);
         pm.stride = h->pstride;
-        pm.nstride = h->tiled ? -(h->pstride - 4) : 0;
+        pm.nstride = (int)h->pdt_mask;
         pm.pad = h->pad;
         pm.k4 = h->pdt_k4;
         pm.div_stride = make_fastdiv((uint32_t)h->pstride);
@@ -1330,6 +1342,8 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.raw_poses = d_poses;
         sp.map = m->d_mp;
         sp.k_max = pl.k_max;
+        sp.cpp = (uint32_t)((num_rays + 63) / 64);
+        sp.div_cpp = make_fastdiv(sp.cpp);
         sp.drain_prio = h->drain_prio;
         sp.dbg = nullptr;
         const int waves_per_wg = pl.block / 64;

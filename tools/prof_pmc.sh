@@ -21,7 +21,7 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $P --output-format csv -d "$OUT/p$i" -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OUT/p$i.json" 2> "$OUT/p$i.err" || echo "pass $i failed: $P"
+  timeout 150 rocprofv3 --pmc $P --output-format csv -d "$OUT/p$i" -- python3 bench.py --no-cpu-baseline --no-extras --no-verify --bursts 2 --steps 5 --warmup 2 "$@" > "$OUT/p$i.json" 2> "$OUT/p$i.err" || echo "pass $i failed: $P"
 done
 python3 tools/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json"
 rm -rf "$OUT"/p[0-9]* 
