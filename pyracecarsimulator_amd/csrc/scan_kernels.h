@@ -743,6 +743,170 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
 }
 
 
+// march_loop with an iteration cap (drain phase: a bounded stretch of the plain loop between two attempts of
+// the speculating loop).  Leaves when no lane is live or after `iters` samples per lane.
+template <bool TILED>
+__device__ __forceinline__ void march_loop_capped(float dx, float dy, float gx, float gy, float &t, int &c, int &r,
+                                                  float &d, const float *pdt, int stride, int nstride, uint32_t k4,
+                                                  float max_range, uint32_t iters)
+{
+    unsigned long long save;
+    uint32_t n = iters;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_cbranch_execz L_cap_done_%=\n"
+        "L_cap_%=:\n\t"
+        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[c], v26\n\t"
+        "v_cvt_i32_f32_e32 %[r], v27\n\t"
+        ".if %[tiled]\n\t"
+        "v_mad_i32_i24 v26, %[r], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v26, %[nstride], v26\n\t"
+        "v_lshl_add_u32 v26, %[c], 4, v26\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v26, %[r], %[stride], %[c]\n\t"
+        "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
+        ".endif\n\t"
+        "global_load_dword %[d], v26, %[base]\n\t"
+        "s_sub_u32 %[n], %[n], 1\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_add_f32_e32 v20, v20, %[d]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_cbranch_execz L_cap_done_%=\n\t"
+        "s_cmp_lg_u32 %[n], 0\n\t"
+        "s_cbranch_scc1 L_cap_%=\n"
+        "L_cap_done_%=:\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        : [t] "+{v20}"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [save] "=&s"(save), [n] "+s"(n)
+        : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy), [mx] "s"(max_range),
+          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [tiled] "n"(TILED ? 1 : 0)
+        : "v26", "v27", "vcc", "scc", "memory");
+}
+
+// ------------------------------------------------------------------------------
+// The DRAIN loop of the one-ray-per-lane kernel: value speculation on the step.
+// When a workgroup's stream has run dry, what is left are single long rays — rays sliding along a wall
+// take 70..240 samples (mean 6.9), each a dependent load (~115 ns), and the launch ends with the longest
+// of them.  Such a ray sees the same step again and again (93 % of the steps of chains >= 80 samples repeat
+// their predecessor, tools: /tmp-free CPU replay in DESIGN.md section 4), so the samples at t, t+g, t+2g,
+// t+3g (g = the last step) are loaded TOGETHER and the k-th is consumed only if the march really arrived
+// at that t: t_k = t_{k-1} + g bit for bit when sample k-1 returned g.  Same t sequence, same cells, same
+// results as march_loop — 1 memory round trip per up to 4 samples instead of per sample.
+// ~51 VALU per iteration: only worth it when few lanes are live and the SIMD is idle (drain phase).
+// Speculative samples are only loaded where t_k < max_range (the ray stays inside the padded map there).
+// (c, r) of the last consumed sample are recomputed from its t (kept in tp) when the loop leaves.
+// Registers: as march_loop + t1 v28, t2 v30, t3 v32 (low halves of pairs), positions / addresses
+// v[34:39], samples v40..v43, tp v44 (pair), g v46.
+// ------------------------------------------------------------------------------
+template <bool TILED>
+__device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float gy, float &t, int &c, int &r,
+                                             float &d, const float *pdt, int stride, int nstride, uint32_t k4,
+                                             float max_range)
+{
+    static_assert(TILED, "the speculative drain loop exists for the tiled step map only");
+    // The loop also leaves when an iteration's FIRST prediction failed on every live lane (a ray along a
+    // diagonal wall alternates between two steps and never repeats its predecessor): the caller then marches a
+    // bounded stretch with the plain loop before the next attempt.
+    unsigned long long save, ent, live, hit;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_mov_b64 %[ent], exec\n\t"
+        "s_mov_b64 %[live], exec\n\t"
+        "s_cbranch_execz L_drain_done_%=\n"
+        "L_drain_%=:\n\t"
+        "v_mov_b32_e32 v46, %[d]\n\t"                       // g
+        "v_add_f32_e32 v28, v20, v46\n\t"                   // t1, t2, t3
+        "v_add_f32_e32 v30, v28, v46\n\t"
+        "v_add_f32_e32 v32, v30, v46\n\t"
+        // sample 0 (every live lane)
+        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 v26, v26\n\t"
+        "v_cvt_i32_f32_e32 v27, v27\n\t"
+        "v_mad_i32_i24 v27, v27, %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v27, %[nstride], v27\n\t"
+        "v_lshl_add_u32 v26, v26, 4, v27\n\t"
+        "global_load_dword v40, v26, %[base]\n\t"
+        // sample 1 where t1 is still inside the range window
+        "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
+        "v_pk_fma_f32 v[34:35], v[22:23], v[28:29], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 v34, v34\n\t"
+        "v_cvt_i32_f32_e32 v35, v35\n\t"
+        "v_mad_i32_i24 v35, v35, %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v35, %[nstride], v35\n\t"
+        "v_lshl_add_u32 v34, v34, 4, v35\n\t"
+        "global_load_dword v41, v34, %[base]\n\t"
+        // sample 2
+        "v_cmpx_gt_f32_e32 %[mx], v30\n\t"
+        "v_pk_fma_f32 v[36:37], v[22:23], v[30:31], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 v36, v36\n\t"
+        "v_cvt_i32_f32_e32 v37, v37\n\t"
+        "v_mad_i32_i24 v37, v37, %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v37, %[nstride], v37\n\t"
+        "v_lshl_add_u32 v36, v36, 4, v37\n\t"
+        "global_load_dword v42, v36, %[base]\n\t"
+        // sample 3
+        "v_cmpx_gt_f32_e32 %[mx], v32\n\t"
+        "v_pk_fma_f32 v[38:39], v[22:23], v[32:33], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 v38, v38\n\t"
+        "v_cvt_i32_f32_e32 v39, v39\n\t"
+        "v_mad_i32_i24 v39, v39, %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v39, %[nstride], v39\n\t"
+        "v_lshl_add_u32 v38, v38, 4, v39\n\t"
+        "global_load_dword v43, v38, %[base]\n\t"
+        // stage 0: the sample at t is always real
+        "s_mov_b64 exec, %[live]\n\t"
+        "s_waitcnt vmcnt(3)\n\t"
+        "v_mov_b32_e32 v44, v20\n\t"
+        "v_mov_b32_e32 %[d], v40\n\t"
+        "v_add_f32_e32 v20, v20, v40\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"                  // still marching ...
+        "v_cmpx_eq_f32_e32 v40, v46\n\t"                    // ... and the step was the predicted one
+        "s_mov_b64 %[hit], exec\n\t"
+        // stage 1: the march arrived at t1 exactly
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_mov_b32_e32 v44, v20\n\t"
+        "v_mov_b32_e32 %[d], v41\n\t"
+        "v_add_f32_e32 v20, v20, v41\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "v_cmpx_eq_f32_e32 v41, v46\n\t"
+        // stage 2
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_mov_b32_e32 v44, v20\n\t"
+        "v_mov_b32_e32 %[d], v42\n\t"
+        "v_add_f32_e32 v20, v20, v42\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "v_cmpx_eq_f32_e32 v42, v46\n\t"
+        // stage 3
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_mov_b32_e32 v44, v20\n\t"
+        "v_mov_b32_e32 %[d], v43\n\t"
+        "v_add_f32_e32 v20, v20, v43\n\t"
+        // who is still marching
+        "s_mov_b64 exec, %[live]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_mov_b64 %[live], exec\n\t"
+        "s_cbranch_execz L_drain_out_%=\n\t"
+        "s_cmp_lg_u64 %[hit], 0\n\t"
+        "s_cbranch_scc1 L_drain_%=\n"
+        "L_drain_out_%=:\n\t"
+        // cell of the last consumed sample of every ray that went through this loop
+        "s_mov_b64 exec, %[ent]\n\t"
+        "v_pk_fma_f32 v[26:27], v[22:23], v[44:45], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[c], v26\n\t"
+        "v_cvt_i32_f32_e32 %[r], v27\n"
+        "L_drain_done_%=:\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        : [t] "+{v20}"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [save] "=&s"(save), [ent] "=&s"(ent),
+          [live] "=&s"(live), [hit] "=&s"(hit)
+        : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy), [mx] "s"(max_range),
+          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt)
+        : "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40",
+          "v41", "v42", "v43", "v44", "v45", "v46", "vcc", "scc", "memory");
+}
+
+
 // Two rays per lane (SLOTS = 2 of the stream kernel): slot A and slot B of a lane are two independent
 // rays with their own live masks.  The wave alternates EXEC between the masks — switching is scalar
 // work — so the VALU count per sample stays 9 and a finished slot needs no predication, while BOTH
@@ -939,6 +1103,9 @@ struct StreamParams {
     uint32_t cpp;            // INLINE only: 64-ray blocks per pose, ceil(num_rays / 64) — blocks never straddle a pose
     FastDiv div_cpp;
     int drain_prio;          // raise wave priority once the workgroup's stream is exhausted
+    int spec_drain;          // one ray per lane, stream exhausted: switch to the value-speculating loop (march_drain4)
+                             //   once at most this many lanes are live (0 = never)
+    int spec_stretch;        //   ... after this many samples of the plain loop, and again between two attempts
     int run_log2;            // a workgroup's stream interleaves RUNS of 2^run_log2 consecutive 64-ray blocks
     int stripe;              // INLINE only, where the band's pose ids come from: 0 = the caller's order
                              //   (band = index range), 1 = row stripes of the map compacted by every
@@ -1360,6 +1527,23 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         if (AUX && sp.dbg && exhausted && !t_drain) {       // drain phase starts: samples so far per lane
             t_drain = wall_clock64();
             ns_drain = nstep;
+        }
+        if constexpr (!AUX && TILED) {
+            // drain phase: the plain loop while more than a handful of lanes are live, then the
+            // value-speculating loop for the last long rays (march_drain4)
+            if (exhausted && sp.spec_drain > 0) {
+                march_loop<AUX, TILED>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, nstep, pm.pdt,
+                                       pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)sp.spec_drain);
+                // what is still marching after a stretch of the plain loop is a long chain: speculate on it
+                // while that pays, fall back to the plain loop for a stretch when it does not
+                while (__ballot(s1.t < f.max_range)) {
+                    march_loop_capped<TILED>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, pm.pdt,
+                                             pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)sp.spec_stretch);
+                    march_drain4<TILED>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, pm.pdt, pm.stride,
+                                        pm.nstride, pm.k4, f.max_range);
+                }
+                continue;
+            }
         }
         march_loop<AUX, TILED>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, nstep, pm.pdt, pm.stride,
                                pm.nstride, pm.k4, f.max_range, exhausted ? 0u : (uint32_t)sp.low_water);
