@@ -328,6 +328,12 @@ int rl_ranges_from_u16_device(int device, const uint16_t *d_in_u16, size_t n, fl
 int rl_probe_gather_rate(int device, int active_lanes, double *lanes_per_clk_per_cu,
                          double *clock_hz_or_null, int *n_cu_or_null);
 
+/* diagnostics: HBM stream rates of this device with hand-written 16-B-per-lane kernels on two buffers of
+ * `bytes`: gbs_out5 = {copy, read-only, write-only, copy with non-temporal stores, fill with non-temporal
+ * stores} in GB/s (copy counts read + write).  The practical ceiling next to the 8 TB/s spec of
+ * bench.py's roofline (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy).                     */
+int rl_probe_hbm(int device, size_t bytes, double *gbs_out5);
+
 #ifdef __cplusplus
 }
 #endif

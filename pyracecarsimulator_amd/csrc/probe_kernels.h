@@ -29,4 +29,52 @@ __global__ __launch_bounds__(1024) void gather_probe_kernel(const float *__restr
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+// ------------------------------------------------------------------------------
+// HBM stream probe (rl_probe_hbm): what a hand-written 16-B-per-lane grid-stride kernel moves on this box —
+// the practical ceiling the bandwidth-bound kernels (GiantLUT) are held against.  tools/hbm_probe.py measured
+// torch's elementwise kernels (copy 4.7, fill 6.8, sum 4.0 TB/s); MI355X_MICROARCH.md quotes 6.29 TB/s for a
+// float4 copy: these kernels are that copy (mode 0), a read-only sweep (1), a write-only fill (2), and the
+// copy / fill with non-temporal stores (3, 4).  Persistent grid (8 workgroups of 256 per CU), 4 x 16 B in
+// flight per lane.
+// ------------------------------------------------------------------------------
+typedef unsigned int probe_v4u __attribute__((ext_vector_type(4)));   // (the non-temporal builtin wants a native vector)
+
+__device__ __forceinline__ void nt_store16(uint4 *p, const uint4 &v)
+{
+    probe_v4u w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<probe_v4u *>(p));
+}
+
+__global__ __launch_bounds__(256) void hbm_probe_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+                                                        int mode, uint32_t *__restrict__ sink)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    const uint4 fillv = make_uint4(1u, 2u, 3u, 4u);
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        uint4 a = fillv, b = fillv, c = fillv, d = fillv;
+        if (mode == 0 || mode == 1 || mode == 3) {
+            a = src[i]; b = src[i + stride]; c = src[i + 2 * stride]; d = src[i + 3 * stride];
+        }
+        if (mode == 1) {
+            acc ^= a.x ^ b.y ^ c.z ^ d.w;
+        } else if (mode == 3 || mode == 4) {
+            nt_store16(dst + i, a);
+            nt_store16(dst + i + stride, b);
+            nt_store16(dst + i + 2 * stride, c);
+            nt_store16(dst + i + 3 * stride, d);
+        } else {
+            dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+        }
+    }
+    for (; i < n16; i += stride) {
+        uint4 a = fillv;
+        if (mode == 0 || mode == 1 || mode == 3) a = src[i];
+        if (mode == 1) acc ^= a.x;
+        else dst[i] = a;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 }  // namespace scan

@@ -1524,7 +1524,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         // a wave that can no longer refill is on the launch's critical path (its longest ray
         // decides when the kernel ends): let it win issue arbitration against refilling waves
         if (exhausted && sp.drain_prio) __builtin_amdgcn_s_setprio(3);
-        if (AUX && sp.dbg && exhausted && !t_drain) {       // drain phase starts: samples so far per lane
+        if (sp.dbg && exhausted && !t_drain) {              // drain phase starts: samples so far per lane
             t_drain = wall_clock64();
             ns_drain = nstep;
         }
@@ -1701,7 +1701,8 @@ __global__ __launch_bounds__(256) void lut_fan_kernel(MapParams m, FanParams f, 
 // fan needs (fov/2pi of the row), which costs less than narrow requests do.  Software-pipelined:
 // the next pose's row is in flight while the current one is gathered and stored.
 template <int NL, int CH>
-__global__ __launch_bounds__(256) void lut_fan_lds_kernel(MapParams m, FanParams f, LutParams lp,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(88)))     // (+ VCC etc. <= 96: the eighth wave per SIMD)
+void lut_fan_lds_kernel(MapParams m, FanParams f, LutParams lp,
                                                           const float *__restrict__ poses,
                                                           float *__restrict__ out)
 {
@@ -1717,7 +1718,11 @@ __global__ __launch_bounds__(256) void lut_fan_lds_kernel(MapParams m, FanParams
     const int D = lp.theta_disc >> 1;                        // dwords per row (theta_disc even)
 
     uint4 regs[NL];
-    auto issue = [&](int pose, float &thg, bool &inb) {
+    // fast: the fan's bins are ONE ascending circular run shorter than a row (fov >= 0, span < theta_disc,
+    // |bin index before the wrap| < 2^23): beam j's bin is then (u_j - ubase) with at most one wrap, ubase =
+    // u_0 - bin_0 a multiple of theta_disc — the same integer as the statement's ((int)u % td + td) % td
+    // (every float involved is an exactly represented integer), for 8 instead of ~20 instructions per beam
+    auto issue = [&](int pose, float &thg, bool &inb, bool &fast, float &ubase) {
         float gx, gy;
         world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
                       poses[3 * (size_t)pose + 2], gx, gy, thg);
@@ -1733,6 +1738,9 @@ __global__ __launch_bounds__(256) void lut_fan_lds_kernel(MapParams m, FanParams
         const bool all = !(spanf >= 0.0f && spanf < td_f - 8.0f) || !(__builtin_fabsf(u0) < 8388608.0f);
         const int span = all ? 0 : (int)spanf;
         const int b0 = all ? 0 : lut_bin_fast(thg + fan_alpha(f, 0), lp, td_f, inv_td);
+        fast = f.inc >= 0.0f && spanf >= 0.0f && spanf < td_f && __builtin_fabsf(u0) < 4194304.0f &&
+               __builtin_fabsf(u1) < 4194304.0f;
+        ubase = u0 - (float)(all ? lut_bin_fast(thg + fan_alpha(f, 0), lp, td_f, inv_td) : b0);
 #pragma unroll
         for (int n = 0; n < NL; ++n) {
             const int idx = (n * 64 + lane) * 4;               // dword index; bins 2*idx .. 2*idx+7
@@ -1746,30 +1754,54 @@ __global__ __launch_bounds__(256) void lut_fan_lds_kernel(MapParams m, FanParams
 
     int pose = wave;
     if (pose >= f.n_poses) return;
-    float thg, thg_n = 0.0f;
-    bool inb, inb_n = false;
-    issue(pose, thg, inb);
+    float thg, thg_n = 0.0f, ubase, ubase_n = 0.0f;
+    bool inb, inb_n = false, fast, fast_n = false;
+    issue(pose, thg, inb, fast, ubase);
+    const uint32_t td_u = (uint32_t)lp.theta_disc;
     for (;;) {
 #pragma unroll
         for (int n = 0; n < NL; ++n) *reinterpret_cast<uint4 *>(my + (n * 64 + lane) * 4) = regs[n];
         const int next = pose + n_waves;
-        if (next < f.n_poses) issue(next, thg_n, inb_n);      // in flight during the gather
+        if (next < f.n_poses) issue(next, thg_n, inb_n, fast_n, ubase_n);      // in flight during the gather
         float *dst = out + (size_t)pose * f.num_rays;
+        if (fast && inb && !(f.noise_std > 0.0f) && !(lp.debug & 2)) {       // wave-uniform
+            // (groups of four chunks: the whole fan unrolled at once keeps 17 bins + 17 ranges live and costs
+            //  the kernel three of its eight waves per SIMD)
+#pragma unroll 1
+            for (int k0 = 0; k0 < CH; k0 += 4) {
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const int j = (k << 6) + lane;
-            if (j < f.num_rays) {
-                float r = miss;
-                if (inb) r = (float)my16[lut_bin_fast(thg + fan_alpha(f, j), lp, td_f, inv_td)] * scale * m.res;
-                if (f.noise_std > 0.0f)
-                    r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (size_t)pose * f.num_rays + j);
-                if (!(lp.debug & 2) || r < 0.0f) dst[j] = r;
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int j = ((k0 + kk) << 6) + lane;
+                    if (k0 + kk < CH && j < f.num_rays) {
+                        const float u = __builtin_rintf((thg + fan_alpha(f, j)) * lp.bins_per_rad);
+                        const uint32_t b = (uint32_t)(int)(u - ubase);
+                        const uint32_t bw = min(b, b - td_u);                   // one wrap at most
+                        const float r = (float)my16[bw] * scale * m.res;
+                        if (lp.debug & 8) __builtin_nontemporal_store(r, dst + j); else dst[j] = r;
+                    }
+                }
+            }
+        } else {
+            // the general statement (poses outside the map, noise, fov < 0, fans as long as a row, headings
+            // beyond 2^22 bins): rare — kept rolled so that it does not set the kernel's register count
+#pragma unroll 1
+            for (int k = 0; k < CH; ++k) {
+                const int j = (k << 6) + lane;
+                if (j < f.num_rays) {
+                    float r = miss;
+                    if (inb) r = (float)my16[lut_bin_fast(thg + fan_alpha(f, j), lp, td_f, inv_td)] * scale * m.res;
+                    if (f.noise_std > 0.0f)
+                        r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (size_t)pose * f.num_rays + j);
+                    if (!(lp.debug & 2) || r < 0.0f) dst[j] = r;
+                }
             }
         }
         if (next >= f.n_poses) break;
         pose = next;
         thg = thg_n;
         inb = inb_n;
+        fast = fast_n;
+        ubase = ubase_n;
     }
 }
 

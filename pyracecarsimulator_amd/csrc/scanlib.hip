@@ -2055,6 +2055,54 @@ extern "C" int rl_followgap_eval_device(rl_followgap *g, const float *d_scans, i
     return followgap_launch(g, d_scans, n_scans, size, d_angles, (hipStream_t)hip_stream);
 }
 
+// ---------------------------------------------------------------- diagnostics: HBM stream probe
+extern "C" int rl_probe_hbm(int device, size_t bytes, double *gbs_out5)
+{
+    if (!gbs_out5) return fail(RL_ERR_INVALID, "rl_probe_hbm: null pointer");
+    if (bytes < ((size_t)1 << 20)) return fail(RL_ERR_INVALID, "rl_probe_hbm: at least 1 MiB per buffer");
+    int ndev = rl_device_count();
+    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    uint4 *a = nullptr, *b = nullptr;
+    uint32_t *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr;
+    int rc = RL_OK;
+    const size_t n16 = bytes / 16;
+    if (hipMalloc((void **)&a, n16 * 16) != hipSuccess || hipMalloc((void **)&b, n16 * 16) != hipSuccess ||
+        hipMalloc((void **)&sink, 4) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess ||
+        hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipMemsetAsync(a, 1, n16 * 16, st) != hipSuccess ||
+        hipMemsetAsync(b, 2, n16 * 16, st) != hipSuccess) {
+        rc = fail(RL_ERR_NOMEM, "rl_probe_hbm: setup failed (2 x %zu bytes)", n16 * 16);
+    } else {
+        const int grid = prop.multiProcessorCount * 8, reps = 10;
+        for (int mode = 0; mode < 5 && rc == RL_OK; ++mode) {
+            hipLaunchKernelGGL(hbm_probe_kernel, dim3(grid), dim3(256), 0, st, a, b, n16, mode, sink);     // warm
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < reps; ++r)
+                hipLaunchKernelGGL(hbm_probe_kernel, dim3(grid), dim3(256), 0, st, a, b, n16, mode, sink);
+            (void)hipEventRecord(e1, st);
+            float ms = 0.f;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) {
+                rc = fail(RL_ERR_HIP, "rl_probe_hbm: launch failed");
+                break;
+            }
+            const double moved = (double)n16 * 16.0 * ((mode == 0 || mode == 3) ? 2.0 : 1.0);
+            gbs_out5[mode] = moved * reps / ((double)ms * 1e-3) / 1e9;
+        }
+    }
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (sink) (void)hipFree(sink);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+    return rc;
+}
+
 // ---------------------------------------------------------------- 16-bit ranges for the xGMI exchange (opt-in, lossy)
 static int u16_args(int device, size_t n, float max_range_m, const void *a, const void *b)
 {

@@ -29,3 +29,16 @@ t = timed(lambda: b.fill_(1.0))
 print("fill  (write only)              : %.0f GB/s" % (gb / t))
 t = timed(lambda: a.sum())
 print("sum   (read only)               : %.0f GB/s" % (gb / t))
+
+
+# the same three patterns from hand-written 16-B-per-lane kernels (rl_probe_hbm): torch's elementwise copy /
+# reduction kernels are not the ceiling — MI355X_MICROARCH.md's 6.29 TB/s is a float4 copy like this one
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyracecarsimulator_amd import _lib
+del a, b
+torch.cuda.empty_cache()
+out = (ctypes.c_double * 5)()
+_lib.check(_lib.lib().rl_probe_hbm(0, 2 << 30, out))
+for name, v in zip(("copy", "read only", "write only", "copy, non-temporal stores", "fill, non-temporal stores"), out):
+    print("rl_probe_hbm %-26s: %.0f GB/s" % (name, v))
