@@ -46,7 +46,8 @@ inline void default_opts(rl_plan_opts &o)
     o.inline_prep = 1;
     o.inline_max = 512;
     o.inline_map_kb = 2048;
-    o.stripe_max = 2560;
+    o.stripe_max = 1536;      // (profiles/r03/plan_sweep.txt: row stripes tie with the keys-only binning launch at 1024
+                              //  poses and lose 8..20 % at 2048..2560 on both big maps)
     o.order_inline = 1;
     o.bin_multi_min = 8192;
     o.bin_generic = 0;

@@ -71,13 +71,22 @@ extern "C" int rl_device_count(void)
 // them is written by the kernel directly — no staging copy on the way back
 // ------------------------------------------------------------------------------
 static std::mutex g_host_mu;
-static std::vector<std::pair<char *, size_t>> g_host_blocks;
+struct HostBlock {
+    char *p;
+    size_t bytes;
+    uint64_t devices;      // devices that may have work in flight on the block: where it was allocated and
+};                         // every device a scan was launched from with its output inside the block
+static std::vector<HostBlock> g_host_blocks;
 
-static bool in_host_block(const void *p, size_t bytes)
+// is [p, p+bytes) inside a block of rl_host_alloc?  `device` >= 0: a launch on that device is about to write it
+static bool in_host_block(const void *p, size_t bytes, int device = -1)
 {
     std::lock_guard<std::mutex> lk(g_host_mu);
-    for (const auto &b : g_host_blocks)
-        if ((const char *)p >= b.first && (const char *)p + bytes <= b.first + b.second) return true;
+    for (auto &b : g_host_blocks)
+        if ((const char *)p >= b.p && (const char *)p + bytes <= b.p + b.bytes) {
+            if (device >= 0 && device < 64) b.devices |= 1ull << device;
+            return true;
+        }
     return false;
 }
 
@@ -89,9 +98,11 @@ extern "C" int rl_host_alloc(size_t bytes, void **out)
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess)
         return fail(RL_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
     memset(p, 0, bytes);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
     {
         std::lock_guard<std::mutex> lk(g_host_mu);
-        g_host_blocks.emplace_back((char *)p, bytes);
+        g_host_blocks.push_back(HostBlock{(char *)p, bytes, (cur >= 0 && cur < 64) ? 1ull << cur : 0ull});
     }
     *out = p;
     return RL_OK;
@@ -100,18 +111,21 @@ extern "C" int rl_host_alloc(size_t bytes, void **out)
 extern "C" int rl_host_free(void *p)
 {
     if (!p) return RL_OK;
+    uint64_t devices = 0;
     {
         std::lock_guard<std::mutex> lk(g_host_mu);
         auto it = std::find_if(g_host_blocks.begin(), g_host_blocks.end(),
-                               [&](const std::pair<char *, size_t> &b) { return b.first == (char *)p; });
+                               [&](const HostBlock &b) { return b.p == (char *)p; });
         if (it == g_host_blocks.end()) return fail(RL_ERR_INVALID, "rl_host_free: not a block of rl_host_alloc");
+        devices = it->devices;
         g_host_blocks.erase(it);
     }
-    // a kernel (on any device) may still be writing into it
+    // a kernel may still be writing into it: wait for the devices that were handed the block — not for every
+    // visible device (a rank of an N-GPU job would create contexts on, and stall, its neighbours' GPUs)
     int ndev = 0, cur = 0;
     if (hipGetDeviceCount(&ndev) == hipSuccess && hipGetDevice(&cur) == hipSuccess) {
-        for (int d = 0; d < ndev; ++d)
-            if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+        for (int d = 0; d < ndev && d < 64; ++d)
+            if (((devices >> d) & 1ull) && hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
         (void)hipSetDevice(cur);
     }
     HIPCHK(hipHostFree(p));
@@ -279,7 +293,7 @@ struct rl_method {
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
     int bin_ppw = POSES_PER_WG;  // ... poses per workgroup of those kernels
     int order_inline = 1;        // big maps, stripe_max..8192 poses: keys-only binning launch + INLINE march
-    int stripe_max = 2560;       // big maps, inline_max..stripe_max poses: no binning launch, workgroups compact
+    int stripe_max = 1536;       // big maps, inline_max..stripe_max poses: no binning launch, workgroups compact
                                  // their own row-stripe band of the pose list (0 = off)
     int inline_map_kb = 2048;    // maps up to this size (f32 cells) never take the binning launch while the records fit LDS
     int run_log2 = -1;           // stream interleave granularity: runs of 2^run_log2 blocks; -1 = by batch size
@@ -1559,7 +1573,7 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     }
     // small calls: zero-copy through pinned host memory (scan() 45 -> ~25 us host-visible)
     // output buffer inside a pinned block of rl_host_alloc: the kernel writes the ranges straight into it
-    const bool direct_out = outs && !hits && !steps && in_host_block(outs, n_rays * sizeof(float));
+    const bool direct_out = outs && !hits && !steps && in_host_block(outs, n_rays * sizeof(float), h->map->device);
     const bool zc = !hits && !steps && (direct_out || n_rays <= (size_t)h->pinned_max_rays);
     const size_t off_out = ((size_t)n_poses * 3 * sizeof(float) + 255) & ~(size_t)255;
     const size_t off_end = off_out + (direct_out ? 0 : ((n_rays * sizeof(float) + 255) & ~(size_t)255));

@@ -104,24 +104,9 @@ class RacecarSimulator:
         return (x + self.scan_dist_to_base * math.cos(th), y + self.scan_dist_to_base * math.sin(th), th)
 
     def runScan(self):
-        """One scan from the lidar pose (:108-116).  The crash test of the same tick
-        (``checkCollision``, :134-144) rides along: scan + Car::isCrashed are ONE fused device call, the
-        ranges land in the simulator's cached output vector (same alias semantics as ``scan()``) and the
-        crash code is kept for ``checkCollision``."""
-        sim = self.scan_simulator
-        method = sim.scan_method
-        if method is None or not hasattr(method, "check_collision_many"):
-            self.scan = sim.scan(*self.getScanPose())              # a foreign range_libc object
-            self._crash_of = None
-            return
-        x, y, th = self.getScanPose()
-        sim.input_vector[0, 0] = x                                 # what scan() records (scan_simulator.py:97-99)
-        sim.input_vector[0, 1] = y
-        sim.input_vector[0, 2] = th
-        code = method.check_collision_many(sim.input_vector[:1], self.scan_fov, self.num_rays,
-                                           self.edge_distances, self.ttc_thresh, ranges=sim.output_vector)
-        self.scan = sim.output_vector
-        self._crash_of = (self.scan, 0 if code == 0 else -2)
+        """One scan from the lidar pose (:108-116); the ranges land in the simulator's cached output vector
+        (same alias semantics as ``scan()``)."""
+        self.scan = self.scan_simulator.scan(*self.getScanPose())
 
     def drive(self, desired_speed, desired_steer_ang):
         self.desired_speed = desired_speed
@@ -135,12 +120,10 @@ class RacecarSimulator:
         self._state = out[0]
 
     def checkCollision(self):
-        """isCrashed(scan, num_rays, 1): 0 when the current scan touches the car outline, else -2.
-        The code was computed on the device together with the scan (``runScan``); a scan array that did
-        not come from there goes through the native host test."""
-        tag = getattr(self, "_crash_of", None)
-        if tag is not None and tag[0] is self.scan:
-            return tag[1]
+        """isCrashed(scan, num_rays, 1) on the scan array's CURRENT contents, as the reference evaluates it
+        (:134-144): 0 when the scan touches the car outline, else -2.  ``self.scan`` aliases the simulator's
+        cached vector — a later ``scan()`` or an in-place edit changes what is tested, exactly as in the
+        reference — so nothing is cached here: the native host test is one pass over num_rays floats."""
         return RC.is_crashed(self.scan, self.num_rays, 1, self.edge_distances, self.ttc_thresh)
 
     def checkCollisionMany(self, poses):

@@ -73,7 +73,8 @@ def one_case(seed):
                                  "run_log2": int(r.choice([-1, 0, 2, 5])), "xcd_bands": int(r.choice([1, 3, 8])),
                                  "grid_mult": int(r.choice([1, 8])), "wg_threads": int(r.choice([256, 512, 1024])),
                                  "bin_multi_min": int(r.choice([64, 8192])), "bin_ppw": int(r.choice([256, 512, 2048])), "pinned_max_rays": int(r.choice([0, 262144])),
-                                 "slots": int(r.choice([1, 2, 3]))}
+                                 "slots": int(r.choice([1, 2, 3])), "spec_drain": int(r.choice([0, 8, 64])),
+                                 "spec_stretch": int(r.choice([1, 4, 16]))}
                         for k_, v_ in sched.items():
                             m.set_option(k_, v_)
                     out = np.empty(n, np.float32); hits = np.empty((n, 2), np.int32); st = np.empty(n, np.uint16)

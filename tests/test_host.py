@@ -273,10 +273,10 @@ def test_launch_plan_thresholds_and_lds_budget():
     """The planner's case boundaries on a big map, and that no plan asks for more LDS than two
     1024-lane workgroups per CU can have."""
     RMGPU = _lib.RL_RM_GPU
-    src = {n: _plan(RMGPU, 2049, 2049, n, 1081)["record_source"] for n in (64, 511, 512, 2560, 2561, 8191, 8192, 65536)}
-    assert src == {64: 1, 511: 1, 512: 2, 2560: 2, 2561: 3, 8191: 3, 8192: 0, 65536: 0}
-    bins = {n: _plan(RMGPU, 2049, 2049, n, 1081)["binning"] for n in (511, 2560, 2561, 8192)}
-    assert bins == {511: "none", 2560: "none", 2561: "small_keys", 8192: "grid_sort"}
+    src = {n: _plan(RMGPU, 2049, 2049, n, 1081)["record_source"] for n in (64, 511, 512, 1536, 1537, 8191, 8192, 65536)}
+    assert src == {64: 1, 511: 1, 512: 2, 1536: 2, 1537: 3, 8191: 3, 8192: 0, 65536: 0}
+    bins = {n: _plan(RMGPU, 2049, 2049, n, 1081)["binning"] for n in (511, 1536, 1537, 8192)}
+    assert bins == {511: "none", 1536: "none", 1537: "small_keys", 8192: "grid_sort"}
     for rows, cols in ((350, 435), (2049, 2049), (4096, 4096)):
         for n in (1, 63, 64, 200, 512, 1000, 2560, 4096, 8191, 8192, 40000, 65536, 1 << 20):
             for B in (64, 271, 720, 1081, 7680):
