@@ -25,7 +25,7 @@
  *     points left in flight are waited for with a device synchronisation);
  *   - streams: *_device calls on ONE method handle may use different streams and then run
  *     concurrently on the GPU (that is how bench.py pipelines consecutive pose batches).
- *     Per-launch scratch is kept per stream (up to 4 streams per handle without any
+ *     Per-launch scratch is kept per stream (rl_launch_contexts() = 8 streams per handle without any
  *     synchronisation, more are served after a device synchronisation), lazily built
  *     tables are guarded by events.  The caller's own buffers (poses, ranges) are the
  *     caller's to order.  A stream must not be destroyed while a launch enqueued on it
@@ -231,7 +231,9 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *   binning    inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min,
  *              bin_generic, bin_ppw (poses per workgroup of the grid-wide binning kernels)
  *   launches   slice_log2 (pose slices below 2^n rays), pinned_max_rays (zero-copy host calls)
- *   diagnosis  timing (1 launch sequence | 2 march kernel only), debug_stamps, drain_prio, lut_debug */
+ *              spec_drain / spec_stretch (one ray per lane: value-speculating drain loop from <= N live lanes,
+ *              plain samples between attempts)
+ *   diagnosis  timing (1 launch sequence | 2 main kernel only), debug_stamps, drain_prio, lut_debug */
 int rl_method_set_option(rl_method *h, const char *name, int value);
 int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
 /* ---- launch planning -------------------------------------------------------------------------

@@ -12,7 +12,7 @@ find "$OUT/trace" -name '*kernel_trace.csv' -exec cp {} "$OUT/kernel_trace.csv" 
 rm -rf "$OUT/trace"
 # keep the trace small: only our kernels
 if [ -f "$OUT/kernel_trace.csv" ]; then
-  (head -1 "$OUT/kernel_trace.csv"; grep -E "rm_fan|pose_bin|rm_rays|edt_|bl_|lut_|cddt_" "$OUT/kernel_trace.csv" | tail -60) > "$OUT/kernel_trace_tail.csv"
+  (head -1 "$OUT/kernel_trace.csv"; grep -E "rm_fan|pose_bin|rm_rays|edt_|bl_|lut_|cddt_" "$OUT/kernel_trace.csv" | tail -${KEEP:-1500}) > "$OUT/kernel_trace_tail.csv"
   rm -f "$OUT/kernel_trace.csv"
 fi
 cat "$OUT/kernel_stats.csv" 2>/dev/null | head -20
