@@ -575,6 +575,7 @@ def test_giant_lut_fan_every_row_width_bit_equal_to_oracle(oracle_mod, td):
     poses[1] = [np.nan, 0.0, 0.0]
     poses[2, 2] = 1e4
     poses[3, 2] = -3e7                                      # |bin index| > 2^23: integer path
+    poses[4, 2] = 2.5e4                                     # between the one-wrap form's 2^22 bound and 2^23 (td 1442)
     for B, fov in ((1081, 4.71), (271, 4.71), (1081, 2 * math.pi), (1088, 7.0), (720, -2.0), (64, 0.0),
                    (1081, 6.25), (700, 6.2831855)):
         out = np.empty(len(poses) * B, np.float32)
@@ -1233,3 +1234,106 @@ def test_fused_crash_marks_poses_then_reduces(oracle_mod, n, slots):
     got = m.check_collision_groups(poses, grp, fov, B, edge, 0.001)
     exp = [oracle_mod.is_crashed(r0[k * grp * B:(k + 1) * grp * B], B, grp, edge, 0.001) for k in range(n // grp)]
     assert got.tolist() == exp
+
+
+# ---------------------------------------------------------------- K1b drain phase: value speculation on the step
+@pytest.mark.parametrize("coeff_cls", ["RM", "RMGPU"])
+def test_speculating_drain_loop_on_long_chains_bit_equal_to_oracle(oracle_mod, coeff_cls):
+    """march_drain4 (one ray per lane, stream dry): rays grazing long straight walls (the step repeats: the
+    loop consumes four samples per round trip), rays along a diagonal staircase wall (the step alternates:
+    the first prediction fails, the loop must fall back to a plain stretch) and ordinary rays, with the loop
+    off, on from 8 / 64 live lanes, stretches of 1 and 16 plain samples — ranges bit-equal to the oracle."""
+    n = 640
+    occ = np.zeros((n, n), np.uint8)
+    occ[0, :] = occ[-1, :] = occ[:, 0] = occ[:, -1] = 1
+    occ[100:103, 20:620] = 1                       # long horizontal walls
+    occ[300:302, 40:600] = 1
+    occ[120:600, 500:503] = 1                      # a long vertical wall
+    for k in range(0, 260):                        # a diagonal staircase wall
+        occ[330 + k, 60 + k] = 1
+        occ[331 + k, 60 + k] = 1
+    g = maps.GridMap(occ, 0.05, (-3.0, 1.0, 0.2), "walls")
+    mrx = 300
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    omap = range_libc.PyOMap(g)
+    assert np.array_equal(omap.distance_transform(), om.dt)
+    rng = np.random.default_rng(5)
+    P, B, fov = 700, 257, 0.35
+    # grid poses a cell or two off the walls, heading almost along them (both directions), plus random ones
+    gx = np.concatenate([rng.uniform(30, 600, 250), rng.uniform(496.0, 499.5, 150), 62 + rng.uniform(0, 250, 150),
+                         rng.uniform(5, 630, 150)])
+    gy = np.concatenate([np.where(rng.random(250) < 0.5, rng.uniform(103.5, 106.0, 250), rng.uniform(296.0, 299.5, 250)),
+                         rng.uniform(130, 590, 150), np.zeros(150), rng.uniform(5, 630, 150)])
+    gy[400:550] = 330 + (gx[400:550] - 60) + rng.uniform(3.0, 6.0, 150)        # just above the staircase
+    th = np.concatenate([rng.choice([0.0, math.pi], 250) + rng.uniform(-0.03, 0.03, 250),
+                         rng.choice([math.pi / 2, -math.pi / 2], 150) + rng.uniform(-0.03, 0.03, 150),
+                         rng.choice([math.pi / 4, -3 * math.pi / 4], 150) + rng.uniform(-0.02, 0.02, 150),
+                         rng.uniform(-math.pi, math.pi, 150)])
+    c, s_ = math.cos(g.origin[2]), math.sin(g.origin[2])
+    poses = np.stack([g.origin[0] + (c * gx - s_ * gy) * g.resolution, g.origin[1] + (s_ * gx + c * gy) * g.resolution,
+                      th + g.origin[2]], 1).astype(np.float32)
+    coeff = 1.0 if coeff_cls == "RMGPU" else 0.999
+    want, _, steps = om.rm_fan(poses, fov, B, step_coeff=coeff, nthreads=oracle_mod.max_threads())
+    assert steps.max() >= 120 and (steps >= 60).sum() > 500          # the chains this test is about exist
+    cls = range_libc.PyRayMarchingGPU if coeff_cls == "RMGPU" else range_libc.PyRayMarching
+    m = cls(omap, mrx)
+    m.set_option("slots", 1)
+    out = np.empty(P * B, np.float32)
+    for big_map_policy in (0, 1):
+        m.set_option("inline_map_kb", 0 if big_map_policy else 2048)
+        for sd, stretch, lw in ((0, 16, 12), (8, 16, 12), (8, 1, 12), (64, 16, 12), (64, 1, 0), (8, 4, 40), (3, 2, 12)):
+            m.set_option("spec_drain", sd)
+            m.set_option("spec_stretch", stretch)
+            m.set_option("low_water", lw)
+            out[:] = -1.0
+            m.calc_range_fan(poses, out, fov, B)
+            assert np.array_equal(out, want), (coeff_cls, big_map_policy, sd, stretch, lw, int((out != want).sum()))
+    assert m.last_plan()["slots"] == 1 and m.get_info("spec_drain") == 3
+
+
+def test_cfg3_cddt_full_size(oracle_mod):
+    """configs[2] names "CDDT/LUT": the CDDT variant at full size — 2000^2 maze, 65536 poses x 1081 beams,
+    theta_disc 108 (/root/reference/scripts/two_player/scan.py:46; 112 in rcs_two_player.py:121 is covered by
+    the small-map tests) — bit-equal to the oracle's CDDT on every 1024th pose, deterministic, within range,
+    and the same answer from the per-ray kernel and from the two-argument per-ray API."""
+    w = workloads.cfg3()
+    g, B, mrx = w.gmap, w.num_rays, w.max_range_px
+    omap = range_libc.PyOMap(g)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    om._dt = omap.distance_transform()
+    m = range_libc.PyCDDTCast(omap, mrx, 108)
+    poses = workloads.make_poses(w, dt=om.dt)
+    assert len(poses) == 65536
+    assert m.plan_fan(len(poses), B)["kernel"] == "cddt_bins"
+    out = np.empty(len(poses) * B, np.float32)
+    m.calc_range_fan(poses, out, w.fov, B)
+    assert out.min() >= 0.0 and out.max() <= mrx * g.resolution
+    again = np.empty_like(out)
+    m.calc_range_fan(poses, again, w.fov, B)
+    assert np.array_equal(out, again)
+    sub = np.arange(0, len(poses), 1024)
+    pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
+    want = om.cddt_fan(108, poses[sub], w.fov, B, nthreads=oracle_mod.max_threads())
+    assert np.array_equal(out[pick], want), int((out[pick] != want).sum())
+    # the per-ray kernel (one search per ray) on the subsample, and the upstream 2-argument form
+    m.set_option("cddt_bins", 0)
+    o2 = np.empty(len(sub) * B, np.float32)
+    m.calc_range_fan(poses[sub], o2, w.fov, B)
+    assert np.array_equal(o2, want)
+    ins = np.zeros((B, 3), np.float32)
+    ins[:, :2] = poses[sub[3], :2]
+    ins[:, 2] = poses[sub[3], 2] + (np.float32(-0.5) * np.float32(w.fov) + np.arange(B, dtype=np.float32) * (np.float32(w.fov) / np.float32(B)))
+    o3 = np.empty(B, np.float32)
+    m.calc_range_many(ins, o3)
+    assert np.array_equal(o3, om.cddt_rays(108, ins))
+    # against exact ray marching: CDDT is approximate in angle only — the median error stays below two cells
+    rm = om.rm_fan(poses[sub], w.fov, B, nthreads=oracle_mod.max_threads(), want_hits=False, want_steps=False)[0]
+    err = np.abs(want - np.minimum(rm, mrx * g.resolution)) / g.resolution
+    assert np.median(err) < 2.0
+
+
+def test_hbm_probe_reports_plausible_rates():
+    import ctypes
+    out = (ctypes.c_double * 5)()
+    _lib.check(_lib.lib().rl_probe_hbm(0, 512 << 20, out))
+    assert all(1000.0 < v < 8000.0 for v in out), list(out)
