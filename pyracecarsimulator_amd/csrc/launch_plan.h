@@ -257,11 +257,11 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     const int slots = o.slots ? o.slots : (rays >= (1L << 23) ? 2 : 1);
     bool a = in.aux, c = in.crash, t = o.tiled != 0;
     int s = 1;
-    if (slots == 3 && !in.aux && !in.crash && !o.debug_stamps && (inl || (nt == 1024 && o.tiled))) {
+    if (slots == 3 && !in.aux && !in.crash && (inl || (nt == 1024 && o.tiled))) {
         s = 3;
         nt = 1024;
         if (!inl) t = true;
-    } else if (slots >= 2 && !in.aux && o.tiled && !o.debug_stamps) {
+    } else if (slots >= 2 && !in.aux && o.tiled) {
         s = 2;
         t = true;
     }

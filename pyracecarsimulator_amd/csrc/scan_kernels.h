@@ -1250,6 +1250,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                           int32_t *__restrict__ hits, uint16_t *__restrict__ steps, CrashParams cp)
 {
     extern __shared__ __attribute__((aligned(32))) float lds_f[];
+    const unsigned long long t_entry = sp.dbg ? wall_clock64() : 0ull;   // diagnostics
     uint32_t *q_next = reinterpret_cast<uint32_t *>(lds_f);     // shared slot counter
     // [2 .. STREAM_HDR): CRASH only — poses this workgroup has already reported as crashed
     // (direct-mapped): a pose scraping a wall crashes on hundreds of beams, all marched by this
@@ -1449,6 +1450,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 !__ballot(sa.oidx != NO_RAY) && !__ballot(sb.oidx != NO_RAY) &&
                 (SLOTS < 3 || (!__ballot(sc.t < f.max_range) && !__ballot(sc.oidx != NO_RAY))))
                 break;
+            if (sp.dbg && exhausted && !t_drain) t_drain = wall_clock64();
             if (SLOTS == 3)
                 march_loop3<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
                             sb.t, sb.pc, sb.pr, sb.d_last, sc.dx, sc.dy, sc.gx, sc.gy, sc.t, sc.pc, sc.pr, sc.d_last,
@@ -1458,6 +1460,15 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 march_loop2<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
                             sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
                             exhausted ? 0u : 2u * (uint32_t)sp.low_water);
+        }
+        if (sp.dbg && lane == 0) {
+            // diagnostics of the several-rays-per-lane form: absolute stamps {kernel entry, wave end, prologue done,
+            // stream dry (0: never marched after exhaustion)} — tools/gpu_stamps_pipe.py
+            const size_t gw = ((size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * 4;
+            sp.dbg[gw] = t_entry;
+            sp.dbg[gw + 1] = wall_clock64();
+            sp.dbg[gw + 2] = t_start;
+            sp.dbg[gw + 3] = t_drain;
         }
         return;
     }
