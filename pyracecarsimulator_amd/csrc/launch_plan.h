@@ -23,6 +23,7 @@ constexpr int STRIPE_BINS = 64;
 constexpr int STRIPE_MAX_PER_LANE = 8;
 constexpr int INLINE_LDS_BUDGET = 56 * 1024;   // LDS an INLINE workgroup may use (two 1024-lane workgroups per CU)
 constexpr int INLINE_REC_BYTES = 32;     // one BlockRec per owned 64-ray block (scan_kernels.h)
+constexpr int DRAIN_CAP = 24, DRAIN_FIELDS = 9;   // several rays per lane: per-wave compaction scratch of the drain phase
 
 struct In {
     int kind = RL_RM_GPU, n_cu = 256, rows = 0, cols = 0, theta_disc = 0;
@@ -208,7 +209,13 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     // INLINE launches cut every pose's fan into cpp blocks of 64 rays (the last one partly filled): a block
     // never straddles two poses, so ONE record per block serves every ray slot of it
     const long n_blocks_inl = (long)n_poses * cpp;
-    const size_t inl_tables = (((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays + 7) & ~(size_t)7) * sizeof(float);
+    // several rays per lane (decided from the ray count before the record source, which needs the LDS size):
+    // every wave of a workgroup gets DRAIN_FIELDS x DRAIN_CAP dwords of compaction scratch behind the tables
+    const int slots_req = o.slots ? o.slots : (rays >= (1L << 23) ? 2 : 1);
+    const bool multi = slots_req >= 2 && !in.aux && o.tiled;          // <=> the launch takes 2 or 3 rays per lane
+    auto drain_bytes = [&](int nthreads) { return multi ? (size_t)(nthreads / 64) * DRAIN_FIELDS * DRAIN_CAP * 4 : (size_t)0; };
+    const size_t tables_b = (((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays + 7) & ~(size_t)7) * sizeof(float);
+    const size_t inl_tables = tables_b + drain_bytes(1024);
     if (inl) {
         nt = 1024;
         const long g_min = std::max(1L, std::min((n_blocks_inl + 15) / 16, (long)n_cu * o.grid_mult * WG / nt) / bands);
@@ -252,9 +259,7 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     p->run_log2 = inl ? inl_rl : rl2;          // (the inline LDS record table was sized for inl_rl)
     p->bands = bands;
     p->k_max = inl ? k_max : 0;
-    p->lds_bytes = (int)(inl ? inl_tables + (size_t)k_max * INLINE_REC_BYTES + lds_extra
-                             : ((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays) * sizeof(float));
-    const int slots = o.slots ? o.slots : (rays >= (1L << 23) ? 2 : 1);
+    const int slots = slots_req;
     bool a = in.aux, c = in.crash, t = o.tiled != 0;
     int s = 1;
     if (slots == 3 && !in.aux && !in.crash && (inl || (nt == 1024 && o.tiled))) {
@@ -269,6 +274,10 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     p->slots = s;
     p->tiled = t;
     p->block = inl ? 1024 : nt;
+    // (several rays per lane: the compaction scratch sits between the tables and the block records)
+    p->lds_bytes = (int)(inl ? inl_tables + (size_t)k_max * INLINE_REC_BYTES + lds_extra
+                             : (s >= 2 ? tables_b + drain_bytes(p->block)
+                                       : ((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays) * sizeof(float)));
     std::snprintf(p->name, sizeof p->name, "scan::rm_fan_stream_kernel<%s, %s, %d, %s, %s, %d>", tf(a), tf(c),
                   p->block, tf(inl), tf(t), s);
     return RL_OK;

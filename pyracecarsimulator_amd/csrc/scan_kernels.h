@@ -796,8 +796,10 @@ __device__ __forceinline__ void march_loop_capped(float dx, float dy, float gx, 
 // ~51 VALU per iteration: only worth it when few lanes are live and the SIMD is idle (drain phase).
 // Speculative samples are only loaded where t_k < max_range (the ray stays inside the padded map there).
 // (c, r) of the last consumed sample are recomputed from its t (kept in tp) when the loop leaves.
-// Registers: as march_loop + t1 v28, t2 v30, t3 v32 (low halves of pairs), positions / addresses
-// v[34:39], samples v40..v43, tp v44 (pair), g v46.
+// Registers: as march_loop + t1 v28, t2 v30, t3 v32 (low halves of pairs, whose high halves the packed fma
+// names but never reads: g v29, samples 1 and 2 in v31 / v33), positions / addresses v[34:39], tp v40 (pair),
+// samples 0 and 3 in v42 / v43 — exactly the fixed registers of slots B and C of the several-rays-per-lane
+// kernels, which are dead when this loop runs there (no register beyond theirs).
 // ------------------------------------------------------------------------------
 template <bool TILED>
 __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float gy, float &t, int &c, int &r,
@@ -816,10 +818,10 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "s_mov_b64 %[live], exec\n\t"
         "s_cbranch_execz L_drain_done_%=\n"
         "L_drain_%=:\n\t"
-        "v_mov_b32_e32 v46, %[d]\n\t"                       // g
-        "v_add_f32_e32 v28, v20, v46\n\t"                   // t1, t2, t3
-        "v_add_f32_e32 v30, v28, v46\n\t"
-        "v_add_f32_e32 v32, v30, v46\n\t"
+        "v_mov_b32_e32 v29, %[d]\n\t"                       // g
+        "v_add_f32_e32 v28, v20, v29\n\t"                   // t1, t2, t3
+        "v_add_f32_e32 v30, v28, v29\n\t"
+        "v_add_f32_e32 v32, v30, v29\n\t"
         // sample 0 (every live lane)
         "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
         "v_cvt_i32_f32_e32 v26, v26\n\t"
@@ -827,7 +829,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "v_mad_i32_i24 v27, v27, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v27, %[nstride], v27\n\t"
         "v_lshl_add_u32 v26, v26, 4, v27\n\t"
-        "global_load_dword v40, v26, %[base]\n\t"
+        "global_load_dword v42, v26, %[base]\n\t"
         // sample 1 where t1 is still inside the range window
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         "v_pk_fma_f32 v[34:35], v[22:23], v[28:29], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
@@ -836,7 +838,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "v_mad_i32_i24 v35, v35, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v35, %[nstride], v35\n\t"
         "v_lshl_add_u32 v34, v34, 4, v35\n\t"
-        "global_load_dword v41, v34, %[base]\n\t"
+        "global_load_dword v31, v34, %[base]\n\t"
         // sample 2
         "v_cmpx_gt_f32_e32 %[mx], v30\n\t"
         "v_pk_fma_f32 v[36:37], v[22:23], v[30:31], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
@@ -845,7 +847,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "v_mad_i32_i24 v37, v37, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v37, %[nstride], v37\n\t"
         "v_lshl_add_u32 v36, v36, 4, v37\n\t"
-        "global_load_dword v42, v36, %[base]\n\t"
+        "global_load_dword v33, v36, %[base]\n\t"
         // sample 3
         "v_cmpx_gt_f32_e32 %[mx], v32\n\t"
         "v_pk_fma_f32 v[38:39], v[22:23], v[32:33], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
@@ -858,29 +860,29 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         // stage 0: the sample at t is always real
         "s_mov_b64 exec, %[live]\n\t"
         "s_waitcnt vmcnt(3)\n\t"
-        "v_mov_b32_e32 v44, v20\n\t"
-        "v_mov_b32_e32 %[d], v40\n\t"
-        "v_add_f32_e32 v20, v20, v40\n\t"
+        "v_mov_b32_e32 v40, v20\n\t"
+        "v_mov_b32_e32 %[d], v42\n\t"
+        "v_add_f32_e32 v20, v20, v42\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v20\n\t"                  // still marching ...
-        "v_cmpx_eq_f32_e32 v40, v46\n\t"                    // ... and the step was the predicted one
+        "v_cmpx_eq_f32_e32 v42, v29\n\t"                    // ... and the step was the predicted one
         "s_mov_b64 %[hit], exec\n\t"
         // stage 1: the march arrived at t1 exactly
         "s_waitcnt vmcnt(2)\n\t"
-        "v_mov_b32_e32 v44, v20\n\t"
-        "v_mov_b32_e32 %[d], v41\n\t"
-        "v_add_f32_e32 v20, v20, v41\n\t"
+        "v_mov_b32_e32 v40, v20\n\t"
+        "v_mov_b32_e32 %[d], v31\n\t"
+        "v_add_f32_e32 v20, v20, v31\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
-        "v_cmpx_eq_f32_e32 v41, v46\n\t"
+        "v_cmpx_eq_f32_e32 v31, v29\n\t"
         // stage 2
         "s_waitcnt vmcnt(1)\n\t"
-        "v_mov_b32_e32 v44, v20\n\t"
-        "v_mov_b32_e32 %[d], v42\n\t"
-        "v_add_f32_e32 v20, v20, v42\n\t"
+        "v_mov_b32_e32 v40, v20\n\t"
+        "v_mov_b32_e32 %[d], v33\n\t"
+        "v_add_f32_e32 v20, v20, v33\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
-        "v_cmpx_eq_f32_e32 v42, v46\n\t"
+        "v_cmpx_eq_f32_e32 v33, v29\n\t"
         // stage 3
         "s_waitcnt vmcnt(0)\n\t"
-        "v_mov_b32_e32 v44, v20\n\t"
+        "v_mov_b32_e32 v40, v20\n\t"
         "v_mov_b32_e32 %[d], v43\n\t"
         "v_add_f32_e32 v20, v20, v43\n\t"
         // who is still marching
@@ -893,7 +895,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "L_drain_out_%=:\n\t"
         // cell of the last consumed sample of every ray that went through this loop
         "s_mov_b64 exec, %[ent]\n\t"
-        "v_pk_fma_f32 v[26:27], v[22:23], v[44:45], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_pk_fma_f32 v[26:27], v[22:23], v[40:41], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
         "v_cvt_i32_f32_e32 %[c], v26\n\t"
         "v_cvt_i32_f32_e32 %[r], v27\n"
         "L_drain_done_%=:\n\t"
@@ -903,7 +905,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy), [mx] "s"(max_range),
           [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt)
         : "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40",
-          "v41", "v42", "v43", "v44", "v45", "v46", "vcc", "scc", "memory");
+          "v41", "v42", "v43", "vcc", "scc", "memory");
 }
 
 
@@ -1244,8 +1246,14 @@ struct __attribute__((aligned(32))) BlockRec {
 
 constexpr uint32_t NO_RAY = 0xffffffffu;       // output index of a slot that holds no ray
 
+// Several rays per lane, stream dry: once at most DRAIN_CAP rays are live in a wave they are compacted into slot
+// A (through DRAIN_FIELDS x DRAIN_CAP dwords of LDS per wave) and finished by the one-ray-per-lane drain loops
+// (march_loop_capped / march_drain4).
+constexpr int DRAIN_CAP = 24;
+constexpr int DRAIN_FIELDS = 9;
+
 template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED, int SLOTS = 1>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80)))
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
 void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__restrict__ out,
                           int32_t *__restrict__ hits, uint16_t *__restrict__ steps, CrashParams cp)
 {
@@ -1262,8 +1270,12 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     // store's acknowledgement and the kernel 2.5x slower)
     double *edge_l = reinterpret_cast<double *>(lds_f + STREAM_HDR + 2 * (size_t)f.num_rays);
     const size_t tables = STREAM_HDR + (CRASH ? 4 : 2) * (size_t)f.num_rays;
+    // several rays per lane: per-wave compaction scratch of the drain phase (DRAIN_FIELDS x DRAIN_CAP dwords)
+    constexpr size_t DRAIN_WORDS = (SLOTS >= 2 && TILED) ? (size_t)(NT / 64) * DRAIN_FIELDS * DRAIN_CAP : 0;
+    uint32_t *drain_scr = reinterpret_cast<uint32_t *>(lds_f + ((tables + 7) & ~(size_t)7)) +
+                          (size_t)(threadIdx.x >> 6) * DRAIN_FIELDS * DRAIN_CAP;
     // INLINE: one BlockRec per owned block, filled below
-    BlockRec *lrec = reinterpret_cast<BlockRec *>(lds_f + ((tables + 7) & ~(size_t)7));   // 32-B aligned
+    BlockRec *lrec = reinterpret_cast<BlockRec *>(lds_f + ((tables + 7) & ~(size_t)7) + DRAIN_WORDS);   // 32-B aligned
     if (threadIdx.x == 0) *q_next = 0;
     if (CRASH && threadIdx.x < STREAM_HDR - 2) crash_seen[threadIdx.x] = 0xffffffffu;
     // (the beam directions are the same for every workgroup of every launch with this fan: a table
@@ -1451,6 +1463,83 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 (SLOTS < 3 || (!__ballot(sc.t < f.max_range) && !__ballot(sc.oidx != NO_RAY))))
                 break;
             if (sp.dbg && exhausted && !t_drain) t_drain = wall_clock64();
+            if constexpr (TILED) {
+                if (exhausted && sp.spec_drain > 0) {
+                    // drain phase.  (Every idle slot has been finished by the service above: what is live below is
+                    // all this wave still owes.)
+                    const unsigned long long la = __ballot(sa.t < f.max_range), lb = __ballot(sb.t < f.max_range);
+                    const unsigned long long lc = SLOTS == 3 ? __ballot(sc.t < f.max_range) : 0ull;
+                    const uint32_t na = (uint32_t)__popcll(la), nb2 = (uint32_t)__popcll(lb), nc = (uint32_t)__popcll(lc);
+                    const uint32_t nlive = na + nb2 + nc;
+                    if (nlive > (uint32_t)DRAIN_CAP) {
+                        // the plain loop until few rays are left
+                        if (SLOTS == 3)
+                            march_loop3<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx,
+                                        sb.gy, sb.t, sb.pc, sb.pr, sb.d_last, sc.dx, sc.dy, sc.gx, sc.gy, sc.t, sc.pc, sc.pr,
+                                        sc.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)DRAIN_CAP);
+                        else
+                            march_loop2<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx,
+                                        sb.gy, sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4,
+                                        f.max_range, (uint32_t)DRAIN_CAP);
+                        continue;
+                    }
+                    if (nlive > 0) {
+                        // rays claimed a moment ago that were born finished (pose outside the map: a miss without a
+                        // sample) still wait for their store: do it before their slots are recycled
+                        if (!(sa.t < f.max_range) && sa.oidx != NO_RAY) finish(sa);
+                        if (!(sb.t < f.max_range) && sb.oidx != NO_RAY) finish(sb);
+                        if (SLOTS == 3 && !(sc.t < f.max_range) && sc.oidx != NO_RAY) finish(sc);
+                        // compact the live rays of every slot into slot A, lanes 0 .. nlive-1, through LDS
+                        auto put = [&](const Slot &s, uint32_t r) {
+                            drain_scr[0 * DRAIN_CAP + r] = __builtin_bit_cast(uint32_t, s.gx);
+                            drain_scr[1 * DRAIN_CAP + r] = __builtin_bit_cast(uint32_t, s.gy);
+                            drain_scr[2 * DRAIN_CAP + r] = __builtin_bit_cast(uint32_t, s.dx);
+                            drain_scr[3 * DRAIN_CAP + r] = __builtin_bit_cast(uint32_t, s.dy);
+                            drain_scr[4 * DRAIN_CAP + r] = __builtin_bit_cast(uint32_t, s.t);
+                            drain_scr[5 * DRAIN_CAP + r] = __builtin_bit_cast(uint32_t, s.d_last);
+                            drain_scr[6 * DRAIN_CAP + r] = s.oidx;
+                            if (CRASH) {
+                                drain_scr[7 * DRAIN_CAP + r] = s.pose;
+                                drain_scr[8 * DRAIN_CAP + r] = (uint32_t)s.jbeam;
+                            }
+                        };
+                        if (sa.t < f.max_range)
+                            put(sa, __builtin_amdgcn_mbcnt_hi((uint32_t)(la >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)la, 0u)));
+                        if (sb.t < f.max_range)
+                            put(sb, na + __builtin_amdgcn_mbcnt_hi((uint32_t)(lb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lb, 0u)));
+                        if (SLOTS == 3 && sc.t < f.max_range)
+                            put(sc, na + nb2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(lc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lc, 0u)));
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: LDS operations complete in order)
+                        sa.t = sb.t = INF;
+                        sa.oidx = sb.oidx = NO_RAY;
+                        if (SLOTS == 3) { sc.t = INF; sc.oidx = NO_RAY; }
+                        if (lane < nlive) {
+                            sa.gx = __builtin_bit_cast(float, drain_scr[0 * DRAIN_CAP + lane]);
+                            sa.gy = __builtin_bit_cast(float, drain_scr[1 * DRAIN_CAP + lane]);
+                            sa.dx = __builtin_bit_cast(float, drain_scr[2 * DRAIN_CAP + lane]);
+                            sa.dy = __builtin_bit_cast(float, drain_scr[3 * DRAIN_CAP + lane]);
+                            sa.t = __builtin_bit_cast(float, drain_scr[4 * DRAIN_CAP + lane]);
+                            sa.d_last = __builtin_bit_cast(float, drain_scr[5 * DRAIN_CAP + lane]);
+                            sa.oidx = drain_scr[6 * DRAIN_CAP + lane];
+                            if (CRASH) {
+                                sa.pose = drain_scr[7 * DRAIN_CAP + lane];
+                                sa.jbeam = (int)drain_scr[8 * DRAIN_CAP + lane];
+                            }
+                        }
+                        // ... and finish them with the one-ray-per-lane drain loops (value speculation on the step).
+                        // Nothing of slots B / C is needed any more: the wave leaves from here (the drain loops use
+                        // the registers of those slots as scratch).
+                        while (__ballot(sa.t < f.max_range)) {
+                            march_loop_capped<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt,
+                                                     pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)sp.spec_stretch);
+                            march_drain4<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt, pm.stride,
+                                                pm.nstride, pm.k4, f.max_range);
+                        }
+                        if (sa.oidx != NO_RAY) finish(sa);
+                        break;
+                    }
+                }
+            }
             if (SLOTS == 3)
                 march_loop3<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
                             sb.t, sb.pc, sb.pr, sb.d_last, sc.dx, sc.dy, sc.gx, sc.gy, sc.t, sc.pc, sc.pr, sc.d_last,

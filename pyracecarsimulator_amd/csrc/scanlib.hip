@@ -29,7 +29,8 @@
 using namespace scan;
 
 static_assert(plan::WG == scan::WG && plan::STREAM_HDR == scan::STREAM_HDR && plan::STRIPE_BINS == scan::STRIPE_BINS &&
-                  plan::STRIPE_MAX_PER_LANE == scan::STRIPE_MAX_PER_LANE,
+                  plan::STRIPE_MAX_PER_LANE == scan::STRIPE_MAX_PER_LANE && plan::DRAIN_CAP == scan::DRAIN_CAP &&
+                  plan::DRAIN_FIELDS == scan::DRAIN_FIELDS && plan::INLINE_REC_BYTES == (int)sizeof(scan::BlockRec),
               "launch_plan.h and scan_kernels.h disagree about the stream kernels' LDS layout");
 
 // ------------------------------------------------------------------------------

@@ -1270,6 +1270,11 @@ def test_speculating_drain_loop_on_long_chains_bit_equal_to_oracle(oracle_mod, c
                          rng.choice([math.pi / 4, -3 * math.pi / 4], 150) + rng.uniform(-0.02, 0.02, 150),
                          rng.uniform(-math.pi, math.pi, 150)])
     c, s_ = math.cos(g.origin[2]), math.sin(g.origin[2])
+    # every 9th pose outside the map, every 11th inside a wall: rays that are born finished / hit at once, claimed
+    # next to the long chains (the compaction of the several-rays-per-lane drain must not lose their stores)
+    gx[::9] = rng.uniform(-40.0, -2.0, len(gx[::9]))
+    gy[::11] = 101.3
+    gx[::11] = rng.uniform(30, 600, len(gx[::11]))
     poses = np.stack([g.origin[0] + (c * gx - s_ * gy) * g.resolution, g.origin[1] + (s_ * gx + c * gy) * g.resolution,
                       th + g.origin[2]], 1).astype(np.float32)
     coeff = 1.0 if coeff_cls == "RMGPU" else 0.999
@@ -1289,6 +1294,28 @@ def test_speculating_drain_loop_on_long_chains_bit_equal_to_oracle(oracle_mod, c
             m.calc_range_fan(poses, out, fov, B)
             assert np.array_equal(out, want), (coeff_cls, big_map_policy, sd, stretch, lw, int((out != want).sum()))
     assert m.last_plan()["slots"] == 1 and m.get_info("spec_drain") == 3
+    # several rays per lane: once at most 24 rays of a wave are live after the stream ran dry they are compacted
+    # into slot A and finished by the same loops
+    for slots in (2, 3):
+        m.set_option("slots", slots)
+        for big_map_policy in (0, 1):
+            m.set_option("inline_map_kb", 0 if big_map_policy else 2048)
+            for sd, stretch, lw, gm in ((0, 16, 12, 8), (8, 16, 12, 8), (8, 1, 12, 3), (8, 16, 0, 1), (8, 4, 30, 8)):
+                for k_, v_ in (("spec_drain", sd), ("spec_stretch", stretch), ("low_water", lw), ("grid_mult", gm)):
+                    m.set_option(k_, v_)
+                out[:] = -1.0
+                m.calc_range_fan(poses, out, fov, B)
+                assert m.last_plan()["slots"] == slots
+                assert np.array_equal(out, want), (coeff_cls, slots, big_map_policy, sd, stretch, lw, gm, int((out != want).sum()))
+    # ... and with the fused crash test riding along (two rays per lane keeps it)
+    edge = oracle_mod.edge_distances(B, -fov / 2, fov / B, 0.275, 0.2032, 0.3302)
+    m.set_option("slots", 2)
+    m.set_option("spec_drain", 8)
+    m.set_option("grid_mult", 8)
+    m.set_option("low_water", 12)
+    got = m.check_collision_groups(poses, 100, fov, B, edge, 0.001, ranges=out)
+    exp = [oracle_mod.is_crashed(want[k * 100 * B:(k + 1) * 100 * B], B, 100, edge, 0.001) for k in range(P // 100)]
+    assert got.tolist() == exp and np.array_equal(out, want)
 
 
 def test_cfg3_cddt_full_size(oracle_mod):
