@@ -328,7 +328,9 @@ def main():
     P = len(streams)
     default_gm = meth.get_info("grid_mult")
     gm = a.grid_mult or (3 if P > 1 else default_gm)
-    pipe_slots = (3 if n <= 8192 else 2) if (P > 1 and method in ("RM", "RMGPU")) else 0
+    # (two rays per lane: since the waves compact their last rays — DESIGN.md section 4 — two beat three at
+    # every batch but 8192 poses, where three lead by 2 %: profiles/r03/ab_slots.txt)
+    pipe_slots = 2 if (P > 1 and method in ("RM", "RMGPU")) else 0
 
     def apply_schedule(pipelined: bool):
         meth.set_option("grid_mult", gm if pipelined else default_gm)

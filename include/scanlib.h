@@ -232,7 +232,9 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *              bin_generic, bin_ppw (poses per workgroup of the grid-wide binning kernels)
  *   launches   slice_log2 (pose slices below 2^n rays), pinned_max_rays (zero-copy host calls)
  *              spec_drain / spec_stretch (one ray per lane: value-speculating drain loop from <= N live lanes,
- *              plain samples between attempts)
+ *              plain samples between attempts); drain_cap / drain_stretch (several rays per lane: a wave whose
+ *              stream is dry compacts its last <= N rays (<= 64) into one ray per lane and finishes them with
+ *              that loop)
  *   diagnosis  timing (1 launch sequence | 2 main kernel only), debug_stamps, drain_prio, lut_debug */
 int rl_method_set_option(rl_method *h, const char *name, int value);
 int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);

@@ -21,9 +21,10 @@ constexpr int WG = 256;                  // threads of the unit workgroup grid_m
 constexpr int STREAM_HDR = 66;           // LDS header words of the stream kernels
 constexpr int STRIPE_BINS = 64;
 constexpr int STRIPE_MAX_PER_LANE = 8;
-constexpr int INLINE_LDS_BUDGET = 56 * 1024;   // LDS an INLINE workgroup may use (two 1024-lane workgroups per CU)
+constexpr int INLINE_LDS_BUDGET = 72 * 1024;   // LDS an INLINE workgroup may use (two 1024-lane workgroups per CU)
 constexpr int INLINE_REC_BYTES = 32;     // one BlockRec per owned 64-ray block (scan_kernels.h)
-constexpr int DRAIN_CAP = 24, DRAIN_FIELDS = 9;   // several rays per lane: per-wave compaction scratch of the drain phase
+constexpr int DRAIN_CAP = 64, DRAIN_FIELDS = 7;   // several rays per lane: per-wave compaction scratch of the drain phase
+                                                  // (7 dwords per ray, 9 with the fused crash test)
 
 struct In {
     int kind = RL_RM_GPU, n_cu = 256, rows = 0, cols = 0, theta_disc = 0;
@@ -211,10 +212,13 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     const long n_blocks_inl = (long)n_poses * cpp;
     // several rays per lane (decided from the ray count before the record source, which needs the LDS size):
     // every wave of a workgroup gets DRAIN_FIELDS x DRAIN_CAP dwords of compaction scratch behind the tables
-    const int slots_req = o.slots ? o.slots : (rays >= (1L << 23) ? 2 : 1);
-    const bool multi = slots_req >= 2 && !in.aux && o.tiled;          // <=> the launch takes 2 or 3 rays per lane
-    auto drain_bytes = [&](int nthreads) { return multi ? (size_t)(nthreads / 64) * DRAIN_FIELDS * DRAIN_CAP * 4 : (size_t)0; };
     const size_t tables_b = (((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays + 7) & ~(size_t)7) * sizeof(float);
+    const size_t drain_wave = (size_t)(DRAIN_FIELDS + (in.crash ? 2 : 0)) * DRAIN_CAP * 4;
+    int slots_req = o.slots ? o.slots : (rays >= (1L << 23) ? 2 : 1);
+    // (a fan whose tables leave no room for the scratch of 16 waves marches one ray per lane)
+    if (slots_req >= 2 && (in.aux || !o.tiled || tables_b + 16 * drain_wave > (size_t)INLINE_LDS_BUDGET)) slots_req = 1;
+    const bool multi = slots_req >= 2;                                // <=> the launch takes 2 or 3 rays per lane
+    auto drain_bytes = [&](int nthreads) { return multi ? (size_t)(nthreads / 64) * drain_wave : (size_t)0; };
     const size_t inl_tables = tables_b + drain_bytes(1024);
     if (inl) {
         nt = 1024;

@@ -1108,6 +1108,9 @@ struct StreamParams {
     int spec_drain;          // one ray per lane, stream exhausted: switch to the value-speculating loop (march_drain4)
                              //   once at most this many lanes are live (0 = never)
     int spec_stretch;        //   ... after this many samples of the plain loop, and again between two attempts
+    int drain_cap;           // several rays per lane, stream dry: compact the wave's live rays into ONE slot once at most
+                             //   this many are left (<= DRAIN_CAP)
+    int drain_stretch;       //   ... and the plain stretch between two speculation attempts there
     int run_log2;            // a workgroup's stream interleaves RUNS of 2^run_log2 consecutive 64-ray blocks
     int stripe;              // INLINE only, where the band's pose ids come from: 0 = the caller's order
                              //   (band = index range), 1 = row stripes of the map compacted by every
@@ -1249,8 +1252,8 @@ constexpr uint32_t NO_RAY = 0xffffffffu;       // output index of a slot that ho
 // Several rays per lane, stream dry: once at most DRAIN_CAP rays are live in a wave they are compacted into slot
 // A (through DRAIN_FIELDS x DRAIN_CAP dwords of LDS per wave) and finished by the one-ray-per-lane drain loops
 // (march_loop_capped / march_drain4).
-constexpr int DRAIN_CAP = 24;
-constexpr int DRAIN_FIELDS = 9;
+constexpr int DRAIN_CAP = 64;                  // capacity; the threshold is StreamParams::drain_cap <= DRAIN_CAP
+constexpr int DRAIN_FIELDS = 7;                // gx, gy, dx, dy, t, last step, output offset (+ 2 with the crash test)
 
 template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED, int SLOTS = 1>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
@@ -1271,9 +1274,10 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     double *edge_l = reinterpret_cast<double *>(lds_f + STREAM_HDR + 2 * (size_t)f.num_rays);
     const size_t tables = STREAM_HDR + (CRASH ? 4 : 2) * (size_t)f.num_rays;
     // several rays per lane: per-wave compaction scratch of the drain phase (DRAIN_FIELDS x DRAIN_CAP dwords)
-    constexpr size_t DRAIN_WORDS = (SLOTS >= 2 && TILED) ? (size_t)(NT / 64) * DRAIN_FIELDS * DRAIN_CAP : 0;
+    constexpr int DRAIN_F = DRAIN_FIELDS + (CRASH ? 2 : 0);
+    constexpr size_t DRAIN_WORDS = (SLOTS >= 2 && TILED) ? (size_t)(NT / 64) * DRAIN_F * DRAIN_CAP : 0;
     uint32_t *drain_scr = reinterpret_cast<uint32_t *>(lds_f + ((tables + 7) & ~(size_t)7)) +
-                          (size_t)(threadIdx.x >> 6) * DRAIN_FIELDS * DRAIN_CAP;
+                          (size_t)(threadIdx.x >> 6) * DRAIN_F * DRAIN_CAP;
     // INLINE: one BlockRec per owned block, filled below
     BlockRec *lrec = reinterpret_cast<BlockRec *>(lds_f + ((tables + 7) & ~(size_t)7) + DRAIN_WORDS);   // 32-B aligned
     if (threadIdx.x == 0) *q_next = 0;
@@ -1471,16 +1475,17 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                     const unsigned long long lc = SLOTS == 3 ? __ballot(sc.t < f.max_range) : 0ull;
                     const uint32_t na = (uint32_t)__popcll(la), nb2 = (uint32_t)__popcll(lb), nc = (uint32_t)__popcll(lc);
                     const uint32_t nlive = na + nb2 + nc;
-                    if (nlive > (uint32_t)DRAIN_CAP) {
+                    const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane(min(max(sp.drain_cap, 1), DRAIN_CAP));
+                    if (nlive > cap) {
                         // the plain loop until few rays are left
                         if (SLOTS == 3)
                             march_loop3<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx,
                                         sb.gy, sb.t, sb.pc, sb.pr, sb.d_last, sc.dx, sc.dy, sc.gx, sc.gy, sc.t, sc.pc, sc.pr,
-                                        sc.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)DRAIN_CAP);
+                                        sc.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range, cap);
                         else
                             march_loop2<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx,
                                         sb.gy, sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4,
-                                        f.max_range, (uint32_t)DRAIN_CAP);
+                                        f.max_range, cap);
                         continue;
                     }
                     if (nlive > 0) {
@@ -1531,7 +1536,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                         // the registers of those slots as scratch).
                         while (__ballot(sa.t < f.max_range)) {
                             march_loop_capped<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt,
-                                                     pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)sp.spec_stretch);
+                                                     pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)sp.drain_stretch);
                             march_drain4<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt, pm.stride,
                                                 pm.nstride, pm.k4, f.max_range);
                         }

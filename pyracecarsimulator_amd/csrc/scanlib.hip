@@ -236,6 +236,8 @@ struct rl_method {
     int drain_prio = 0;
     int spec_drain = 8;          // one ray per lane: value-speculating drain loop once <= this many lanes are live (0 = off)
     int spec_stretch = 16;       //   ... after this many plain samples, and between two attempts whose first prediction failed
+    int drain_cap = 64;          // several rays per lane: compact a wave's last rays into one slot from <= this many (<= 64)
+    int drain_stretch = 8;       //   ... plain samples between two speculation attempts of the compacted rays
     int wg_threads = 1024;       // stream kernel: workgroup size (256/512/1024) sharing one ray stream
     // GiantLUT (K3)
     DevBuf lut;
@@ -600,6 +602,8 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "drain_prio")) h->drain_prio = value != 0;
     else if (!strcmp(name, "spec_drain")) h->spec_drain = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(name, "spec_stretch")) h->spec_stretch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
+    else if (!strcmp(name, "drain_cap")) h->drain_cap = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (!strcmp(name, "drain_stretch")) h->drain_stretch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
     else if (!strcmp(name, "timing")) h->timing = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
     else if (!strcmp(name, "bin_ppw")) h->bin_ppw = value < 256 ? 256 : (value > 8192 ? 8192 : value);
@@ -641,6 +645,8 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "drain_prio")) *value_out = h->drain_prio;
     else if (!strcmp(name, "spec_drain")) *value_out = h->spec_drain;
     else if (!strcmp(name, "spec_stretch")) *value_out = h->spec_stretch;
+    else if (!strcmp(name, "drain_cap")) *value_out = h->drain_cap;
+    else if (!strcmp(name, "drain_stretch")) *value_out = h->drain_stretch;
     else if (!strcmp(name, "timing")) *value_out = h->timing;
     else if (!strcmp(name, "bin_multi_min")) *value_out = h->bin_multi_min;
     else if (!strcmp(name, "bin_ppw")) *value_out = h->bin_ppw;
@@ -1368,6 +1374,8 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.drain_prio = h->drain_prio;
         sp.spec_drain = h->spec_drain;
         sp.spec_stretch = h->spec_stretch;
+        sp.drain_cap = h->drain_cap;
+        sp.drain_stretch = h->drain_stretch;
         sp.dbg = nullptr;
         const int waves_per_wg = pl.block / 64;
         if (h->debug_stamps) {

@@ -74,7 +74,8 @@ def one_case(seed):
                                  "grid_mult": int(r.choice([1, 8])), "wg_threads": int(r.choice([256, 512, 1024])),
                                  "bin_multi_min": int(r.choice([64, 8192])), "bin_ppw": int(r.choice([256, 512, 2048])), "pinned_max_rays": int(r.choice([0, 262144])),
                                  "slots": int(r.choice([1, 2, 3])), "spec_drain": int(r.choice([0, 8, 64])),
-                                 "spec_stretch": int(r.choice([1, 4, 16]))}
+                                 "spec_stretch": int(r.choice([1, 4, 16])), "drain_cap": int(r.choice([1, 24, 64])),
+                                 "drain_stretch": int(r.choice([1, 8]))}
                         for k_, v_ in sched.items():
                             m.set_option(k_, v_)
                     out = np.empty(n, np.float32); hits = np.empty((n, 2), np.int32); st = np.empty(n, np.uint16)

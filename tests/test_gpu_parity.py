@@ -1294,19 +1294,24 @@ def test_speculating_drain_loop_on_long_chains_bit_equal_to_oracle(oracle_mod, c
             m.calc_range_fan(poses, out, fov, B)
             assert np.array_equal(out, want), (coeff_cls, big_map_policy, sd, stretch, lw, int((out != want).sum()))
     assert m.last_plan()["slots"] == 1 and m.get_info("spec_drain") == 3
-    # several rays per lane: once at most 24 rays of a wave are live after the stream ran dry they are compacted
-    # into slot A and finished by the same loops
+    # several rays per lane: once at most drain_cap (<= 64) rays of a wave are live after the stream ran dry they
+    # are compacted into slot A and finished by the same loops
     for slots in (2, 3):
         m.set_option("slots", slots)
         for big_map_policy in (0, 1):
             m.set_option("inline_map_kb", 0 if big_map_policy else 2048)
-            for sd, stretch, lw, gm in ((0, 16, 12, 8), (8, 16, 12, 8), (8, 1, 12, 3), (8, 16, 0, 1), (8, 4, 30, 8)):
-                for k_, v_ in (("spec_drain", sd), ("spec_stretch", stretch), ("low_water", lw), ("grid_mult", gm)):
+            for sd, cap, stretch, lw, gm in ((0, 64, 16, 12, 8), (8, 64, 8, 12, 8), (8, 24, 1, 12, 3), (8, 1, 16, 0, 1),
+                                             (8, 48, 4, 30, 8), (8, 64, 1, 40, 3), (8, 7, 8, 12, 2)):
+                for k_, v_ in (("spec_drain", sd), ("drain_cap", cap), ("drain_stretch", stretch), ("low_water", lw),
+                               ("grid_mult", gm)):
                     m.set_option(k_, v_)
                 out[:] = -1.0
                 m.calc_range_fan(poses, out, fov, B)
                 assert m.last_plan()["slots"] == slots
-                assert np.array_equal(out, want), (coeff_cls, slots, big_map_policy, sd, stretch, lw, gm, int((out != want).sum()))
+                assert np.array_equal(out, want), (coeff_cls, slots, big_map_policy, sd, cap, stretch, lw, gm,
+                                                   int((out != want).sum()))
+    m.set_option("drain_cap", 64)
+    m.set_option("drain_stretch", 8)
     # ... and with the fused crash test riding along (two rays per lane keeps it)
     edge = oracle_mod.edge_distances(B, -fov / 2, fov / B, 0.275, 0.2032, 0.3302)
     m.set_option("slots", 2)

@@ -236,7 +236,7 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
     p = _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, grid_mult=3)
     assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 3>"
     assert (p["grid"], p["slots"], p["binning"]) == (192, 3, "small_keys")
-    assert p["lds_bytes"] <= 56 * 1024
+    assert p["lds_bytes"] <= 72 * 1024
     # diagnostics and the fused crash test keep one or two rays per lane
     assert _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, aux=True)["slots"] == 1
     assert _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, crash=True)["name"] == \
@@ -285,7 +285,7 @@ def test_launch_plan_thresholds_and_lds_budget():
                     # (the fused crash test cannot be cut into pose slices: 2^30 rays and more keep the chunk kernel)
                     assert p["kernel"] == ("rm_chunk" if kw.get("crash") and n * B >= 1 << 30 else "rm_stream")
                     assert p["grid"] >= 1
-                    assert p["lds_bytes"] <= (56 if p["record_source"] else 150) * 1024, (rows, n, B, kw, p)
+                    assert p["lds_bytes"] <= (72 if p["record_source"] else 150) * 1024, (rows, n, B, kw, p)
                     if p["record_source"] in (2, 3):
                         assert p["bands"] == 8
                     if p["slots"] > 1:
