@@ -477,7 +477,7 @@ def main():
             scan.slots[-1].local[n * B // 2] += 1.0
         apply_schedule(False)
         if method in ("RM", "RMGPU"):
-            meth.set_option("slots", 1)             # (auto would take two rays per lane from 2^23 rays up)
+            meth.set_option("slots", 1)             # (auto may take two rays per lane: launch_plan.h)
         d_ref = torch.empty(n * B, dtype=torch.float32, device=dev)
         bad = []
         for k, sl in enumerate(scan.slots):

@@ -214,7 +214,10 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     // every wave of a workgroup gets DRAIN_FIELDS x DRAIN_CAP dwords of compaction scratch behind the tables
     const size_t tables_b = (((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays + 7) & ~(size_t)7) * sizeof(float);
     const size_t drain_wave = (size_t)(DRAIN_FIELDS + (in.crash ? 2 : 0)) * DRAIN_CAP * 4;
-    int slots_req = o.slots ? o.slots : (rays >= (1L << 23) ? 2 : 1);
+    // auto: two rays per lane from 2^23 rays up, and from 2^20 on maps beyond the small-map bound (long rays:
+    // +6 % on a lone 2049^2 launch of 1024 ... 16 384 poses since dry waves compact their last rays; colombia's
+    // short rays lose 3 % — profiles/r03/sweep_serial_slots.txt)
+    int slots_req = o.slots ? o.slots : ((rays >= (1L << 23) || (rays >= (1L << 20) && !small_map)) ? 2 : 1);
     // (a fan whose tables leave no room for the scratch of 16 waves marches one ray per lane)
     if (slots_req >= 2 && (in.aux || !o.tiled || tables_b + 16 * drain_wave > (size_t)INLINE_LDS_BUDGET)) slots_req = 1;
     const bool multi = slots_req >= 2;                                // <=> the launch takes 2 or 3 rays per lane

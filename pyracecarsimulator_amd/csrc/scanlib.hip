@@ -254,10 +254,10 @@ struct rl_method {
     int cd_geom_rows = -1, cd_geom_cols = -1;              // map shape the constants were made for
     bool cd_sort_attr = false;
     bool cd_counts_clean = false;                          // bucket counters are all zero (see ensure_cddt)
-    int slots = 0;               // stream kernel: rays per lane; 2 (3: inline form only, +4 % with four launches in flight) = plain-range launches on the tiled step map keep two
-                                 // loads in flight per lane; 0 = auto (2 from 2^23 rays per launch up: +3..5 % there, while a
-                                 // lone small launch ends 8 % later with its tail on half as many waves; callers that keep
-                                 // several launches in flight set 2: +15..20 %)
+    int slots = 0;               // stream kernel: rays per lane; 2 (3: inline form only) = plain-range launches on the tiled step
+                                 // map keep two loads in flight per lane and compact a dry wave's last rays into one slot;
+                                 // 0 = auto (launch_plan.h: 2 from 2^23 rays per launch up, from 2^20 on maps beyond the
+                                 // small-map bound; callers that keep several launches in flight set 2: +15..30 %)
     int cddt_sort = 0;                                     // per-bin fan kernel walks the poses in map-tile order, XCD bands
                                                            // (measured: -13 % at 4096 poses - the binning launch and no
                                                            // reuse at that density -, +3 % at 32768: off by default)

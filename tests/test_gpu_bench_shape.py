@@ -144,7 +144,7 @@ def test_bench_default_line_is_verified_and_complete():
     rf = d["roofline"]
     assert rf["kernel"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2>" and rf["grid"] == 192
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["launches_in_flight"] == 4
-    assert "measured_hbm_gbs" in rf and rf["serial"]["kernel"].endswith(", 1>")
+    assert "measured_hbm_gbs" in rf and rf["serial"]["kernel"].endswith(", 2>") and rf["serial"]["grid"] == 512
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["bresenham"]["value"] > 0
     assert cb["cpu_model"] and "-ffp-contract=off" in cb["flags"] and cb["cores"] >= 1

@@ -230,7 +230,7 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
     assert (p["kernel"], p["binning"], p["record_source"], p["grid"], p["bands"]) == ("rm_stream", "none", 1, 2, 1)
     # cfg2 through the library's defaults (a lone launch): keys-only binning + INLINE march, whole machine
     p = _plan(RMGPU, 2049, 2049, 4096, 1081)
-    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 1>"
+    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2>"
     assert (p["binning"], p["record_source"], p["grid"], p["block"], p["bands"]) == ("small_keys", 3, 512, 1024, 8)
     # cfg2 the way bench.py pipelines it: three rays per lane, 0.75 workgroups per CU
     p = _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, grid_mult=3)
