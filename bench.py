@@ -618,6 +618,21 @@ def main():
                                 "floor_ms_per_step": round(ingress / (peak * 1e9) * 1e3, 4),
                                 "measured_on": "same-device dry run (no xGMI)" if a.same_device else (
                                     "one rank (no peer)" if world == 1 else "%d GPUs" % world)}
+        if mode in ("ranges", "ranges_u16", "root") and not a.no_extras:
+            # the same steps with the shards left on their GPUs: what the ranks COMPUTE per second next to
+            # `value`, which includes the exchange — a SCALE record then separates the march's scaling from
+            # the xGMI bound of the exchange (its own timed loop, after the verified one)
+            scan.finish()
+            barrier()
+            scan.gather = False
+            k3 = a.steps
+            runs3 = timed(scan.step, scan_drain, k3, min(a.warmup, 5), min(a.bursts, 7))
+            scan.gather = True
+            r3 = summarise(runs3, k3, rays_per_step)
+            out["march_only"] = {"value": round(r3["value"], 2), "unit": "Mrays/s",
+                                 "ms_per_step": round(r3["ms_per_step"], 4), "steps": k3, "bursts": r3["bursts"],
+                                 "what": "the same sharded steps without the exchange (ranges stay on the GPU "
+                                         "that computed them); `value` includes the exchange"}
         if crash_gather is not None and mode != "crash" and not a.no_crash_line:
             # the reduced exchange on batch 0, serial schedule (its own timed loop)
             k2 = max(10, a.steps // 4)

@@ -118,6 +118,7 @@ def test_bench_eight_ranks_on_one_device():
     x = d["roofline_xgmi"]
     assert x["ingress_bytes_per_gpu_per_step"] == 7 * 4 * 256 * 1081 and x["peak"] == pytest.approx(7 * 76.5)
     assert d["crash_mode"]["value"] > 0
+    assert d["march_only"]["value"] > 0 and d["march_only"]["steps"] == 4
 
 
 @pytest.mark.parametrize("gather", ["root", "ranges_u16"])
@@ -135,6 +136,7 @@ def test_bench_exchange_modes_two_ranks(gather):
     per = 384 * 1081
     assert d["gather_bytes_per_step"] == (2 if gather == "ranges_u16" else 4) * per * 2
     assert ("LOSSY" in d["config"]["gather"]) == (gather == "ranges_u16")
+    assert d["march_only"]["value"] > 0
 
 
 def test_bench_single_rank_through_rccl():
