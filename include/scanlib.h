@@ -283,7 +283,8 @@ typedef struct rl_launch_plan {
                             3 derived in LDS, tile order from the keys-only binning pass                  */
     int slots;           /* rays per lane                                                                 */
     int bands, run_log2, k_max, tiled, aux, crash;
-    int nl, ch;          /* GiantLUT: 16-B loads per lane and row, 64-beam chunks per pose                */
+    int nl, ch;          /* GiantLUT: 16-B loads per lane and row, 64-beam chunks per pose; CDDT per-bin
+                            kernel: lanes per pose, poses per workgroup pass                              */
     int slices;          /* > 1: the batch goes through in this many pose slices of slice_poses poses,    */
     int slice_poses;     /*      each its own launch sequence planned like this one (for its own size)    */
     char name[192];

@@ -120,12 +120,18 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     }
     if (in.kind == RL_CDDT) {
         if (o.cddt_bins && in.theta_disc <= num_rays && in.theta_disc <= 8192) {
-            // one lane per theta bin, up to 1024; the grid keeps every CU's 2048 lanes occupied
-            const int bnt = std::min(1024, ((in.theta_disc + 63) / 64) * 64);
+            // one lane per (pose, TABLE bin) — a table bin answers both raw bins half a turn apart —, pp poses
+            // per workgroup pass; the grid keeps every CU's 2048 lanes occupied
+            const int n_tb = (in.theta_disc + 1) / 2;
+            const int bnt = n_tb <= 256 ? 256 : 1024;
+            const int lpp = std::min(bnt, ((n_tb + 63) / 64) * 64);
+            const int pp = bnt / lpp;
             p->kernel = RL_K_CDDT_BINS;
             p->block = bnt;
-            p->grid = (int)std::max(1L, std::min((long)n_poses, (long)n_cu * (2048 / bnt)));
-            p->lds_bytes = in.theta_disc * (int)sizeof(float);
+            p->nl = lpp;                               // lanes per pose
+            p->ch = pp;                                // poses per workgroup pass
+            p->grid = (int)std::max(1L, std::min(((long)n_poses + pp - 1) / pp, (long)n_cu * (2048 / bnt)));
+            p->lds_bytes = pp * in.theta_disc * (int)sizeof(float);
             if (o.sort_poses && o.cddt_sort && n_poses >= 512 && p->grid >= o.xcd_bands) {
                 p->binning = binning_for(o, n_poses, keys_only_ok(o, n_poses));
                 p->bands = o.xcd_bands;

@@ -2497,9 +2497,17 @@ struct CddtParams {
     const float *cosv, *sinv, *trans;   // per bin
     const int *width;                   // per bin: buckets
     const uint32_t *bucket_off;         // per bin: first bucket (n_bins + 1)
-    uint32_t *offsets;                  // per bucket: [start, end) in xs (n_buckets + 1)
-    float *xs;
+    uint32_t *offsets;                  // per bucket: [start, end) in xs (n_buckets + 1)   (build intermediate)
+    float *xs;                          // CSR values as projected, unsorted                 (build intermediate)
+    // what the queries read: the blocked table.  A bucket of n values owns a run of 128-B lines starting at
+    // line hdr[b].x: its values in LEAVES of 32 (sorted, the last one padded with +inf), and — more than one
+    // leaf — in front of them the SEPARATORS, the first value of every leaf, 32 per line (padded with +inf).
+    // A query reads the header, one separator line and one leaf line: two table lines instead of the 3.6 a
+    // bisection over the packed CSR run touched, three dependent loads instead of eight.
+    uint2 *hdr;                         // per bucket: {first line, n}
+    float *tab;
     float bins_per_rad;
+    int debug;                          // diagnostics only: bit0 skip the bucket searches, bit1 skip the range stores
 };
 
 constexpr int EDGE_ROWS_PER_WG = 8;
@@ -2619,46 +2627,68 @@ __global__ __launch_bounds__(256) void cddt_project_kernel(CddtParams cp, const 
 // buckets (coalesced 256-wide tiles, running carry) and publish the bin's total, (2) add the totals
 // of the bins in front.  (One workgroup walking all ~30 000 counters with a lane-strided pattern
 // took 42 us on colombia.)  Pass 2 also queues the buckets too large for the one-wave sort.
-__global__ __launch_bounds__(256) void cddt_scan_bins_kernel(CddtParams cp, const uint32_t *__restrict__ counts,
-                                                             uint32_t *__restrict__ bin_total)
+// lines of the blocked table a bucket of n values owns: its leaves of 32 + (more than one leaf) the separator lines
+__device__ __forceinline__ uint32_t cddt_bucket_lines(uint32_t n)
 {
-    __shared__ uint32_t part[4];
+    const uint32_t nleaf = (n + 31u) >> 5;
+    return nleaf + (nleaf > 1u ? (nleaf + 31u) >> 5 : 0u);
+}
+
+__global__ __launch_bounds__(256) void cddt_scan_bins_kernel(CddtParams cp, const uint32_t *__restrict__ counts,
+                                                             uint32_t *__restrict__ bin_total,
+                                                             uint32_t *__restrict__ bin_lines)
+{
+    __shared__ uint32_t part[4], part2[4];
     const int a = blockIdx.x;
     const int wdt = cp.width[a];
     const uint32_t b0 = cp.bucket_off[a];
-    uint32_t carry = 0;
+    uint32_t carry = 0, carry2 = 0;
     for (int i0 = 0; i0 < wdt; i0 += 256) {
         const int i = i0 + (int)threadIdx.x;
         const uint32_t v = i < wdt ? counts[b0 + (uint32_t)i] : 0u;
-        uint32_t tot;
+        uint32_t tot, tot2;
         const uint32_t ex = wg256_excl_scan(v, part, tot);
-        if (i < wdt) cp.offsets[b0 + (uint32_t)i] = carry + ex;
+        const uint32_t ex2 = wg256_excl_scan(cddt_bucket_lines(v), part2, tot2);
+        if (i < wdt) {
+            cp.offsets[b0 + (uint32_t)i] = carry + ex;
+            cp.hdr[b0 + (uint32_t)i] = make_uint2(carry2 + ex2, v);
+        }
         carry += tot;
+        carry2 += tot2;
     }
-    if (threadIdx.x == 0) bin_total[a] = carry;
+    if (threadIdx.x == 0) {
+        bin_total[a] = carry;
+        bin_lines[a] = carry2;
+    }
 }
 
 __global__ __launch_bounds__(256) void cddt_scan_add_kernel(CddtParams cp, const uint32_t *__restrict__ counts,
                                                             const uint32_t *__restrict__ bin_total,
+                                                            const uint32_t *__restrict__ bin_lines,
                                                             uint32_t *__restrict__ big_list,
                                                             uint32_t *__restrict__ big_count)
 {
-    __shared__ uint32_t part[4];
+    __shared__ uint32_t part[4], part2[4];
     const int a = blockIdx.x;
-    uint32_t mine = 0;
-    for (int k = threadIdx.x; k < a; k += 256) mine += bin_total[k];
-    uint32_t base;
+    uint32_t mine = 0, mine2 = 0;
+    for (int k = threadIdx.x; k < a; k += 256) {
+        mine += bin_total[k];
+        mine2 += bin_lines[k];
+    }
+    uint32_t base, base2;
     (void)wg256_excl_scan(mine, part, base);           // base = sum of the totals of bins 0 .. a-1
+    (void)wg256_excl_scan(mine2, part2, base2);
     const int wdt = cp.width[a];
     const uint32_t b0 = cp.bucket_off[a];
     for (int i = threadIdx.x; i < wdt; i += 256) {
         cp.offsets[b0 + (uint32_t)i] += base;
+        cp.hdr[b0 + (uint32_t)i].x += base2;
         if (counts[b0 + (uint32_t)i] > 64u) big_list[atomicAdd(big_count, 1u)] = b0 + (uint32_t)i;
     }
     if (a == cp.n_bins - 1 && threadIdx.x == 0) cp.offsets[b0 + (uint32_t)wdt] = base + bin_total[a];
 }
 
-// Sort of every bucket, src -> dst (same CSR offsets), ONE launch.  No library call: hipcub's
+// Sort of every bucket, CSR run -> its lines of the blocked table, ONE launch.  No library call: hipcub's
 // segmented sort reads segment statistics back to the host, and the two-player tick must stay a pure
 // enqueue.
 //  * workgroups >= n_big_wg: buckets of up to 64 values — nearly all of them — one wave each: a lane
@@ -2669,8 +2699,36 @@ __global__ __launch_bounds__(256) void cddt_scan_add_kernel(CddtParams cp, const
 //    rank sort straight from global memory (quadratic, but such a bucket needs a wall of > 5000 cells).
 constexpr uint32_t CDDT_LDS_SORT = 16384;
 
+// where rank r of a bucket goes in the blocked table, and the padding the ranks leave free
+struct CddtRun {
+    float *sep, *leaves;
+    uint32_t n, nleaf, nsl;
+};
+__device__ __forceinline__ CddtRun cddt_run(const uint2 *__restrict__ hdr, float *__restrict__ tab, uint32_t b)
+{
+    const uint2 hd = hdr[b];
+    CddtRun r;
+    r.n = hd.y;
+    r.nleaf = (r.n + 31u) >> 5;
+    r.nsl = r.nleaf > 1u ? (r.nleaf + 31u) >> 5 : 0u;
+    r.sep = tab + (size_t)hd.x * 32;
+    r.leaves = r.sep + (size_t)r.nsl * 32;
+    return r;
+}
+__device__ __forceinline__ void cddt_put(const CddtRun &r, uint32_t rank, float x)
+{
+    r.leaves[rank] = x;
+    if ((rank & 31u) == 0u && r.nsl) r.sep[rank >> 5] = x;
+}
+__device__ __forceinline__ void cddt_pad(const CddtRun &r, uint32_t tid, uint32_t nt)
+{
+    for (uint32_t i = r.n + tid; i < r.nleaf * 32u; i += nt) r.leaves[i] = __builtin_inff();
+    for (uint32_t k = r.nleaf + tid; k < r.nsl * 32u; k += nt) r.sep[k] = __builtin_inff();
+}
+
 __global__ __launch_bounds__(256) void cddt_sort_kernel(const uint32_t *__restrict__ offsets, uint32_t n_buckets,
-                                                        const float *__restrict__ src, float *__restrict__ dst,
+                                                        const float *__restrict__ src,
+                                                        const uint2 *__restrict__ hdr, float *__restrict__ tab,
                                                         const uint32_t *__restrict__ big_list,
                                                         const uint32_t *__restrict__ big_count,
                                                         uint32_t n_big_wg, uint32_t lds_cap)
@@ -2683,13 +2741,15 @@ __global__ __launch_bounds__(256) void cddt_sort_kernel(const uint32_t *__restri
         for (uint32_t b = wave; b < n_buckets; b += n_waves) {
             const uint32_t lo = offsets[b], n = offsets[b + 1] - lo;
             if (n == 0 || n > 64u) continue;
+            const CddtRun run = cddt_run(hdr, tab, b);
             const float x = (uint32_t)lane < n ? src[lo + lane] : __builtin_inff();
             uint32_t rank = 0;
             for (uint32_t j = 0; j < n; ++j) {
                 const float xj = __shfl(x, (int)j);
                 rank += (xj < x || (xj == x && j < (uint32_t)lane)) ? 1u : 0u;
             }
-            if ((uint32_t)lane < n) dst[lo + rank] = x;
+            if ((uint32_t)lane < n) cddt_put(run, rank, x);
+            cddt_pad(run, (uint32_t)lane, 64u);
         }
         return;
     }
@@ -2697,6 +2757,7 @@ __global__ __launch_bounds__(256) void cddt_sort_kernel(const uint32_t *__restri
     for (uint32_t q = blockIdx.x; q < nbig; q += n_big_wg) {
         const uint32_t b = big_list[q];
         const uint32_t lo = offsets[b], n = offsets[b + 1] - lo;
+        const CddtRun run = cddt_run(hdr, tab, b);
         if (n <= lds_cap) {
             uint32_t m2 = 128;
             while (m2 < n) m2 <<= 1;
@@ -2714,7 +2775,7 @@ __global__ __launch_bounds__(256) void cddt_sort_kernel(const uint32_t *__restri
                     }
                     __syncthreads();
                 }
-            for (uint32_t i = threadIdx.x; i < n; i += 256) dst[lo + i] = sv[i];
+            for (uint32_t i = threadIdx.x; i < n; i += 256) cddt_put(run, i, sv[i]);
             __syncthreads();
         } else {
             for (uint32_t i = threadIdx.x; i < n; i += 256) {
@@ -2724,12 +2785,86 @@ __global__ __launch_bounds__(256) void cddt_sort_kernel(const uint32_t *__restri
                     const float xj = src[lo + j];
                     rank += (xj < x || (xj == x && j < i)) ? 1u : 0u;
                 }
-                dst[lo + rank] = x;
+                cddt_put(run, rank, x);
             }
+        }
+        cddt_pad(run, threadIdx.x, 256u);
+    }
+}
+
+// BOTH directions of one table bin from a grid origin: raw bin t (the ray runs along +x of the bin's frame:
+// first stored x >= origin) and raw bin t + theta_disc/2 (half a turn away: last stored x <= origin) project
+// the origin with the same rotation into the same bucket.  On the blocked table: count the separators <= lx
+// (the leaf whose first value is the last one <= lx holds the backward answer and, unless all of it is below
+// lx, the forward one — otherwise that is the next separator), then one pass of min / max over the leaf's 32
+// values.  No bisection, no sortedness needed inside a line; the padding (+inf) never wins.  out_f / out_b
+// are the two ranges in pixels (max_range when nothing is stored on that side).
+__device__ __forceinline__ void cddt_query_pair(const CddtParams &cp, float max_range, float gx, float gy, int t,
+                                                float &out_f, float &out_b)
+{
+    const float cs = cp.cosv[t], sn = cp.sinv[t];
+    const float lx = __builtin_fmaf(gx, cs, -(gy * sn));
+    const float ly = __builtin_fmaf(gx, sn, gy * cs) + cp.trans[t];
+    out_f = max_range;
+    out_b = max_range;
+    if (ly >= 0.0f && ly < (float)cp.width[t]) {
+        const uint2 hd = cp.hdr[cp.bucket_off[t] + (uint32_t)(int)ly];
+        const uint32_t n = hd.y;
+        if (n) {
+            const float INF = __builtin_inff();
+            const uint32_t nleaf = (n + 31u) >> 5;
+            const float4 *lines = reinterpret_cast<const float4 *>(cp.tab) + (size_t)hd.x * 8;
+            float fwd = INF, bwd = -INF;
+            uint32_t leaf = 0;
+            bool have_leaf = true;
+            if (nleaf > 1u) {
+                const uint32_t nsl = (nleaf + 31u) >> 5;
+                uint32_t L = 0;
+                if (nsl > 1u) {                        // > 1024 values: the separator line whose first value is the last <= lx
+                    uint32_t a = 0, z = nsl;
+                    while (z - a > 1u) {
+                        const uint32_t mid = (a + z) >> 1;
+                        if (lines[(size_t)mid * 8].x <= lx) a = mid; else z = mid;
+                    }
+                    L = a;
+                    if (L + 1u < nsl) fwd = lines[(size_t)(L + 1u) * 8].x;      // (> lx: line z was probed)
+                }
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 q = lines[(size_t)L * 8 + i];
+                    c += (q.x <= lx ? 1u : 0u) + (q.y <= lx ? 1u : 0u) + (q.z <= lx ? 1u : 0u) + (q.w <= lx ? 1u : 0u);
+                    fwd = __builtin_fminf(fwd, q.x > lx ? q.x : INF);
+                    fwd = __builtin_fminf(fwd, q.y > lx ? q.y : INF);
+                    fwd = __builtin_fminf(fwd, q.z > lx ? q.z : INF);
+                    fwd = __builtin_fminf(fwd, q.w > lx ? q.w : INF);
+                }
+                have_leaf = L * 32u + c > 0u;
+                leaf = L * 32u + c - 1u;
+                lines += (size_t)nsl * 8;
+            }
+            if (have_leaf) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 q = lines[(size_t)leaf * 8 + i];
+                    fwd = __builtin_fminf(fwd, q.x >= lx ? q.x : INF);
+                    fwd = __builtin_fminf(fwd, q.y >= lx ? q.y : INF);
+                    fwd = __builtin_fminf(fwd, q.z >= lx ? q.z : INF);
+                    fwd = __builtin_fminf(fwd, q.w >= lx ? q.w : INF);
+                    bwd = __builtin_fmaxf(bwd, q.x <= lx ? q.x : -INF);
+                    bwd = __builtin_fmaxf(bwd, q.y <= lx ? q.y : -INF);
+                    bwd = __builtin_fmaxf(bwd, q.z <= lx ? q.z : -INF);
+                    bwd = __builtin_fmaxf(bwd, q.w <= lx ? q.w : -INF);
+                }
+            }
+            out_f = __builtin_fminf(fwd - lx, max_range);
+            out_b = __builtin_fminf(lx - bwd, max_range);
         }
     }
 }
 
+// one ray: the nearest bin of -heading; bins of the second half turn use the table bin half a turn away,
+// searching backwards (CDDTCast::calc_range)
 __device__ __forceinline__ float cddt_query(const MapParams &m, const CddtParams &cp, float max_range,
                                             float gx, float gy, float th)
 {
@@ -2740,121 +2875,90 @@ __device__ __forceinline__ float cddt_query(const MapParams &m, const CddtParams
     bool flipped = false;
     if (b >= cp.n_bins) { b -= cp.theta_disc / 2; flipped = true; }
     if (b >= cp.n_bins) b = cp.n_bins - 1;
-    const float cs = cp.cosv[b], sn = cp.sinv[b];
-    const float lx = __builtin_fmaf(gx, cs, -(gy * sn));
-    const float ly = __builtin_fmaf(gx, sn, gy * cs) + cp.trans[b];
-    float out = max_range;
-    if (ly >= 0.0f && ly < (float)cp.width[b]) {
-        const uint32_t bk = cp.bucket_off[b] + (uint32_t)(int)ly;
-        const uint32_t lo = cp.offsets[bk], hi = cp.offsets[bk + 1];
-        uint32_t a = lo, z = hi;
-        if (!flipped) {                        // first stored x >= lx
-            while (a < z) { const uint32_t mid = (a + z) >> 1; if (cp.xs[mid] < lx) a = mid + 1; else z = mid; }
-            if (a < hi) out = __builtin_fminf(cp.xs[a] - lx, max_range);
-        } else {                               // last stored x <= lx
-            while (a < z) { const uint32_t mid = (a + z) >> 1; if (cp.xs[mid] <= lx) a = mid + 1; else z = mid; }
-            if (a > lo) out = __builtin_fminf(lx - cp.xs[a - 1], max_range);
-        }
-    }
-    return out * m.res;
-}
-
-// query of ONE theta bin (raw index in [0, theta_disc)) from a grid origin: what cddt_query computes
-// once the bin is known.  The bisection stops at 8 candidates, which are read with 8 independent loads
-// (one or two cache lines): position = number of stored values below (not above, for the flipped half
-// turn) the origin — the same index the bisection would end at, the bucket being sorted — and the
-// answer is picked from those registers.
-__device__ __forceinline__ float cddt_query_bin(const CddtParams &cp, float max_range, float gx, float gy,
-                                                int raw_bin)
-{
-    int b = raw_bin;
-    bool flipped = false;
-    if (b >= cp.n_bins) { b -= cp.theta_disc / 2; flipped = true; }
-    if (b >= cp.n_bins) b = cp.n_bins - 1;
-    const float cs = cp.cosv[b], sn = cp.sinv[b];
-    const float lx = __builtin_fmaf(gx, cs, -(gy * sn));
-    const float ly = __builtin_fmaf(gx, sn, gy * cs) + cp.trans[b];
-    float out = max_range;
-    if (ly >= 0.0f && ly < (float)cp.width[b]) {
-        const uint32_t bk = cp.bucket_off[b] + (uint32_t)(int)ly;
-        const uint32_t lo = cp.offsets[bk], hi = cp.offsets[bk + 1];
-        uint32_t a = lo, z = hi;
-        // bisection down to 8 candidates (every probe is a different cache line of a table far larger
-        // than L2: a 9-ary search with 8 probes per round was tried and is 1.5x SLOWER — the kernel is
-        // bound by the number of lines it touches, not by the dependent-load chain)
-        while (z - a > 8u) {
-            const uint32_t mid = (a + z) >> 1;
-            const float pv = cp.xs[mid];
-            if (flipped ? pv <= lx : pv < lx) a = mid + 1; else z = mid;
-        }
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = a + (uint32_t)k < z ? cp.xs[a + k] : __builtin_inff();
-        uint32_t below = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) below += (flipped ? v[k] <= lx : v[k] < lx) ? 1u : 0u;
-        // the neighbour of the insertion point is among the 8 values just read, unless it lies just
-        // outside the window
-        if (!flipped) {                        // first stored x >= lx: xs[a + below]
-            if (a + below < hi) {
-                float hit = below == 0 ? v[0] : below == 1 ? v[1] : below == 2 ? v[2] : below == 3 ? v[3]
-                          : below == 4 ? v[4] : below == 5 ? v[5] : below == 6 ? v[6] : v[7];
-                if (below >= 8u || a + below >= z) hit = cp.xs[a + below];
-                out = __builtin_fminf(hit - lx, max_range);
-            }
-        } else {                               // last stored x <= lx: xs[a + below - 1]
-            if (a + below > lo) {
-                float hit = below <= 1 ? v[0] : below == 2 ? v[1] : below == 3 ? v[2] : below == 4 ? v[3]
-                          : below == 5 ? v[4] : below == 6 ? v[5] : below == 7 ? v[6] : v[7];
-                if (below == 0) hit = cp.xs[a - 1];
-                out = __builtin_fminf(lx - hit, max_range);
-            }
-        }
-    }
-    return out;
+    float rf, rb;
+    cddt_query_pair(cp, max_range, gx, gy, b, rf, rb);
+    return (flipped ? rb : rf) * m.res;
 }
 
 // The fan form.  A CDDT answer depends on the ray's ORIGIN and its theta BIN only, so every beam of a
 // pose whose heading falls into one bin gets the same range (theta_disc 108 over a 4.71-rad fan of
-// 1081 beams: ~13 beams per bin).  One workgroup per pose with one lane per theta bin (up to 1024
-// lanes; more bins: several per lane): theta_disc bucket searches per pose instead of num_rays, all of
-// them in flight at once, the per-bin constants read with coalesced loads (lane <-> bin); the results
-// are parked in LDS and the beams only look their bin up — the kernel turns from a latency-bound
-// search per ray into a stream of range stores.  Bit-identical to the per-ray statement (same bin
-// index arithmetic, same query).
+// 1081 beams: ~13 beams per bin), and the two raw bins half a turn apart share one bucket search
+// (cddt_query_pair).  A workgroup takes PP poses at a time, one lane per (pose, TABLE bin): only the
+// table bins the fan touches in either direction are searched (fov 4.71: all 54 of theta_disc 108, for 81-82
+// raw bins — a third fewer searches and table lines than one per raw bin, half of one per bin of the full
+// turn), all of them in flight at once; the results are parked in LDS and the beams only look their bin up —
+// the kernel turns from a latency-bound search per ray into a stream of range stores.  Bit-identical to the
+// per-ray statement (same bin index arithmetic, same insertion points).
 // `order` (optional): the poses in map-tile order (the keys-only binning launch of the ray-marching
 // path); the sorted list is cut into n_bands bands, band x walked by the workgroups with
 // blockIdx % n_bands == x — one XCD under round-robin dispatch —, so the workgroups of an XCD query
 // neighbouring origins at the same time: for every theta bin they land in neighbouring buckets, and the
 // table lines one pose fetched are L2 hits for the next (the table is ~10x an XCD's L2).
-__global__ __launch_bounds__(1024) void cddt_fan_bins_kernel(MapParams m, FanParams f, CddtParams cp,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(88), amdgpu_waves_per_eu(8, 8))) void cddt_fan_bins_kernel(MapParams m, FanParams f, CddtParams cp,
                                                              const float *__restrict__ poses,
                                                              float *__restrict__ out,
-                                                             const uint32_t *__restrict__ order, int n_bands)
+                                                             const uint32_t *__restrict__ order, int n_bands,
+                                                             int lanes_per_pose, int pp)
 {
-    extern __shared__ float bin_range[];                 // theta_disc floats (this workgroup's pose)
-    const int nt = (int)blockDim.x;
+    extern __shared__ float bin_range[];                 // pp x theta_disc floats (this workgroup's poses)
+    const int nt = (int)blockDim.x, td = cp.theta_disc, half = td / 2;
     LutParams lp{};
-    lp.theta_disc = cp.theta_disc;
+    lp.theta_disc = td;
     lp.bins_per_rad = cp.bins_per_rad;
-    const float td_f = (float)cp.theta_disc, inv_td = 1.0f / (float)cp.theta_disc;
+    const float td_f = (float)td, inv_td = 1.0f / (float)td;
     const int band = (int)(blockIdx.x % (unsigned)n_bands), g = (int)(blockIdx.x / (unsigned)n_bands);
     const int G = ((int)gridDim.x - band + n_bands - 1) / n_bands;
     const int lo = (int)(((long)f.n_poses * band) / n_bands), hi = (int)(((long)f.n_poses * (band + 1)) / n_bands);
-    for (int slot = lo + g; slot < hi; slot += G) {
-        const int pose = order ? (int)(order[slot] & ~POSE_INVALID) : slot;
-        float gx, gy, thg;
-        world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
-                      poses[3 * (size_t)pose + 2], gx, gy, thg);
-        for (int bin = threadIdx.x; bin < cp.theta_disc; bin += nt)
-            bin_range[bin] = cddt_query_bin(cp, f.max_range, gx, gy, bin) * m.res;
+    const int q = (int)threadIdx.x / lanes_per_pose, t0 = (int)threadIdx.x % lanes_per_pose;
+    for (int s0 = lo + g * pp; s0 < hi; s0 += G * pp) {
+        if (q < pp && s0 + q < hi) {
+            const int pose = order ? (int)(order[s0 + q] & ~POSE_INVALID) : s0 + q;
+            float gx, gy, thg;
+            world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
+                          poses[3 * (size_t)pose + 2], gx, gy, thg);
+            // the raw bins the fan can touch: beam angles grow with j, so the bins of -(heading + alpha_j) are
+            // the circular run from the last beam's bin up to the first beam's, one bin of margin either side
+            const float u0 = __builtin_rintf(-(thg + fan_alpha(f, 0)) * cp.bins_per_rad);
+            const float u1 = __builtin_rintf(-(thg + fan_alpha(f, f.num_rays - 1)) * cp.bins_per_rad);
+            const float spanf = u0 - u1;
+            const bool all = !(spanf >= 0.0f && spanf < td_f - 4.0f) || !(__builtin_fabsf(u0) < 8388608.0f) ||
+                             !(__builtin_fabsf(u1) < 8388608.0f);
+            int first = 0, cnt = td;
+            if (!all) {
+                first = lut_bin_fast(-(thg + fan_alpha(f, f.num_rays - 1)), lp, td_f, inv_td) - 1;
+                if (first < 0) first += td;
+                cnt = (int)spanf + 3;
+            }
+            float *br = bin_range + (size_t)q * td;
+            for (int t = t0; t < cp.n_bins; t += lanes_per_pose) {
+                // raw bin t searches forward in table bin t; raw bin t + td/2 (if it maps here: >= n_bins)
+                // backward
+                const int rb = t + half;
+                const bool has_b = rb >= cp.n_bins && rb < td;
+                int df = t - first, db = rb - first;
+                df += df < 0 ? td : 0;
+                db += db < 0 ? td : 0;
+                const bool need_f = df < cnt, need_b = has_b && db < cnt;
+                if (need_f || need_b) {
+                    float rf = 1.0f, rbk = 1.0f;
+                    if (!(cp.debug & 1)) cddt_query_pair(cp, f.max_range, gx, gy, t, rf, rbk);
+                    if (need_f) br[t] = rf * m.res;
+                    if (need_b) br[rb] = rbk * m.res;
+                }
+            }
+        }
         __syncthreads();
-        float *dst = out + (size_t)pose * f.num_rays;
-        for (int j = threadIdx.x; j < f.num_rays; j += nt) {
-            float r = bin_range[lut_bin_fast(-(thg + fan_alpha(f, j)), lp, td_f, inv_td)];
-            if (f.noise_std > 0.0f)
-                r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (size_t)pose * f.num_rays + j);
-            dst[j] = r;
+        for (int qq = 0; qq < pp && s0 + qq < hi; ++qq) {
+            const int pose = order ? (int)(order[s0 + qq] & ~POSE_INVALID) : s0 + qq;
+            const float thg = poses[3 * (size_t)pose + 2] + m.wa;
+            const float *br = bin_range + (size_t)qq * td;
+            float *dst = out + (size_t)pose * f.num_rays;
+            for (int j = threadIdx.x; j < f.num_rays; j += nt) {
+                float r = br[lut_bin_fast(-(thg + fan_alpha(f, j)), lp, td_f, inv_td)];
+                if (f.noise_std > 0.0f)
+                    r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (size_t)pose * f.num_rays + j);
+                if (!(cp.debug & 2) || r == 123.456f) dst[j] = r;
+            }
         }
         __syncthreads();
     }

@@ -244,7 +244,7 @@ struct rl_method {
     uint64_t lut_epoch = ~0ull;
     LutParams lp{};
     // CDDT (K3b)
-    DevBuf cd_cos, cd_sin, cd_trans, cd_width, cd_boff, cd_offsets, cd_xs, cd_xs2, cd_cursor, cd_tmp;
+    DevBuf cd_cos, cd_sin, cd_trans, cd_width, cd_boff, cd_offsets, cd_xs2, cd_cursor, cd_tmp, cd_hdr, cd_tab;
     uint64_t cddt_epoch = ~0ull;
     CddtParams cdp{};
     uint32_t cd_buckets = 0;
@@ -570,7 +570,7 @@ extern "C" void rl_method_destroy(rl_method *h)
     h->blpad.release();
     h->lut.release();
     for (DevBuf *b : {&h->cd_cos, &h->cd_sin, &h->cd_trans, &h->cd_width, &h->cd_boff, &h->cd_offsets,
-                      &h->cd_xs, &h->cd_xs2, &h->cd_cursor, &h->cd_tmp})
+                      &h->cd_xs2, &h->cd_cursor, &h->cd_tmp, &h->cd_hdr, &h->cd_tab})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -617,7 +617,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "run_log2")) h->run_log2 = value < 0 ? -1 : value > 8 ? 8 : value;
     else if (!strcmp(name, "slice_log2")) h->slice_log2 = value < 8 ? 8 : (value > 30 ? 30 : value);
     else if (!strcmp(name, "inline_max")) h->inline_max = value;
-    else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; }
+    else if (!strcmp(name, "lut_debug")) { h->lut_debug = value; h->lp.debug = value; h->cdp.debug = value; }
     else if (!strcmp(name, "wg_threads")) h->wg_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256);
     else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
     else if (!strcmp(name, "slots")) h->slots = value >= 3 ? 3 : (value == 2 ? 2 : (value == 1 ? 1 : 0));
@@ -817,8 +817,8 @@ static int ensure_lut(rl_method *h, hipStream_t stream)
 static int ensure_cddt(rl_method *h, hipStream_t stream)
 {
     rl_map *m = h->map;
-    if (h->cddt_epoch == m->epoch && h->cd_xs.p) return table_wait(h->cddt_dep, stream);
-    if (h->cd_xs.p) HIPCHK(hipDeviceSynchronize());     // launches of other streams may still read the old table
+    if (h->cddt_epoch == m->epoch && h->cd_tab.p) return table_wait(h->cddt_dep, stream);
+    if (h->cd_tab.p) HIPCHK(hipDeviceSynchronize());     // launches of other streams may still read the old table
     const int td = h->theta_disc, nb = (td + 1) / 2;
     int rc;
     if (h->cd_geom_rows != m->rows || h->cd_geom_cols != m->cols) {
@@ -859,7 +859,12 @@ static int ensure_cddt(rl_method *h, hipStream_t stream)
     const uint32_t nbk = h->cd_buckets;
     const size_t cap = std::max<size_t>((size_t)m->n_edges * nb * 3, 1);    // stored values, upper bound
     if (cap > (size_t)INT_MAX) return fail(RL_ERR_UNSUPPORTED, "CDDT table too large (%zu values)", cap);
-    if ((rc = h->cd_xs.ensure(cap * 4)) || (rc = h->cd_xs2.ensure(cap * 4))) return rc;
+    if ((rc = h->cd_xs2.ensure(cap * 4))) return rc;
+    // the blocked table the queries read (scan_kernels.h, CddtParams): leaves of 32 values + separator lines;
+    // upper bound: every bucket pads its last leaf and, with more than one leaf, its last separator line
+    const size_t tab_lines = cap / 32 + cap / 1024 + 2 * (size_t)nbk + 2;
+    if (tab_lines > (size_t)UINT32_MAX) return fail(RL_ERR_UNSUPPORTED, "CDDT table too large (%zu lines)", tab_lines);
+    if ((rc = h->cd_hdr.ensure((size_t)nbk * 8)) || (rc = h->cd_tab.ensure(tab_lines * 128))) return rc;
     CddtParams &cp = h->cdp;
     cp.theta_disc = td;
     cp.n_bins = nb;
@@ -870,8 +875,11 @@ static int ensure_cddt(rl_method *h, hipStream_t stream)
     cp.bucket_off = (const uint32_t *)h->cd_boff.p;
     cp.offsets = (uint32_t *)h->cd_offsets.p;
     cp.xs = (float *)h->cd_xs2.p;
+    cp.hdr = (uint2 *)h->cd_hdr.p;
+    cp.tab = (float *)h->cd_tab.p;
     cp.bins_per_rad = (float)td * 0.15915494309189535f;
-    if ((rc = h->cd_tmp.ensure(((size_t)nbk + nb + 64) * 4))) return rc;   // big-bucket count, bin totals, list
+    cp.debug = h->lut_debug;
+    if ((rc = h->cd_tmp.ensure(((size_t)nbk + 2 * nb + 64) * 4))) return rc;   // big-bucket count, bin totals (values, lines), list
     if (!h->cd_sort_attr) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cddt_sort_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CDDT_LDS_SORT * sizeof(float))));
@@ -900,25 +908,26 @@ static int ensure_cddt(rl_method *h, hipStream_t stream)
                        (const uint32_t *)m->d_edges, (const uint32_t *)m->d_n_edges, (uint32_t *)h->cd_cursor.p);
     // [0] big-bucket count (zeroed by the sort's last reader), [1..64) spare, [64..64+nb) bin totals, then the list
     uint32_t *big_count = (uint32_t *)h->cd_tmp.p, *bin_total = (uint32_t *)h->cd_tmp.p + 64;
-    uint32_t *big_list = bin_total + nb;
+    uint32_t *bin_lines = bin_total + nb, *big_list = bin_lines + nb;
     HIPCHK(hipMemsetAsync(big_count, 0, 4, stream));
     hipLaunchKernelGGL(cddt_scan_bins_kernel, dim3(nb), dim3(256), 0, stream, cp, (const uint32_t *)h->cd_cursor.p,
-                       bin_total);
+                       bin_total, bin_lines);
     hipLaunchKernelGGL(cddt_scan_add_kernel, dim3(nb), dim3(256), 0, stream, cp, (const uint32_t *)h->cd_cursor.p,
-                       (const uint32_t *)bin_total, big_list, big_count);
+                       (const uint32_t *)bin_total, (const uint32_t *)bin_lines, big_list, big_count);
     hipLaunchKernelGGL(cddt_project_kernel<true>, pgrid, dim3(256), lds_fill, stream, cp,
                        (const uint32_t *)m->d_edges, (const uint32_t *)m->d_n_edges, (uint32_t *)h->cd_cursor.p);
     // two launches of the sort kernel: the large buckets (workgroup each, 64 KB of LDS) and the small ones
     // (wave each, no LDS — in one launch the LDS size of the large path would cap everybody's occupancy)
     const uint32_t n_big_wg = (uint32_t)m->n_cu;
     hipLaunchKernelGGL(cddt_sort_kernel, dim3(n_big_wg), dim3(256), (size_t)h->cddt_lds_sort * sizeof(float), stream,
-                       (const uint32_t *)h->cd_offsets.p, nbk, (const float *)h->cd_xs2.p, (float *)h->cd_xs.p,
-                       (const uint32_t *)big_list, (const uint32_t *)big_count, n_big_wg, (uint32_t)h->cddt_lds_sort);
+                       (const uint32_t *)h->cd_offsets.p, nbk, (const float *)h->cd_xs2.p, (const uint2 *)h->cd_hdr.p,
+                       (float *)h->cd_tab.p, (const uint32_t *)big_list, (const uint32_t *)big_count, n_big_wg,
+                       (uint32_t)h->cddt_lds_sort);
     const int sgrid = (int)std::max(1L, std::min(((long)nbk + 3) / 4, (long)m->n_cu * 32));
     hipLaunchKernelGGL(cddt_sort_kernel, dim3(sgrid), dim3(256), 0, stream,
-                       (const uint32_t *)h->cd_offsets.p, nbk, (const float *)h->cd_xs2.p, (float *)h->cd_xs.p,
-                       (const uint32_t *)big_list, (const uint32_t *)big_count, 0u, (uint32_t)h->cddt_lds_sort);
-    cp.xs = (float *)h->cd_xs.p;
+                       (const uint32_t *)h->cd_offsets.p, nbk, (const float *)h->cd_xs2.p, (const uint2 *)h->cd_hdr.p,
+                       (float *)h->cd_tab.p, (const uint32_t *)big_list, (const uint32_t *)big_count, 0u,
+                       (uint32_t)h->cddt_lds_sort);
     HIPCHK(hipGetLastError());
     h->cddt_epoch = m->epoch;
     return table_built(h->cddt_dep, stream);
@@ -1279,7 +1288,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         }
         if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
         hipLaunchKernelGGL(cddt_fan_bins_kernel, grid, block, lds, stream, m->mp, f, h->cdp, d_poses, d_out, d_order,
-                           pl.bands);
+                           pl.bands, pl.nl, pl.ch);
         break;
     }
     case RL_K_CDDT_RAYS:

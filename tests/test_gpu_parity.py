@@ -619,6 +619,31 @@ def test_cddt_queries_bit_equal_to_oracle(oracle_mod, td):
     assert np.array_equal(outs, om2.cddt_rays(td, ins))
 
 
+def test_cddt_fan_searches_only_the_bins_the_fan_touches(oracle_mod):
+    """The per-bin fan kernel searches the circular run of theta bins between the last and the first beam
+    (one bin of margin): narrow and wide fans, fans past a full turn, one beam, headings whose bin index wraps
+    many times or leaves the float-exact range — bit-equal to the per-ray statement of the oracle."""
+    g, z = load_golden("rm_maze256")
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    omap = range_libc.PyOMap(g)
+    rng = np.random.default_rng(11)
+    poses = z["poses"][:40].copy()
+    poses[:, 2] = rng.uniform(-math.pi, math.pi, 40).astype(np.float32)
+    poses[5, 2] = 1.0e4
+    poses[6, 2] = -3.0e5
+    poses[7, 2] = 2.0e7                                   # |bin index| beyond 2^23 at theta_disc 720: integer path
+    poses[8, 2] = 0.0
+    poses[9, 2] = math.pi
+    for td in (4, 16, 108, 113, 720):                    # (113: odd, table bin 0 has no half-turn partner)
+        m = range_libc.PyCDDTCast(omap, 300, td)
+        for fov, B in ((0.05, 33), (1.0, 257), (4.71, 1081), (6.2, 720), (6.2831855, 1081), (7.5, 1081), (4.71, 1),
+                       (3.0, 2)):
+            out = np.empty(len(poses) * B, np.float32)
+            m.calc_range_fan(poses, out, fov, B)
+            assert m.last_plan()["kernel"] == ("cddt_bins" if td <= B else "cddt_rays")
+            assert np.array_equal(out, om.cddt_fan(td, poses, fov, B)), (td, fov, B)
+
+
 @pytest.mark.parametrize("lds_sort", [16384, 128])      # 128: buckets above it take the global rank sort
 def test_cddt_long_walls_fill_large_buckets(oracle_mod, lds_sort):
     """Straight walls parallel to a bin's direction put thousands of values into ONE bucket: the

@@ -245,7 +245,10 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
     p = _plan(GLT, 2000, 2000, 65536, 1081, theta_disc=1442)
     assert (p["name"], p["grid"], p["block"], p["lds_bytes"]) == ("scan::lut_fan_lds_kernel<3, 17>", 2048, 256, 12288)
     p = _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=108)
-    assert (p["kernel"], p["block"], p["grid"], p["lds_bytes"]) == ("cddt_bins", 128, 4096, 432)
+    # (54 table bins -> 64 lanes per pose, 4 poses per pass of a 256-lane workgroup, 8 workgroups per CU)
+    assert (p["kernel"], p["block"], p["grid"], p["lds_bytes"], p["nl"], p["ch"]) == ("cddt_bins", 256, 2048, 1728, 64, 4)
+    p = _plan(CDDT, 2000, 2000, 3, 1081, theta_disc=720)
+    assert (p["block"], p["grid"], p["nl"], p["ch"], p["lds_bytes"]) == (1024, 2, 384, 2, 5760)
     assert _plan(CDDT, 2000, 2000, 65536, 64, theta_disc=108)["kernel"] == "cddt_rays"   # fewer beams than bins
     # cfg4: the whole 2^20-pose batch goes through in two pose slices (32-bit ray offsets); a rank's
     # shard in one; colombia sits in every XCD's L2, so big batches take grid-wide binning + two rays per lane
