@@ -227,7 +227,8 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *   schedule   variant (1 stream kernel | 0 chunk-per-wave | 2 occ_fan_lds: unit steps on an LDS occupancy
  *              window, approximate), grid_mult, wg_threads, low_water, run_log2 (-1 auto), xcd_bands,
  *              sort_poses, tiled (step-map layout), slots (rays per lane: 1 | 2 | 3 | 0 auto),
- *              cddt_bins (one search per pose and theta bin), cddt_lds_sort
+ *              cddt_bins (one look-up per pose and table bin), cddt_theta_min (poses from which the look-ups
+ *              run theta-major: all poses against one table bin at a time), cddt_lds_sort
  *   binning    inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min,
  *              bin_generic, bin_ppw (poses per workgroup of the grid-wide binning kernels)
  *   launches   slice_log2 (pose slices below 2^n rays), pinned_max_rays (zero-copy host calls)
@@ -248,7 +249,7 @@ int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
 typedef struct rl_plan_opts {
     int variant, grid_mult, wg_threads, low_water, sort_poses, xcd_bands, slots, tiled;
     int inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min, bin_generic;
-    int run_log2, cddt_bins, cddt_sort, lut_debug, debug_stamps, slice_log2, reserved[3];
+    int run_log2, cddt_bins, cddt_sort, lut_debug, debug_stamps, slice_log2, cddt_theta_min, reserved[2];
 } rl_plan_opts;
 
 typedef enum rl_kernel_id {
@@ -261,7 +262,8 @@ typedef enum rl_kernel_id {
     RL_K_LUT_LDS = 6,       /* lut_fan_lds_kernel<NL, CH>                                                 */
     RL_K_LUT_FAN = 7,       /* lut_fan_kernel<CH>                                                         */
     RL_K_CDDT_BINS = 8,     /* cddt_fan_bins_kernel                                                       */
-    RL_K_CDDT_RAYS = 9      /* cddt_fan_kernel                                                            */
+    RL_K_CDDT_RAYS = 9,     /* cddt_fan_kernel                                                            */
+    RL_K_CDDT_THETA = 10    /* cddt_theta_search_kernel + cddt_theta_fan_kernel (theta-major, large batches) */
 } rl_kernel_id;
 
 typedef enum rl_binning {

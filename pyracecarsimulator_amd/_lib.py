@@ -31,8 +31,8 @@ class PlanOpts(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "variant", "grid_mult", "wg_threads", "low_water", "sort_poses", "xcd_bands", "slots", "tiled",
         "inline_prep", "inline_max", "inline_map_kb", "stripe_max", "order_inline", "bin_multi_min",
-        "bin_generic", "run_log2", "cddt_bins", "cddt_sort", "lut_debug", "debug_stamps", "slice_log2")] + [
-        ("reserved", C.c_int * 3)]
+        "bin_generic", "run_log2", "cddt_bins", "cddt_sort", "lut_debug", "debug_stamps", "slice_log2",
+        "cddt_theta_min")] + [("reserved", C.c_int * 2)]
 
 
 class LaunchPlan(C.Structure):
@@ -50,7 +50,7 @@ class LaunchPlan(C.Structure):
 
 
 KERNEL_IDS = {0: "none", 1: "rm_chunk", 2: "rm_stream", 3: "occ_lds", 4: "bl_stream", 5: "bl_lds", 6: "lut_lds",
-              7: "lut_fan", 8: "cddt_bins", 9: "cddt_rays"}
+              7: "lut_fan", 8: "cddt_bins", 9: "cddt_rays", 10: "cddt_theta"}
 BINNINGS = {0: "none", 1: "small_keys", 2: "small_records", 3: "grid_sort", 4: "grid_unsorted", 5: "generic"}
 
 #: every symbol include/scanlib.h declares: name -> (restype, argtypes)

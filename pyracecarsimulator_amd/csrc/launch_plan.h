@@ -56,6 +56,7 @@ inline void default_opts(rl_plan_opts &o)
     o.run_log2 = -1;
     o.cddt_bins = 1;
     o.cddt_sort = 0;
+    o.cddt_theta_min = 32768;
     o.lut_debug = 0;
     o.debug_stamps = 0;
     o.slice_log2 = 30;
@@ -119,6 +120,22 @@ inline int plan_one(const In &in, rl_launch_plan *p)
         return RL_OK;
     }
     if (in.kind == RL_CDDT) {
+        if (o.cddt_bins && in.theta_disc <= num_rays && in.theta_disc <= 4096 && o.cddt_theta_min > 0 &&
+            n_poses >= o.cddt_theta_min) {
+            // theta-major: all poses against one table bin at a time, bins pinned to XCDs; the fan kernel takes
+            // 2^ch poses per pass (theta_disc x poses floats of LDS, at most 16 K)
+            int ppb_log2 = 5;
+            while (ppb_log2 > 0 && ((in.theta_disc | 1) << ppb_log2) > 16384) --ppb_log2;
+            p->kernel = RL_K_CDDT_THETA;
+            p->block = 256;
+            p->grid = (int)std::max(1L, std::min((long)((in.theta_disc + 1) / 2) * ((n_poses + 127) / 128), (long)n_cu * 8));
+            p->bands = (p->grid >= o.xcd_bands && (in.theta_disc + 1) / 2 >= o.xcd_bands) ? std::max(o.xcd_bands, 1) : 1;
+            p->ch = ppb_log2;
+            p->nl = in.theta_disc | 1;                 // LDS row stride of the fan kernel
+            p->lds_bytes = (p->nl << ppb_log2) * (int)sizeof(float);
+            std::snprintf(p->name, sizeof p->name, "scan::cddt_theta_search_kernel");
+            return RL_OK;
+        }
         if (o.cddt_bins && in.theta_disc <= num_rays && in.theta_disc <= 8192) {
             // one lane per (pose, TABLE bin) — a table bin answers both raw bins half a turn apart —, pp poses
             // per workgroup pass; the grid keeps every CU's 2048 lanes occupied

@@ -2863,6 +2863,59 @@ __device__ __forceinline__ void cddt_query_pair(const CddtParams &cp, float max_
     }
 }
 
+// ---- reductions inside an aligned group of 8 lanes (the theta-major search kernel does a look-up with 8 lanes:
+// lane c reads float4 #c of the separator line and of the leaf line — a 128-B line is ONE coalesced access of
+// two quads instead of eight 16-B loads per lane to 64 different lines): three DPP steps, quad_perm xor 1,
+// xor 2, row_half_mirror; every lane of the group ends with the group's result
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    // (bound_ctrl: lets the compiler fold the move into the consuming VALU instruction's DPP operand; every
+    // source lane of these three patterns exists)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float min8(float v)
+{
+    v = __builtin_fminf(v, dpp_f<0xB1>(v));            // quad_perm [1,0,3,2]
+    v = __builtin_fminf(v, dpp_f<0x4E>(v));            // quad_perm [2,3,0,1]
+    return __builtin_fminf(v, dpp_f<0x141>(v));        // row_half_mirror: lane i <-> 7 - i
+}
+__device__ __forceinline__ float max8(float v)
+{
+    v = __builtin_fmaxf(v, dpp_f<0xB1>(v));
+    v = __builtin_fmaxf(v, dpp_f<0x4E>(v));
+    return __builtin_fmaxf(v, dpp_f<0x141>(v));
+}
+__device__ __forceinline__ uint32_t sum8(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
+    return v + (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);
+}
+// a lane's four values are ascending (ranks 4c .. 4c+3 of a sorted run, +inf padding last): the first one
+// >= x / > x and the last one <= x by select chains
+__device__ __forceinline__ float first_ge(const float4 &q, float x, float none)
+{
+    float r = q.w >= x ? q.w : none;
+    r = q.z >= x ? q.z : r;
+    r = q.y >= x ? q.y : r;
+    return q.x >= x ? q.x : r;
+}
+__device__ __forceinline__ float first_gt(const float4 &q, float x, float none)
+{
+    float r = q.w > x ? q.w : none;
+    r = q.z > x ? q.z : r;
+    r = q.y > x ? q.y : r;
+    return q.x > x ? q.x : r;
+}
+__device__ __forceinline__ float last_le(const float4 &q, float x, float none)
+{
+    float r = q.x <= x ? q.x : none;
+    r = q.y <= x ? q.y : r;
+    r = q.z <= x ? q.z : r;
+    return q.w <= x ? q.w : r;
+}
+
 // one ray: the nearest bin of -heading; bins of the second half turn use the table bin half a turn away,
 // searching backwards (CDDTCast::calc_range)
 __device__ __forceinline__ float cddt_query(const MapParams &m, const CddtParams &cp, float max_range,
@@ -2878,6 +2931,26 @@ __device__ __forceinline__ float cddt_query(const MapParams &m, const CddtParams
     float rf, rb;
     cddt_query_pair(cp, max_range, gx, gy, b, rf, rb);
     return (flipped ? rb : rf) * m.res;
+}
+
+// the raw theta bins a fan can touch: beam angles grow with j, so the bins of -(heading + alpha_j) are the
+// circular run from the last beam's bin up to the first beam's — `cnt` bins from `first`, one bin of margin on
+// either side (all theta_disc bins for fans close to a full turn, negative increments and huge headings)
+__device__ __forceinline__ void cddt_fan_run(const FanParams &f, const CddtParams &cp, const LutParams &lp, float thg,
+                                             float td_f, float inv_td, int &first, int &cnt)
+{
+    const float u0 = __builtin_rintf(-(thg + fan_alpha(f, 0)) * cp.bins_per_rad);
+    const float u1 = __builtin_rintf(-(thg + fan_alpha(f, f.num_rays - 1)) * cp.bins_per_rad);
+    const float spanf = u0 - u1;
+    const bool all = !(spanf >= 0.0f && spanf < td_f - 4.0f) || !(__builtin_fabsf(u0) < 8388608.0f) ||
+                     !(__builtin_fabsf(u1) < 8388608.0f);
+    first = 0;
+    cnt = cp.theta_disc;
+    if (!all) {
+        first = lut_bin_fast(-(thg + fan_alpha(f, f.num_rays - 1)), lp, td_f, inv_td) - 1;
+        if (first < 0) first += cp.theta_disc;
+        cnt = (int)spanf + 3;
+    }
 }
 
 // The fan form.  A CDDT answer depends on the ray's ORIGIN and its theta BIN only, so every beam of a
@@ -2916,19 +2989,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(88), amdgpu_wa
             float gx, gy, thg;
             world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1],
                           poses[3 * (size_t)pose + 2], gx, gy, thg);
-            // the raw bins the fan can touch: beam angles grow with j, so the bins of -(heading + alpha_j) are
-            // the circular run from the last beam's bin up to the first beam's, one bin of margin either side
-            const float u0 = __builtin_rintf(-(thg + fan_alpha(f, 0)) * cp.bins_per_rad);
-            const float u1 = __builtin_rintf(-(thg + fan_alpha(f, f.num_rays - 1)) * cp.bins_per_rad);
-            const float spanf = u0 - u1;
-            const bool all = !(spanf >= 0.0f && spanf < td_f - 4.0f) || !(__builtin_fabsf(u0) < 8388608.0f) ||
-                             !(__builtin_fabsf(u1) < 8388608.0f);
-            int first = 0, cnt = td;
-            if (!all) {
-                first = lut_bin_fast(-(thg + fan_alpha(f, f.num_rays - 1)), lp, td_f, inv_td) - 1;
-                if (first < 0) first += td;
-                cnt = (int)spanf + 3;
-            }
+            int first, cnt;
+            cddt_fan_run(f, cp, lp, thg, td_f, inv_td, first, cnt);
             float *br = bin_range + (size_t)q * td;
             for (int t = t0; t < cp.n_bins; t += lanes_per_pose) {
                 // raw bin t searches forward in table bin t; raw bin t + td/2 (if it maps here: >= n_bins)
@@ -2954,6 +3016,179 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(88), amdgpu_wa
             const float *br = bin_range + (size_t)qq * td;
             float *dst = out + (size_t)pose * f.num_rays;
             for (int j = threadIdx.x; j < f.num_rays; j += nt) {
+                float r = br[lut_bin_fast(-(thg + fan_alpha(f, j)), lp, td_f, inv_td)];
+                if (f.noise_std > 0.0f)
+                    r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (size_t)pose * f.num_rays + j);
+                if (!(cp.debug & 2) || r == 123.456f) dst[j] = r;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- theta-major form (large batches) ------------------------------------------------------------------
+// The pose-major kernel above misses L2 on nearly every table line (75 MB of table, 4 MB of L2 per XCD).  Here
+// ALL poses go against ONE table bin at a time: a unit of work is (table bin, block of 256 poses), lane = pose;
+// the units are laid out bin-major and cut into n_xcd equal runs, run x walked in order by the workgroups
+// with blockIdx % n_xcd == x — one XCD under round-robin dispatch — so an XCD works on one bin (two at a
+// run's ends) at any time and that bin's slice of the blocked table (1.4 MB at cfg3) stays in its L2.  Both
+// ranges of a look-up go to an intermediate R[raw bin][pose] (coalesced along the poses); the second kernel
+// turns `ppb` poses x theta_disc bins into fans — the store phase of the pose-major kernel.  Same look-up,
+// same bin arithmetic: bit-identical.
+constexpr int CDDT_TK = 4;            // look-ups an 8-lane group keeps in flight (theta-major search kernel)
+
+// per pose, once per launch: grid origin and the run of raw bins its fan touches {gx, gy, first, cnt} — the
+// search kernel visits every pose once per table bin
+__global__ __launch_bounds__(256) void cddt_theta_prep_kernel(MapParams m, FanParams f, CddtParams cp,
+                                                              const float *__restrict__ poses, float4 *__restrict__ prep)
+{
+    LutParams lp{};
+    lp.theta_disc = cp.theta_disc;
+    lp.bins_per_rad = cp.bins_per_rad;
+    const float td_f = (float)cp.theta_disc, inv_td = 1.0f / (float)cp.theta_disc;
+    for (int pose = blockIdx.x * 256 + threadIdx.x; pose < f.n_poses; pose += gridDim.x * 256) {
+        float gx, gy, thg;
+        world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1], poses[3 * (size_t)pose + 2], gx, gy, thg);
+        int first, cnt;
+        cddt_fan_run(f, cp, lp, thg, td_f, inv_td, first, cnt);
+        prep[pose] = make_float4(gx, gy, __builtin_bit_cast(float, first), __builtin_bit_cast(float, cnt));
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(88), amdgpu_waves_per_eu(8, 8)))
+void cddt_theta_search_kernel(MapParams m, FanParams f, CddtParams cp, const float *__restrict__ poses,
+                              const float4 *__restrict__ prep, float *__restrict__ R, int n_xcd)
+{
+    const int td = cp.theta_disc, half = td / 2;
+    const float INF = __builtin_inff();
+    // 8 lanes per look-up (cddt_query_pair8's scheme), CDDT_TK look-ups of consecutive poses per group in flight
+    // at once — branch-free: a look-up that needs no line reads line 0 and drops it — so the three dependent
+    // loads of a look-up overlap with its neighbours'.  A unit = (table bin, block of 32 x CDDT_TK poses); XCD
+    // x owns the WHOLE bins [n_bins * x / n_xcd, n_bins * (x + 1) / n_xcd) and walks them bin by bin.
+    constexpr int PB = 32 * CDDT_TK;
+    const int n_pb = (f.n_poses + PB - 1) / PB;
+    const int x = (int)(blockIdx.x % (unsigned)n_xcd), g = (int)(blockIdx.x / (unsigned)n_xcd);
+    const int G = ((int)gridDim.x - x + n_xcd - 1) / n_xcd;
+    const int t_lo = (int)((long)cp.n_bins * x / n_xcd), t_hi = (int)((long)cp.n_bins * (x + 1) / n_xcd);
+    const long u1 = (long)(t_hi - t_lo) * n_pb;
+    const int c = (int)threadIdx.x & 7, grp = (int)threadIdx.x >> 3;
+    const float4 *tab4 = reinterpret_cast<const float4 *>(cp.tab);
+    for (long u = g; u < u1; u += G) {
+        const int t = t_lo + (int)(u / n_pb), p0 = (int)(u % n_pb) * PB + grp * CDDT_TK;
+        const float cs = cp.cosv[t], sn = cp.sinv[t], tr = cp.trans[t], wdt = (float)cp.width[t];
+        const uint32_t boff = cp.bucket_off[t];
+        const int rb = t + half;
+        const bool has_b = rb >= cp.n_bins && rb < td;
+        float lx[CDDT_TK];
+        bool need_f[CDDT_TK], need_b[CDDT_TK], slow[CDDT_TK];
+        uint2 hd[CDDT_TK];
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            const float4 pr = prep[min(p0 + k, f.n_poses - 1)];
+            const float gx = pr.x, gy = pr.y;
+            const int first = __builtin_bit_cast(int, pr.z), cnt = __builtin_bit_cast(int, pr.w);
+            int df = t - first, db = rb - first;
+            df += df < 0 ? td : 0;
+            db += db < 0 ? td : 0;
+            const bool live = p0 + k < f.n_poses && !(cp.debug & 1);
+            need_f[k] = live && df < cnt;
+            need_b[k] = live && has_b && db < cnt;
+            lx[k] = __builtin_fmaf(gx, cs, -(gy * sn));
+            const float ly = __builtin_fmaf(gx, sn, gy * cs) + tr;
+            const bool inside = (need_f[k] || need_b[k]) && ly >= 0.0f && ly < wdt;
+            hd[k] = cp.hdr[inside ? boff + (uint32_t)(int)ly : 0u];
+            if (!inside) hd[k].y = 0u;                       // (nothing stored: both ranges stay max_range)
+        }
+        float4 sq[CDDT_TK];
+        uint32_t nleaf[CDDT_TK];
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            nleaf[k] = (hd[k].y + 31u) >> 5;
+            slow[k] = nleaf[k] > 32u;                        // several separator lines: the general look-up below
+            sq[k] = tab4[(nleaf[k] > 1u && !slow[k]) ? (size_t)hd[k].x * 8 + c : (size_t)c];
+        }
+        float fwd[CDDT_TK];
+        float4 lq[CDDT_TK];
+        bool have_leaf[CDDT_TK];
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            const bool seps = nleaf[k] > 1u && !slow[k];
+            const float x_ = lx[k];
+            const float4 q = sq[k];
+            const uint32_t cnt = sum8((q.x <= x_ ? 1u : 0u) + (q.y <= x_ ? 1u : 0u) + (q.z <= x_ ? 1u : 0u) +
+                                      (q.w <= x_ ? 1u : 0u));
+            const float fs = min8(first_gt(q, x_, INF));
+            fwd[k] = seps ? fs : INF;
+            // one leaf: it is the leaf; separators: the leaf whose first value is the last one <= x (none: cnt 0)
+            have_leaf[k] = hd[k].y != 0u && !slow[k] && (!seps || cnt > 0u);
+            const uint32_t leaf = seps ? cnt - 1u : 0u;
+            lq[k] = tab4[have_leaf[k] ? ((size_t)hd[k].x + (seps ? 1u : 0u) + leaf) * 8 + c : (size_t)c];
+        }
+        float my_f = 0.0f, my_b = 0.0f;
+        bool my_nf = false, my_nb = false;
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            const float x_ = lx[k];
+            const float4 q = lq[k];
+            const float f4 = min8(first_ge(q, x_, INF));
+            const float b4 = max8(last_le(q, x_, -INF));
+            const float rf = __builtin_fminf((have_leaf[k] ? __builtin_fminf(fwd[k], f4) : fwd[k]) - x_, f.max_range);
+            const float rbk = __builtin_fminf(x_ - (have_leaf[k] ? b4 : -INF), f.max_range);
+            // lane k of the group stores look-up k: a wave's 8 groups x CDDT_TK consecutive poses are one line
+            if (c == k) {
+                my_f = rf;
+                my_b = rbk;
+                my_nf = need_f[k] && !slow[k];
+                my_nb = need_b[k] && !slow[k];
+            }
+        }
+        if (my_nf) R[(size_t)t * f.n_poses + p0 + c] = my_f * m.res;
+        if (my_nb) R[(size_t)rb * f.n_poses + p0 + c] = my_b * m.res;
+        // buckets beyond 1024 values (several separator lines; a long straight wall along the bin's direction):
+        // the general one-lane look-up, rolled
+        uint32_t slow_mask = 0;
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) slow_mask |= slow[k] ? (((need_f[k] ? 1u : 0u) | (need_b[k] ? 2u : 0u)) << (2 * k)) : 0u;
+#pragma unroll 1
+        for (int k = 0; slow_mask >> (2 * k); ++k) {
+            const uint32_t need = (slow_mask >> (2 * k)) & 3u;
+            if (!need || c != 0) continue;
+            const int pose = p0 + k;
+            float gx, gy, thg, rf, rbk;
+            world_to_grid(m, poses[3 * (size_t)pose], poses[3 * (size_t)pose + 1], poses[3 * (size_t)pose + 2], gx, gy, thg);
+            cddt_query_pair(cp, f.max_range, gx, gy, t, rf, rbk);
+            if (need & 1u) R[(size_t)t * f.n_poses + pose] = rf * m.res;
+            if (need & 2u) R[(size_t)rb * f.n_poses + pose] = rbk * m.res;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cddt_theta_fan_kernel(MapParams m, FanParams f, CddtParams cp,
+                                                             const float *__restrict__ poses,
+                                                             const float *__restrict__ R, float *__restrict__ out,
+                                                             int ppb_log2, int stride)
+{
+    extern __shared__ float bin_range[];                 // ppb x stride floats (stride: theta_disc made odd)
+    const int td = cp.theta_disc, ppb = 1 << ppb_log2;
+    LutParams lp{};
+    lp.theta_disc = td;
+    lp.bins_per_rad = cp.bins_per_rad;
+    const float td_f = (float)td, inv_td = 1.0f / (float)td;
+    const int n_grp = (f.n_poses + ppb - 1) >> ppb_log2;
+    for (int grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+        const int p0 = grp << ppb_log2, np = min(ppb, f.n_poses - p0);
+        // (bins the fan does not touch were never written: read as they are, never looked up)
+        for (int i = threadIdx.x; i < (td << ppb_log2); i += 256) {
+            const int bin = i >> ppb_log2, q = i & (ppb - 1);
+            if (q < np) bin_range[q * stride + bin] = R[(size_t)bin * f.n_poses + p0 + q];
+        }
+        __syncthreads();
+        for (int q = 0; q < np; ++q) {
+            const int pose = p0 + q;
+            const float thg = poses[3 * (size_t)pose + 2] + m.wa;
+            const float *br = bin_range + (size_t)q * stride;
+            float *dst = out + (size_t)pose * f.num_rays;
+            for (int j = threadIdx.x; j < f.num_rays; j += 256) {
                 float r = br[lut_bin_fast(-(thg + fan_alpha(f, j)), lp, td_f, inv_td)];
                 if (f.noise_std > 0.0f)
                     r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (size_t)pose * f.num_rays + j);

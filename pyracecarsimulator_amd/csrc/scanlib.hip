@@ -200,11 +200,11 @@ struct LaunchCtx {
     hipStream_t stream = nullptr;
     bool bound = false;
     uint64_t last_use = 0;
-    DevBuf rec, rec_sorted, order, keys, hist, pose_first, dbg, d0;
+    DevBuf rec, rec_sorted, order, keys, hist, pose_first, dbg, d0, cddt_r;   // cddt_r: theta-major CDDT, R[raw bin][pose]
     int crash_epoch = 0;           // mark value of the last per-pose crash launch (pose_marks)
     void release()
     {
-        for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg, &d0}) b->release();
+        for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg, &d0, &cddt_r}) b->release();
     }
 };
 constexpr int N_LAUNCH_CTX = 8;      // (HIP's default 4 hardware queues carry 4 concurrent streams; GPU_MAX_HW_QUEUES=8 carries 8)
@@ -258,6 +258,7 @@ struct rl_method {
                                  // map keep two loads in flight per lane and compact a dry wave's last rays into one slot;
                                  // 0 = auto (launch_plan.h: 2 from 2^23 rays per launch up, from 2^20 on maps beyond the
                                  // small-map bound; callers that keep several launches in flight set 2: +15..30 %)
+    int cddt_theta_min = 32768;                            // poses per launch from which the CDDT look-ups run theta-major (0: never)
     int cddt_sort = 0;                                     // per-bin fan kernel walks the poses in map-tile order, XCD bands
                                                            // (measured: -13 % at 4096 poses - the binning launch and no
                                                            // reuse at that density -, +3 % at 32768: off by default)
@@ -623,6 +624,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "slots")) h->slots = value >= 3 ? 3 : (value == 2 ? 2 : (value == 1 ? 1 : 0));
     else if (!strcmp(name, "cddt_bins")) h->cddt_bins_kernel = value != 0;
     else if (!strcmp(name, "cddt_sort")) h->cddt_sort = value != 0;
+    else if (!strcmp(name, "cddt_theta_min")) h->cddt_theta_min = value < 0 ? 0 : value;
     else if (!strcmp(name, "cddt_lds_sort")) {
         int v = 128;                                   // a power of two in [128, CDDT_LDS_SORT]: the bitonic network pads to one
         while (v * 2 <= value && v * 2 <= (int)CDDT_LDS_SORT) v *= 2;
@@ -666,6 +668,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "slots")) *value_out = h->slots;
     else if (!strcmp(name, "cddt_bins")) *value_out = h->cddt_bins_kernel;
     else if (!strcmp(name, "cddt_sort")) *value_out = h->cddt_sort;
+    else if (!strcmp(name, "cddt_theta_min")) *value_out = h->cddt_theta_min;
     else if (!strcmp(name, "cddt_lds_sort")) *value_out = h->cddt_lds_sort;
     else if (!strcmp(name, "map_epoch")) *value_out = (int64_t)h->map->epoch;
     else return fail(RL_ERR_INVALID, "unknown info '%s'", name);
@@ -1095,6 +1098,7 @@ static rl_plan_opts opts_of(const rl_method *h)
     o.run_log2 = h->run_log2;
     o.cddt_bins = h->cddt_bins_kernel;
     o.cddt_sort = h->cddt_sort;
+    o.cddt_theta_min = h->cddt_theta_min;
     o.lut_debug = h->lut_debug;
     o.debug_stamps = h->debug_stamps;
     o.slice_log2 = h->slice_log2;
@@ -1289,6 +1293,23 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
         hipLaunchKernelGGL(cddt_fan_bins_kernel, grid, block, lds, stream, m->mp, f, h->cdp, d_poses, d_out, d_order,
                            pl.bands, pl.nl, pl.ch);
+        break;
+    }
+    case RL_K_CDDT_THETA: {
+        if ((rc = ensure_cddt(h, stream))) return rc;
+        // scratch of the launch context: R[raw bin][pose] behind the per-pose records {gx, gy, first bin, bins}
+        const size_t prep_bytes = (((size_t)n_poses * 16) + 255) & ~(size_t)255;
+        if ((rc = cx->cddt_r.ensure(prep_bytes + (size_t)h->cdp.theta_disc * (size_t)n_poses * sizeof(float)))) return rc;
+        float4 *d_prep = (float4 *)cx->cddt_r.p;
+        float *d_r = (float *)((char *)cx->cddt_r.p + prep_bytes);
+        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+        hipLaunchKernelGGL(cddt_theta_prep_kernel, dim3((unsigned)std::max(1, std::min((n_poses + 255) / 256, m->n_cu * 8))),
+                           dim3(256), 0, stream, m->mp, f, h->cdp, d_poses, d_prep);
+        hipLaunchKernelGGL(cddt_theta_search_kernel, grid, block, 0, stream, m->mp, f, h->cdp, d_poses,
+                           (const float4 *)d_prep, d_r, pl.bands);
+        const int n_grp = (n_poses + (1 << pl.ch) - 1) >> pl.ch;
+        hipLaunchKernelGGL(cddt_theta_fan_kernel, dim3((unsigned)std::max(1, std::min(n_grp, m->n_cu * 8))), block, lds,
+                           stream, m->mp, f, h->cdp, d_poses, (const float *)d_r, d_out, pl.ch, pl.nl);
         break;
     }
     case RL_K_CDDT_RAYS:

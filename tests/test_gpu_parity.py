@@ -641,7 +641,15 @@ def test_cddt_fan_searches_only_the_bins_the_fan_touches(oracle_mod):
             out = np.empty(len(poses) * B, np.float32)
             m.calc_range_fan(poses, out, fov, B)
             assert m.last_plan()["kernel"] == ("cddt_bins" if td <= B else "cddt_rays")
-            assert np.array_equal(out, om.cddt_fan(td, poses, fov, B)), (td, fov, B)
+            want = om.cddt_fan(td, poses, fov, B)
+            assert np.array_equal(out, want), (td, fov, B)
+            if td <= B:                                   # the theta-major pair of kernels on the same fans
+                m.set_option("cddt_theta_min", 1)
+                out[:] = -1.0
+                m.calc_range_fan(poses, out, fov, B)
+                assert m.last_plan()["kernel"] == "cddt_theta"
+                assert np.array_equal(out, want), ("theta-major", td, fov, B)
+                m.set_option("cddt_theta_min", 32768)
 
 
 @pytest.mark.parametrize("lds_sort", [16384, 128])      # 128: buckets above it take the global rank sort
@@ -669,6 +677,12 @@ def test_cddt_long_walls_fill_large_buckets(oracle_mod, lds_sort):
             out = np.empty(len(poses) * 1081, np.float32)
             m.calc_range_fan(poses, out, 4.71, 1081)
             assert np.array_equal(out, want), (td, bins)
+        m.set_option("cddt_bins", 1)
+        m.set_option("cddt_theta_min", 1)                 # theta-major (buckets beyond 1024 values: several separator lines)
+        out = np.empty(len(poses) * 1081, np.float32)
+        m.calc_range_fan(poses, out, 4.71, 1081)
+        assert m.last_plan()["kernel"] == "cddt_theta" and np.array_equal(out, want), td
+        m.set_option("cddt_theta_min", 32768)
         # a rebuild (map update) goes through the same enqueue-only path again
         occ2 = occ.copy()
         occ2[40, 50:2500] = 1
@@ -1361,10 +1375,17 @@ def test_cfg3_cddt_full_size(oracle_mod):
     m = range_libc.PyCDDTCast(omap, mrx, 108)
     poses = workloads.make_poses(w, dt=om.dt)
     assert len(poses) == 65536
-    assert m.plan_fan(len(poses), B)["kernel"] == "cddt_bins"
+    assert m.plan_fan(len(poses), B)["kernel"] == "cddt_theta"        # theta-major from 32 768 poses up
     out = np.empty(len(poses) * B, np.float32)
     m.calc_range_fan(poses, out, w.fov, B)
+    assert m.last_plan()["kernel"] == "cddt_theta"
     assert out.min() >= 0.0 and out.max() <= mrx * g.resolution
+    m.set_option("cddt_theta_min", 0)                                 # the pose-major kernel on the same batch
+    pm = np.empty_like(out)
+    m.calc_range_fan(poses, pm, w.fov, B)
+    assert m.last_plan()["kernel"] == "cddt_bins" and np.array_equal(pm, out)
+    del pm
+    m.set_option("cddt_theta_min", 32768)
     again = np.empty_like(out)
     m.calc_range_fan(poses, again, w.fov, B)
     assert np.array_equal(out, again)

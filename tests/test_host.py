@@ -244,7 +244,16 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
     # cfg3: GiantLUT rows of 1442 bins = 3 x 16-B loads per lane, 17 chunks of 64 beams; and the CDDT variant
     p = _plan(GLT, 2000, 2000, 65536, 1081, theta_disc=1442)
     assert (p["name"], p["grid"], p["block"], p["lds_bytes"]) == ("scan::lut_fan_lds_kernel<3, 17>", 2048, 256, 12288)
+    # cfg3's 65 536 poses run theta-major (all poses against one table bin at a time, bins pinned to XCDs;
+    # the fan kernel takes 32 poses x 109 floats of LDS per pass); below cddt_theta_min pose-major:
     p = _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=108)
+    assert (p["kernel"], p["block"], p["grid"], p["bands"], p["ch"], p["nl"], p["lds_bytes"]) == \
+        ("cddt_theta", 256, 2048, 8, 5, 109, 32 * 109 * 4)
+    assert _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=720)["ch"] == 4      # 16 poses x 721 floats
+    assert _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=108, cddt_theta_min=0)["kernel"] == "cddt_bins"
+    p = _plan(CDDT, 2000, 2000, 3, 1081, theta_disc=4, cddt_theta_min=1)
+    assert (p["kernel"], p["grid"], p["bands"]) == ("cddt_theta", 2, 1)          # fewer units than XCDs: one run
+    p = _plan(CDDT, 2000, 2000, 32767, 1081, theta_disc=108)
     # (54 table bins -> 64 lanes per pose, 4 poses per pass of a 256-lane workgroup, 8 workgroups per CU)
     assert (p["kernel"], p["block"], p["grid"], p["lds_bytes"], p["nl"], p["ch"]) == ("cddt_bins", 256, 2048, 1728, 64, 4)
     p = _plan(CDDT, 2000, 2000, 3, 1081, theta_disc=720)
