@@ -1,0 +1,119 @@
+// edt_kernels.h — K0: exact Euclidean distance transform of the occupancy grid (range_libc DistanceTransform,
+// SURVEY.md row a7).  Part of scan_kernels.h.
+#pragma once
+#include "scan_device.h"
+
+namespace scan {
+
+constexpr int GINF = 30000;             // "no obstacle in this column" (maps <= 16384 per side)
+constexpr uint32_t GINF2 = (uint32_t)GINF * (uint32_t)GINF;
+
+// ------------------------------------------------------------------------------
+// K0: exact EDT.  Pass 1: per column, distance to the nearest occupied cell of the
+// column.  A workgroup owns 64 adjacent columns (one lane each, so every row access is
+// a coalesced 64-byte read) and splits the rows into 16 segments, one per wave; the
+// waves exchange "last occupied row below / first occupied row above my segment"
+// through LDS, so a column is swept by 16 waves in parallel instead of one lane
+// walking all rows (1.5 ms -> ~0.1 ms at 2049^2: the table rebuild must keep up with
+// per-tick map changes, scripts/two_player/rcs_two_player.py:110-121).
+// ------------------------------------------------------------------------------
+constexpr int EDT_SEGS = 16;
+
+__global__ __launch_bounds__(1024) void edt_cols_kernel(const uint8_t *__restrict__ occ, int rows,
+                                                        int cols, int *__restrict__ g)
+{
+    __shared__ int s_last[EDT_SEGS][64], s_first[EDT_SEGS][64];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < cols;
+    const int seg_len = (rows + EDT_SEGS - 1) / EDT_SEGS;
+    const int r0 = seg * seg_len, r1 = min(rows, r0 + seg_len);
+    // (a) last / first occupied row inside my segment
+    int last = -GINF, first = 4 * GINF;
+    if (ok) {
+#pragma unroll 8
+        for (int r = r0; r < r1; ++r) {
+            if (occ[(size_t)r * cols + c]) {
+                last = r;
+                first = min(first, r);
+            }
+        }
+    }
+    s_last[seg][lane] = last;
+    s_first[seg][lane] = first;
+    __syncthreads();
+    if (!ok) return;
+    // (b) carries from the segments below / above
+    int below = -GINF, above = 4 * GINF;
+    for (int k = 0; k < seg; ++k) below = max(below, s_last[k][lane]);
+    for (int k = seg + 1; k < EDT_SEGS; ++k) above = min(above, s_first[k][lane]);
+    // (c) down sweep then up sweep over my segment
+    last = below;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {
+        if (occ[(size_t)r * cols + c]) last = r;
+        const int d = r - last;
+        g[(size_t)r * cols + c] = d > GINF ? GINF : d;
+    }
+    int nxt = above;
+#pragma unroll 8
+    for (int r = r1 - 1; r >= r0; --r) {
+        if (occ[(size_t)r * cols + c]) nxt = r;
+        const int d = nxt - r;
+        const int old = g[(size_t)r * cols + c];
+        g[(size_t)r * cols + c] = d < old ? d : old;
+    }
+}
+
+// Pass 2: one workgroup per row, the row of column distances staged in LDS; each
+// cell widens its search k = 1,2,.. while k^2 can still beat the best d^2 found, so
+// the work per cell is O(distance), not O(cols).  d^2 is an exact integer; the
+// result is sqrtf((float)d2), correctly rounded == the CPU statement.
+__global__ __launch_bounds__(256) void edt_rows_kernel(const int *__restrict__ g, int rows,
+                                                       int cols, float *__restrict__ dt)
+{
+    extern __shared__ int grow[];
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) grow[c] = g[(size_t)r * cols + c];
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        uint32_t v0 = (uint32_t)grow[c];
+        uint32_t best = v0 * v0;
+        for (int k = 1; (uint32_t)k * (uint32_t)k < best; ++k) {
+            const bool l_ok = c - k >= 0, r_ok = c + k < cols;
+            if (!l_ok && !r_ok) break;
+            const uint32_t kk = (uint32_t)k * (uint32_t)k;
+            if (l_ok) {
+                uint32_t v = (uint32_t)grow[c - k];
+                uint32_t cand = kk + v * v;
+                best = cand < best ? cand : best;
+            }
+            if (r_ok) {
+                uint32_t v = (uint32_t)grow[c + k];
+                uint32_t cand = kk + v * v;
+                best = cand < best ? cand : best;
+            }
+        }
+        dt[(size_t)r * cols + c] = best >= GINF2 ? 1e10f : sqrtf((float)best);
+    }
+}
+
+// bit-packed occupancy rows (bit c&31 of word c>>5), for the LDS-tiled kernels
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *__restrict__ occ, int rows,
+                                                        int cols, int stride,
+                                                        uint32_t *__restrict__ bits)
+{
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.y;
+    if (w >= stride || r >= rows) return;
+    uint32_t word = 0;
+    int c0 = w * 32;
+#pragma unroll 4
+    for (int b = 0; b < 32; ++b) {
+        int c = c0 + b;
+        if (c < cols && occ[(size_t)r * cols + c]) word |= 1u << b;
+    }
+    bits[(size_t)r * stride + w] = word;
+}
+
+}  // namespace scan

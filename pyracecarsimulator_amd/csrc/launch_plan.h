@@ -16,13 +16,13 @@
 
 namespace plan {
 
-// layout constants shared with scan_kernels.h (static_asserts in scanlib.hip tie them together)
+// layout constants shared with rm_kernels.h (static_asserts in scanlib.hip tie them together)
 constexpr int WG = 256;                  // threads of the unit workgroup grid_mult counts in
 constexpr int STREAM_HDR = 66;           // LDS header words of the stream kernels
 constexpr int STRIPE_BINS = 64;
 constexpr int STRIPE_MAX_PER_LANE = 8;
 constexpr int INLINE_LDS_BUDGET = 72 * 1024;   // LDS an INLINE workgroup may use (two 1024-lane workgroups per CU)
-constexpr int INLINE_REC_BYTES = 32;     // one BlockRec per owned 64-ray block (scan_kernels.h)
+constexpr int INLINE_REC_BYTES = 32;     // one BlockRec per owned 64-ray block (rm_kernels.h)
 constexpr int DRAIN_CAP = 64, DRAIN_FIELDS = 7;   // several rays per lane: per-wave compaction scratch of the drain phase
                                                   // (7 dwords per ray, 9 with the fused crash test)
 

@@ -31,7 +31,7 @@ using namespace scan;
 static_assert(plan::WG == scan::WG && plan::STREAM_HDR == scan::STREAM_HDR && plan::STRIPE_BINS == scan::STRIPE_BINS &&
                   plan::STRIPE_MAX_PER_LANE == scan::STRIPE_MAX_PER_LANE && plan::DRAIN_CAP == scan::DRAIN_CAP &&
                   plan::DRAIN_FIELDS == scan::DRAIN_FIELDS && plan::INLINE_REC_BYTES == (int)sizeof(scan::BlockRec),
-              "launch_plan.h and scan_kernels.h disagree about the stream kernels' LDS layout");
+              "launch_plan.h and rm_kernels.h disagree about the stream kernels' LDS layout");
 
 // ------------------------------------------------------------------------------
 // errors
@@ -863,7 +863,7 @@ static int ensure_cddt(rl_method *h, hipStream_t stream)
     const size_t cap = std::max<size_t>((size_t)m->n_edges * nb * 3, 1);    // stored values, upper bound
     if (cap > (size_t)INT_MAX) return fail(RL_ERR_UNSUPPORTED, "CDDT table too large (%zu values)", cap);
     if ((rc = h->cd_xs2.ensure(cap * 4))) return rc;
-    // the blocked table the queries read (scan_kernels.h, CddtParams): leaves of 32 values + separator lines;
+    // the blocked table the queries read (cddt_kernels.h, CddtParams): leaves of 32 values + separator lines;
     // upper bound: every bucket pads its last leaf and, with more than one leaf, its last separator line
     const size_t tab_lines = cap / 32 + cap / 1024 + 2 * (size_t)nbk + 2;
     if (tab_lines > (size_t)UINT32_MAX) return fail(RL_ERR_UNSUPPORTED, "CDDT table too large (%zu lines)", tab_lines);
