@@ -121,7 +121,7 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     }
     if (in.kind == RL_CDDT) {
         if (o.cddt_bins && in.theta_disc <= num_rays && in.theta_disc <= 4096 && o.cddt_theta_min > 0 &&
-            n_poses >= o.cddt_theta_min) {
+            n_poses >= o.cddt_theta_min && (long)n_poses * in.theta_disc <= (1L << 29)) {   // (R[bin][pose]: <= 2 GiB)
             // theta-major: all poses against one table bin at a time, bins pinned to XCDs; the fan kernel takes
             // 2^ch poses per pass (theta_disc x poses floats of LDS, at most 16 K)
             int ppb_log2 = 5;

@@ -253,6 +253,7 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
     assert _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=108, cddt_theta_min=0)["kernel"] == "cddt_bins"
     p = _plan(CDDT, 2000, 2000, 3, 1081, theta_disc=4, cddt_theta_min=1)
     assert (p["kernel"], p["grid"], p["bands"]) == ("cddt_theta", 2, 1)          # fewer units than XCDs: one run
+    assert _plan(CDDT, 2000, 2000, 1 << 20, 1081, theta_disc=1024)["kernel"] == "cddt_bins"    # R would pass 2 GiB
     p = _plan(CDDT, 2000, 2000, 32767, 1081, theta_disc=108)
     # (54 table bins -> 64 lanes per pose, 4 poses per pass of a 256-lane workgroup, 8 workgroups per CU)
     assert (p["kernel"], p["block"], p["grid"], p["lds_bytes"], p["nl"], p["ch"]) == ("cddt_bins", 256, 2048, 1728, 64, 4)
