@@ -443,6 +443,51 @@ __device__ __forceinline__ float last_le(const float4 &q, float x, float none)
     return q.w <= x ? q.w : r;
 }
 
+// Eight independent 8-lane reductions, hand-interleaved (the theta-major search kernel reduces two values of
+// each of its four look-ups per stage): the DPP permutation rides on the min / max / add itself, and step s of
+// a chain sits eight instructions behind step s-1 — no DPP read-after-write no-ops, no canonicalising copies.
+#define CDDT_DPP3(OPA, OPB, CTRL)                                                                     \
+    OPA " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t" OPB " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+    OPA " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t" OPB " %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+    OPA " %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t" OPB " %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+    OPA " %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\t" OPB " %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+// (count, min) x 4
+__device__ __forceinline__ void red8_add_min_x4(uint32_t &n0, float &f0, uint32_t &n1, float &f1, uint32_t &n2, float &f2,
+                                                uint32_t &n3, float &f3)
+{
+    asm volatile("s_nop 1\n\t"
+                 CDDT_DPP3("v_add_u32_dpp", "v_min_f32_dpp", "quad_perm:[1,0,3,2]")
+                 CDDT_DPP3("v_add_u32_dpp", "v_min_f32_dpp", "quad_perm:[2,3,0,1]")
+                 CDDT_DPP3("v_add_u32_dpp", "v_min_f32_dpp", "row_half_mirror")
+                 : "+v"(n0), "+v"(f0), "+v"(n1), "+v"(f1), "+v"(n2), "+v"(f2), "+v"(n3), "+v"(f3));
+}
+// (min, max) x 4
+__device__ __forceinline__ void red8_min_max_x4(float &a0, float &b0, float &a1, float &b1, float &a2, float &b2, float &a3,
+                                                float &b3)
+{
+    asm volatile("s_nop 1\n\t"
+                 CDDT_DPP3("v_min_f32_dpp", "v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+                 CDDT_DPP3("v_min_f32_dpp", "v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+                 CDDT_DPP3("v_min_f32_dpp", "v_max_f32_dpp", "row_half_mirror")
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3));
+}
+#undef CDDT_DPP3
+// min / max of two finite-or-infinite floats without the canonicalising copies fminf / fmaxf carry
+__device__ __forceinline__ float vmin(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// how many of a lane's four ascending values are <= x
+__device__ __forceinline__ uint32_t count_le(const float4 &q, float x)
+{
+    uint32_t n = q.x <= x ? 1u : 0u;
+    n = q.y <= x ? 2u : n;
+    n = q.z <= x ? 3u : n;
+    return q.w <= x ? 4u : n;
+}
+
 // one ray: the nearest bin of -heading; bins of the second half turn use the table bin half a turn away,
 // searching backwards (CDDTCast::calc_range)
 __device__ __forceinline__ float cddt_query(const MapParams &m, const CddtParams &cp, float max_range,
@@ -588,7 +633,7 @@ void cddt_theta_search_kernel(MapParams m, FanParams f, CddtParams cp, const flo
 {
     const int td = cp.theta_disc, half = td / 2;
     const float INF = __builtin_inff();
-    // 8 lanes per look-up (cddt_query_pair8's scheme), CDDT_TK look-ups of consecutive poses per group in flight
+    // 8 lanes per look-up (lane c reads float4 #c of a line), CDDT_TK look-ups of consecutive poses per group in flight
     // at once — branch-free: a look-up that needs no line reads line 0 and drops it — so the three dependent
     // loads of a look-up overlap with its neighbours'.  A unit = (table bin, block of 32 x CDDT_TK poses); XCD
     // x owns the WHOLE bins [n_bins * x / n_xcd, n_bins * (x + 1) / n_xcd) and walks them bin by bin.
@@ -597,18 +642,21 @@ void cddt_theta_search_kernel(MapParams m, FanParams f, CddtParams cp, const flo
     const int x = (int)(blockIdx.x % (unsigned)n_xcd), g = (int)(blockIdx.x / (unsigned)n_xcd);
     const int G = ((int)gridDim.x - x + n_xcd - 1) / n_xcd;
     const int t_lo = (int)((long)cp.n_bins * x / n_xcd), t_hi = (int)((long)cp.n_bins * (x + 1) / n_xcd);
-    const long u1 = (long)(t_hi - t_lo) * n_pb;
+    const uint32_t u1 = (uint32_t)(t_hi - t_lo) * (uint32_t)n_pb;      // (< 2^31: the planner bounds poses x theta_disc)
     const int c = (int)threadIdx.x & 7, grp = (int)threadIdx.x >> 3;
     const float4 *tab4 = reinterpret_cast<const float4 *>(cp.tab);
-    for (long u = g; u < u1; u += G) {
-        const int t = t_lo + (int)(u / n_pb), p0 = (int)(u % n_pb) * PB + grp * CDDT_TK;
+    for (uint32_t u = (uint32_t)g; u < u1; u += (uint32_t)G) {
+        const uint32_t ut = u / (uint32_t)n_pb;
+        const int t = t_lo + (int)ut, p0 = (int)(u - ut * (uint32_t)n_pb) * PB + grp * CDDT_TK;
         const float cs = cp.cosv[t], sn = cp.sinv[t], tr = cp.trans[t], wdt = (float)cp.width[t];
         const uint32_t boff = cp.bucket_off[t];
         const int rb = t + half;
         const bool has_b = rb >= cp.n_bins && rb < td;
+        static_assert(CDDT_TK == 4, "the reductions below are written for four look-ups per group");
         float lx[CDDT_TK];
         bool need_f[CDDT_TK], need_b[CDDT_TK], slow[CDDT_TK];
         uint2 hd[CDDT_TK];
+        const bool dbg_off = !(cp.debug & 1);
 #pragma unroll
         for (int k = 0; k < CDDT_TK; ++k) {
             const float4 pr = prep[min(p0 + k, f.n_poses - 1)];
@@ -617,57 +665,64 @@ void cddt_theta_search_kernel(MapParams m, FanParams f, CddtParams cp, const flo
             int df = t - first, db = rb - first;
             df += df < 0 ? td : 0;
             db += db < 0 ? td : 0;
-            const bool live = p0 + k < f.n_poses && !(cp.debug & 1);
-            need_f[k] = live && df < cnt;
-            need_b[k] = live && has_b && db < cnt;
+            const bool live = (p0 + k < f.n_poses) & dbg_off;
+            need_f[k] = live & (df < cnt);
+            need_b[k] = live & has_b & (db < cnt);
             lx[k] = __builtin_fmaf(gx, cs, -(gy * sn));
             const float ly = __builtin_fmaf(gx, sn, gy * cs) + tr;
-            const bool inside = (need_f[k] || need_b[k]) && ly >= 0.0f && ly < wdt;
+            const bool inside = (need_f[k] | need_b[k]) & (ly >= 0.0f) & (ly < wdt);
             hd[k] = cp.hdr[inside ? boff + (uint32_t)(int)ly : 0u];
-            if (!inside) hd[k].y = 0u;                       // (nothing stored: both ranges stay max_range)
+            hd[k].y = inside ? hd[k].y : 0u;                 // (nothing stored: both ranges stay max_range)
         }
         float4 sq[CDDT_TK];
         uint32_t nleaf[CDDT_TK];
+        bool seps[CDDT_TK];
 #pragma unroll
         for (int k = 0; k < CDDT_TK; ++k) {
             nleaf[k] = (hd[k].y + 31u) >> 5;
             slow[k] = nleaf[k] > 32u;                        // several separator lines: the general look-up below
-            sq[k] = tab4[(nleaf[k] > 1u && !slow[k]) ? (size_t)hd[k].x * 8 + c : (size_t)c];
+            seps[k] = (nleaf[k] > 1u) & !slow[k];
+            sq[k] = tab4[seps[k] ? (size_t)hd[k].x * 8 + c : (size_t)c];
         }
-        float fwd[CDDT_TK];
+        uint32_t cn[CDDT_TK];
+        float fs[CDDT_TK];
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            cn[k] = count_le(sq[k], lx[k]);
+            fs[k] = first_gt(sq[k], lx[k], INF);
+        }
+        red8_add_min_x4(cn[0], fs[0], cn[1], fs[1], cn[2], fs[2], cn[3], fs[3]);
         float4 lq[CDDT_TK];
         bool have_leaf[CDDT_TK];
 #pragma unroll
         for (int k = 0; k < CDDT_TK; ++k) {
-            const bool seps = nleaf[k] > 1u && !slow[k];
-            const float x_ = lx[k];
-            const float4 q = sq[k];
-            const uint32_t cnt = sum8((q.x <= x_ ? 1u : 0u) + (q.y <= x_ ? 1u : 0u) + (q.z <= x_ ? 1u : 0u) +
-                                      (q.w <= x_ ? 1u : 0u));
-            const float fs = min8(first_gt(q, x_, INF));
-            fwd[k] = seps ? fs : INF;
-            // one leaf: it is the leaf; separators: the leaf whose first value is the last one <= x (none: cnt 0)
-            have_leaf[k] = hd[k].y != 0u && !slow[k] && (!seps || cnt > 0u);
-            const uint32_t leaf = seps ? cnt - 1u : 0u;
-            lq[k] = tab4[have_leaf[k] ? ((size_t)hd[k].x + (seps ? 1u : 0u) + leaf) * 8 + c : (size_t)c];
+            fs[k] = seps[k] ? fs[k] : INF;
+            // one leaf: it is the leaf; separators: the leaf whose first value is the last one <= x (none: count 0)
+            have_leaf[k] = (hd[k].y != 0u) & !slow[k] & (!seps[k] | (cn[k] > 0u));
+            // (a NaN origin counts the +inf padding as well: stay inside the bucket's lines)
+            const uint32_t leaf = seps[k] ? min(cn[k], nleaf[k]) - 1u : 0u;
+            lq[k] = tab4[have_leaf[k] ? ((size_t)hd[k].x + (seps[k] ? 1u : 0u) + leaf) * 8 + c : (size_t)c];
         }
+        float f4[CDDT_TK], b4[CDDT_TK];
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            f4[k] = first_ge(lq[k], lx[k], INF);
+            b4[k] = last_le(lq[k], lx[k], -INF);
+        }
+        red8_min_max_x4(f4[0], b4[0], f4[1], b4[1], f4[2], b4[2], f4[3], b4[3]);
         float my_f = 0.0f, my_b = 0.0f;
         bool my_nf = false, my_nb = false;
 #pragma unroll
         for (int k = 0; k < CDDT_TK; ++k) {
             const float x_ = lx[k];
-            const float4 q = lq[k];
-            const float f4 = min8(first_ge(q, x_, INF));
-            const float b4 = max8(last_le(q, x_, -INF));
-            const float rf = __builtin_fminf((have_leaf[k] ? __builtin_fminf(fwd[k], f4) : fwd[k]) - x_, f.max_range);
-            const float rbk = __builtin_fminf(x_ - (have_leaf[k] ? b4 : -INF), f.max_range);
+            const float rf = vmin((have_leaf[k] ? vmin(fs[k], f4[k]) : fs[k]) - x_, f.max_range);
+            const float rbk = vmin(x_ - (have_leaf[k] ? b4[k] : -INF), f.max_range);
             // lane k of the group stores look-up k: a wave's 8 groups x CDDT_TK consecutive poses are one line
-            if (c == k) {
-                my_f = rf;
-                my_b = rbk;
-                my_nf = need_f[k] && !slow[k];
-                my_nb = need_b[k] && !slow[k];
-            }
+            const bool mine = c == k;
+            my_f = mine ? rf : my_f;
+            my_b = mine ? rbk : my_b;
+            my_nf = mine ? (need_f[k] & !slow[k]) : my_nf;
+            my_nb = mine ? (need_b[k] & !slow[k]) : my_nb;
         }
         if (my_nf) R[(size_t)t * f.n_poses + p0 + c] = my_f * m.res;
         if (my_nb) R[(size_t)rb * f.n_poses + p0 + c] = my_b * m.res;
