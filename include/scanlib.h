@@ -225,7 +225,7 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
 /* tuning / diagnostics: integer options by name.  None changes a result bit; defaults are the
  * measured optima on MI355X.
  *   schedule   variant (1 stream kernel | 0 chunk-per-wave | 2 occ_fan_lds: unit steps on an LDS occupancy
- *              window, approximate), grid_mult, wg_threads, low_water, run_log2 (-1 auto), xcd_bands,
+ *              window, approximate), grid_mult, wg_threads, low_water (-1 auto), run_log2 (-1 auto), xcd_bands,
  *              sort_poses, tiled (step-map layout), slots (rays per lane: 1 | 2 | 3 | 0 auto),
  *              cddt_bins (one look-up per pose and table bin), cddt_theta_min (poses from which the look-ups
  *              run theta-major: all poses against one table bin at a time), cddt_lds_sort

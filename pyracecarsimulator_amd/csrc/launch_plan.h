@@ -40,7 +40,7 @@ inline void default_opts(rl_plan_opts &o)
     o.variant = 1;
     o.grid_mult = 8;          // workgroups (x256 threads) per CU of a persistent launch
     o.wg_threads = 1024;
-    o.low_water = 12;
+    o.low_water = -1;                          // (auto: scanlib.hip)
     o.sort_poses = 1;
     o.xcd_bands = 8;
     o.slots = 0;              // auto

@@ -227,7 +227,9 @@ struct rl_method {
     uint64_t noise_seed = 0, ray_offset = 0;
     int variant = 1;             // 0: chunk kernel (K1); 1: binned + banded + lane-refill stream kernel (K1b)
     int grid_mult = 8;           // workgroups per CU for the persistent launches (8 resident: <= 80 SGPRs, <= 64 VGPRs)
-    int low_water = 12;          // stream kernel: refill when <= this many lanes still march (re-tuned for the hand-scheduled loop)
+    int low_water = -1;          // stream kernel: refill when <= this many lanes (per ray slot) still march.  -1 = auto: 12, and 20
+                                 // for the several-rays-per-lane launches that derive their records in LDS (small and mid-size
+                                 // batches: +3 % with four in flight; big batches lose 3-6 % above 12: profiles/r03/ab_low_water.txt)
     int sort_poses = 1;          // stream kernel: order poses by map tile
     int xcd_bands = 8;           // stream kernel: bands of the sorted list, one per XCD
     int timing = 0;              // 1: HIP events around every launch sequence (rl_last_kernel_ms);
@@ -597,7 +599,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     std::lock_guard<std::mutex> lk(h->mu);
     if (!strcmp(name, "variant")) h->variant = value;
     else if (!strcmp(name, "grid_mult")) h->grid_mult = value < 1 ? 1 : value;
-    else if (!strcmp(name, "low_water")) h->low_water = value < 0 ? 0 : (value > 63 ? 63 : value);
+    else if (!strcmp(name, "low_water")) h->low_water = value < 0 ? -1 : (value > 63 ? 63 : value);
     else if (!strcmp(name, "sort_poses")) h->sort_poses = value != 0;
     else if (!strcmp(name, "debug_stamps")) h->debug_stamps = value != 0;
     else if (!strcmp(name, "drain_prio")) h->drain_prio = value != 0;
@@ -1325,7 +1327,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.rec = (const PoseRec *)cx->rec_sorted.p;
         sp.order = (const uint32_t *)cx->order.p;
         sp.div_B = make_fastdiv((uint32_t)num_rays);
-        sp.low_water = h->low_water;
+        sp.low_water = h->low_water >= 0 ? h->low_water : 12;
         sp.n_bands = pl.bands;
         if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
         if (aux)
@@ -1394,7 +1396,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.d0 = (const float *)cx->d0.p;
         if ((rc = ensure_fan_table(h, f, fov, stream, &sp.fan_tab))) return rc;
         sp.div_B = make_fastdiv((uint32_t)num_rays);
-        sp.low_water = h->low_water;
+        sp.low_water = h->low_water >= 0 ? h->low_water : ((pl.record_source != 0 && pl.slots >= 2) ? 20 : 12);
         sp.n_bands = pl.bands;
         sp.raw_poses = d_poses;
         sp.map = m->d_mp;
