@@ -806,7 +806,8 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "s_mov_b64 exec, %[save]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         "s_mov_b64 %[mB], exec\n"
-        "L_march2_%=:\n\t"
+        // (decoupled slots: a slot's next load is issued as soon as ITS previous one has returned — not after both
+        //  have — so the two dependent chains only share the instruction stream, not each other's latency)
         "s_mov_b64 exec, %[mA]\n\t"
         "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
@@ -833,6 +834,47 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "v_lshl_add_u32 v34, v34, 2, %[k4]\n\t"
         ".endif\n\t"
         "global_load_dword %[dB], v34, %[base]\n\t"
+        "L_march2_%=:\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_add_f32_e32 v20, v20, %[dA]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_mov_b64 %[mA], exec\n\t"
+        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[cA], v26\n\t"
+        "v_cvt_i32_f32_e32 %[rA], v27\n\t"
+        ".if %[tiled]\n\t"
+        "v_mad_i32_i24 v26, %[rA], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v26, %[nstride], v26\n\t"
+        "v_lshl_add_u32 v26, %[cA], 4, v26\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v26, %[rA], %[stride], %[cA]\n\t"
+        "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
+        ".endif\n\t"
+        "global_load_dword %[dA], v26, %[base]\n\t"
+        "s_mov_b64 exec, %[mB]\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_add_f32_e32 v28, v28, %[dB]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
+        "s_mov_b64 %[mB], exec\n\t"
+        "v_pk_fma_f32 v[34:35], v[30:31], v[28:29], v[32:33] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[cB], v34\n\t"
+        "v_cvt_i32_f32_e32 %[rB], v35\n\t"
+        ".if %[tiled]\n\t"
+        "v_mad_i32_i24 v34, %[rB], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v34, %[nstride], v34\n\t"
+        "v_lshl_add_u32 v34, %[cB], 4, v34\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v34, %[rB], %[stride], %[cB]\n\t"
+        "v_lshl_add_u32 v34, v34, 2, %[k4]\n\t"
+        ".endif\n\t"
+        "global_load_dword %[dB], v34, %[base]\n\t"
+        "s_bcnt1_i32_b64 %[n], %[mA]\n\t"
+        "s_bcnt1_i32_b64 %[n2], %[mB]\n\t"
+        "s_add_u32 %[n], %[n], %[n2]\n\t"
+        "s_cmp_gt_u32 %[n], %[low]\n\t"
+        "s_cbranch_scc1 L_march2_%=\n\t"
+        // the two samples in flight belong to live rays: consume them
         "s_mov_b64 exec, %[mA]\n\t"
         "s_waitcnt vmcnt(1)\n\t"
         "v_add_f32_e32 v20, v20, %[dA]\n\t"
@@ -843,11 +885,6 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "v_add_f32_e32 v28, v28, %[dB]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         "s_mov_b64 %[mB], exec\n\t"
-        "s_bcnt1_i32_b64 %[n], %[mA]\n\t"
-        "s_bcnt1_i32_b64 %[n2], exec\n\t"
-        "s_add_u32 %[n], %[n], %[n2]\n\t"
-        "s_cmp_gt_u32 %[n], %[low]\n\t"
-        "s_cbranch_scc1 L_march2_%=\n\t"
         "s_mov_b64 exec, %[save]\n\t"
         : [tA] "+{v20}"(tA), [cA] "+v"(cA), [rA] "+v"(rA), [dA] "+v"(dA), [tB] "+{v28}"(tB), [cB] "+v"(cB),
           [rB] "+v"(rB), [dB] "+v"(dB), [save] "=&s"(save), [mA] "=&s"(mA), [mB] "=&s"(mB), [n] "=&s"(n),
@@ -883,7 +920,7 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "s_mov_b64 exec, %[save]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v36\n\t"
         "s_mov_b64 %[mC], exec\n"
-        "L_march3_%=:\n\t"
+        // (decoupled slots, like march_loop2: a slot's next load goes out as soon as its own previous one is back)
         "s_mov_b64 exec, %[mA]\n\t"
         "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
@@ -923,6 +960,66 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "v_lshl_add_u32 v42, v42, 2, %[k4]\n\t"
         ".endif\n\t"
         "global_load_dword %[dC], v42, %[base]\n\t"
+        "L_march3_%=:\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_add_f32_e32 v20, v20, %[dA]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_mov_b64 %[mA], exec\n\t"
+        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[cA], v26\n\t"
+        "v_cvt_i32_f32_e32 %[rA], v27\n\t"
+        ".if %[tiled]\n\t"
+        "v_mad_i32_i24 v26, %[rA], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v26, %[nstride], v26\n\t"
+        "v_lshl_add_u32 v26, %[cA], 4, v26\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v26, %[rA], %[stride], %[cA]\n\t"
+        "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
+        ".endif\n\t"
+        "global_load_dword %[dA], v26, %[base]\n\t"
+        "s_mov_b64 exec, %[mB]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_add_f32_e32 v28, v28, %[dB]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
+        "s_mov_b64 %[mB], exec\n\t"
+        "v_pk_fma_f32 v[34:35], v[30:31], v[28:29], v[32:33] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[cB], v34\n\t"
+        "v_cvt_i32_f32_e32 %[rB], v35\n\t"
+        ".if %[tiled]\n\t"
+        "v_mad_i32_i24 v34, %[rB], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v34, %[nstride], v34\n\t"
+        "v_lshl_add_u32 v34, %[cB], 4, v34\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v34, %[rB], %[stride], %[cB]\n\t"
+        "v_lshl_add_u32 v34, v34, 2, %[k4]\n\t"
+        ".endif\n\t"
+        "global_load_dword %[dB], v34, %[base]\n\t"
+        "s_mov_b64 exec, %[mC]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_add_f32_e32 v36, v36, %[dC]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v36\n\t"
+        "s_mov_b64 %[mC], exec\n\t"
+        "v_pk_fma_f32 v[42:43], v[38:39], v[36:37], v[40:41] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_i32_f32_e32 %[cC], v42\n\t"
+        "v_cvt_i32_f32_e32 %[rC], v43\n\t"
+        ".if %[tiled]\n\t"
+        "v_mad_i32_i24 v42, %[rC], %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v42, %[nstride], v42\n\t"
+        "v_lshl_add_u32 v42, %[cC], 4, v42\n\t"
+        ".else\n\t"
+        "v_mad_i32_i24 v42, %[rC], %[stride], %[cC]\n\t"
+        "v_lshl_add_u32 v42, v42, 2, %[k4]\n\t"
+        ".endif\n\t"
+        "global_load_dword %[dC], v42, %[base]\n\t"
+        "s_bcnt1_i32_b64 %[n], %[mA]\n\t"
+        "s_bcnt1_i32_b64 %[n2], %[mB]\n\t"
+        "s_add_u32 %[n], %[n], %[n2]\n\t"
+        "s_bcnt1_i32_b64 %[n2], %[mC]\n\t"
+        "s_add_u32 %[n], %[n], %[n2]\n\t"
+        "s_cmp_gt_u32 %[n], %[low]\n\t"
+        "s_cbranch_scc1 L_march3_%=\n\t"
+        // the three samples in flight belong to live rays: consume them
         "s_mov_b64 exec, %[mA]\n\t"
         "s_waitcnt vmcnt(2)\n\t"
         "v_add_f32_e32 v20, v20, %[dA]\n\t"
@@ -938,13 +1035,6 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "v_add_f32_e32 v36, v36, %[dC]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v36\n\t"
         "s_mov_b64 %[mC], exec\n\t"
-        "s_bcnt1_i32_b64 %[n], %[mA]\n\t"
-        "s_bcnt1_i32_b64 %[n2], %[mB]\n\t"
-        "s_add_u32 %[n], %[n], %[n2]\n\t"
-        "s_bcnt1_i32_b64 %[n2], exec\n\t"
-        "s_add_u32 %[n], %[n], %[n2]\n\t"
-        "s_cmp_gt_u32 %[n], %[low]\n\t"
-        "s_cbranch_scc1 L_march3_%=\n\t"
         "s_mov_b64 exec, %[save]\n\t"
         : [tA] "+{v20}"(tA), [cA] "+v"(cA), [rA] "+v"(rA), [dA] "+v"(dA), [tB] "+{v28}"(tB), [cB] "+v"(cB),
           [rB] "+v"(rB), [dB] "+v"(dB), [tC] "+{v36}"(tC), [cC] "+v"(cC), [rC] "+v"(rC), [dC] "+v"(dC),
