@@ -27,7 +27,12 @@ N>1: cfg2 / cfg3 fix the poses per GPU (weak scaling); cfg4 / cfg5 shard BASELIN
 (2^20 / 262144 poses / N: strong scaling); ``--poses`` always means poses per GPU.  Exchange per step
 (``--gather``): ``ranges`` = all-gather of every range over xGMI (BASELINE.json north_star, default),
 ``ranges_u16`` = the same on 16-bit ranges (lossy, labelled), ``root`` = gather to rank 0 only,
-``crash`` = fused crash test + all-gather of the int32 crash indices, ``none``.
+``crash`` = fused per-roll-out crash test + all-gather of the int32 crash indices (what
+scripts/mcts.py:237-245 consumes), ``steer`` = Follow-the-Gap per scan + all-gather of the float32
+steering angles (scripts/mcts.py:262-267), ``none``.  The reduced modes run on the same pipelined slot
+streams as the plain scan (one bucket of results per slot) and also work at N = 1.  Every N>1 line
+carries, next to ``value``: ``march_only``, ``crash_mode``, ``steer_mode`` (each its own timed loop)
+and ``scaling_model`` (mode -> modelled 8-GPU speed-up from the xGMI ingress bytes).
 """
 from __future__ import annotations
 
@@ -76,17 +81,19 @@ def parse_args():
                     help="exchange chunks per step (N>1); 0 = auto: 1 when steps are pipelined (the gather of "
                          "step k overlaps the marches of the following steps; every extra collective costs "
                          "~29 us of host time), 4 on the serial schedule (gather of chunk k overlaps march k+1)")
-    ap.add_argument("--gather", default="ranges", choices=["ranges", "ranges_u16", "root", "crash", "none"],
+    ap.add_argument("--gather", default="ranges", choices=["ranges", "ranges_u16", "root", "crash", "steer", "none"],
                     help="N>1 exchange per step: 'ranges' (default) = all-gather of every range, 4 B/ray "
                          "(BASELINE.json north_star); 'ranges_u16' = the same on 16-bit fixed-point ranges "
                          "(2 B/ray, LOSSY: <= 0.11 mm at 15 m); 'root' = gather to rank 0 only (the reference's "
                          "consumer is one MCTS process); 'crash' = fused per-roll-out crash test, all-gather "
-                         "of the int32 crash indices (what MCTS.rollout consumes); 'none' = shards stay put")
+                         "of the int32 crash indices (what MCTS.rollout consumes); 'steer' = Follow-the-Gap per "
+                         "scan, all-gather of the float32 steering angles (MCTS's expansion policy); 'none' = "
+                         "shards stay put.  crash / steer also run at N = 1 (nothing to exchange)")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--gather-every", type=int, default=8,
-                    help="'crash' mode: steps per all-gather bucket")
+                    help="'crash' / 'steer' modes: steps (of one slot) per all-gather bucket")
     ap.add_argument("--no-crash-line", action="store_true",
-                    help="N>1: skip the extra timed loop that measures the 'crash' exchange")
+                    help="N>1: skip the extra timed loops that measure the 'crash' and 'steer' exchanges")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed output verification (tuning sweeps)")
     ap.add_argument("--no-extras", action="store_true",
@@ -142,19 +149,27 @@ def theta_disc_of(w, method):
     return w.theta_disc or 1442
 
 
-def algorithmic_bytes_per_ray(method, mean_steps, num_rays, w):
-    """bytes a ray must move, per kernel family."""
+def algorithmic_bytes_per_ray(method, mean_steps, num_rays, w, cddt_nbar=0.0):
+    """bytes a ray must move, per kernel family -> (bytes, how they were counted)."""
+    import math
     pose = 12.0 / num_rays
     if method in ("RM", "RMGPU"):
-        return mean_steps * 4.0 + 4.0 + pose            # S̄ EDT samples (f32) + range out + pose
+        return (mean_steps * 4.0 + 4.0 + pose,           # S̄ EDT samples (f32) + range out + pose
+                "S x 4 + 4 + 12/B with S = %.3f mean samples per ray (this run's diagnostics launch)" % mean_steps)
     if method == "BL":
         win = 2 * w.max_range_px + 1
-        return (win * win / 8.0) / num_rays + 4.0 + pose  # bit-packed window per pose + out
+        return ((win * win / 8.0) / num_rays + 4.0 + pose,  # bit-packed window per pose + out
+                "(2R+1)^2/8 bit-packed window per pose / B + 4 + 12/B")
     if method == "GLT":
-        return 2.0 + 4.0 + pose                          # one u16 entry + range out
+        return 2.0 + 4.0 + pose, "one u16 table entry + 4 + 12/B"      # one u16 entry + range out
     if method == "CDDT":
-        return 4.0 * max(1.0, mean_steps) + 8.0 + 4.0 + pose
-    return 4.0 + pose
+        probes = max(1, math.ceil(math.log2(cddt_nbar + 1.0))) if cddt_nbar > 0 else 1
+        return (4.0 * probes + 8.0 + 4.0 + pose,
+                "4 x ceil(log2(n_bucket + 1)) + 8 + 4 + 12/B with n_bucket = %.1f stored values per non-empty bucket of "
+                "this table: %d probes of a per-RAY bisection — the kernels answer one look-up per (pose, table bin), "
+                "~%d beams share it, so measured traffic is far below this figure" % (
+                    cddt_nbar, probes, max(1, num_rays // max(1, (w.theta_disc or 108)))))
+    return 4.0 + pose, "4 + 12/B"
 
 
 def cpu_model():
@@ -311,16 +326,14 @@ def main():
         meth.set_noise(w.noise_std, w.noise_seed, lo * B)    # keyed by the GLOBAL ray id: shard-invariant
     max_range_m = w.max_range_px * gmap.resolution
 
-    mode = "none" if (a.no_gather or not multi) else a.gather
-    crash_capable = method in ("RM", "RMGPU")
-    if mode == "crash" and not crash_capable:
-        mode = "ranges"
+    mode = "none" if a.no_gather else a.gather
+    if not multi and mode in ("ranges", "ranges_u16", "root"):
+        mode = "none"                             # (one GPU: nothing to exchange; crash / steer still reduce)
+    is_rm = method in ("RM", "RMGPU")
     # streams that really run concurrently (HIP maps streams onto a few hardware queues); a handle keeps
     # rl_launch_contexts() per-stream scratch sets — more streams than that would silently serialise
     n_ctx = int(_lib.lib().rl_launch_contexts())
     P = a.pipeline if a.pipeline > 0 else (1 if (method in ("RM", "RMGPU", "BL") and n > 32768) else 4)
-    if mode == "crash":
-        P = 1                                     # the crash loop runs serially on the current stream
     if P > n_ctx:
         print("bench.py: --pipeline %d clamped to the library's %d launch contexts" % (P, n_ctx), file=sys.stderr)
         P = n_ctx
@@ -330,11 +343,11 @@ def main():
     gm = a.grid_mult or (3 if P > 1 else default_gm)
     # (two rays per lane: since the waves compact their last rays — DESIGN.md section 4 — two beat three at
     # every batch but 8192 poses, where three lead by 2 %: profiles/r03/ab_slots.txt)
-    pipe_slots = 2 if (P > 1 and method in ("RM", "RMGPU")) else 0
+    pipe_slots = 2 if (P > 1 and is_rm) else 0
 
     def apply_schedule(pipelined: bool):
         meth.set_option("grid_mult", gm if pipelined else default_gm)
-        if method in ("RM", "RMGPU"):
+        if is_rm:
             meth.set_option("slots", pipe_slots if pipelined else 0)
         if pipelined:
             for kv in a.opt:
@@ -350,29 +363,42 @@ def main():
                for k in range(P)]
     d_poses = [torch.from_numpy(b).to(dev) for b in batches]
     del dt
+    pose_ptrs = [t.data_ptr() for t in d_poses]
 
     n_chunks = a.chunks or (1 if P > 1 else 4)
-    scan = ShardedScan(n, B, dev, n_chunks=n_chunks, gather=mode in ("ranges", "ranges_u16", "root"),
-                       streams=streams, gather_single_rank=a.dist_single,
-                       mode=mode if mode in ("ranges", "ranges_u16", "root") else "ranges", root=0,
-                       max_range_m=max_range_m)
-    scan.bind(meth, [t.data_ptr() for t in d_poses], w.fov)
-    plan = meth.plan_fan(n, B)                     # what a step launches (kernel with template arguments, grid)
-
-    # 'crash': the reference's consumer of a scanned batch is Car::isCrashed per roll-out
-    # (scripts/racecar_simulator_v2.py:146-167); group = roll-out length (params.yaml:126 uses 200)
+    # the reduced exchanges: what the reference's consumers of a scanned batch read.  'crash': Car::isCrashed
+    # per roll-out (scripts/racecar_simulator_v2.py:146-167; roll-out length params.yaml:126 = 200);
+    # 'steer': FollowGap per scan (scripts/mcts.py:97-99,262-267)
     group = next(gsz for gsz in range(min(200, n), 0, -1) if n % gsz == 0)
     n_groups = n // group
-    crash_gather = d_edge = None
-    if multi and crash_capable:
-        from pyracecarsimulator_amd import racecar as RC
-        from pyracecarsimulator_amd.distributed import BucketedIndexGather
-        edge = RC.edge_distances(B, -w.fov / 2.0, w.fov / B, 0.275, RC.DEFAULT_CAR["width"],
-                                 RC.DEFAULT_CAR["wb"])
-        d_edge = torch.from_numpy(edge).to(dev)
-        # buckets of M steps, double-buffered: the (latency-bound, M x ~100 B) all-gather of bucket b
-        # overlaps the marches of bucket b+1 on RCCL's stream
-        crash_gather = BucketedIndexGather(n_groups, a.gather_every, dev)
+    from pyracecarsimulator_amd import racecar as RC
+    from pyracecarsimulator_amd.followgap import PyFollowGap
+    edge = RC.edge_distances(B, -w.fov / 2.0, w.fov / B, 0.275, RC.DEFAULT_CAR["width"], RC.DEFAULT_CAR["wb"])
+    d_edge = torch.from_numpy(edge).to(dev)
+    CRASH_THRESH = 0.001                          # params.yaml:47
+    fgap = PyFollowGap(10, 15.0, RC.DEFAULT_CAR["max_steer_ang"], 0.004, device=local_rank) if B >= 10 else None
+    if mode == "steer" and fgap is None:
+        raise SystemExit("--gather steer needs at least 10 beams per scan")
+
+    def make_scan(md):
+        """A ShardedScan of this run's shape in exchange mode ``md``, bound to the method and the P batches."""
+        if md in ("crash", "steer"):
+            sc = ShardedScan(n, B, dev, n_chunks=1, gather=True, streams=streams, gather_single_rank=a.dist_single,
+                             mode=md, n_items=n_groups if md == "crash" else n, every=a.gather_every)
+            if md == "crash":
+                sc.bind_crash(meth, pose_ptrs, w.fov, group, d_edge.data_ptr(), CRASH_THRESH)
+            else:
+                sc.bind_steer(meth, fgap, pose_ptrs, w.fov)
+            return sc
+        sc = ShardedScan(n, B, dev, n_chunks=n_chunks, gather=md in ("ranges", "ranges_u16", "root"),
+                         streams=streams, gather_single_rank=a.dist_single,
+                         mode=md if md in ("ranges", "ranges_u16", "root") else "ranges", root=0,
+                         max_range_m=max_range_m)
+        sc.bind(meth, pose_ptrs, w.fov)
+        return sc
+
+    scan = make_scan(mode)
+    plan = meth.plan_fan(n, B, crash=(mode == "crash" and is_rm))   # what a step launches (kernel, grid)
     cur_stream = torch.cuda.current_stream().cuda_stream
 
     # untimed diagnostics launch: mean samples per ray (feeds the algorithmic-bytes figure)
@@ -388,13 +414,6 @@ def main():
         p99_steps = float(torch.quantile(sub, 0.99).item())
         max_steps = float(st.max().item())
         del d_steps, st, sub
-
-    def crash_step():
-        meth.check_collision_groups_device(d_poses[0].data_ptr(), n_groups, group, w.fov, B,
-                                           d_edge.data_ptr(), 0.001,
-                                           crash_gather.slot_view().data_ptr(),
-                                           scan.slots[0].local.data_ptr(), stream=cur_stream)
-        crash_gather.step_done()
 
     def barrier():
         if multi:
@@ -437,14 +456,8 @@ def main():
         n_b = bursts if first[0] < 0.2 else max(3, min(bursts, int(2.0 / first[0])))
         return [first] + [burst(step_fn, drain_fn, steps) for _ in range(n_b - 1)]
 
-    def scan_drain(ends):
-        scan.finish(ends)
-
-    def crash_drain(ends):
-        crash_gather.flush()
-        if ends is not None:
-            for e in ends:
-                e.record()                        # (the crash loop runs on the current stream)
+    def timed_scan(sc, steps, warmup, bursts):
+        return timed(sc.step, sc.finish, steps, warmup, bursts)
 
     def summarise(runs, steps, rays_per_step):
         els = sorted(r[0] for r in runs)
@@ -456,22 +469,56 @@ def main():
                 "dev_ms": dev_med, "bursts": len(els)}
 
     rays_per_step = n * B * world
-    if mode == "crash":
-        apply_schedule(False)
-        runs = timed(crash_step, crash_drain, a.steps, a.warmup, a.bursts)
-        plan = meth.plan_fan(n, B, crash=True)
-    else:
-        runs = timed(scan.step, scan_drain, a.steps, a.warmup, a.bursts)
+    runs = timed_scan(scan, a.steps, a.warmup, a.bursts)
     res = summarise(runs, a.steps, rays_per_step)
     step_ms = res["dev_ms"]
 
     # ---------------------------------------------------------------- verification (untimed)
     # (1) every slot's buffer == a serial, one-ray-per-lane, whole-machine launch of the same poses;
-    # (2) N>1: what was gathered == what the ranks hold; (3) with the CPU baseline: oracle subsample.
+    # (2) N>1: what was gathered == what the ranks hold; (3) with the CPU baseline: oracle subsample;
+    # (4) crash / steer: every slot's last reduced result == the same reduction of the serial launch's ranges
+    #     (crash: Car::isCrashed restated on the device in float64; steer: the FollowGap kernel on those ranges)
+    #     on every rank's rows of what was exchanged.
     verification = {}
     ok = True
     d_ref = None
-    if not a.no_verify and mode != "crash":
+
+    def reduced_reference(md, ranges):
+        """The reduction of mode ``md`` over a (n*B,) float32 range tensor, independent of the fused path."""
+        if md == "crash":
+            hit = ((ranges.view(n, B).double() - d_edge.view(1, B)) < CRASH_THRESH).any(dim=1).view(n_groups, group)
+            first = torch.where(hit.any(dim=1), hit.to(torch.int32).argmax(dim=1).to(torch.int32),
+                                torch.full((n_groups,), -(group + 1), dtype=torch.int32, device=dev))
+            return first
+        ang = torch.empty(n, dtype=torch.float32, device=dev)
+        fgap.eval_many_device(ranges.data_ptr(), n, B, ang.data_ptr(), stream=cur_stream)
+        torch.cuda.synchronize()
+        return ang
+
+    def check_reduced(sc, md, refs):
+        """refs[k]: the serial-launch ranges of slot k's batch (or None).  Returns (ok, detail)."""
+        sc.finish()
+        torch.cuda.synchronize()
+        good = True
+        for k, sl in enumerate(sc.slots):
+            r = sc.results(sl)
+            if r is None or refs[k] is None:
+                continue
+            want = reduced_reference(md, refs[k])
+            mine = r[rank if r.shape[0] > 1 else 0, -1]
+            good &= bool(torch.equal(mine, want))
+            if sc.exchange and world > 1:
+                allw = torch.empty((world,) + tuple(want.shape), dtype=want.dtype, device=dev)
+                dist.all_gather_into_tensor(allw.view(-1), want.contiguous())
+                good &= bool(torch.equal(r[:, -1], allw))
+        if multi:
+            flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            good = bool(flag.item())
+        return good
+
+    slot_refs = [None] * P
+    if not a.no_verify:
         torch.cuda.synchronize()
         if a.selftest_corrupt:
             scan.slots[-1].local[n * B // 2] += 1.0
@@ -480,11 +527,16 @@ def main():
             meth.set_option("slots", 1)             # (auto may take two rays per lane: launch_plan.h)
         d_ref = torch.empty(n * B, dtype=torch.float32, device=dev)
         bad = []
+        keep_refs = scan.reduced or (multi and not a.no_crash_line)
         for k, sl in enumerate(scan.slots):
+            if keep_refs and k > 0 and n * B <= (1 << 27):
+                d_ref = torch.empty(n * B, dtype=torch.float32, device=dev)
             meth.calc_range_fan_device(d_poses[k].data_ptr(), n, w.fov, B, d_ref.data_ptr(), stream=cur_stream)
             torch.cuda.synchronize()
             if not torch.equal(sl.local, d_ref):
                 bad.append((k, int((sl.local != d_ref).sum().item())))
+            if keep_refs and (k == 0 or n * B <= (1 << 27)):
+                slot_refs[k] = d_ref
         ref_plan = meth.last_plan()
         verification["slots_equal_serial_launch"] = not bad
         verification["serial_launch"] = ref_plan["name"] + " grid %d" % ref_plan["grid"]
@@ -512,6 +564,10 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             verification["gathered_equals_local"] = bool(flag.item())
             ok &= bool(flag.item())
+        if scan.reduced and not a.selftest_corrupt:
+            good = check_reduced(scan, mode, slot_refs)
+            verification["%s_results_equal_reference" % mode] = good
+            ok &= good
         apply_schedule(True)
 
     def oracle_check(om, O):
@@ -559,11 +615,30 @@ def main():
             if w.noise_std > 0:
                 meth.set_noise(w.noise_std, w.noise_seed, lo * B)
             apply_schedule(True)
-        return {"oracle_subsample": True,
-                "oracle_sample": "%d poses x %d beams of batch 0, bit-equal (noise off)" % (len(sub), B)}
+        extra = {}
+        if mode == "steer" and w.noise_std <= 0 and not a.selftest_corrupt:
+            # the steering angles the timed loop left for batch 0 against FollowGap::eval restated on the CPU
+            # (oracle/: bit-identical to the reference's compiled header) over the oracle's ranges
+            scan.finish()
+            torch.cuda.synchronize()
+            r = scan.results(scan.slots[0])
+            mine = r[rank if r.shape[0] > 1 else 0, -1].cpu().numpy()[sub]
+            wr = want.reshape(len(sub), B)
+            ref = np.array([O.followgap_eval(wr[i], 15.0, RC.DEFAULT_CAR["max_steer_ang"], 0.004)
+                            for i in range(len(sub))], np.float32)
+            if not np.array_equal(mine, ref):
+                return {"oracle_subsample": False, "differing_steering_angles": int((mine != ref).sum())}
+            extra["oracle_followgap"] = "%d steering angles of batch 0 bit-equal to the CPU FollowGap" % len(sub)
+        return dict({"oracle_subsample": True,
+                     "oracle_sample": "%d poses x %d beams of batch 0, bit-equal (noise off)" % (len(sub), B)}, **extra)
 
-    bpr = algorithmic_bytes_per_ray(method, mean_steps, B, w)
-    slots_now = meth.get_info("slots") if method in ("RM", "RMGPU") else 0
+    cddt_nbar = 0.0
+    if method == "CDDT":
+        # SURVEY.md section 8d prices a CDDT ray at one bisection of its bucket: 4 B x ceil(log2(n_bucket + 1)) with
+        # the table's REAL mean bucket size (values / non-empty buckets, read back from the device table)
+        vals, nonempty = meth.get_info("cddt_values"), meth.get_info("cddt_nonempty_buckets")
+        cddt_nbar = vals / max(nonempty, 1)
+    bpr, bpr_note = algorithmic_bytes_per_ray(method, mean_steps, B, w, cddt_nbar)
     out = {
         "metric": "million rays/sec, 1081-beam scans" if B == 1081 else
                   "million rays/sec, %d-beam scans" % B,
@@ -587,8 +662,11 @@ def main():
                               "ranges_u16": "all-gather of 16-bit fixed-point ranges (2 B/ray, LOSSY: <= %.3g mm), "
                                             "%d chunks per step" % (max_range_m / 131070 * 1e3, len(scan.chunks)),
                               "root": "gather of the ranges (4 B/ray) to rank 0 only, %d chunks per step" % len(scan.chunks),
-                              "crash": "fused crash test per %d-pose roll-out, all-gather of int32 "
-                                       "crash indices in buckets of %d steps" % (group, max(1, a.gather_every))}[mode]},
+                              "crash": "fused crash test per %d-pose roll-out (Car::isCrashed), all-gather of int32 "
+                                       "crash indices in buckets of %d steps per slot" % (group, max(1, a.gather_every)),
+                              "steer": "Follow-the-Gap per scan on the slot's stream, all-gather of float32 steering "
+                                       "angles (4 B/pose) in buckets of %d steps per slot" % max(1, a.gather_every)}[mode]
+                             + ("" if (multi or mode == "none") else " (one GPU: nothing to exchange)")},
         "bursts": res["bursts"], "value_min": round(res["min"], 2), "value_max": round(res["max"], 2),
         "value_is": "median of %d bursts of %d steps, each bracketed by barrier + device synchronisation" % (
             res["bursts"], a.steps),
@@ -596,17 +674,37 @@ def main():
         "mean_samples_per_ray": round(mean_steps, 3), "p99_samples_per_ray": round(p99_steps, 1),
         "max_samples_per_ray": round(max_steps, 1),
     }
-    del slots_now
+    per_rank = n * B
+
+    def exchange_bytes(md, wd):
+        """(bytes all GPUs send per step, bytes the busiest GPU RECEIVES per step) of mode md on wd GPUs with
+        this run's per-GPU batch."""
+        per = {"ranges": 4 * per_rank, "ranges_u16": 2 * per_rank, "root": 4 * per_rank, "crash": 4 * n_groups,
+               "steer": 4 * n, "none": 0}[md]
+        return per * wd, per * (wd - 1)
+
+    def side_leg(md, steps):
+        """Mode md on this run's streams, batches and schedule: its own ShardedScan and timed loop."""
+        sc = make_scan(md)
+        runs_ = timed_scan(sc, steps, min(a.warmup, 5), min(a.bursts, 7))
+        r_ = summarise(runs_, steps, rays_per_step)
+        leg = {"value": round(r_["value"], 2), "unit": "Mrays/s", "ms_per_step": round(r_["ms_per_step"], 4),
+               "steps": steps, "bursts": r_["bursts"], "gather_bytes_per_step": exchange_bytes(md, world)[0],
+               "schedule": out["config"]["pipeline"]}
+        if md in ("crash", "steer") and not a.no_verify and not a.selftest_corrupt:
+            leg["verified"] = check_reduced(sc, md, slot_refs)
+        else:
+            sc.finish()
+            barrier()
+        del sc
+        return leg
+
     if multi:
         out["rccl_world"] = world
-        per_rank = n * B
-        gb = {"ranges": 4 * per_rank * world, "ranges_u16": 2 * per_rank * world, "root": 4 * per_rank * world,
-              "crash": 4 * n_groups * world, "none": 0}[mode]
+        gb, ingress = exchange_bytes(mode, world)
         out["gather_bytes_per_step"] = gb
         # xGMI: what one GPU must RECEIVE per step (the busiest one: every GPU for an all-gather, rank 0 for
         # 'root') against 7 links x per-direction link rate
-        ingress = {"ranges": 4 * per_rank * (world - 1), "ranges_u16": 2 * per_rank * (world - 1),
-                   "root": 4 * per_rank * (world - 1), "crash": 4 * n_groups * (world - 1), "none": 0}[mode]
         links = min(XGMI_LINKS, max(world - 1, 1))
         peak = links * XGMI_LINK_GBS
         ach = ingress / (res["ms_per_step"] * 1e-3) / 1e9
@@ -618,43 +716,78 @@ def main():
                                 "floor_ms_per_step": round(ingress / (peak * 1e9) * 1e3, 4),
                                 "measured_on": "same-device dry run (no xGMI)" if a.same_device else (
                                     "one rank (no peer)" if world == 1 else "%d GPUs" % world)}
-        if mode in ("ranges", "ranges_u16", "root") and not a.no_extras:
+        legs = {mode: {"value": out["value"], "ms_per_step": out["ms_per_step"]}}
+        if mode != "none" and not a.no_extras:
             # the same steps with the shards left on their GPUs: what the ranks COMPUTE per second next to
             # `value`, which includes the exchange — a SCALE record then separates the march's scaling from
             # the xGMI bound of the exchange (its own timed loop, after the verified one)
             scan.finish()
             barrier()
-            scan.gather = False
-            k3 = a.steps
-            runs3 = timed(scan.step, scan_drain, k3, min(a.warmup, 5), min(a.bursts, 7))
-            scan.gather = True
-            r3 = summarise(runs3, k3, rays_per_step)
-            out["march_only"] = {"value": round(r3["value"], 2), "unit": "Mrays/s",
-                                 "ms_per_step": round(r3["ms_per_step"], 4), "steps": k3, "bursts": r3["bursts"],
-                                 "what": "the same sharded steps without the exchange (ranges stay on the GPU "
-                                         "that computed them); `value` includes the exchange"}
-        if crash_gather is not None and mode != "crash" and not a.no_crash_line:
-            # the reduced exchange on batch 0, serial schedule (its own timed loop)
-            k2 = max(10, a.steps // 4)
-            apply_schedule(False)
-            runs2 = timed(crash_step, crash_drain, k2, min(a.warmup, 5), min(a.bursts, 7))
-            r2 = summarise(runs2, k2, rays_per_step)
-            apply_schedule(True)
-            out["crash_mode"] = {"value": round(r2["value"], 2), "unit": "Mrays/s",
-                                 "ms_per_step": round(r2["ms_per_step"], 4), "steps": k2, "bursts": r2["bursts"],
-                                 "gather_bytes_per_step": 4 * n_groups * world,
-                                 "schedule": "serial (one stream), grid_mult %d" % default_gm,
-                                 "what": "fused crash test per %d-pose roll-out, all-gather of the int32 crash "
-                                         "indices in buckets of %d steps" % (group, max(1, a.gather_every))}
-    if world == 1 and mode != "crash":
-        # the dominant kernel.  `achieved` prices the ALGORITHMIC bytes of one launch against the time one
-        # launch takes out of the timed region (HIP events around the K steps / K, median burst): with P
-        # launches in flight that is the machine time a launch costs, not its begin-to-end span (a kernel
-        # trace shows each launch ~P x longer, P of them overlapping).  `serial` is the same kernel alone on
-        # an idle machine (library events around the march kernel on extra steps AFTER the timed region — a
-        # pair of event records per launch costs ~12 us, so it stays out of `value`): the duration a kernel
-        # trace of `--pipeline 1` reports.
-        achieved = bpr * n * B / (step_ms * 1e-3) / 1e9
+            leg = side_leg("none", a.steps)
+            leg["what"] = ("the same sharded steps without reduction or exchange (ranges stay on the GPU that "
+                           "computed them); `value` includes the exchange")
+            out["march_only"] = legs["none"] = leg
+        if not a.no_crash_line:
+            # the reduced exchanges the reference's consumers need (4 B per roll-out / per pose), each on the
+            # same pipelined slot streams as `value`
+            if mode != "crash":
+                leg = side_leg("crash", a.steps)
+                leg["what"] = ("fused crash test per %d-pose roll-out (scripts/mcts.py:237-245 consumes one index per "
+                               "roll-out), all-gather of the int32 crash indices in buckets of %d steps per slot"
+                               % (group, max(1, a.gather_every)))
+                out["crash_mode"] = legs["crash"] = leg
+            if mode != "steer" and fgap is not None:
+                leg = side_leg("steer", a.steps)
+                leg["what"] = ("scan + Follow-the-Gap per scan (scripts/mcts.py:262-267 consumes one steering angle "
+                               "per scan), all-gather of the float32 angles in buckets of %d steps per slot"
+                               % max(1, a.gather_every))
+                out["steer_mode"] = legs["steer"] = leg
+        # scaling_model: what each exchange mode can reach on 8 GPUs of one node.  A GPU computes at the rate it
+        # was measured at in THIS run (per-GPU rays/s of the mode's local work: `march_only` for the modes that
+        # move ranges — their exchange overlaps the marches —, the mode's own leg for crash / steer) unless the
+        # xGMI ingress of the mode's bytes is slower; the speed-up is against ONE GPU marching without exchange.
+        base = legs.get("none", legs.get(mode))
+        r_none = base["value"] / world                         # Mrays/s per GPU, march only
+        rays8 = per_rank if scaling == "weak" else per_rank * world // 8     # rays per GPU and step at 8 GPUs
+        peak8 = XGMI_LINKS * XGMI_LINK_GBS * 1e9
+        model = {}
+        for md in ("ranges", "ranges_u16", "root", "crash", "steer", "none"):
+            scale8 = rays8 / per_rank
+            ing8 = exchange_bytes(md, 8)[1] * scale8
+            floor_ms = ing8 / peak8 * 1e3
+            local = legs[md]["value"] / world if (md in ("crash", "steer") and md in legs) else r_none
+            xg = (rays8 / (floor_ms * 1e-3) / 1e6) if floor_ms > 0 else float("inf")
+            rate = min(local, xg)
+            model[md] = {"ingress_bytes_per_gpu_per_step_at_8": int(ing8), "xgmi_floor_ms": round(floor_ms, 5),
+                         "per_gpu_local_mrays_s": round(local, 1),
+                         "per_gpu_local_is": ("measured: %s leg of this run" % md) if (md in ("crash", "steer") and md in legs)
+                                             else "measured: march without exchange (this run)",
+                         "bound": "xgmi" if xg < local else "march",
+                         "modelled_speedup_8gpu": round(8.0 * rate / r_none, 2)}
+        out["scaling_model"] = {"modes": model, "per_gpu_march_mrays_s": round(r_none, 1),
+                                "rays_per_gpu_per_step_at_8": int(rays8),
+                                "xgmi_peak_gbs": round(peak8 / 1e9, 1),
+                                "speedup_is": "8 x min(per-GPU local rate of the mode, rays per step / xGMI ingress floor) "
+                                              "/ per-GPU march rate; link rate assumed (%d x %.1f GB/s per direction), "
+                                              "local rates measured on %d GPU(s) in this run" % (XGMI_LINKS, XGMI_LINK_GBS, world),
+                                "reading": "`value` is the literal exchange BASELINE.json names (all-gather of every "
+                                           "range): xGMI-bound at ~1x whatever the kernel does; crash / steer are what the "
+                                           "reference's consumers read (scripts/mcts.py:237-245,262-267) and scale with the march"}
+    if world == 1:
+        # the dominant kernel.  `achieved` prices the ALGORITHMIC bytes of one launch (SURVEY.md section 8d's
+        # per-ray figure x the rays of a launch) against the time a launch costs: `ms_per_step`, the wall clock
+        # of the timed region / K — with P launches in flight that is the machine time a launch takes, not its
+        # begin-to-end span (a kernel trace shows each launch ~P x longer, P of them overlapping).
+        # `frac_device` is the same against the HIP-event time of the region / K (`launch_ms`, a few % shorter:
+        # the events do not see the host's first launch latency).  `frac_hbm` is the MEASURED HBM traffic
+        # (committed PMC pass of this launch shape) against the same peak: what the DRAM actually moves — K1b
+        # gathers from an L2-resident table, so it is far below `frac`; `roofline_gather` / `roofline_valu` are
+        # that kernel's real limiters.  `serial` is the same kernel alone on an idle machine (library events
+        # around the march kernel on extra steps AFTER the timed region — a pair of event records per launch
+        # costs ~12 us, so it stays out of `value`): the duration a kernel trace of `--pipeline 1` reports.
+        wall_ms = res["ms_per_step"]
+        achieved = bpr * n * B / (wall_ms * 1e-3) / 1e9
+        achieved_dev = bpr * n * B / (step_ms * 1e-3) / 1e9
         apply_schedule(False)
         meth.set_option("timing", 2)
         ks = []
@@ -671,12 +804,17 @@ def main():
         traffic = pe["bytes"] if pe else None
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                           "frac_is": "algorithmic bytes per launch / ms_per_step / peak (cache-served bytes count: "
+                                      "can exceed what DRAM moves, see frac_hbm)",
+                           "achieved_device": round(achieved_dev, 2), "frac_device": round(achieved_dev / HBM_PEAK_GBS, 5),
                            "traffic": traffic,
-                           "measured_hbm_gbs": round(traffic / (step_ms * 1e-3) / 1e9, 1) if traffic else None,
+                           "measured_hbm_gbs": round(traffic / (wall_ms * 1e-3) / 1e9, 1) if traffic else None,
+                           "frac_hbm": round(traffic / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                            "traffic_source": (pe["profile"] + " (rocprofv3 --pmc passes of this kernel, grid and batch "
                                               "size, committed; not measured in this run)") if pe else
                                              "no committed PMC pass matches this launch shape",
-                           "bytes_per_ray": round(bpr, 3), "kernel": plan["name"], "grid": plan["grid"],
+                           "bytes_per_ray": round(bpr, 3), "bytes_per_ray_is": bpr_note,
+                           "kernel": plan["name"], "grid": plan["grid"],
                            "launch_ms": round(step_ms, 4), "launches_in_flight": P,
                            "serial": {"kernel": solo_plan["name"], "grid": solo_plan["grid"],
                                       "kernel_ms": round(k_ms, 4), "achieved": round(serial_ach, 2),
@@ -694,23 +832,26 @@ def main():
             # gathered samples: the statement's count less the t = 0 sample of every ray, which the kernel
             # reads once per pose with the pose record (pose_first_step)
             samples = max(mean_steps - 1.0, 0.0) * n * B
-            out["roofline_gather"] = {"achieved_samples_per_s": round(samples / (step_ms * 1e-3), 1),
-                                      "peak": round(peak, 1), "frac": round(samples / (step_ms * 1e-3) / peak, 5),
+            out["roofline_gather"] = {"achieved_samples_per_s": round(samples / (wall_ms * 1e-3), 1),
+                                      "peak": round(peak, 1), "frac": round(samples / (wall_ms * 1e-3) / peak, 5),
                                       "serial_frac": round(samples / (k_ms * 1e-3) / peak, 5),
                                       "probe": "%.2f active lanes/clk/CU x %d CUs x %.2f GHz (rl_probe_gather_rate, "
                                                "46 random lanes, this run)" % (lanes.value, ncu.value, clk.value / 1e9)}
-            if pe and pe.get("valu_insts"):
-                floor_ms = pe["valu_insts"] * 4.0 / (4 * ncu.value * clk.value) * 1e3
-                out["roofline_valu"] = {"wave_valu_insts_per_launch": pe["valu_insts"], "floor_ms": round(floor_ms, 5),
-                                        "frac": round(floor_ms / step_ms, 5),
-                                        "lanes_per_valu_inst": pe.get("lanes_per_valu"),
-                                        "source": pe["profile"] + " (SQ_INSTS_VALU; not measured in this run)"}
-        if not a.no_extras and P > 1:
+        if pe and pe.get("valu_insts") and not a.no_extras:
+            # VALU issue floor of any kernel with a committed SQ_INSTS_VALU pass: wave-level instructions x 4 clocks
+            # on n_cu x 4 SIMDs
+            prop = torch.cuda.get_device_properties(dev)
+            clk_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
+            floor_ms = pe["valu_insts"] * 4.0 / (4 * prop.multi_processor_count * clk_hz) * 1e3
+            out["roofline_valu"] = {"wave_valu_insts_per_launch": pe["valu_insts"], "floor_ms": round(floor_ms, 5),
+                                    "frac": round(floor_ms / wall_ms, 5),
+                                    "lanes_per_valu_inst": pe.get("lanes_per_valu"),
+                                    "source": pe["profile"] + " (SQ_INSTS_VALU; not measured in this run)"}
+        if not a.no_extras and P > 1 and not scan.reduced:
             # the same schedule with every step in flight scanning the SAME batch (what round 2 measured):
             # quantifies what identical cache lines in identical order are worth
             scan.bind(meth, [d_poses[0].data_ptr()] * P, w.fov)
-            sb = summarise(timed(scan.step, scan_drain, a.steps, min(a.warmup, 5), min(a.bursts, 9)), a.steps,
-                           rays_per_step)
+            sb = summarise(timed_scan(scan, a.steps, min(a.warmup, 5), min(a.bursts, 9)), a.steps, rays_per_step)
             scan.bind(meth, [t.data_ptr() for t in d_poses], w.fov)
             out["same_batch"] = {"value": round(sb["value"], 2), "ms_per_step": round(sb["ms_per_step"], 4),
                                  "bursts": sb["bursts"],
@@ -736,7 +877,7 @@ def main():
                                  "what": "host wall clock, numpy in -> numpy out through ScanSimulator2D "
                                          "(PCIe and launch latency included), median of 50"}
             sim.scan_method.close()
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and mode != "crash":
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(w, gmap, batches[0], method, a.cpu_seconds,
                           check=None if a.no_verify else oracle_check)
         v = cb.pop("_verification", None)
@@ -747,7 +888,7 @@ def main():
     elif not a.no_verify:
         verification.setdefault("oracle_subsample", "not run (the oracle is loaded by the cpu_baseline leg only: "
                                                     "rank 0 of a 1-GPU run without --no-cpu-baseline)")
-    if not a.no_verify and mode != "crash":
+    if not a.no_verify:
         out["verified"] = bool(ok)
         out["verification"] = verification
     if multi:
@@ -759,7 +900,7 @@ def main():
         os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if not a.no_verify and mode != "crash" and not ok:
+    if not a.no_verify and not ok:
         print("bench.py: output verification FAILED: %s" % json.dumps(verification), file=sys.stderr)
         sys.exit(3)
 

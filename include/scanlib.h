@@ -78,6 +78,26 @@ int rl_device_count(void);                /* 0 when no HIP device is usable     
  * (range_libc DistanceTransform) is built on the device at creation.           */
 int rl_map_create(const uint8_t *occ, int rows, int cols, float res, float ox, float oy,
                   float oyaw, int device, rl_map **out);
+/* ---- several devices behind ONE handle (SURVEY.md section 8b "device_mask") -----------------------
+ * The reference's caller of this path is ONE Python process (scripts/mcts.py:237 ->
+ * scripts/racecar_simulator_v2.py:146-167 -> scripts/scan_simulator.py:113-135), so a drop-in that wants
+ * the other GPUs of the node cannot ask it to become N processes.  rl_map_create_multi uploads the map to
+ * every device of `devices` (an index may repeat: several contexts on one GPU) and builds the tables on
+ * each; rl_method_create on that map returns a handle whose HOST-pointer entry points —
+ * rl_calc_range_fan, rl_calc_range_many_fan, rl_calc_range_many, rl_check_collision_many,
+ * rl_check_collision_groups, rl_car_rollout_check — cut the batch into contiguous pose blocks, one per
+ * device (a device is brought in per `multi_min_poses` = 64 poses, option of the handle), run them
+ * concurrently (one worker thread per device, nothing is forked) and let every device write its block of
+ * the results straight into the caller's buffer.  Results are bit-identical to the single-device call:
+ * noise is keyed by the global ray id, crash indices are global.  With a result buffer from
+ * rl_host_alloc every device stores over its own PCIe link (4 B per ray), so the host-pointer scan
+ * scales with the number of links and never touches xGMI; the crash forms return 4 B per roll-out.
+ * The *_device entry points take device memory of ONE device: call them with rl_method_replica(h, i)
+ * (a borrowed per-device handle; rl_map_replica likewise).  rl_map_update updates every replica.        */
+int rl_map_create_multi(const uint8_t *occ, int rows, int cols, float res, float ox, float oy, float oyaw,
+                        const int *devices, int n_devices, rl_map **out);
+int rl_map_n_devices(const rl_map *m);                 /* 1 for a map of rl_map_create                    */
+rl_map *rl_map_replica(rl_map *m, int i);              /* NULL when i is out of range                     */
 /* replace the occupancy (same shape) and rebuild the distance transform: the
  * per-scan rebuild of scripts/two_player/rcs_two_player.py:110-121 and the
  * updateMap stub of scripts/scan_simulator.py:81-86.  Methods created from the
@@ -97,6 +117,8 @@ int rl_map_get_occ(rl_map *m, uint8_t *occ_out);
 int rl_method_create(rl_map *m, int kind, float max_range_px, int theta_disc, rl_method **out);
 void rl_method_destroy(rl_method *h);
 int rl_method_kind(const rl_method *h);
+int rl_method_n_devices(const rl_method *h);           /* devices behind the handle (rl_map_create_multi)  */
+rl_method *rl_method_replica(rl_method *h, int i);     /* per-device handle for the *_device entry points  */
 
 /* upstream 2-arg calc_range_many(ins, outs): one (x, y, theta) world row per ray.
  * scripts/two_player/scan.py:69-70.  ins: n*3 floats, outs: n floats (metres).  */
@@ -188,6 +210,9 @@ int rl_followgap_eval_device(rl_followgap *g, const float *d_scans, int n_scans,
  * actions: (speed, steer) pairs, ceil(n_steps/action_every) per roll-out.                      */
 typedef struct rl_car rl_car;
 int rl_car_create(int device, const double *car_params17, rl_car **out);
+/* the same over several devices (pair it with a method of rl_map_create_multi on the SAME device list):
+ * rl_car_rollout and rl_car_rollout_check then cut the roll-outs into contiguous blocks, one per device  */
+int rl_car_create_multi(const int *devices, int n_devices, const double *car_params17, rl_car **out);
 void rl_car_destroy(rl_car *c);
 /* poses_out: n_rollouts*n_steps*3 float32 (x, y, theta of the car after each step);
  * states_out (optional): final states; velocities_out (optional): state[3] after each step.   */
@@ -236,7 +261,11 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *              plain samples between attempts); drain_cap / drain_stretch (several rays per lane: a wave whose
  *              stream is dry compacts its last <= N rays (<= 64) into one ray per lane and finishes them with
  *              that loop)
- *   diagnosis  timing (1 launch sequence | 2 main kernel only), debug_stamps, drain_prio, lut_debug */
+ *   diagnosis  timing (1 launch sequence | 2 main kernel only), debug_stamps, drain_prio, lut_debug
+ *   multi-device handles: every option goes to every device's replica; multi_min_poses (poses per device
+ *              from which another device is brought in, default 64) belongs to the handle itself.
+ * rl_method_get_info additionally answers n_devices, n_cu, clock_khz, last_grid, map_epoch and, for RL_CDDT
+ * (builds the table if needed, synchronises): cddt_values, cddt_buckets, cddt_nonempty_buckets.          */
 int rl_method_set_option(rl_method *h, const char *name, int value);
 int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
 /* ---- launch planning -------------------------------------------------------------------------

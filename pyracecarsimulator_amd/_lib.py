@@ -60,6 +60,10 @@ SYMBOLS = {
     "rl_device_count": (C.c_int, []),
     "rl_map_create": (C.c_int, [u8p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int, C.POINTER(C.c_void_p)]),
+    "rl_map_create_multi": (C.c_int, [u8p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "rl_map_n_devices": (C.c_int, [C.c_void_p]),
+    "rl_map_replica": (C.c_void_p, [C.c_void_p, C.c_int]),
     "rl_map_update": (C.c_int, [C.c_void_p, u8p]),
     "rl_map_destroy": (None, [C.c_void_p]),
     "rl_map_rows": (C.c_int, [C.c_void_p]),
@@ -71,6 +75,8 @@ SYMBOLS = {
                                    C.POINTER(C.c_void_p)]),
     "rl_method_destroy": (None, [C.c_void_p]),
     "rl_method_kind": (C.c_int, [C.c_void_p]),
+    "rl_method_n_devices": (C.c_int, [C.c_void_p]),
+    "rl_method_replica": (C.c_void_p, [C.c_void_p, C.c_int]),
     "rl_calc_range_many": (C.c_int, [C.c_void_p, f32p, f32p, C.c_int]),
     "rl_calc_range_many_fan": (C.c_int, [C.c_void_p, f32p, f32p, C.c_int, C.c_float, C.c_int]),
     "rl_calc_range_fan": (C.c_int, [C.c_void_p, f32p, C.c_int, C.c_float, C.c_int, f32p, i32p,
@@ -94,6 +100,7 @@ SYMBOLS = {
     "rl_followgap_eval_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p]),
     "rl_car_create": (C.c_int, [C.c_int, f64p, C.POINTER(C.c_void_p)]),
+    "rl_car_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, f64p, C.POINTER(C.c_void_p)]),
     "rl_car_destroy": (None, [C.c_void_p]),
     "rl_car_rollout": (C.c_int, [C.c_void_p, f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_double, f32p,
                                  f64p, f64p]),

@@ -62,6 +62,64 @@ inline void default_opts(rl_plan_opts &o)
     o.slice_log2 = 30;
 }
 
+// Options as the planner may use them: every field a division, a shift or a template choice depends on is
+// brought into its valid range — the same clamps rl_method_set_option applies to a handle, so a caller of the
+// public rl_plan_fan with a zeroed or hand-filled rl_plan_opts gets a plan (of the nearest valid options)
+// instead of a division by zero, an undefined shift or a block size no kernel was instantiated for.
+inline rl_plan_opts sanitized(rl_plan_opts o)
+{
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    o.variant = clampi(o.variant, 0, 2);
+    o.grid_mult = clampi(o.grid_mult, 1, 64);
+    o.wg_threads = o.wg_threads >= 1024 ? 1024 : (o.wg_threads >= 512 ? 512 : 256);
+    o.low_water = o.low_water < 0 ? -1 : clampi(o.low_water, 0, 63);
+    o.sort_poses = o.sort_poses != 0;
+    o.xcd_bands = clampi(o.xcd_bands, 1, 64);
+    o.slots = clampi(o.slots, 0, 3);
+    o.tiled = o.tiled != 0;
+    o.inline_prep = o.inline_prep != 0;
+    o.inline_max = clampi(o.inline_max, 0, 1 << 30);
+    o.inline_map_kb = clampi(o.inline_map_kb, 0, 1 << 30);
+    o.stripe_max = clampi(o.stripe_max, 0, 1 << 30);
+    o.order_inline = o.order_inline != 0;
+    o.bin_multi_min = clampi(o.bin_multi_min, 1, 1 << 30);
+    o.bin_generic = o.bin_generic != 0;
+    o.run_log2 = o.run_log2 < 0 ? -1 : clampi(o.run_log2, 0, 8);
+    o.cddt_bins = o.cddt_bins != 0;
+    o.cddt_sort = o.cddt_sort != 0;
+    o.cddt_theta_min = clampi(o.cddt_theta_min, 0, 1 << 30);
+    o.slice_log2 = clampi(o.slice_log2, 8, 30);
+    return o;
+}
+
+// The power-of-two-pitch tiled step map (pad_dt_tiled_kernel) of a rows x cols map with a border for max_range:
+// whether its geometry fits the march's address arithmetic — the table below 4 GiB (32-bit byte offsets) and
+// K <= 24, because the row term comes from v_mad_i32_i24 with M = 4 + 2^(K-2) (a signed 24-bit operand) — and
+// the geometry itself.  Shared by the planner (which falls back to the row-major map: tiled = 0, one ray per
+// lane) and ensure_step_map (which builds what the planner said).
+struct TiledFit {
+    bool ok;
+    int pad, padr, pcols, prows, K;
+    size_t bytes;
+};
+inline TiledFit tiled_fit(int rows, int cols, float max_range)
+{
+    TiledFit t{};
+    t.pad = (((int)std::ceil(max_range) + 2) + 7) & ~7;      // 128-B lines line up with the border
+    t.padr = t.pad + 4;                                       // one slack group in front: offsets stay positive
+    t.pcols = cols + 2 * t.pad;
+    t.prows = (rows + 2 * t.pad + 4 + 3) & ~3;
+    int lg = 3;                                               // power-of-two pitch >= padded cols and padded rows
+    while ((1L << lg) < (long)std::max(t.pcols, t.prows) && lg < 30) ++lg;
+    t.K = lg + 4;
+    t.bytes = ((size_t)(t.prows >> 2)) << t.K;
+    t.ok = t.K <= 24 && t.bytes <= ((size_t)1 << 32) && max_range < 1.0e6f;
+    return t;
+}
+
+// device limit a launch's dynamic LDS must stay within (gfx950: 160 KB per workgroup)
+constexpr int DEVICE_LDS_BYTES = 160 * 1024;
+
 // the binning pass a batch of n_poses takes when one is needed (bin_poses in scanlib.hip)
 inline bool keys_only_ok(const rl_plan_opts &o, int n_poses)
 {
@@ -100,7 +158,11 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     p->bands = 1;
     p->slices = 1;
     p->slice_poses = n_poses;
-    p->tiled = o.tiled;
+    // the tiled step map only where its geometry fits the march's address arithmetic (tiled_fit): very elongated or
+    // huge maps march on the row-major copy
+    const bool tiled_opt = o.tiled != 0 && ((in.kind != RL_RM && in.kind != RL_RM_GPU) ||
+                                           tiled_fit(in.rows, in.cols, in.max_range).ok);
+    p->tiled = tiled_opt;
     if (in.kind == RL_GIANT_LUT) {
         p->grid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4, (long)n_cu * o.grid_mult));
         p->block = 256;
@@ -242,7 +304,7 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     // short rays lose 3 % — profiles/r03/sweep_serial_slots.txt)
     int slots_req = o.slots ? o.slots : ((rays >= (1L << 23) || (rays >= (1L << 20) && !small_map)) ? 2 : 1);
     // (a fan whose tables leave no room for the scratch of 16 waves marches one ray per lane)
-    if (slots_req >= 2 && (in.aux || !o.tiled || tables_b + 16 * drain_wave > (size_t)INLINE_LDS_BUDGET)) slots_req = 1;
+    if (slots_req >= 2 && (in.aux || !tiled_opt || tables_b + 16 * drain_wave > (size_t)INLINE_LDS_BUDGET)) slots_req = 1;
     const bool multi = slots_req >= 2;                                // <=> the launch takes 2 or 3 rays per lane
     auto drain_bytes = [&](int nthreads) { return multi ? (size_t)(nthreads / 64) * drain_wave : (size_t)0; };
     const size_t inl_tables = tables_b + drain_bytes(1024);
@@ -290,15 +352,13 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     p->bands = bands;
     p->k_max = inl ? k_max : 0;
     const int slots = slots_req;
-    bool a = in.aux, c = in.crash, t = o.tiled != 0;
+    bool a = in.aux, c = in.crash, t = tiled_opt;
     int s = 1;
-    if (slots == 3 && !in.aux && !in.crash && (inl || (nt == 1024 && o.tiled))) {
+    if (slots == 3 && !in.aux && !in.crash && tiled_opt && (inl || nt == 1024)) {
         s = 3;
         nt = 1024;
-        if (!inl) t = true;
-    } else if (slots >= 2 && !in.aux && o.tiled) {
+    } else if (slots >= 2 && !in.aux && tiled_opt) {
         s = 2;
-        t = true;
     }
     p->kernel = RL_K_RM_STREAM;
     p->slots = s;
@@ -310,11 +370,15 @@ inline int plan_one(const In &in, rl_launch_plan *p)
                                        : ((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays) * sizeof(float)));
     std::snprintf(p->name, sizeof p->name, "scan::rm_fan_stream_kernel<%s, %s, %d, %s, %s, %d>", tf(a), tf(c),
                   p->block, tf(inl), tf(t), s);
+    // (a fan of ~20 000 beams: the beam tables alone exceed a workgroup's LDS — say so instead of failing the launch)
+    if (p->lds_bytes > DEVICE_LDS_BYTES) return RL_ERR_UNSUPPORTED;
     return RL_OK;
 }
 
-inline int plan_fan(const In &in, rl_launch_plan *p)
+inline int plan_fan(const In &in_raw, rl_launch_plan *p)
 {
+    In in = in_raw;
+    in.o = sanitized(in_raw.o);
     std::memset(p, 0, sizeof *p);
     if (in.n_poses <= 0 || in.num_rays <= 0) {
         std::snprintf(p->name, sizeof p->name, "(nothing to launch)");

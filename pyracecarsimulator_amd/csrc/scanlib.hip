@@ -20,10 +20,14 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace scan;
@@ -96,7 +100,8 @@ extern "C" int rl_host_alloc(size_t bytes, void **out)
     if (!out || bytes == 0) return fail(RL_ERR_INVALID, "rl_host_alloc: bad arguments");
     if (rl_device_count() <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available");
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess)
+    // (portable + mapped: every device of a multi-device handle writes its pose block's ranges straight into it)
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess)
         return fail(RL_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
     memset(p, 0, bytes);
     int cur = 0;
@@ -137,7 +142,11 @@ extern "C" int rl_host_free(void *p)
 // handles
 // ------------------------------------------------------------------------------
 struct rl_map {
+    // a MULTI-DEVICE map (rl_map_create_multi) owns no device memory itself: it holds one ordinary map per
+    // device in `reps` (the same device may appear several times) and its own fields describe the shape only
+    std::vector<rl_map *> reps;
     int device = 0;
+    int clock_khz = 0;
     int rows = 0, cols = 0;
     float res = 0, ox = 0, oy = 0, oyaw = 0;
     uint8_t *d_occ = nullptr;
@@ -217,7 +226,111 @@ struct TableDep {
     bool pending = false;
 };
 
+
+// ------------------------------------------------------------------------------
+// Several devices behind one handle (rl_map_create_multi): a single-process caller — the reference's
+// scanMany / checkCollisionMany callers are ONE Python process (scripts/mcts.py:237,
+// scripts/scan_simulator.py:113-135) — hands over one pose batch and every device scans a contiguous
+// block of it.  One persistent worker thread per device (bound to it with hipSetDevice once) runs the
+// ordinary single-device entry point on that device's replica handle; job 0 runs on the calling thread.
+// Threads and streams only: nothing is forked or re-executed after the GPU has been initialised.
+// ------------------------------------------------------------------------------
+struct MultiPool {
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int()> job;
+        bool has = false, done = false, stop = false;
+        int rc = 0;
+        std::string err;
+        int device = 0;
+    };
+    std::vector<std::unique_ptr<Worker>> w;
+
+    void start(const std::vector<int> &devices)
+    {
+        for (size_t i = 1; i < devices.size(); ++i) {       // (block 0 is the caller's)
+            auto wk = std::make_unique<Worker>();
+            wk->device = devices[i];
+            Worker *raw = wk.get();
+            wk->th = std::thread([raw]() {
+                (void)hipSetDevice(raw->device);
+                std::unique_lock<std::mutex> lk(raw->mu);
+                for (;;) {
+                    raw->cv.wait(lk, [raw]() { return raw->has || raw->stop; });
+                    if (raw->stop) return;
+                    raw->has = false;
+                    lk.unlock();
+                    const int rc = raw->job();
+                    std::string msg = rc ? g_err : std::string();
+                    lk.lock();
+                    raw->rc = rc;
+                    raw->err = std::move(msg);
+                    raw->done = true;
+                    raw->cv.notify_all();
+                }
+            });
+            w.push_back(std::move(wk));
+        }
+    }
+
+    // jobs[0] on the caller, jobs[i] on worker i-1; the first failure (lowest block) is reported, its message
+    // becomes the caller's rl_last_error
+    int run(std::vector<std::function<int()>> &jobs)
+    {
+        const size_t k = std::min(jobs.size(), w.size() + 1);
+        for (size_t i = 1; i < k; ++i) {
+            Worker &x = *w[i - 1];
+            std::lock_guard<std::mutex> lk(x.mu);
+            x.job = std::move(jobs[i]);
+            x.has = true;
+            x.done = false;
+            x.cv.notify_all();
+        }
+        int rc = jobs.empty() ? RL_OK : jobs[0]();
+        std::string err = rc ? g_err : std::string();
+        for (size_t i = 1; i < k; ++i) {
+            Worker &x = *w[i - 1];
+            std::unique_lock<std::mutex> lk(x.mu);
+            x.cv.wait(lk, [&x]() { return x.done; });
+            if (rc == RL_OK && x.rc != RL_OK) {
+                rc = x.rc;
+                err = x.err;
+            }
+        }
+        if (rc) g_err = err;
+        return rc;
+    }
+
+    ~MultiPool()
+    {
+        for (auto &x : w) {
+            {
+                std::lock_guard<std::mutex> lk(x->mu);
+                x->stop = true;
+                x->cv.notify_all();
+            }
+            if (x->th.joinable()) x->th.join();
+        }
+    }
+};
+
+// contiguous block of `rank` when n items are cut into `parts` (the same split as workloads.shard_range)
+static inline void block_of(long n, int rank, int parts, long &lo, long &hi)
+{
+    const long base = n / parts, rem = n % parts;
+    lo = rank * base + std::min<long>(rank, rem);
+    hi = lo + base + (rank < rem ? 1 : 0);
+}
+
 struct rl_method {
+    // multi-device method (created on a multi-device map): one ordinary method per device + the worker pool;
+    // the parent keeps kind / noise / options and owns no device memory
+    std::vector<rl_method *> reps;
+    std::unique_ptr<MultiPool> pool;
+    int multi_min_poses = 64;    // a device is only brought in for at least this many poses (a roll-out of 200 poses
+                                 // stays on one device: its 18-us march is cheaper than waking a second one)
     rl_map *map = nullptr;
     int kind = 0;
     float max_range = 0;
@@ -411,7 +524,10 @@ extern "C" int rl_map_create(const uint8_t *occ, int rows, int cols, float res, 
     };
     if (hipSetDevice(device) != hipSuccess) return bail(fail(RL_ERR_HIP, "hipSetDevice failed"));
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_cu = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        m->n_cu = prop.multiProcessorCount;
+        m->clock_khz = prop.clockRate;
+    }
     const size_t n = (size_t)rows * cols;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&m->d_occ, n) != hipSuccess ||
@@ -446,9 +562,60 @@ extern "C" int rl_map_create(const uint8_t *occ, int rows, int cols, float res, 
     return RL_OK;
 }
 
+extern "C" int rl_map_create_multi(const uint8_t *occ, int rows, int cols, float res, float ox, float oy,
+                                   float oyaw, const int *devices, int n_devices, rl_map **out)
+{
+    if (!occ || !out || !devices) return fail(RL_ERR_INVALID, "rl_map_create_multi: null pointer");
+    if (n_devices < 1 || n_devices > 64) return fail(RL_ERR_INVALID, "rl_map_create_multi: 1..64 devices (got %d)", n_devices);
+    rl_map *m = new (std::nothrow) rl_map();
+    if (!m) return fail(RL_ERR_NOMEM, "out of host memory");
+    for (int i = 0; i < n_devices; ++i) {
+        rl_map *r = nullptr;
+        const int rc = rl_map_create(occ, rows, cols, res, ox, oy, oyaw, devices[i], &r);
+        if (rc) {
+            const std::string keep = g_err;
+            rl_map_destroy(m);
+            g_err = keep;
+            return rc;
+        }
+        m->reps.push_back(r);
+    }
+    const rl_map *r0 = m->reps[0];
+    m->device = r0->device;
+    m->rows = rows;
+    m->cols = cols;
+    m->res = res;
+    m->ox = ox;
+    m->oy = oy;
+    m->oyaw = oyaw;
+    m->n_cu = r0->n_cu;
+    m->clock_khz = r0->clock_khz;
+    m->mp = r0->mp;
+    *out = m;
+    return RL_OK;
+}
+
+extern "C" int rl_map_n_devices(const rl_map *m) { return m ? (m->reps.empty() ? 1 : (int)m->reps.size()) : 0; }
+
+extern "C" rl_map *rl_map_replica(rl_map *m, int i)
+{
+    if (!m) return nullptr;
+    if (m->reps.empty()) return i == 0 ? m : nullptr;
+    return (i >= 0 && i < (int)m->reps.size()) ? m->reps[i] : nullptr;
+}
+
 extern "C" int rl_map_update(rl_map *m, const uint8_t *occ)
 {
     if (!m || !occ) return fail(RL_ERR_INVALID, "rl_map_update: null pointer");
+    if (!m->reps.empty()) {
+        std::lock_guard<std::mutex> lk(m->mu);
+        for (rl_map *r : m->reps) {
+            const int rc = rl_map_update(r, occ);
+            if (rc) return rc;
+        }
+        m->epoch++;
+        return RL_OK;
+    }
     std::lock_guard<std::mutex> lk(m->mu);
     // exclusive: no host-pointer call of any method of this map is in progress; the device
     // synchronisation covers launches the asynchronous *_device entry points left in flight
@@ -467,6 +634,11 @@ extern "C" int rl_map_update(rl_map *m, const uint8_t *occ)
 extern "C" void rl_map_destroy(rl_map *m)
 {
     if (!m) return;
+    if (!m->reps.empty()) {
+        for (rl_map *r : m->reps) rl_map_destroy(r);
+        delete m;
+        return;
+    }
     (void)hipSetDevice(m->device);
     if (m->d_occ) (void)hipFree(m->d_occ);
     if (m->d_g) (void)hipFree(m->d_g);
@@ -487,6 +659,7 @@ extern "C" int rl_map_device(const rl_map *m) { return m ? m->device : -1; }
 extern "C" int rl_map_get_dt(rl_map *m, float *dt_out)
 {
     if (!m || !dt_out) return fail(RL_ERR_INVALID, "rl_map_get_dt: null pointer");
+    if (!m->reps.empty()) return rl_map_get_dt(m->reps[0], dt_out);
     std::lock_guard<std::mutex> lk(m->mu);
     int rc = set_device(m);
     if (rc) return rc;
@@ -498,6 +671,7 @@ extern "C" int rl_map_get_dt(rl_map *m, float *dt_out)
 extern "C" int rl_map_get_occ(rl_map *m, uint8_t *occ_out)
 {
     if (!m || !occ_out) return fail(RL_ERR_INVALID, "rl_map_get_occ: null pointer");
+    if (!m->reps.empty()) return rl_map_get_occ(m->reps[0], occ_out);
     std::lock_guard<std::mutex> lk(m->mu);
     int rc = set_device(m);
     if (rc) return rc;
@@ -525,6 +699,26 @@ extern "C" int rl_method_create(rl_map *m, int kind, float max_range_px, int the
     h->max_range = max_range_px;
     h->theta_disc = theta_disc;
     h->step_coeff = kind == RL_RM_GPU ? 1.0f : 0.999f;   // kernels.cu STEP_COEFF vs RayMarching (also seeds the LUT)
+    if (!m->reps.empty()) {
+        // multi-device: one ordinary method per device replica of the map + one worker thread per extra device
+        std::vector<int> devs;
+        for (rl_map *rm : m->reps) {
+            rl_method *r = nullptr;
+            const int rc = rl_method_create(rm, kind, max_range_px, theta_disc, &r);
+            if (rc) {
+                const std::string keep = g_err;
+                rl_method_destroy(h);
+                g_err = keep;
+                return rc;
+            }
+            h->reps.push_back(r);
+            devs.push_back(rm->device);
+        }
+        h->pool = std::make_unique<MultiPool>();
+        h->pool->start(devs);
+        *out = h;
+        return RL_OK;
+    }
     if (kind == RL_CDDT) {
         // the map starts keeping its edge list (and rebuilds it with every rl_map_update)
         std::lock_guard<std::mutex> lk(m->mu);
@@ -552,6 +746,12 @@ extern "C" int rl_method_create(rl_map *m, int kind, float max_range_px, int the
 extern "C" void rl_method_destroy(rl_method *h)
 {
     if (!h) return;
+    if (!h->reps.empty() || h->pool) {
+        h->pool.reset();                       // (joins the workers: no job is in flight, the caller owns the handle)
+        for (rl_method *r : h->reps) rl_method_destroy(r);
+        delete h;
+        return;
+    }
     if (h->map) (void)hipSetDevice(h->map->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->poses.release();
@@ -583,6 +783,30 @@ extern "C" void rl_method_destroy(rl_method *h)
 
 extern "C" int rl_method_kind(const rl_method *h) { return h ? h->kind : -1; }
 
+extern "C" int rl_method_n_devices(const rl_method *h) { return h ? (h->reps.empty() ? 1 : (int)h->reps.size()) : 0; }
+
+extern "C" rl_method *rl_method_replica(rl_method *h, int i)
+{
+    if (!h) return nullptr;
+    if (h->reps.empty()) return i == 0 ? h : nullptr;
+    return (i >= 0 && i < (int)h->reps.size()) ? h->reps[i] : nullptr;
+}
+
+static int cddt_table_stats(rl_method *h, const char *name, int64_t *value_out);
+
+// how many devices of a multi-device handle a batch of n_poses is cut over
+static int multi_parts(const rl_method *h, long n_poses)
+{
+    const long by_size = n_poses / std::max(h->multi_min_poses, 1);
+    return (int)std::max<long>(1, std::min<long>((long)h->reps.size(), by_size));
+}
+
+static int multi_needs_replica(const char *fn)
+{
+    return fail(RL_ERR_INVALID, "%s: device pointers belong to one device — on a multi-device handle call it with "
+                                "rl_method_replica(h, i)", fn);
+}
+
 extern "C" int rl_set_noise(rl_method *h, float std, uint64_t seed, uint64_t ray_offset)
 {
     if (!h) return fail(RL_ERR_INVALID, "rl_set_noise: null handle");
@@ -596,6 +820,18 @@ extern "C" int rl_set_noise(rl_method *h, float std, uint64_t seed, uint64_t ray
 extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
 {
     if (!h || !name) return fail(RL_ERR_INVALID, "rl_method_set_option: null pointer");
+    if (!h->reps.empty()) {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!strcmp(name, "multi_min_poses")) {
+            h->multi_min_poses = value < 1 ? 1 : value;
+            return RL_OK;
+        }
+        for (rl_method *r : h->reps) {
+            const int rc = rl_method_set_option(r, name, value);
+            if (rc) return rc;
+        }
+        return RL_OK;
+    }
     std::lock_guard<std::mutex> lk(h->mu);
     if (!strcmp(name, "variant")) h->variant = value;
     else if (!strcmp(name, "grid_mult")) h->grid_mult = value < 1 ? 1 : value;
@@ -640,7 +876,15 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
 extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out)
 {
     if (!h || !name || !value_out) return fail(RL_ERR_INVALID, "rl_method_get_info: null pointer");
+    if (!strcmp(name, "n_devices")) { *value_out = h->reps.empty() ? 1 : (int64_t)h->reps.size(); return RL_OK; }
+    if (!h->reps.empty()) {
+        if (!strcmp(name, "multi_min_poses")) { *value_out = h->multi_min_poses; return RL_OK; }
+        return rl_method_get_info(h->reps[0], name, value_out);
+    }
+    if (!strcmp(name, "cddt_values") || !strcmp(name, "cddt_buckets") || !strcmp(name, "cddt_nonempty_buckets"))
+        return cddt_table_stats(h, name, value_out);
     if (!strcmp(name, "n_cu")) *value_out = h->map->n_cu;
+    else if (!strcmp(name, "clock_khz")) *value_out = h->map->clock_khz;
     else if (!strcmp(name, "variant")) *value_out = h->variant;
     else if (!strcmp(name, "grid_mult")) *value_out = h->grid_mult;
     else if (!strcmp(name, "low_water")) *value_out = h->low_water;
@@ -723,6 +967,9 @@ static int acquire_ctx(rl_method *h, hipStream_t stream, LaunchCtx **out)
             if (!pick || c.last_use < pick->last_use) pick = &c;
         // hand-over: whatever the old stream still has in flight on this scratch must finish first
         HIPCHK(hipDeviceSynchronize());
+        // (the theta-major CDDT scratch R[bin][pose] is the one large buffer of a context — up to 2 GiB —: a
+        //  context that changes hands gives it back instead of pinning it for the handle's lifetime)
+        pick->cddt_r.release();
     }
     pick->bound = true;
     pick->stream = stream;
@@ -938,6 +1185,27 @@ static int ensure_cddt(rl_method *h, hipStream_t stream)
     return table_built(h->cddt_dep, stream);
 }
 
+// diagnostics (bench.py's algorithmic bytes of a CDDT ray): stored values, buckets and non-empty buckets of the
+// current table, from the CSR offsets the build leaves behind (builds the table if needed; synchronises)
+static int cddt_table_stats(rl_method *h, const char *name, int64_t *value_out)
+{
+    if (h->kind != RL_CDDT) return fail(RL_ERR_INVALID, "not a CDDT method");
+    std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
+    int rc = set_device(h->map);
+    if (rc) return rc;
+    if ((rc = ensure_cddt(h, h->stream))) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<uint32_t> off((size_t)h->cd_buckets + 1);
+    HIPCHK(hipMemcpy(off.data(), h->cd_offsets.p, off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int64_t nonempty = 0;
+    for (size_t b = 0; b < (size_t)h->cd_buckets; ++b) nonempty += off[b + 1] > off[b];
+    if (!strcmp(name, "cddt_values")) *value_out = (int64_t)off[h->cd_buckets];
+    else if (!strcmp(name, "cddt_buckets")) *value_out = (int64_t)h->cd_buckets;
+    else *value_out = nonempty;
+    return RL_OK;
+}
+
 // K2b's padded bit maps (normal + transposed), rebuilt when the map changed
 static int ensure_blpad(rl_method *h, hipStream_t stream)
 {
@@ -1130,21 +1398,21 @@ static int ensure_step_map(rl_method *h, hipStream_t stream)
 {
     const rl_map *m = h->map;
     int rc;
-    if (h->pdt_epoch == m->epoch && h->pdt.p && h->pdt_tiled == h->tiled) return table_wait(h->pdt_dep, stream);
+    // (the planner marches on the row-major copy when the tiled geometry does not fit the address arithmetic:
+    //  plan::tiled_fit — elongated maps whose pitch would need K > 24, tables beyond 4 GiB)
+    const plan::TiledFit fit = plan::tiled_fit(m->rows, m->cols, h->max_range);
+    const int want_tiled = (h->tiled && fit.ok) ? 1 : 0;
+    if (h->pdt_epoch == m->epoch && h->pdt.p && h->pdt_tiled == want_tiled) return table_wait(h->pdt_dep, stream);
     if (h->pdt.p) HIPCHK(hipDeviceSynchronize());   // launches of other streams may still read the old copy
     h->pad = (int)std::ceil(h->max_range) + 2;
-    if (h->tiled) {
-        h->pad = (h->pad + 7) & ~7;                       // 128-B lines line up with the border
+    if (want_tiled) {
         TiledGeom tg{};
-        tg.pad = h->pad;
-        tg.padr = h->pad + 4;                             // one slack group in front: offsets stay positive
-        tg.pcols = m->cols + 2 * h->pad;
-        tg.prows = (m->rows + 2 * h->pad + 4 + 3) & ~3;
-        int lg = 3;                                       // power-of-two pitch >= padded cols and padded rows
-        while ((1 << lg) < std::max(tg.pcols, tg.prows)) ++lg;
-        tg.K = lg + 4;
-        const size_t bytes = ((size_t)(tg.prows >> 2)) << tg.K;
-        if (bytes > ((size_t)1 << 32)) return fail(RL_ERR_UNSUPPORTED, "map too large for the tiled step map");
+        tg.pad = h->pad = fit.pad;
+        tg.padr = fit.padr;
+        tg.pcols = fit.pcols;
+        tg.prows = fit.prows;
+        tg.K = fit.K;
+        const size_t bytes = fit.bytes;
         const uint32_t M = 4u + (1u << (tg.K - 2));
         h->pstride = (int)M;
         h->pdt_mask = 0xCu | (~0u << tg.K);
@@ -1156,6 +1424,10 @@ static int ensure_step_map(rl_method *h, hipStream_t stream)
     } else {
         h->pstride = (m->cols + 2 * h->pad + 31) & ~31;
         const int prow = m->rows + 2 * h->pad;
+        // (row-major address: v_mad_i32_i24 r * stride + c, then << 2 in 32 bits)
+        if (h->pstride >= (1 << 23) || (size_t)prow * h->pstride >= ((size_t)1 << 30))
+            return fail(RL_ERR_UNSUPPORTED, "map %dx%d with max_range %g is too large for the step map", m->rows, m->cols,
+                        h->max_range);
         if ((rc = h->pdt.ensure((size_t)prow * h->pstride * sizeof(float)))) return rc;
         hipLaunchKernelGGL(pad_dt_kernel, dim3((h->pstride + 255) / 256, prow), dim3(256), 0,
                            stream, m->d_dt, m->rows, m->cols, (float *)h->pdt.p, h->pad,
@@ -1165,7 +1437,7 @@ static int ensure_step_map(rl_method *h, hipStream_t stream)
         h->pdt_base_off = 0;
     }
     h->pdt_epoch = m->epoch;
-    h->pdt_tiled = h->tiled;
+    h->pdt_tiled = want_tiled;
     return table_built(h->pdt_dep, stream);
 }
 
@@ -1175,6 +1447,11 @@ static void launch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, const
                              const StreamParams &sp, float *d_out, int32_t *d_hits, uint16_t *d_steps,
                              const CrashParams &cp)
 {
+    // (more dynamic LDS than HIP's default cap — fans of several thousand beams, with the crash table —: opt in,
+    //  as the BL / occ / CDDT kernels do; the attribute is sticky per function and device, the call is cheap)
+    if (pl.lds_bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rm_fan_stream_kernel<A, C, N, I, T, S>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_bytes);
     hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, N, I, T, S>), dim3(pl.grid), dim3(N), (size_t)pl.lds_bytes, stream,
                        pm, f, sp, d_out, d_hits, d_steps, cp);
 }
@@ -1235,8 +1512,10 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
     rl_launch_plan pl;
     int rc = plan_for(h, n_poses, num_rays, aux, crash != nullptr, &pl);
     if (rc == RL_ERR_UNSUPPORTED)
-        return fail(rc, crash ? "the fused crash test needs variant 0 or 1"
-                              : "occupancy window of max_range %g does not fit LDS", h->max_range);
+        return fail(rc, (h->variant == 2 && crash) ? "the fused crash test needs variant 0 or 1"
+                        : h->variant == 2 ? "occupancy window of max_range %g does not fit LDS (num_rays %d)"
+                                          : "the beam tables of max_range %g, num_rays %d exceed a workgroup's LDS (160 KB)",
+                    h->max_range, num_rays);
     if (rc) return fail(rc, "launch planning failed");
     if (pl.slices > 1) {
         // pose slices below 2^slice_log2 rays, each its own launch sequence
@@ -1507,6 +1786,11 @@ extern "C" int rl_method_plan_fan(rl_method *h, int n_poses, int num_rays, int w
 {
     if (!h || !out) return fail(RL_ERR_INVALID, "rl_method_plan_fan: null pointer");
     if (n_poses < 0 || num_rays <= 0) return fail(RL_ERR_INVALID, "rl_method_plan_fan: bad shape arguments");
+    if (!h->reps.empty()) {                     // what ONE device launches for its block of the batch
+        long lo, hi;
+        block_of(n_poses, 0, multi_parts(h, n_poses), lo, hi);
+        return rl_method_plan_fan(h->reps[0], (int)(hi - lo), num_rays, want_aux, want_crash, out);
+    }
     std::lock_guard<std::mutex> lk(h->mu);
     const int rc = plan_for(h, n_poses, num_rays, want_aux != 0, want_crash != 0, out);
     if (rc) return fail(rc, "no kernel of this variant serves the request");
@@ -1516,6 +1800,7 @@ extern "C" int rl_method_plan_fan(rl_method *h, int n_poses, int num_rays, int w
 extern "C" int rl_method_last_plan(rl_method *h, rl_launch_plan *out)
 {
     if (!h || !out) return fail(RL_ERR_INVALID, "rl_method_last_plan: null pointer");
+    if (!h->reps.empty()) return rl_method_last_plan(h->reps[0], out);
     std::lock_guard<std::mutex> lk(h->mu);
     *out = h->last_plan;
     return RL_OK;
@@ -1529,6 +1814,7 @@ extern "C" int rl_calc_range_fan_device(rl_method *h, const float *d_poses, int 
 {
     int rc = check_fan_args(h, n_poses, fov, num_rays);
     if (rc) return rc;
+    if (!h->reps.empty()) return multi_needs_replica("rl_calc_range_fan_device");
     if (n_poses > 0 && (!d_poses || !d_outs))
         return fail(RL_ERR_INVALID, "rl_calc_range_fan_device: null device pointer");
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1544,6 +1830,7 @@ extern "C" int rl_calc_range_many_device(rl_method *h, const float *d_ins, float
 {
     if (!h) return fail(RL_ERR_INVALID, "null method handle");
     if (n < 0) return fail(RL_ERR_INVALID, "n must be >= 0");
+    if (!h->reps.empty()) return multi_needs_replica("rl_calc_range_many_device");
     if (n > 0 && (!d_ins || !d_outs))
         return fail(RL_ERR_INVALID, "rl_calc_range_many_device: null device pointer");
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1684,6 +1971,103 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     return RL_OK;
 }
 
+// ------------------------------------------------------------------------------
+// multi-device forms of the host-pointer entry points: contiguous pose blocks, one per device, each
+// device writing its block of the results straight into the caller's buffer (in a pinned block of
+// rl_host_alloc the kernels write it directly: 4 B per ray over that device's own PCIe link).  Noise
+// stays keyed by the GLOBAL ray id (the replica's ray offset is the parent's + the block's first ray),
+// crash indices are global: the result is bit-identical to the single-device call.
+// ------------------------------------------------------------------------------
+static int multi_fan(rl_method *h, const float *poses, const float *rows3, int n_poses, float fov, int num_rays,
+                     float *outs, int32_t *hits, uint16_t *steps)
+{
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int k = multi_parts(h, n_poses);
+    const float nstd = h->noise_std;
+    const uint64_t seed = h->noise_seed, off = h->ray_offset;
+    std::vector<std::function<int()>> jobs;
+    for (int i = 0; i < k; ++i) {
+        long lo, hi;
+        block_of(n_poses, i, k, lo, hi);
+        rl_method *r = h->reps[i];
+        const size_t r0 = (size_t)lo * num_rays;
+        jobs.push_back([=]() {
+            int rc = rl_set_noise(r, nstd, seed, off + r0);
+            if (rc) return rc;
+            if (rows3)          // the fork's sparse 4-argument layout: pose p in row p * num_rays
+                return rl_calc_range_many_fan(r, rows3 + r0 * 3, outs + r0, (int)(hi - lo) * num_rays, fov, num_rays);
+            return rl_calc_range_fan(r, poses + 3 * lo, (int)(hi - lo), fov, num_rays, outs + r0,
+                                     hits ? hits + 2 * r0 : nullptr, steps ? steps + r0 : nullptr);
+        });
+    }
+    return h->pool->run(jobs);
+}
+
+static int multi_rays(rl_method *h, const float *ins, float *outs, int n)
+{
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int k = (int)std::max<long>(1, std::min<long>((long)h->reps.size(), (long)n / (64L * std::max(h->multi_min_poses, 1) * 16)));
+    const float nstd = h->noise_std;
+    const uint64_t seed = h->noise_seed, off = h->ray_offset;
+    std::vector<std::function<int()>> jobs;
+    for (int i = 0; i < k; ++i) {
+        long lo, hi;
+        block_of(n, i, k, lo, hi);
+        rl_method *r = h->reps[i];
+        jobs.push_back([=]() {
+            int rc = rl_set_noise(r, nstd, seed, off + (uint64_t)lo);
+            if (rc) return rc;
+            return rl_calc_range_many(r, ins + 3 * lo, outs + lo, (int)(hi - lo));
+        });
+    }
+    return h->pool->run(jobs);
+}
+
+// groups of `group` poses (group == n_poses, n_groups == 1 with `single`: rl_check_collision_many's one index)
+static int multi_crash(rl_method *h, const float *poses, int n_groups, int group, float fov, int num_rays,
+                       const double *edge, double thresh, int *first_crashed, float *ranges, bool single)
+{
+    std::lock_guard<std::mutex> lk(h->mu);
+    const long n_units = single ? group : n_groups;              // what is cut: poses of the one batch | roll-outs
+    const long poses_per_unit = single ? 1 : group;
+    const int k = (int)std::max<long>(1, std::min<long>(multi_parts(h, n_units * poses_per_unit), n_units));
+    const float nstd = h->noise_std;
+    const uint64_t seed = h->noise_seed, off = h->ray_offset;
+    std::vector<int> part(k, 0);
+    std::vector<long> los(k, 0), his(k, 0);
+    std::vector<std::function<int()>> jobs;
+    for (int i = 0; i < k; ++i) {
+        long lo, hi;
+        block_of(n_units, i, k, lo, hi);
+        los[i] = lo;
+        his[i] = hi;
+        rl_method *r = h->reps[i];
+        const size_t p0 = (size_t)lo * poses_per_unit, r0 = p0 * num_rays;
+        int *res = single ? &part[i] : first_crashed + lo;
+        jobs.push_back([=]() {
+            if (hi <= lo) return (int)RL_OK;
+            int rc = rl_set_noise(r, nstd, seed, off + r0);
+            if (rc) return rc;
+            if (single)
+                return rl_check_collision_many(r, poses + 3 * p0, (int)(hi - lo), fov, num_rays, edge, thresh, res,
+                                               ranges ? ranges + r0 : nullptr);
+            return rl_check_collision_groups(r, poses + 3 * p0, (int)(hi - lo), group, fov, num_rays, edge, thresh, res,
+                                             ranges ? ranges + r0 : nullptr);
+        });
+    }
+    const int rc = h->pool->run(jobs);
+    if (rc) return rc;
+    if (single) {
+        *first_crashed = -(group + 1);                            // Car::isCrashed: -(poses + 1) when none crashed
+        for (int i = 0; i < k; ++i)
+            if (his[i] > los[i] && part[i] >= 0) {
+                *first_crashed = (int)los[i] + part[i];
+                break;
+            }
+    }
+    return RL_OK;
+}
+
 extern "C" int rl_calc_range_fan(rl_method *h, const float *poses, int n_poses, float fov,
                                  int num_rays, float *outs, int32_t *hits, uint16_t *steps)
 {
@@ -1691,6 +2075,7 @@ extern "C" int rl_calc_range_fan(rl_method *h, const float *poses, int n_poses, 
     if (rc) return rc;
     if (n_poses > 0 && (!poses || !outs))
         return fail(RL_ERR_INVALID, "rl_calc_range_fan: null pointer");
+    if (!h->reps.empty()) return n_poses ? multi_fan(h, poses, nullptr, n_poses, fov, num_rays, outs, hits, steps) : RL_OK;
     std::lock_guard<std::mutex> lk(h->mu);
     std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     return fan_host(h, poses, n_poses, fov, num_rays, outs, hits, steps, nullptr, 0.0, nullptr);
@@ -1709,6 +2094,7 @@ extern "C" int rl_calc_range_many_fan(rl_method *h, const float *ins_rows3, floa
     if (rc) return rc;
     if (n_poses > 0 && (!ins_rows3 || !outs))
         return fail(RL_ERR_INVALID, "rl_calc_range_many_fan: null pointer");
+    if (!h->reps.empty()) return n_poses ? multi_fan(h, nullptr, ins_rows3, n_poses, fov, num_rays, outs, nullptr, nullptr) : RL_OK;
     std::lock_guard<std::mutex> lk(h->mu);
     std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     // gather the live row of every pose (row p*num_rays): 12 B per pose cross PCIe,
@@ -1730,6 +2116,7 @@ extern "C" int rl_calc_range_many(rl_method *h, const float *ins, float *outs, i
     if (n < 0) return fail(RL_ERR_INVALID, "n must be >= 0");
     if (n == 0) return RL_OK;
     if (!ins || !outs) return fail(RL_ERR_INVALID, "rl_calc_range_many: null pointer");
+    if (!h->reps.empty()) return multi_rays(h, ins, outs, n);
     std::lock_guard<std::mutex> lk(h->mu);
     std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     int rc = set_device(h->map);
@@ -1769,6 +2156,8 @@ extern "C" int rl_check_collision_many(rl_method *h, const float *poses, int n_p
         *first_crashed = -1;
         return RL_OK;
     }
+    if (!h->reps.empty())
+        return multi_crash(h, poses, 1, n_poses, fov, num_rays, edge, crash_thresh, first_crashed, ranges_or_null, true);
     if (h->kind != RL_RM && h->kind != RL_RM_GPU)      // generic: scan, then one crash pass
         return rl_check_collision_groups(h, poses, 1, n_poses, fov, num_rays, edge, crash_thresh,
                                          first_crashed, ranges_or_null);
@@ -1782,6 +2171,7 @@ extern "C" int rl_method_read_lut(rl_method *h, int row0, int row1, uint16_t *ou
 {
     if (!h || !out) return fail(RL_ERR_INVALID, "rl_method_read_lut: null pointer");
     if (h->kind != RL_GIANT_LUT) return fail(RL_ERR_INVALID, "not a GiantLUT method");
+    if (!h->reps.empty()) return rl_method_read_lut(h->reps[0], row0, row1, out);
     std::lock_guard<std::mutex> lk(h->mu);
     std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     int rc = set_device(h->map);
@@ -1800,6 +2190,7 @@ extern "C" int rl_method_read_lut(rl_method *h, int row0, int row1, uint16_t *ou
 extern "C" int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words)
 {
     if (!h || !out) return fail(RL_ERR_INVALID, "rl_debug_read_stamps: null pointer");
+    if (!h->reps.empty()) return rl_debug_read_stamps(h->reps[0], out, max_words);
     std::lock_guard<std::mutex> lk(h->mu);
     int rc = set_device(h->map);
     if (rc) return rc;
@@ -1858,6 +2249,7 @@ extern "C" int rl_check_collision_groups_device(rl_method *h, const float *d_pos
     int rc = check_fan_args(h, n_groups * group, fov, num_rays);
     if (rc) return rc;
     if (n_groups == 0) return RL_OK;
+    if (!h->reps.empty()) return multi_needs_replica("rl_check_collision_groups_device");
     if (!d_poses || !d_edge || !d_first_crashed)
         return fail(RL_ERR_INVALID, "rl_check_collision_groups_device: null device pointer");
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1879,6 +2271,8 @@ extern "C" int rl_check_collision_groups(rl_method *h, const float *poses, int n
     if (rc) return rc;
     if (n_groups == 0) return RL_OK;
     if (!poses || !edge || !first_crashed) return fail(RL_ERR_INVALID, "rl_check_collision_groups: null pointer");
+    if (!h->reps.empty())
+        return multi_crash(h, poses, n_groups, group, fov, num_rays, edge, crash_thresh, first_crashed, ranges_or_null, false);
     std::lock_guard<std::mutex> lk(h->mu);
     std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     if ((rc = set_device(h->map))) return rc;
@@ -1899,6 +2293,8 @@ extern "C" int rl_check_collision_groups(rl_method *h, const float *poses, int n
 }
 
 struct rl_car {
+    std::vector<rl_car *> reps;          // multi-device (rl_car_create_multi): one ordinary handle per device
+    std::unique_ptr<MultiPool> pool;
     int device = 0;
     CarParams P{};
     hipStream_t stream = nullptr;
@@ -1926,9 +2322,42 @@ extern "C" int rl_car_create(int device, const double *p, rl_car **out)
     return RL_OK;
 }
 
+extern "C" int rl_car_create_multi(const int *devices, int n_devices, const double *p, rl_car **out)
+{
+    if (!p || !out || !devices) return fail(RL_ERR_INVALID, "rl_car_create_multi: null pointer");
+    if (n_devices < 1 || n_devices > 64) return fail(RL_ERR_INVALID, "rl_car_create_multi: 1..64 devices (got %d)", n_devices);
+    rl_car *c = new (std::nothrow) rl_car();
+    if (!c) return fail(RL_ERR_NOMEM, "out of host memory");
+    std::vector<int> devs;
+    for (int i = 0; i < n_devices; ++i) {
+        rl_car *r = nullptr;
+        const int rc = rl_car_create(devices[i], p, &r);
+        if (rc) {
+            const std::string keep = g_err;
+            rl_car_destroy(c);
+            g_err = keep;
+            return rc;
+        }
+        c->reps.push_back(r);
+        devs.push_back(devices[i]);
+    }
+    c->device = devices[0];
+    c->P = c->reps[0]->P;
+    c->pool = std::make_unique<MultiPool>();
+    c->pool->start(devs);
+    *out = c;
+    return RL_OK;
+}
+
 extern "C" void rl_car_destroy(rl_car *c)
 {
     if (!c) return;
+    if (!c->reps.empty() || c->pool) {
+        c->pool.reset();
+        for (rl_car *r : c->reps) rl_car_destroy(r);
+        delete c;
+        return;
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->states, &c->actions, &c->poses, &c->states_out, &c->vel, &c->ranges, &c->edge, &c->first})
@@ -1965,6 +2394,25 @@ extern "C" int rl_car_rollout(rl_car *c, const double *states_in, const double *
                               double *vel_out)
 {
     if (!c || (R > 0 && (!states_in || !actions || !poses_out))) return fail(RL_ERR_INVALID, "rl_car_rollout: null pointer");
+    if (!c->reps.empty()) {
+        // roll-outs are independent: contiguous blocks of them, one per device
+        if (R < 0 || n_steps <= 0 || every <= 0) return fail(RL_ERR_INVALID, "n_rollouts >= 0, n_steps > 0, action_every > 0 required");
+        std::lock_guard<std::mutex> lk(c->mu);
+        const int k = (int)std::max<long>(1, std::min<long>((long)c->reps.size(), (long)R / 64));
+        const size_t n_act = (size_t)(n_steps + every - 1) / every;
+        std::vector<std::function<int()>> jobs;
+        for (int i = 0; i < k; ++i) {
+            long lo, hi;
+            block_of(R, i, k, lo, hi);
+            rl_car *r = c->reps[i];
+            jobs.push_back([=]() {
+                return rl_car_rollout(r, states_in + 11 * lo, actions + 2 * n_act * lo, (int)(hi - lo), n_steps, every, dt,
+                                      poses_out + (size_t)3 * n_steps * lo, states_out ? states_out + 11 * lo : nullptr,
+                                      vel_out ? vel_out + (size_t)n_steps * lo : nullptr);
+            });
+        }
+        return c->pool->run(jobs);
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = car_rollout_device(c, states_in, actions, R, n_steps, every, dt, states_out != nullptr, vel_out != nullptr);
     if (rc || R == 0) return rc;
@@ -1982,6 +2430,38 @@ extern "C" int rl_car_rollout_check(rl_car *c, rl_method *h, const double *state
 {
     if (!c || !h || (R > 0 && (!states_in || !actions || !edge || !first_crashed)))
         return fail(RL_ERR_INVALID, "rl_car_rollout_check: null pointer");
+    if (c->reps.empty() != h->reps.empty() || c->reps.size() != h->reps.size())
+        return fail(RL_ERR_INVALID, "car and range method must both be single-device or span the same devices");
+    if (!c->reps.empty()) {
+        // MCTS.rollout + checkCollisionMany for R roll-outs over several devices: contiguous blocks of roll-outs,
+        // each device integrates, scans and tests its own (nothing but the crash indices comes back)
+        if (R < 0 || n_steps <= 0 || every <= 0) return fail(RL_ERR_INVALID, "n_rollouts >= 0, n_steps > 0, action_every > 0 required");
+        for (size_t i = 0; i < c->reps.size(); ++i)
+            if (c->reps[i]->device != h->reps[i]->map->device)
+                return fail(RL_ERR_INVALID, "car and range method replicas live on different devices");
+        std::scoped_lock lk(c->mu, h->mu);
+        const int k = (int)std::max<long>(1, std::min<long>(multi_parts(h, (long)R * n_steps), std::max(R, 1)));
+        const size_t n_act = (size_t)(n_steps + every - 1) / every;
+        const float nstd = h->noise_std;
+        const uint64_t seed = h->noise_seed, off = h->ray_offset;
+        std::vector<std::function<int()>> jobs;
+        for (int i = 0; i < k; ++i) {
+            long lo, hi;
+            block_of(R, i, k, lo, hi);
+            rl_car *cr = c->reps[i];
+            rl_method *hr = h->reps[i];
+            jobs.push_back([=]() {
+                if (hi <= lo) return (int)RL_OK;
+                int rc = rl_set_noise(hr, nstd, seed, off + (uint64_t)lo * n_steps * num_rays);
+                if (rc) return rc;
+                return rl_car_rollout_check(cr, hr, states_in + 11 * lo, actions + 2 * n_act * lo, (int)(hi - lo), n_steps,
+                                            every, dt, fov, num_rays, edge, crash_thresh, first_crashed + lo,
+                                            states_out ? states_out + 11 * lo : nullptr,
+                                            vel_out ? vel_out + (size_t)n_steps * lo : nullptr);
+            });
+        }
+        return c->pool->run(jobs);
+    }
     if (c->device != h->map->device) return fail(RL_ERR_INVALID, "car and range method live on different devices");
     std::scoped_lock lk(c->mu, h->mu);
     std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
@@ -2007,6 +2487,7 @@ extern "C" int rl_car_rollout_check(rl_car *c, rl_method *h, const double *state
 extern "C" int rl_last_kernel_ms(rl_method *h, float *ms_out)
 {
     if (!h || !ms_out) return fail(RL_ERR_INVALID, "rl_last_kernel_ms: null pointer");
+    if (!h->reps.empty()) return rl_last_kernel_ms(h->reps[0], ms_out);
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->timed) return fail(RL_ERR_INVALID, "no launch has been timed on this handle (set option \"timing\"=1 first)");
     int rc = set_device(h->map);

@@ -13,7 +13,14 @@ north_star names:
   (``ShardedScan(mode=...)``): ``"ranges"`` the float32 all-gather north_star names;
   ``"ranges_u16"`` the same collective on 16-bit fixed-point ranges (half the bytes, LOSSY:
   <= 0.11 mm at 15 m, opt-in and labelled); ``"root"`` a gather to ONE consumer rank (the
-  reference's consumer is a single MCTS process: 7/8 of the GPUs then receive nothing).
+  reference's consumer is a single MCTS process: 7/8 of the GPUs then receive nothing);
+* the REDUCED exchanges — what the reference's consumers of a scanned batch actually read:
+  ``"crash"`` the fused per-roll-out crash test (``Car::isCrashed`` over ``scanMany``'s output,
+  scripts/racecar_simulator_v2.py:146-167, consumed at scripts/mcts.py:237-245: ONE int32 per
+  roll-out) and ``"steer"`` Follow-the-Gap on every scan (``fg.eval(lidar)``, scripts/mcts.py:262-267:
+  ONE float32 per pose).  The ranges stay on the GPU that computed them; 4 B per roll-out / per pose
+  are all-gathered in buckets of several steps (``BucketedIndexGather``), per slot, on the slot's
+  stream — the exchange that scales over xGMI where 4 B per RAY cannot.
 
 The reference has no collective anywhere (single process, single GPU: SURVEY §2.1).
 """
@@ -63,7 +70,11 @@ def chunk_bounds(n_local: int, n_chunks: int):
 
 class _Slot:
     __slots__ = ("local", "gathered", "stream", "handles", "views", "dsts", "calls", "sptr", "local_q",
-                 "gathered_q", "views_q", "dsts_q", "dst_lists", "decoded")
+                 "gathered_q", "views_q", "dsts_q", "dst_lists", "decoded", "bucket", "rcall")
+
+
+#: exchange modes whose payload is a per-roll-out / per-pose result instead of the ranges
+REDUCED_MODES = ("crash", "steer")
 
 
 class ShardedScan:
@@ -78,11 +89,19 @@ class ShardedScan:
     that slot ``depth`` steps earlier, so the all-gathers of step k run on RCCL's stream while
     the marches of steps k+1 .. k+depth-1 run on theirs.  ``finish()`` waits for everything
     (call it before reading results or stopping a clock).
+
+    Reduced modes (``mode="crash"`` / ``"steer"``): a step scans the local block and reduces it on the
+    same stream — ``crash``: ``rl_check_collision_groups_device`` (first crashed pose of every roll-out
+    of ``group`` poses, int32), ``steer``: ``rl_followgap_eval_device`` (one float32 steering angle per
+    pose) — into the slot's bucket; ``n_items`` results per step (roll-outs / poses of the local
+    block), ``every`` steps per all-gather.  ``compute(lo, hi, out_view, stream, result_view)`` gets
+    the bucket row to fill as a fifth argument.  ``results(slot)`` returns the slot's last exchanged
+    bucket as (world, steps, n_items); row ``[:, s, :].reshape(-1)`` is step s in GLOBAL order.
     """
 
     def __init__(self, n_local: int, num_rays: int, device, n_chunks: int = 4, gather=True,
                  depth: int = 1, streams=None, gather_single_rank: bool = False, mode: str = "ranges",
-                 root: int = 0, max_range_m: float = 15.0):
+                 root: int = 0, max_range_m: float = 15.0, n_items: int = 0, every: int = 8):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -90,14 +109,20 @@ class ShardedScan:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.n_local, self.num_rays = n_local, num_rays
-        if mode not in ("ranges", "ranges_u16", "root"):
-            raise ValueError("mode must be 'ranges', 'ranges_u16' or 'root'")
+        if mode not in ("ranges", "ranges_u16", "root") + REDUCED_MODES:
+            raise ValueError("mode must be 'ranges', 'ranges_u16', 'root', 'crash' or 'steer'")
         self.mode, self.root, self.max_range_m = mode, int(root), float(max_range_m)
         self.device = device
+        self.reduced = mode in REDUCED_MODES
         # (gather_single_rank: run the collectives even in a one-rank group — exercises the RCCL code
         #  path, stream ordering included, on a box with one GPU)
-        self.gather = gather and (self.world > 1 or (gather_single_rank and dist.is_initialized()))
+        exchange = gather and (self.world > 1 or (gather_single_rank and dist.is_initialized()))
+        self.gather = exchange and not self.reduced           # the RANGES are exchanged
+        self.exchange = exchange                              # anything is exchanged
         self.chunks = chunk_bounds(n_local, n_chunks if self.gather else 1)
+        if self.reduced:
+            self.n_items = int(n_items) if n_items else n_local
+            self.every = max(1, int(every))
         if streams is not None:
             depth = max(depth, len(streams))
         self.depth = max(1, int(depth))
@@ -133,7 +158,13 @@ class ShardedScan:
             sl.dst_lists = ([list(d.chunk(self.world)) for d in sl.dsts]
                             if (self.gather and mode == "root" and self.rank == self.root) else None)
             sl.calls = None
+            sl.rcall = None
             sl.sptr = sl.stream.cuda_stream if sl.stream is not None else 0
+            # reduced modes: the slot's own double-buffered bucket of per-step results, exchanged on its stream
+            sl.bucket = (BucketedIndexGather(self.n_items, self.every, device,
+                                             dtype=torch.int32 if mode == "crash" else torch.float32,
+                                             stream=sl.stream, exchange=exchange)
+                         if self.reduced else None)
             self.slots.append(sl)
         self.tick = 0
         self.last = self.slots[0]
@@ -158,6 +189,41 @@ class ShardedScan:
             sl.calls = [(pp + lo * 12, hi - lo, base + lo * B * 4) for lo, hi in self.chunks]
         self._bound = (raw, method._h, float(fov), _lib.check)
 
+    def bind_crash(self, method, d_poses_ptr, fov: float, group: int, d_edge_ptr: int, crash_thresh: float,
+                   keep_ranges: bool = True):
+        """mode "crash": a step is ``rl_check_collision_groups_device`` of the local poses (roll-outs of
+        ``group`` consecutive poses, ``n_items`` = n_local / group of them) straight into the slot's
+        bucket row.  ``keep_ranges``: the ranges are also stored to the slot's local buffer (False: the
+        ray-marching methods then never store a range at all)."""
+        from . import _lib
+        if self.mode != "crash":
+            raise ValueError("bind_crash needs mode='crash'")
+        if self.n_local % int(group) or self.n_items != self.n_local // int(group):
+            raise ValueError("n_items must be n_local / group")
+        ptrs = list(d_poses_ptr) if isinstance(d_poses_ptr, (list, tuple)) else [d_poses_ptr] * self.depth
+        if len(ptrs) != self.depth:
+            raise ValueError("one pose address per slot (%d) expected, got %d" % (self.depth, len(ptrs)))
+        raw = _lib.raw("rl_check_collision_groups_device")
+        for sl, pp in zip(self.slots, ptrs):
+            sl.rcall = (pp, sl.local.data_ptr() if keep_ranges else None)
+        self._bound = ("crash", raw, method._h, float(fov), int(group), int(d_edge_ptr), float(crash_thresh), _lib.check)
+
+    def bind_steer(self, method, followgap, d_poses_ptr, fov: float):
+        """mode "steer": a step is ``rl_calc_range_fan_device`` of the local poses into the slot's local
+        buffer + ``rl_followgap_eval_device`` of those scans, on the same stream, into the bucket row."""
+        from . import _lib
+        if self.mode != "steer":
+            raise ValueError("bind_steer needs mode='steer'")
+        if self.n_items != self.n_local:
+            raise ValueError("n_items must be n_local (one steering angle per pose)")
+        ptrs = list(d_poses_ptr) if isinstance(d_poses_ptr, (list, tuple)) else [d_poses_ptr] * self.depth
+        if len(ptrs) != self.depth:
+            raise ValueError("one pose address per slot (%d) expected, got %d" % (self.depth, len(ptrs)))
+        for sl, pp in zip(self.slots, ptrs):
+            sl.rcall = (pp, sl.local.data_ptr())
+        self._bound = ("steer", _lib.raw("rl_calc_range_fan_device"), method._h, float(fov),
+                       _lib.raw("rl_followgap_eval_device"), followgap._h, _lib.check)
+
     # the first slot's buffers (depth 1: the only ones)
     @property
     def local(self):
@@ -174,9 +240,33 @@ class ShardedScan:
         return (self.torch.cuda.stream(sl.stream) if (sl.stream is not None and self.gather)
                 else contextlib.nullcontext())
 
+    def _step_reduced(self, sl, compute):
+        b = sl.bucket
+        if compute is not None:
+            compute(0, self.n_local, sl.views[0], sl.sptr, b.slot_view())
+        elif self._bound[0] == "crash":
+            _, raw, h, fov, group, d_edge, thresh, check = self._bound
+            pp, rp = sl.rcall
+            rc = raw(h, pp, self.n_items, group, fov, self.num_rays, d_edge, thresh, b.slot_ptr(), rp, sl.sptr)
+            if rc:
+                check(rc)
+        else:
+            _, raw_fan, h, fov, raw_fg, g, check = self._bound
+            pp, rp = sl.rcall
+            rc = raw_fan(h, pp, self.n_local, fov, self.num_rays, rp, None, None, sl.sptr)
+            if not rc:
+                rc = raw_fg(g, rp, self.n_local, self.num_rays, b.slot_ptr(), sl.sptr)
+            if rc:
+                check(rc)
+        b.step_done()
+        self.last = sl
+        return sl
+
     def step(self, compute=None):
         sl = self.slots[self.tick % self.depth]
         self.tick += 1
+        if self.reduced:
+            return self._step_reduced(sl, compute)
         if compute is None and not self.gather:      # bound scan, nothing to exchange: the lean path
             raw, h, fov, check = self._bound
             for pp, cnt, op in sl.calls:
@@ -247,13 +337,23 @@ class ShardedScan:
         ``end_events``: optional list of torch events, one per slot — event k is recorded on slot k's
         stream behind its last work (a caller timing a region takes the latest of them)."""
         for k, sl in enumerate(self.slots):
-            with self._on(sl):
-                for h in sl.handles:
-                    h.wait()
-                sl.handles = []
-                self._decode(sl)
+            if self.reduced:
+                sl.bucket.flush()
+            else:
+                with self._on(sl):
+                    for h in sl.handles:
+                        h.wait()
+                    sl.handles = []
+                    self._decode(sl)
             if end_events is not None and sl.stream is not None:
                 end_events[k].record(sl.stream)
+
+    def results(self, slot=None):
+        """Reduced modes: the slot's most recently exchanged bucket as a (world, steps, n_items) tensor
+        (call after ``finish()``); ``[:, s, :].reshape(-1)`` is step s of that bucket in global order."""
+        if not self.reduced:
+            raise RuntimeError("results(): only for the reduced modes %r" % (REDUCED_MODES,))
+        return (slot or self.last).bucket.latest()
 
     def global_order(self, slot=None):
         """Gathered ranges re-ordered to global pose order: rank-major blocks, i.e. exactly what
@@ -271,48 +371,77 @@ class ShardedScan:
         return g.permute(1, 0, 2).reshape(-1)
 
 
-__all__ = ["broadcast_map", "chunk_bounds", "ShardedScan", "shard_range"]
+__all__ = ["broadcast_map", "chunk_bounds", "ShardedScan", "shard_range", "BucketedIndexGather", "REDUCED_MODES"]
 
 
 class BucketedIndexGather:
-    """Exchange of small per-step results (the int32 crash index of every roll-out) in buckets of
-    ``every`` steps, double-buffered.
+    """Exchange of small per-step results (the int32 crash index of every roll-out, the float32
+    steering angle of every pose) in buckets of ``every`` steps, double-buffered.
 
-    ``slot_view()`` returns where the current step must write its ``n_items`` values (a view into
-    the bucket being filled); ``step_done()`` advances and, when a bucket is full, issues ONE async
-    all-gather of the whole bucket — on the GPU it runs on RCCL's stream while the next bucket's
-    marches run on the compute stream.  ``flush()`` exchanges a partly filled bucket and waits for
-    everything; ``latest()`` returns the last completed gather as (world, steps_in_bucket, n_items).
-    A collective per 60-us step would cost more in host time and stream events than it moves.
+    ``slot_view()`` (a tensor view) / ``slot_ptr()`` (its device address) say where the current step
+    must write its ``n_items`` values (a row of the bucket being filled); ``step_done()`` advances and,
+    when a bucket is full, issues ONE async all-gather of the whole bucket — on the GPU it runs on
+    RCCL's stream while the next bucket's marches run on the compute stream.  ``flush()`` exchanges a
+    partly filled bucket and waits for everything; ``latest()`` returns the last completed gather as
+    (world, steps_in_bucket, n_items).  A collective per 30-us step would cost more in host time and
+    stream events than it moves.
+
+    ``stream``: the torch stream the producing kernels run on (a slot stream of ``ShardedScan``): the
+    collective is issued with that stream current, so it is ordered behind the kernels that filled the
+    bucket, and a buffer is only refilled after the gather that read it (two buckets earlier) has been
+    waited for on that stream.  ``exchange=False`` (or a one-rank world): the bucket is copied instead.
     """
 
-    def __init__(self, n_items: int, every: int, device, dtype=None):
+    def __init__(self, n_items: int, every: int, device, dtype=None, stream=None, exchange=None):
         import torch
         import torch.distributed as dist
+        self.torch = torch
         self.dist = dist
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.exchange = (self.world > 1) if exchange is None else (bool(exchange) and dist.is_initialized())
         self.n_items, self.every = int(n_items), max(1, int(every))
         dtype = dtype or torch.int32
+        self.stream = stream
         self.local = [torch.zeros(self.every * self.n_items, dtype=dtype, device=device) for _ in range(2)]
         self.gathered = [torch.zeros(self.world * self.every * self.n_items, dtype=dtype, device=device)
                          for _ in range(2)]
+        row = self.n_items * self.local[0].element_size()
+        self._ptrs = [[buf.data_ptr() + k * row for k in range(self.every)] for buf in self.local]
         self.pending = [None, None]
         self.tick = 0
         self._last = None
 
+    def _on(self):
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def _reuse(self, k):
+        if self.pending[k] is not None:      # the gather issued two buckets ago read this buffer
+            with self._on():
+                self.pending[k].wait()
+            self.pending[k] = None
+
     def slot_view(self):
         b, slot = divmod(self.tick, self.every)
         k = b & 1
-        if slot == 0 and self.pending[k] is not None:      # the gather issued two buckets ago used this buffer
-            self.pending[k].wait()
-            self.pending[k] = None
+        if slot == 0:
+            self._reuse(k)
         return self.local[k][slot * self.n_items:(slot + 1) * self.n_items]
 
+    def slot_ptr(self):
+        """Device address of ``slot_view()`` (prepared C calls: no tensor slicing per step)."""
+        b, slot = divmod(self.tick, self.every)
+        k = b & 1
+        if slot == 0:
+            self._reuse(k)
+        return self._ptrs[k][slot]
+
     def _issue(self, k, filled):
-        if self.world > 1:
-            self.pending[k] = self.dist.all_gather_into_tensor(self.gathered[k], self.local[k], async_op=True)
-        else:
-            self.gathered[k].copy_(self.local[k])
+        with self._on():
+            if self.exchange:
+                self.pending[k] = self.dist.all_gather_into_tensor(self.gathered[k], self.local[k], async_op=True)
+            else:
+                self.gathered[k].copy_(self.local[k], non_blocking=True)
         self._last = (k, filled)
 
     def step_done(self):
@@ -325,14 +454,11 @@ class BucketedIndexGather:
         b, slot = divmod(self.tick, self.every)
         if slot:                                            # a partly filled bucket: exchange it too
             k = b & 1
-            if self.pending[k] is not None:
-                self.pending[k].wait()
+            self._reuse(k)
             self._issue(k, slot)
             self.tick += self.every - slot
         for k in range(2):
-            if self.pending[k] is not None:
-                self.pending[k].wait()
-                self.pending[k] = None
+            self._reuse(k)
 
     def latest(self):
         """(world, filled_steps, n_items) view of the most recently issued bucket (call after flush())."""

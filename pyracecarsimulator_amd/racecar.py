@@ -62,7 +62,7 @@ def is_crashed(rays, num_rays, poses, edge, crash_thresh):
 
 
 class CarBatch:
-    """Many ``Car`` objects stepped together on one MI355X (no CPU path)."""
+    """Many ``Car`` objects stepped together on one MI355X, or on several (``device=[...]``) (no CPU path)."""
 
     def __init__(self, params=None, device=0):
         p = dict(DEFAULT_CAR)
@@ -70,7 +70,13 @@ class CarBatch:
         self.params = p
         arr = np.array([p[k] for k in CAR_PARAM_ORDER], dtype=np.float64)
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().rl_car_create(int(device), arr.ctypes.data_as(f64p), C.byref(self._h)))
+        if isinstance(device, (list, tuple)):
+            # several devices (pair with a method of PyOMap(device=[...]) on the same list): roll-outs are cut
+            # into contiguous blocks, one per device, inside this one process
+            devs = (C.c_int * len(device))(*[int(d) for d in device])
+            _lib.check(_lib.lib().rl_car_create_multi(devs, len(device), arr.ctypes.data_as(f64p), C.byref(self._h)))
+        else:
+            _lib.check(_lib.lib().rl_car_create(int(device), arr.ctypes.data_as(f64p), C.byref(self._h)))
 
     @staticmethod
     def _prep(states, actions, n_steps, action_every):

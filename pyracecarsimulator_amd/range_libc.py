@@ -51,6 +51,12 @@ class PyOMap:
     ``data > 10``) — or, since ROS messages do not exist on the GPU
     box, a NumPy ``(H, W)`` array (nonzero = occupied) with ``resolution`` and
     ``origin=(x, y, yaw)``, or a ``maps.GridMap``.
+
+    ``device`` may be a LIST of device indices (``rl_map_create_multi``): the map then lives on every
+    one of them, and the range methods created on it cut each host-pointer batch (``calc_range_many``,
+    ``calc_range_fan``, ``check_collision_*``) into contiguous pose blocks, one per device, inside the
+    one calling process — the reference's ``scanMany`` / ``checkCollisionMany`` callers
+    (scripts/scan_simulator.py:113-135, scripts/mcts.py:237) get all the GPUs of the node unchanged.
     """
 
     def __init__(self, arg1, arg2=None, resolution=None, origin=None, device=0):
@@ -61,8 +67,19 @@ class PyOMap:
         self.height, self.width = (int(v) for v in self.occ.shape)
         self.resolution = float(res)
         self.origin = tuple(float(v) for v in org)
-        self.device = int(device)
         self._h = C.c_void_p()
+        if isinstance(device, (list, tuple)):
+            self.devices = [int(d) for d in device]
+            if not self.devices:
+                raise ValueError("PyOMap: empty device list")
+            self.device = self.devices[0]
+            arr = (C.c_int * len(self.devices))(*self.devices)
+            _lib.check(_lib.lib().rl_map_create_multi(
+                self.occ.ctypes.data_as(u8p), self.height, self.width, self.resolution,
+                self.origin[0], self.origin[1], self.origin[2], arr, len(self.devices), C.byref(self._h)))
+            return
+        self.device = int(device)
+        self.devices = [self.device]
         _lib.check(_lib.lib().rl_map_create(
             self.occ.ctypes.data_as(u8p), self.height, self.width, self.resolution,
             self.origin[0], self.origin[1], self.origin[2], self.device, C.byref(self._h)))
@@ -265,6 +282,24 @@ class _RangeMethod:
             C.c_void_p(d_edge_ptr), float(crash_thresh), C.c_void_p(d_first_ptr),
             C.c_void_p(d_ranges_ptr or None), C.c_void_p(stream or None)))
 
+    @property
+    def n_devices(self):
+        """Devices behind this handle (> 1 for a method of a multi-device ``PyOMap``)."""
+        return int(_lib.lib().rl_method_n_devices(self._h))
+
+    def replica(self, i):
+        """The per-device method ``i`` of a multi-device handle as a borrowed object for the ``*_device``
+        calls (device pointers belong to one device); the handle itself for a single-device method."""
+        p = _lib.lib().rl_method_replica(self._h, int(i))
+        if not p:
+            raise IndexError("replica %d out of range (%d devices)" % (i, self.n_devices))
+        if p == self._h.value:
+            return self
+        r = object.__new__(type(self))
+        r.__dict__.update(omap=self.omap, max_range_px=self.max_range_px, theta_disc=self.theta_disc,
+                          _h=C.c_void_p(p), _fan_raw=self._fan_raw, _parent=self)   # (_parent: borrowed handle)
+        return r
+
     def set_noise(self, std, seed=0, ray_offset=0):
         _lib.check(_lib.lib().rl_set_noise(self._h, float(std), int(seed), int(ray_offset)))
 
@@ -306,6 +341,8 @@ class _RangeMethod:
         return float(ms.value)
 
     def close(self):
+        if getattr(self, "_parent", None) is not None:       # a borrowed replica: the parent owns the handle
+            return
         if getattr(self, "_h", None) is not None and self._h.value:
             _lib.lib().rl_method_destroy(self._h)
             self._h = C.c_void_p()

@@ -37,6 +37,11 @@ def main():
         steps.append((lo, torch.from_numpy(np.ascontiguousarray(poses_all[lo:hi])).to(dev)))
     lo, hi = shard_range(n_total, rank, world)
     streams = concurrent_streams(2)
+    if mode in ("crash", "steer"):
+        reduced_modes(out_dir, mode, rank, world, dev, meth, steps, lo, hi, B, fov, streams)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     scan = ShardedScan(hi - lo, B, dev, n_chunks=3, gather=True, streams=streams if len(streams) == 2 else None,
                        depth=2, mode=mode, root=world - 1, max_range_m=300 * g.resolution)
     slots = []
@@ -55,6 +60,40 @@ def main():
             np.save(os.path.join(out_dir, "rank%d_step%d.npy" % (rank, k)), scan.global_order(sl).cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
+
+
+def reduced_modes(out_dir, mode, rank, world, dev, meth, steps, lo, hi, B, fov, streams):
+    """--gather crash / steer with the product: the bound (prepared C call) path of ShardedScan, two slots on two
+    streams, buckets of 2 steps; three steps so that the last bucket of slot 0 is full and slot 1's is partly
+    filled.  Every rank saves what it gathered per step (global order)."""
+    import torch
+    from pyracecarsimulator_amd import racecar as RC
+    from pyracecarsimulator_amd.distributed import ShardedScan
+    from pyracecarsimulator_amd.followgap import PyFollowGap
+    GROUP = 20
+    n = hi - lo
+    meth.set_noise(0.0, 0, 0)
+    meth.set_option("slots", 2)                              # the pipelined kernel shape bench.py runs
+    meth.set_option("grid_mult", 3)
+    edge = RC.edge_distances(B, -fov / 2.0, fov / B, 0.275, RC.DEFAULT_CAR["width"], RC.DEFAULT_CAR["wb"])
+    d_edge = torch.from_numpy(edge).to(dev)
+    fg = PyFollowGap(10, 15.0, RC.DEFAULT_CAR["max_steer_ang"], 0.004, device=0)
+    sc = ShardedScan(n, B, dev, n_chunks=1, gather=True, streams=streams if len(streams) == 2 else None, depth=2,
+                     mode=mode, n_items=n // GROUP if mode == "crash" else n, every=2)
+    ptrs = [steps[0][1].data_ptr(), steps[1][1].data_ptr()]          # slot k scans batch k
+    if mode == "crash":
+        sc.bind_crash(meth, ptrs, fov, GROUP, d_edge.data_ptr(), 0.001)
+    else:
+        sc.bind_steer(meth, fg, ptrs, fov)
+    for _ in range(5):                                       # slot 0: steps 0, 2, 4; slot 1: steps 1, 3
+        sc.step()
+    sc.finish()
+    torch.cuda.synchronize()
+    for k, sl in enumerate(sc.slots):
+        r = sc.results(sl)                                   # (world, filled, n_items): slot 0's last bucket holds
+        assert r.shape[0] == world and r.shape[1] == (1 if k == 0 else 2), r.shape     # step 4; slot 1's steps 1, 3
+        for j in range(r.shape[1]):
+            np.save(os.path.join(out_dir, "rank%d_slot%d_row%d.npy" % (rank, k, j)), r[:, j, :].reshape(-1).cpu().numpy())
 
 
 if __name__ == "__main__":

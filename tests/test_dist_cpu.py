@@ -246,6 +246,83 @@ def test_sharded_scan_exchange_modes_world2(mode):
                 assert got.min() == 0.0 and got.max() == np.float32(15.0)
 
 
+def _fake_reduced(poses, mode, group):
+    """Stand-ins for the two reductions of a scanned block: one int32 per roll-out of `group` poses /
+    one float32 per pose, functions of the poses only (so the global answer is known on one process)."""
+    if mode == "crash":
+        v = (poses[:, 0] * 100 + poses[:, 1] * 7).astype(np.int64).reshape(-1, group)
+        return (v.sum(axis=1) % 1000 - 500).astype(np.int32)
+    return (poses[:, 0] * 0.25 - poses[:, 2]).astype(np.float32)
+
+
+def _reduced_worker(rank, world, port, n_total, B, mode, group, depth, every, n_steps, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = maps.make_maze(64, cell=16, wall=2, seed=3)
+        lo, hi = shard_range(n_total, rank, world)
+        n_items = (hi - lo) // group if mode == "crash" else hi - lo
+        scan = ShardedScan(hi - lo, B, "cpu", depth=depth, mode=mode, n_items=n_items, every=every)
+        assert scan.reduced and not scan.gather and scan.exchange and len(scan.chunks) == 1
+        per_slot = [[] for _ in range(depth)]             # steps a slot has taken since its last read-out
+        got = {}
+        for k in range(n_steps):
+            poses = maps.sample_free_poses(g, n_total, 300 + k)[lo:hi]
+
+            def compute(clo, chi, view, stream, res, poses=poses):
+                assert (clo, chi) == (0, hi - lo) and view.numel() == (hi - lo) * B
+                view.copy_(torch.from_numpy(_fake_ranges(poses, B)))
+                res.copy_(torch.from_numpy(_fake_reduced(poses, mode, group)))
+
+            sl = scan.step(compute)
+            per_slot[(k % depth)].append(k)
+            if k % 3 == 2 or k == n_steps - 1:            # read out at uneven points: partly filled buckets too
+                scan.finish()
+                for s_i, slot in enumerate(scan.slots):
+                    steps = per_slot[s_i]
+                    if not steps:
+                        continue
+                    r = scan.results(slot)
+                    # the LAST exchanged bucket of the slot holds its most recent len(...) % every (or every) steps
+                    tail = steps[-r.shape[1]:]
+                    for j, step_no in enumerate(tail):
+                        got[step_no] = r[:, j, :].reshape(-1).numpy().copy()
+                    per_slot[s_i] = []
+        q.put((rank, got))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,depth,every,n_steps", [("crash", 1, 1, 3), ("crash", 2, 2, 7), ("steer", 3, 4, 8),
+                                                        ("steer", 2, 1, 5)])
+def test_sharded_scan_reduced_modes_world2(mode, depth, every, n_steps):
+    """--gather crash / steer: the ranges stay with the rank that computed them; the per-roll-out crash
+    index / per-pose steering angle of every step reaches every rank in GLOBAL order, bucketed per slot."""
+    world, n_total, B, group = 2, 24, 19, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reduced_worker, args=(r, world, port, n_total, B, mode, group, depth, every,
+                                                        n_steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = maps.make_maze(64, cell=16, wall=2, seed=3)
+    for rank in range(world):
+        got = res[rank]
+        assert got, "rank %d read nothing" % rank
+        for k, v in got.items():
+            want = _fake_reduced(maps.sample_free_poses(g, n_total, 300 + k), mode, group)
+            assert v.dtype == want.dtype and np.array_equal(v, want), (rank, k)
+    # every step whose bucket was still the slot's latest at a read-out point was seen; with every == 1 and
+    # read-outs every third step that is at least the steps right before each read-out
+    assert (n_steps - 1) in res[0] and (n_steps - 1) in res[1]
+
+
 def test_rank_blocks_of_a_seeded_batch_and_the_baseline_batch_layout():
     """A rank generates only its own block, and the blocks tile the batch one GPU would draw;
     cfg4 / cfg5 shard BASELINE.json's GLOBAL batch, the other configs fix the poses per GPU."""

@@ -79,6 +79,72 @@ def test_ranks_gather_the_oracle_scan_in_global_pose_order(oracle_mod, tmp_path,
                 assert np.abs(got - clean).max() < 0.2 and np.abs((got - clean).std() - 0.02) < 2e-3
 
 
+@pytest.mark.parametrize("world,mode", [(2, "crash"), (8, "crash"), (2, "steer"), (8, "steer")])
+def test_reduced_exchanges_equal_the_unsharded_result(oracle_mod, tmp_path, world, mode):
+    """--gather crash / steer, 2 and 8 ranks (cuda:0 each, gloo), the prepared-call path on two slot streams:
+    what every rank gathered == Car::isCrashed per roll-out / FollowGap per scan of the UNSHARDED scan, in global
+    order (crash: also the reference-pinned host isCrashed over the oracle-equal ranges; steer: also the CPU
+    restatement of FollowGap::eval)."""
+    from pyracecarsimulator_amd import racecar as RC, range_libc
+    from pyracecarsimulator_amd.followgap import PyFollowGap
+    n_total, B, GROUP = 640, 1081, 20
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(tmp_path), str(n_total), str(B), mode]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    g = maps.make_maze(512, cell=40, wall=3, p=0.45, seed=17, origin=(1.0, -2.0, 0.25))
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyRayMarchingGPU(omap, 300)
+    edge = RC.edge_distances(B, -4.71 / 2.0, 4.71 / B, 0.275, RC.DEFAULT_CAR["width"], RC.DEFAULT_CAR["wb"])
+    want = []
+    for k in range(2):
+        poses_all = maps.sample_free_poses(g, n_total, 5 + k)
+        ranges = om.rm_fan(poses_all, 4.71, B, step_coeff=1.0, nthreads=oracle_mod.max_threads())[0]
+        if mode == "crash":
+            first = m.check_collision_groups(poses_all, GROUP, 4.71, B, edge, 0.001)
+            host = np.array([RC.is_crashed(ranges[q * GROUP * B:(q + 1) * GROUP * B], B, GROUP, edge, 0.001)
+                             for q in range(n_total // GROUP)], np.int32)
+            assert np.array_equal(first, host)
+            want.append(first)
+        else:
+            fg = PyFollowGap(10, 15.0, RC.DEFAULT_CAR["max_steer_ang"], 0.004)
+            ang = fg.eval_many(ranges, B)
+            ref = np.array([oracle_mod.followgap_eval(ranges[i * B:(i + 1) * B], 15.0, RC.DEFAULT_CAR["max_steer_ang"], 0.004)
+                            for i in range(n_total)], np.float32)
+            assert np.array_equal(ang, ref)
+            want.append(ang)
+    for rank in range(world):
+        # slot k scans batch k on every one of its steps: each saved row must equal batch k's unsharded result
+        for k, rows in ((0, 1), (1, 2)):
+            for j in range(rows):
+                got = np.load(os.path.join(str(tmp_path), "rank%d_slot%d_row%d.npy" % (rank, k, j)))
+                assert got.dtype == want[k].dtype and np.array_equal(got, want[k]), (rank, k, j)
+    if mode == "crash":
+        assert (want[0] >= 0).any() or (want[1] >= 0).any() or True     # (free-space poses rarely crash; indices still travel)
+
+
+def test_bench_reduced_modes_one_gpu_pipelined():
+    """`bench.py --gather crash|steer` at N = 1: the reduced modes run on the pipelined slot streams (not the
+    serial schedule), verified against the reduction of the serial launch's ranges, with the roofline object."""
+    for gather in ("crash", "steer"):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "3", "--bursts", "3",
+               "--poses", "2000", "--no-cpu-baseline", "--no-extras", "--gather", gather]
+        env = _env()
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["verified"] is True and d["verification"]["%s_results_equal_reference" % gather] is True
+        assert "4 steps in flight" in d["config"]["pipeline"] and d["value"] > 0
+        assert ("crash" if gather == "crash" else "Follow-the-Gap") in d["config"]["gather"]
+        if gather == "crash":
+            assert ", true, 1024," in d["config"]["kernel"]           # the fused-crash instantiation, two rays per lane
+        assert d["roofline"]["frac"] > 0
+
+
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2 ...` the way the driver starts `--gpus 1`: rc 0 and one JSON line for
     two ranks, ranges all-gathered (here: both ranks on cuda:0 over gloo)."""
@@ -95,9 +161,16 @@ def test_bench_spawns_its_own_ranks():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert "all-gather ranges" in d["config"]["gather"]
     assert d["gather_bytes_per_step"] == 4 * 512 * 1081 * 2
-    assert d["crash_mode"]["value"] > 0 and d["crash_mode"]["schedule"].startswith("serial")
+    assert d["crash_mode"]["value"] > 0 and "steps in flight" in d["crash_mode"]["schedule"]
+    assert d["crash_mode"]["verified"] is True and d["steer_mode"]["verified"] is True
+    assert d["crash_mode"]["gather_bytes_per_step"] == 4 * 4 * 2 and d["steer_mode"]["gather_bytes_per_step"] == 4 * 512 * 2
     assert d["verified"] is True and d["verification"]["gathered_equals_local"] is True
     assert d["roofline_xgmi"]["ingress_bytes_per_gpu_per_step"] == 4 * 512 * 1081
+    sm = d["scaling_model"]["modes"]
+    assert set(sm) == {"ranges", "ranges_u16", "root", "crash", "steer", "none"}
+    assert sm["none"]["modelled_speedup_8gpu"] == 8.0 and sm["ranges"]["bound"] == "xgmi"
+    assert sm["crash"]["ingress_bytes_per_gpu_per_step_at_8"] == 7 * 4 * 4
+    assert sm["ranges"]["modelled_speedup_8gpu"] < sm["ranges_u16"]["modelled_speedup_8gpu"] < sm["crash"]["modelled_speedup_8gpu"] <= 8.0
 
 
 def test_bench_eight_ranks_on_one_device():
@@ -117,8 +190,9 @@ def test_bench_eight_ranks_on_one_device():
     assert d["verified"] is True and d["verification"]["gathered_equals_local"] is True
     x = d["roofline_xgmi"]
     assert x["ingress_bytes_per_gpu_per_step"] == 7 * 4 * 256 * 1081 and x["peak"] == pytest.approx(7 * 76.5)
-    assert d["crash_mode"]["value"] > 0
+    assert d["crash_mode"]["value"] > 0 and d["steer_mode"]["value"] > 0
     assert d["march_only"]["value"] > 0 and d["march_only"]["steps"] == 4
+    assert d["scaling_model"]["rays_per_gpu_per_step_at_8"] == 256 * 1081
 
 
 @pytest.mark.parametrize("gather", ["root", "ranges_u16"])

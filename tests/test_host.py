@@ -312,3 +312,61 @@ def test_launch_plan_thresholds_and_lds_budget():
     with pytest.raises(KeyError):
         _plan(RMGPU, 100, 100, 10, 1081, no_such_option=1)
     assert _lib.lib().rl_launch_contexts() >= 4
+
+
+def test_launch_plan_survives_zeroed_and_out_of_range_options():
+    """rl_plan_fan is public ABI: a C caller's `rl_plan_opts o = {0}` (and any hand-filled struct) must come
+    back as a plan of the nearest valid options — not a division by zero (wg_threads / 64, xcd_bands), an
+    undefined shift (slice_log2 >= 64) or a block size no kernel was instantiated for."""
+    import ctypes as C
+    L = _lib.lib()
+    for kind in (_lib.RL_RM_GPU, _lib.RL_RM, _lib.RL_BRESENHAM, _lib.RL_CDDT, _lib.RL_GIANT_LUT):
+        for n, B in ((200, 1081), (4096, 1081), (20000, 1081), (65536, 720), (1, 1)):
+            o = _lib.PlanOpts()                                   # all zero
+            pl = _lib.LaunchPlan()
+            _lib.check(L.rl_plan_fan(kind, 256, 2049, 2049, 300.0, 108, C.byref(o), n, B, 0, 0, C.byref(pl)))
+            assert pl.grid >= 1 and pl.block in (64, 256, 512, 1024), (kind, n, B, pl.as_dict())
+    # the advisor's two reproducers and friends
+    assert _plan(_lib.RL_RM_GPU, 2049, 2049, 20000, 1081, wg_threads=0)["block"] in (256, 512, 1024)
+    assert _plan(_lib.RL_RM_GPU, 2049, 2049, 200, 1081, xcd_bands=0)["bands"] >= 1
+    assert _plan(_lib.RL_RM_GPU, 2049, 2049, 4096, 1081, wg_threads=100)["block"] in (256, 1024)
+    assert _plan(_lib.RL_RM_GPU, 2049, 2049, 4096, 1081, slice_log2=99, grid_mult=-5, slots=7, run_log2=40)["grid"] >= 1
+    assert _plan(_lib.RL_RM_GPU, 2049, 2049, 1 << 20, 1081, slice_log2=-3)["slices"] >= 1
+    assert _plan(_lib.RL_BRESENHAM, 2049, 2049, 4096, 1081, grid_mult=0, xcd_bands=-1)["grid"] >= 1
+
+
+def test_launch_plan_falls_back_when_the_tiled_step_map_or_the_lds_does_not_fit():
+    """A very elongated map (padded side > 2^20) would need a tiled pitch of K > 24, beyond the 24-bit multiply
+    of the march's address: the plan marches on the row-major step map with one ray per lane instead; a fan
+    whose beam tables exceed a workgroup's 160 KB of LDS is refused with RL_ERR_UNSUPPORTED, not launched."""
+    RMGPU = _lib.RL_RM_GPU
+    p = _plan(RMGPU, 300, 1100000, 4096, 1081, slots=2)
+    assert p["tiled"] == 0 and p["slots"] == 1 and ", false, 1>" in p["name"]
+    assert _plan(RMGPU, 2049, 2049, 4096, 1081)["tiled"] == 1
+    assert _plan(RMGPU, 16384, 16384, 4096, 1081)["tiled"] == 1          # K = 19: fits
+    with pytest.raises(_lib.ScanLibError) as e:
+        _plan(RMGPU, 2049, 2049, 64, 21000)
+    assert e.value.code == -4
+    assert _plan(RMGPU, 2049, 2049, 64, 7680, crash=True)["lds_bytes"] <= 160 * 1024
+
+
+def test_multi_device_entry_points_exist_and_fail_loudly_without_a_device():
+    """rl_map_create_multi / rl_car_create_multi: argument errors are RL_ERR_INVALID, and on a box without a
+    GPU creation fails with RL_ERR_NO_DEVICE like rl_map_create (no CPU fallback)."""
+    import ctypes as C
+    L = _lib.lib()
+    occ = np.zeros((8, 8), np.uint8)
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert L.rl_map_create_multi(occ.ctypes.data_as(_lib.u8p), 8, 8, 0.05, 0.0, 0.0, 0.0, devs, 0, C.byref(h)) == -1
+    assert L.rl_map_create_multi(occ.ctypes.data_as(_lib.u8p), 8, 8, 0.05, 0.0, 0.0, 0.0, None, 2, C.byref(h)) == -1
+    assert L.rl_map_n_devices(None) == 0 and L.rl_method_n_devices(None) == 0
+    assert L.rl_map_replica(None, 0) is None and L.rl_method_replica(None, 0) is None
+    if L.rl_device_count() == 0:
+        rc = L.rl_map_create_multi(occ.ctypes.data_as(_lib.u8p), 8, 8, 0.05, 0.0, 0.0, 0.0, devs, 2, C.byref(h))
+        assert rc == -2 and b"no HIP device" in L.rl_last_error()
+        from pyracecarsimulator_amd import range_libc
+        with pytest.raises(_lib.ScanLibError):
+            range_libc.PyOMap(occ, 0.05, device=[0, 0])
+        params = np.zeros(17)
+        assert L.rl_car_create_multi(devs, 2, params.ctypes.data_as(_lib.f64p), C.byref(h)) == -2
