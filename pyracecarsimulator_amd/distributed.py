@@ -405,6 +405,11 @@ class BucketedIndexGather:
         self.local = [torch.zeros(self.every * self.n_items, dtype=dtype, device=device) for _ in range(2)]
         self.gathered = [torch.zeros(self.world * self.every * self.n_items, dtype=dtype, device=device)
                          for _ in range(2)]
+        if getattr(self.local[0], "is_cuda", False):
+            # the zero fills above run on the CURRENT stream; the kernels that write the rows and the collective's
+            # copy-back run on other streams, unordered against it — a fill that is still queued (a GPU shared by
+            # several processes: the 8-rank dry runs) would land AFTER the results and wipe them
+            torch.cuda.current_stream(self.local[0].device).synchronize()
         row = self.n_items * self.local[0].element_size()
         self._ptrs = [[buf.data_ptr() + k * row for k in range(self.every)] for buf in self.local]
         self.pending = [None, None]
