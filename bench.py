@@ -195,8 +195,11 @@ def oracle_flags():
 def cpu_baseline(w, gmap, poses_all, method, seconds, check=None):
     """Oracle (kind "port": range_libc's CPU classes are absent from the reference mount) timed
     on this host's cores over a bounded sample of the same poses — RayMarching AND BresenhamsLine,
-    the two CPU classes BASELINE.json's north_star names.  ``check(om, O)`` (optional) runs the
-    oracle-side output verification with the oracle map this leg has loaded anyway."""
+    the two CPU classes BASELINE.json's north_star names.  Two builds of the same C restatement are timed:
+    ``-O3 -march=native`` compiled on this host (quoted as ``value`` when it builds and
+    returns the checker's bits on the sample) and the portable ``-O2`` checker build (``o2_build``).
+    ``check(om, O)`` (optional) runs the oracle-side output verification with the oracle map this leg has
+    loaded anyway."""
     from oracle import oracle as O
     om = O.OracleMap.from_gridmap(gmap, w.max_range_px)
     _ = om.dt
@@ -204,39 +207,59 @@ def cpu_baseline(w, gmap, poses_all, method, seconds, check=None):
     step = 1.0 if method == "RMGPU" else 0.999
     B = w.num_rays
 
-    def run(kind, poses, nt):
-        t = time.perf_counter()
+    def cast(kind, poses, nt, native):
         if kind == "BL":
-            om.bl_fan(poses, w.fov, B, nthreads=nt)
-        else:
-            om.rm_fan(poses, w.fov, B, step_coeff=step, nthreads=nt, want_hits=False, want_steps=False)
+            return om.bl_fan(poses, w.fov, B, nthreads=nt, native=native)[0]
+        return om.rm_fan(poses, w.fov, B, step_coeff=step, nthreads=nt, want_hits=False, want_steps=False,
+                         native=native)[0]
+
+    def run(kind, poses, nt, native):
+        t = time.perf_counter()
+        cast(kind, poses, nt, native)
         return time.perf_counter() - t
 
-    def measure(kind, secs, n1):
+    have_native = O.native_lib() is not None
+    if have_native:
+        # the optimised build must return the checker build's bits (same source, same arithmetic switches)
+        have_native = all(np.array_equal(cast(k, poses_all[:48], nthr, True), cast(k, poses_all[:48], nthr, False))
+                          for k in ("RM", "BL"))
+
+    def measure(kind, secs, n1, native):
         # 1 thread: faithful to range_libc's serial loop; bounded sample
-        run(kind, poses_all[:32], 1)
+        run(kind, poses_all[:32], 1, native)
         n1 = min(len(poses_all), n1)
-        t1 = run(kind, poses_all[:n1], 1)
+        t1 = run(kind, poses_all[:n1], 1, native)
         # all cores: repeat a batch until ~secs elapsed (threads ramp up slowly in VMs)
         batch = poses_all[:min(len(poses_all), 16384 if kind != "BL" else 2048)]
         reps, tot, t_all = 0, 0, 0.0
-        run(kind, batch, nthr)
+        run(kind, batch, nthr, native)
         while t_all < secs and reps < 200:
-            t_all += run(kind, batch, nthr)
+            t_all += run(kind, batch, nthr, native)
             tot += len(batch) * B
             reps += 1
         return (tot / t_all / 1e6, n1 * B / t1 / 1e6,
                 "%d x (%d poses x %d beams) in %.1f s; 1 thread: %d poses" % (reps, len(batch), B, t_all, n1))
 
     primary = "BL" if method == "BL" else "RM"
-    rate, rate1, sample = measure(primary, seconds, 512 if primary == "RM" else 64)
     name = {"RM": "RayMarching", "BL": "BresenhamsLine"}
+    n1 = {"RM": 512, "BL": 64}
+    flags_o2 = oracle_flags()
+    share = 0.6 if have_native else 1.0
+    rate, rate1, sample = measure(primary, seconds * share, n1[primary], have_native)
     out = {"value": round(rate, 3), "unit": "Mrays/s", "cores": nthr, "kind": "port",
            "sample": "%s oracle (oracle/rangelib_oracle.c, OpenMP over poses), %s of the same workload"
                      % (name[primary], sample),
-           "single_thread_Mrays_s": round(rate1, 3), "cpu_model": cpu_model(), "flags": oracle_flags()}
+           "single_thread_Mrays_s": round(rate1, 3), "cpu_model": cpu_model(),
+           "flags": ("gcc " + O.NATIVE_FLAGS + " (built on this host)") if have_native else flags_o2}
+    if have_native:
+        r_o2, r1_o2, s_o2 = measure(primary, seconds * 0.4, n1[primary], False)
+        out["o2_build"] = {"value": round(r_o2, 3), "single_thread_Mrays_s": round(r1_o2, 3), "flags": flags_o2,
+                           "sample": s_o2, "what": "the portable checker build of the same source, timed beside it "
+                                                   "(bit-identical results on the sample)"}
+    else:
+        out["native_build"] = "not available on this host (gcc -O3 -march=native failed or returned different bits)"
     other = "RM" if primary == "BL" else "BL"
-    r2, r21, s2 = measure(other, max(2.0, seconds / 3.0), 64 if other == "BL" else 512)
+    r2, r21, s2 = measure(other, max(2.0, seconds / 3.0), n1[other], have_native)
     out["bresenham" if other == "BL" else "raymarching"] = {
         "value": round(r2, 3), "unit": "Mrays/s", "cores": nthr, "single_thread": round(r21, 3),
         "sample": "%s oracle, %s" % (name[other], s2)}
@@ -420,27 +443,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def burst(step_fn, drain_fn, steps):
+    def burst(step_fn, drain_fn, steps, with_events=False):
         """EXACTLY ``steps`` steps between two barrier + synchronise brackets: (wall seconds, maximum
-        over ranks; device ms per step from HIP events on the slot streams)."""
-        # HIP events around the K timed steps, none between them (an event per step would put two extra
-        # barrier packets between consecutive launches): one before the first step is enqueued — every
-        # stream is idle, the barrier has just synchronised the device — and one per stream behind its
-        # last step; the region ends with the latest of those.  (torch creates the HIP event at the
-        # first record(): done here, outside the timed region.)
-        e0 = torch.cuda.Event(enable_timing=True)
-        ends = [torch.cuda.Event(enable_timing=True) for _ in streams]
-        for e in [e0] + ends:
-            e.record()
+        over ranks; device ms per step from HIP events on the slot streams, or None)."""
+        # The bursts `value` comes from carry NO HIP event: an event record is a barrier packet on its stream plus
+        # ~2 us of host time, five of them (one in front, one per slot stream behind its last step) cost a 20-step
+        # burst ~25 us of its ~600 (tools/r04/burst_overhead.py: an EMPTY bracket with the five records takes
+        # 31 us, without them 6) — timing instrumentation, not the hot path.  The device-time figure
+        # (`roofline.launch_ms`, `frac_device`) comes from separate bursts WITH the events (with_events=True): one
+        # before the first step is enqueued — every stream is idle, the barrier has just synchronised the
+        # device — and one per stream behind its last step; the region ends with the latest of those.  (torch
+        # creates the HIP event at the first record(): done outside the timed region.)
+        e0 = ends = None
+        if with_events:
+            e0 = torch.cuda.Event(enable_timing=True)
+            ends = [torch.cuda.Event(enable_timing=True) for _ in streams]
+            for e in [e0] + ends:
+                e.record()
         barrier()
         t0 = time.perf_counter()
-        e0.record()
+        if with_events:
+            e0.record()
         for _ in range(steps):
             step_fn()
         drain_fn(ends)
         barrier()
         el = time.perf_counter() - t0
-        dev_ms = max(e0.elapsed_time(e) for e in ends) / steps
+        dev_ms = (max(e0.elapsed_time(e) for e in ends) / steps) if with_events else None
         if multi:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -448,21 +477,23 @@ def main():
         return el, dev_ms
 
     def timed(step_fn, drain_fn, steps, warmup, bursts):
-        """W warm-up steps, then bursts of K steps; returns the per-burst (seconds, device ms per step)."""
+        """W warm-up steps, then bursts of K steps; returns the per-burst (seconds, device ms per step or None):
+        the wall-clock bursts first (no events inside), then up to 5 more with HIP events for the device time."""
         for _ in range(max(warmup, P)):             # (at least one step per slot: verification reads them all)
             step_fn()
         drain_fn(None)
         first = burst(step_fn, drain_fn, steps)
         n_b = bursts if first[0] < 0.2 else max(3, min(bursts, int(2.0 / first[0])))
-        return [first] + [burst(step_fn, drain_fn, steps) for _ in range(n_b - 1)]
+        runs_ = [first] + [burst(step_fn, drain_fn, steps) for _ in range(n_b - 1)]
+        return runs_ + [burst(step_fn, drain_fn, steps, with_events=True) for _ in range(min(5, n_b))]
 
     def timed_scan(sc, steps, warmup, bursts):
         return timed(sc.step, sc.finish, steps, warmup, bursts)
 
     def summarise(runs, steps, rays_per_step):
-        els = sorted(r[0] for r in runs)
+        els = sorted(r[0] for r in runs if r[1] is None)         # the wall-clock bursts (no events inside)
         med = els[len(els) // 2] if len(els) % 2 else 0.5 * (els[len(els) // 2 - 1] + els[len(els) // 2])
-        devs = sorted(r[1] for r in runs)
+        devs = sorted(r[1] for r in runs if r[1] is not None)    # the extra bursts with HIP events
         dev_med = devs[len(devs) // 2]
         v = lambda el: rays_per_step * steps / el / 1e6      # noqa: E731
         return {"value": v(med), "min": v(els[-1]), "max": v(els[0]), "ms_per_step": med / steps * 1e3,
@@ -668,7 +699,8 @@ def main():
                                        "angles (4 B/pose) in buckets of %d steps per slot" % max(1, a.gather_every)}[mode]
                              + ("" if (multi or mode == "none") else " (one GPU: nothing to exchange)")},
         "bursts": res["bursts"], "value_min": round(res["min"], 2), "value_max": round(res["max"], 2),
-        "value_is": "median of %d bursts of %d steps, each bracketed by barrier + device synchronisation" % (
+        "value_is": "median of %d bursts of %d steps, each bracketed by barrier + device synchronisation (no HIP "
+                    "event inside these bursts; step_ms_avg / roofline.launch_ms come from extra bursts with events)" % (
             res["bursts"], a.steps),
         "step_ms_avg": round(step_ms, 4),
         "mean_samples_per_ray": round(mean_steps, 3), "p99_samples_per_ray": round(p99_steps, 1),

@@ -41,6 +41,53 @@ def build(force: bool = False) -> str:
     return so
 
 
+_NATIVE = None
+
+
+def native_lib():
+    """The same restatement built ``-O3 -march=native`` FOR THE HOST IT RUNS ON (SURVEY.md section 8d asks for
+    that build of the timed CPU baseline; the checker stays the portable ``-O2`` build).  Compiled on first
+    use into oracle/_native/ under a name that carries a hash of this CPU's feature flags, so a file built on
+    another machine is never loaded.  Returns None when it cannot be built or loaded here.  Only the two
+    timed casters are bound (orc_rm_fan, orc_bl_fan)."""
+    global _NATIVE
+    if _NATIVE is not None:
+        return _NATIVE or None
+    import hashlib
+    flags = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = line
+                break
+    except OSError:
+        pass
+    tag = hashlib.sha1(flags.encode()).hexdigest()[:12]
+    out_dir = os.path.join(_HERE, "_native")
+    so = os.path.join(out_dir, "librangelib_oracle_native_%s.so" % tag)
+    src = os.path.join(_HERE, "rangelib_oracle.c")
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            os.makedirs(out_dir, exist_ok=True)
+            subprocess.check_call(["gcc"] + NATIVE_FLAGS.split() + ["-shared", "-o", so, src, "-lm"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = C.CDLL(so)
+        mp = C.POINTER(_OrcMap)
+        L.orc_rm_fan.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, C.c_float,
+                                 C.c_int, _f32p, _i32p, _u16p, C.c_int]
+        L.orc_bl_fan.argtypes = [mp, C.c_float, _f32p, C.c_int, C.c_float, C.c_int, _f32p, _i32p,
+                                 _u16p, C.c_int]
+        _NATIVE = L
+    except (OSError, subprocess.CalledProcessError):
+        _NATIVE = False
+    return _NATIVE or None
+
+
+#: flags of native_lib(): the arithmetic switches of the checker build are kept (no contraction, no fast-math), so
+#: the two builds return the same bits — bench.py checks that on its sample before it quotes the faster one
+NATIVE_FLAGS = "-O3 -march=native -fPIC -std=c11 -ffp-contract=off -fno-fast-math -fopenmp"
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -147,13 +194,13 @@ class OracleMap:
 
     # -- RayMarching -------------------------------------------------------
     def rm_fan(self, poses, fov, num_rays, step_coeff=0.999, nthreads=1, want_hits=True,
-               want_steps=True):
+               want_steps=True, native=False):
         poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
         n = poses.shape[0] * num_rays
         ranges = np.empty(n, dtype=np.float32)
         hits = np.empty((n, 2), dtype=np.int32) if want_hits else None
         steps = np.empty(n, dtype=np.uint16) if want_steps else None
-        lib().orc_rm_fan(C.byref(self._m), _p(self.dt, _f32p), self.max_range_px, step_coeff,
+        (native_lib() if native else lib()).orc_rm_fan(C.byref(self._m), _p(self.dt, _f32p), self.max_range_px, step_coeff,
                          _p(poses, _f32p), poses.shape[0], fov, num_rays, _p(ranges, _f32p),
                          _p(hits, _i32p), _p(steps, _u16p), nthreads)
         return ranges, hits, steps
@@ -194,13 +241,13 @@ class OracleMap:
         return ranges, hits, steps
 
     # -- BresenhamsLine ----------------------------------------------------
-    def bl_fan(self, poses, fov, num_rays, nthreads=1):
+    def bl_fan(self, poses, fov, num_rays, nthreads=1, native=False):
         poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
         n = poses.shape[0] * num_rays
         ranges = np.empty(n, dtype=np.float32)
         hits = np.empty((n, 2), dtype=np.int32)
         steps = np.empty(n, dtype=np.uint16)
-        lib().orc_bl_fan(C.byref(self._m), self.max_range_px, _p(poses, _f32p), poses.shape[0],
+        (native_lib() if native else lib()).orc_bl_fan(C.byref(self._m), self.max_range_px, _p(poses, _f32p), poses.shape[0],
                          fov, num_rays, _p(ranges, _f32p), _p(hits, _i32p), _p(steps, _u16p),
                          nthreads)
         return ranges, hits, steps

@@ -17,6 +17,8 @@ Run in the build container only (reads /root/reference; the GPU box never does):
 * golden/rm_*.npz         GOLD-A/B: ranges, hit cells, step counts of the C oracle on seeded
                           poses (cross-checked here against the independent NumPy statement
                           before being written).
+* golden/rm_libm_forms.npz  the same poses (first 16 per map) through the upstream-literal libm
+                          form of the oracle: what the canonical form's deviation is gated against.
 """
 from __future__ import annotations
 
@@ -273,6 +275,32 @@ def rm_golden(name, g, n_poses, seed, mrx=300, fov=4.71, num_rays=1081):
           os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024, "KiB")
 
 
+def libm_forms(n_poses=16):
+    """GOLD-A/B in the UPSTREAM-LITERAL form (orc_rm_fan_libm: one libm cosf/sinf cast per beam at
+    theta + (-fov/2 + j*fov/B) rounded to float32, every product and sum its own rounding, calc_range(y, x,
+    theta') — the closest available statement of range_libc's own arithmetic, which is absent from the
+    reference mount) for the first ``n_poses`` poses of every rm_*.npz: hit cells, ranges, sample counts for
+    both step coefficients.  The GPU tests gate the canonical form's deviation from these numbers
+    (tests/test_gpu_parity.py::test_device_fan_vs_upstream_literal_libm_form) instead of leaving it in prose.
+    Generated with this container's glibc; the arrays are committed data."""
+    out = {}
+    for name in ("rm_colombia", "rm_maze256", "rm_maze192_yaw"):
+        z = dict(np.load(os.path.join(GOLD, name + ".npz")))
+        rows, cols = (int(v) for v in z["shape"])
+        occ = np.ascontiguousarray(np.unpackbits(z["occ_packed"], axis=1)[:, :cols].astype(np.uint8))
+        g = maps.GridMap(occ, float(z["resolution"]), tuple(float(v) for v in z["origin"]), name)
+        om = O.OracleMap.from_gridmap(g, int(z["max_range_px"]))
+        poses = z["poses"][:n_poses]
+        for tag, sc in (("cpu", 0.999), ("gpu", 1.0)):
+            r, h, s_ = om.rm_fan_libm(poses, float(z["fov"]), int(z["num_rays"]), step_coeff=sc)
+            out["%s_ranges_%s" % (name, tag)] = r
+            out["%s_hits_%s" % (name, tag)] = h.astype(np.int16)
+            out["%s_steps_%s" % (name, tag)] = s_
+        out[name + "_n_poses"] = np.int32(len(poses))
+    np.savez_compressed(os.path.join(GOLD, "rm_libm_forms.npz"), **out)
+    print("rm_libm_forms", os.path.getsize(os.path.join(GOLD, "rm_libm_forms.npz")) // 1024, "KiB")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     colombia()
@@ -284,6 +312,7 @@ def main():
     g = maps.make_maze(192, cell=24, wall=2, p=0.5, seed=9, resolution=0.1,
                        origin=(-3.0, 2.5, 0.6))           # rotated origin (yaw != 0)
     rm_golden("rm_maze192_yaw", g, 16, 103, mrx=120, fov=6.0, num_rays=360)
+    libm_forms()
     followgap_ref()
 
 

@@ -29,7 +29,9 @@ def test_cfg2_bench_shape_four_batches_in_flight_bit_equal_to_oracle(oracle_mod)
     g, B, fov, mrx = w.gmap, w.num_rays, w.fov, w.max_range_px
     omap = range_libc.PyOMap(g)
     om = oracle_mod.OracleMap.from_gridmap(g, mrx)
-    om._dt = omap.distance_transform()            # (device EDT == oracle EDT is its own test; saves 20 s of CPU here)
+    # the device EDT at FULL size against the oracle's own EDT (Felzenszwalb in C, ~1 s at 4096^2): nothing of the
+    # device is fed to the checker
+    assert np.array_equal(omap.distance_transform(), om.dt), "device EDT differs from the oracle's at full size"
     m = range_libc.PyRayMarchingGPU(omap, mrx)
     n, P = 4096, 4
     batches = [workloads.make_poses(w, dt=om.dt, n_poses=n, seed=w.pose_seed + 7919 * k) for k in range(P)]

@@ -168,9 +168,12 @@ def test_bench_spawns_its_own_ranks():
     assert d["roofline_xgmi"]["ingress_bytes_per_gpu_per_step"] == 4 * 512 * 1081
     sm = d["scaling_model"]["modes"]
     assert set(sm) == {"ranges", "ranges_u16", "root", "crash", "steer", "none"}
-    assert sm["none"]["modelled_speedup_8gpu"] == 8.0 and sm["ranges"]["bound"] == "xgmi"
+    assert sm["none"]["modelled_speedup_8gpu"] == 8.0
     assert sm["crash"]["ingress_bytes_per_gpu_per_step_at_8"] == 7 * 4 * 4
-    assert sm["ranges"]["modelled_speedup_8gpu"] < sm["ranges_u16"]["modelled_speedup_8gpu"] <= 8.0
+    assert sm["ranges"]["ingress_bytes_per_gpu_per_step_at_8"] == 7 * 4 * 512 * 1081 == 2 * sm["ranges_u16"]["ingress_bytes_per_gpu_per_step_at_8"]
+    # (whether the literal ranges exchange is xGMI- or march-bound depends on the measured march rate: on this
+    #  same-device gloo dry run with 512 poses the host paces the steps; on hardware at 4096 poses it is xGMI-bound)
+    assert sm["ranges"]["modelled_speedup_8gpu"] <= sm["ranges_u16"]["modelled_speedup_8gpu"] <= 8.0
     # (crash / steer are march-bound: their modelled speed-up is 8 x their measured local rate / the march rate —
     #  on this same-device gloo dry run the host-side collectives make that rate meaningless, only the bound is checked)
     assert sm["crash"]["bound"] == "march" and sm["steer"]["bound"] == "march"

@@ -115,6 +115,50 @@ def test_rm_fan_reproduces_golden_vectors(name):
         assert np.array_equal(s, z["steps_" + tag]), tag
 
 
+def _libm_gate(a, ha, b, hb, res, what):
+    """The gate north_star's wording allows the canonical form against upstream's literal arithmetic: hit cells
+    identical on all but <= 1e-4 of the rays (grazing rays that catch or pass a corner cell), every range within
+    1.5 cells, every ray whose hit cell agrees within 1e-3 cell."""
+    ha, hb = np.asarray(ha, np.int32).reshape(-1, 2), np.asarray(hb, np.int32).reshape(-1, 2)
+    mism = (ha != hb).any(axis=1)
+    err = np.abs(a - b) / res
+    assert mism.mean() <= 1e-4 or mism.sum() <= 2, (what, int(mism.sum()), len(a))
+    assert err.max() <= 1.5, (what, float(err.max()))
+    assert err[~mism].max() <= 1e-3, (what, float(err[~mism].max()))
+    return int(mism.sum()), float(err.max())
+
+
+def test_device_fan_vs_upstream_literal_libm_form(oracle_mod):
+    """Parity gap, as narrow as the mount allows (range_libc itself is absent: PARITY UNPINNED).  The device
+    kernels reproduce the oracle's CANONICAL float32 form bit for bit; upstream computes every beam's direction
+    with libm cosf/sinf of theta + alpha_j.  This test gates the distance between the two on (1) the committed
+    upstream-literal vectors of GOLD-A/B (tests/golden/rm_libm_forms.npz, made by make_fixtures.py::libm_forms)
+    and (2) a 64-pose subsample of cfg2 cast live by the oracle's libm form: hit-cell mismatches <= 1e-4 of the
+    rays, every range within 1.5 cells (one cell on all but the rays whose hit cell moved)."""
+    L = np.load(os.path.join(GOLD, "rm_libm_forms.npz"))
+    seen = []
+    for name in ("rm_colombia", "rm_maze256", "rm_maze192_yaw"):
+        g, z = load_golden(name)
+        omap = range_libc.PyOMap(g)
+        fov, B, mrx = float(z["fov"]), int(z["num_rays"]), int(z["max_range_px"])
+        npz = int(L[name + "_n_poses"])
+        for tag, cls in (("cpu", range_libc.PyRayMarching), ("gpu", range_libc.PyRayMarchingGPU)):
+            r, h, s_ = _fan(cls(omap, mrx), z["poses"][:npz], fov, B)
+            seen.append((name, tag) + _libm_gate(r, h, L["%s_ranges_%s" % (name, tag)], L["%s_hits_%s" % (name, tag)],
+                                                 g.resolution, name + "/" + tag))
+            assert (s_ != L["%s_steps_%s" % (name, tag)]).mean() < 2e-3
+    w = workloads.cfg2()
+    g, B, mrx = w.gmap, w.num_rays, w.max_range_px
+    omap = range_libc.PyOMap(g)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    poses = workloads.make_poses(w, dt=om.dt)[np.linspace(0, w.n_poses - 1, 64).astype(np.int64)]
+    for tag, cls, sc in (("cpu", range_libc.PyRayMarching, 0.999), ("gpu", range_libc.PyRayMarchingGPU, 1.0)):
+        r, h, _ = _fan(cls(omap, mrx), poses, w.fov, B)
+        rb, hb, _ = om.rm_fan_libm(poses, w.fov, B, step_coeff=sc)
+        seen.append(("cfg2", tag) + _libm_gate(r, h, rb, hb, g.resolution, "cfg2/" + tag))
+    print("canonical (device) vs upstream-literal libm form — (map, coeff, rays with another hit cell, max |d| in cells):", seen)
+
+
 def test_pyomap_from_occupancy_grid_message_scans_like_the_oracle(oracle_mod):
     """Row a6 end to end: PyOMap(map_msg) with a quaternion origin (yaw != 0) and map_server data
     binarised as /root/reference/scripts/ros_interface.py:80-86 does -> ScanSimulator2D.scan."""
@@ -363,7 +407,9 @@ def test_cfg1_one_pose_through_scan_simulator(oracle_mod):
     g = w.gmap
     omap = range_libc.PyOMap(g)
     om = oracle_mod.OracleMap.from_gridmap(g, w.max_range_px)
-    om._dt = omap.distance_transform()
+    # the device EDT at FULL size against the oracle's own EDT (Felzenszwalb in C, ~1 s at 4096^2): nothing of the
+    # device is fed to the checker
+    assert np.array_equal(omap.distance_transform(), om.dt), "device EDT differs from the oracle's at full size"
     sim = ScanSimulator2D(w.num_rays, w.fov, 0.01, batch_size=1)
     sim.setMap(omap, w.max_range_px, g.resolution, g.origin)
     sim.setRaytracingMethod(w.method)
@@ -701,7 +747,9 @@ def test_cfg3_giant_lut_full_size(oracle_mod):
     omap = range_libc.PyOMap(g)
     m = range_libc.PyGiantLUTCast(omap, mrx, td)
     om = oracle_mod.OracleMap.from_gridmap(g, mrx)
-    om._dt = omap.distance_transform()
+    # the device EDT at FULL size against the oracle's own EDT (Felzenszwalb in C, ~1 s at 4096^2): nothing of the
+    # device is fed to the checker
+    assert np.array_equal(omap.distance_transform(), om.dt), "device EDT differs from the oracle's at full size"
     # table slab vs the oracle (2 rows = 5.8 M entries), bit-exact
     slab = om.lut_build(td, 1000, 1002, nthreads=oracle_mod.max_threads())
     assert np.array_equal(m.table(1000, 1002), slab)
@@ -823,7 +871,8 @@ def test_cfg5_noise_shard_reproduces_unsharded(oracle_mod):
     m.calc_range_fan(poses, clean, w.fov, B)
     assert clean.min() >= 0.0 and clean.max() <= (mrx + 1.5) * g.resolution
     om = oracle_mod.OracleMap.from_gridmap(g, mrx)
-    om._dt = dt
+    # the 4096^2 device EDT against the oracle's own (32-bit d^2, the column pass's tiling at 4096 rows)
+    assert np.array_equal(dt, om.dt), "device EDT differs from the oracle's at 4096^2"
     # rank 5's shard, every 128th pose of it, against the oracle
     lo5, hi5 = workloads.shard_range(n, 5, 8)
     assert hi5 - lo5 == 32768
@@ -1371,7 +1420,9 @@ def test_cfg3_cddt_full_size(oracle_mod):
     g, B, mrx = w.gmap, w.num_rays, w.max_range_px
     omap = range_libc.PyOMap(g)
     om = oracle_mod.OracleMap.from_gridmap(g, mrx)
-    om._dt = omap.distance_transform()
+    # the device EDT at FULL size against the oracle's own EDT (Felzenszwalb in C, ~1 s at 4096^2): nothing of the
+    # device is fed to the checker
+    assert np.array_equal(omap.distance_transform(), om.dt), "device EDT differs from the oracle's at full size"
     m = range_libc.PyCDDTCast(omap, mrx, 108)
     poses = workloads.make_poses(w, dt=om.dt)
     assert len(poses) == 65536

@@ -218,6 +218,31 @@ def test_canonical_fan_vs_upstream_literal_fan(oracle_mod):
     assert worst <= 2e-4
 
 
+def test_committed_upstream_literal_vectors_match_this_hosts_libm(oracle_mod):
+    """tests/golden/rm_libm_forms.npz (the upstream-literal libm form of GOLD-A/B, the vectors the GPU gate
+    test_device_fan_vs_upstream_literal_libm_form compares the device with) against the same form recomputed on
+    this host: hit cells and sample counts identical; ranges bit-equal unless this host's libm rounds a cosf /
+    sinf differently in the last place (then: within 1e-3 cell).  And the canonical form stays inside the gate
+    against the committed vectors."""
+    import os
+    from conftest import GOLD
+    L = np.load(os.path.join(GOLD, "rm_libm_forms.npz"))
+    for name in ("rm_colombia", "rm_maze256", "rm_maze192_yaw"):
+        g, z = load_golden(name)
+        om = oracle_mod.OracleMap.from_gridmap(g, int(z["max_range_px"]))
+        npz = int(L[name + "_n_poses"])
+        poses, B, fov = z["poses"][:npz], int(z["num_rays"]), float(z["fov"])
+        for tag, sc in (("cpu", 0.999), ("gpu", 1.0)):
+            r, h, s_ = om.rm_fan_libm(poses, fov, B, step_coeff=sc)
+            gr, gh = L["%s_ranges_%s" % (name, tag)], L["%s_hits_%s" % (name, tag)].astype(np.int32)
+            moved = (h != gh).any(axis=1)
+            assert moved.sum() <= 1, (name, tag, int(moved.sum()))
+            assert np.abs(r - gr)[~moved].max() <= 1e-3 * g.resolution
+            a, ha, _ = om.rm_fan(poses, fov, B, step_coeff=sc)
+            mism = (ha != gh).any(axis=1)
+            assert mism.sum() <= 2 and np.abs(a - gr).max() <= 1.5 * g.resolution
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_other_casters_c_oracle_equals_numpy_statements(oracle_mod, seed):
     """Rows a12-a14: BresenhamsLine, GiantLUTCast queries and CDDTCast (table + queries) of the C
