@@ -275,6 +275,16 @@ int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
  * rl_method_plan_fan applies it with a handle's current options; every launch goes through the
  * same function and rl_method_last_plan returns the plan the last launch of the handle used
  * (`name` is the kernel as a rocprofv3 kernel trace prints it, template arguments included).     */
+/* Which fields still carry weight (round 4; every default is a measured optimum, profiles/r03/plan_sweep.txt):
+ *   set by callers in production   grid_mult + slots (a caller that keeps several launches in flight: 3 and 2,
+ *                                  INTEGRATION.md), slice_log2 (only to force slicing in tests)
+ *   thresholds of the planner      inline_max, inline_map_kb, stripe_max, bin_multi_min, cddt_theta_min, xcd_bands,
+ *                                  low_water (-1 = automatic) — change them only with a sweep in hand
+ *   kernel selection for A/B       variant (0 chunk kernel, 2 occ_fan_lds), tiled (0 = row-major step map; the
+ *                                  planner clears it by itself when the tiled geometry does not fit), cddt_bins
+ *   diagnostics only               wg_threads, sort_poses, inline_prep, order_inline, bin_generic, run_log2,
+ *                                  cddt_sort, lut_debug, debug_stamps
+ * Out-of-range values are clamped by the planner (a zeroed struct is valid input).                              */
 typedef struct rl_plan_opts {
     int variant, grid_mult, wg_threads, low_water, sort_poses, xcd_bands, slots, tiled;
     int inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min, bin_generic;
