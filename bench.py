@@ -417,7 +417,7 @@ def main():
                          streams=streams, gather_single_rank=a.dist_single,
                          mode=md if md in ("ranges", "ranges_u16", "root") else "ranges", root=0,
                          max_range_m=max_range_m)
-        sc.bind(meth, pose_ptrs, w.fov)
+        sc.bind(meth, pose_ptrs, w.fov, noise=(w.noise_std, w.noise_seed, lo * B) if w.noise_std > 0 else None)
         return sc
 
     scan = make_scan(mode)
@@ -548,9 +548,15 @@ def main():
             good = bool(flag.item())
         return good
 
+    def reset_noise():
+        # (a chunked noisy scan leaves the method at its last chunk's ray offset: ShardedScan.bind(noise=...))
+        if w.noise_std > 0:
+            meth.set_noise(w.noise_std, w.noise_seed, lo * B)
+
     slot_refs = [None] * P
     if not a.no_verify:
         torch.cuda.synchronize()
+        reset_noise()
         if a.selftest_corrupt:
             scan.slots[-1].local[n * B // 2] += 1.0
         apply_schedule(False)
@@ -717,6 +723,7 @@ def main():
 
     def side_leg(md, steps):
         """Mode md on this run's streams, batches and schedule: its own ShardedScan and timed loop."""
+        reset_noise()
         sc = make_scan(md)
         runs_ = timed_scan(sc, steps, min(a.warmup, 5), min(a.bursts, 7))
         r_ = summarise(runs_, steps, rays_per_step)
@@ -817,6 +824,7 @@ def main():
         # that kernel's real limiters.  `serial` is the same kernel alone on an idle machine (library events
         # around the march kernel on extra steps AFTER the timed region — a pair of event records per launch
         # costs ~12 us, so it stays out of `value`): the duration a kernel trace of `--pipeline 1` reports.
+        reset_noise()
         wall_ms = res["ms_per_step"]
         achieved = bpr * n * B / (wall_ms * 1e-3) / 1e9
         achieved_dev = bpr * n * B / (step_ms * 1e-3) / 1e9

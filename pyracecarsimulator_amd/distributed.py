@@ -169,17 +169,24 @@ class ShardedScan:
         self.tick = 0
         self.last = self.slots[0]
         self._bound = None
+        self._noise = None
 
-    def bind(self, method, d_poses_ptr, fov: float):
+    def bind(self, method, d_poses_ptr, fov: float, noise=None):
         """Fix the scan a step performs — ``method.calc_range_fan_device`` of the local poses at
         device address ``d_poses_ptr`` into the slot's buffer — so that ``step()`` without a
         ``compute`` callback is one prepared C call per chunk (no per-step tensor slicing, pointer
         look-ups or ctypes argument objects: a step costs the host ~7 us instead of ~10, which is what
         a short burst of steps sees between its first and its last launch).
         ``d_poses_ptr``: one address, or one PER SLOT (``depth`` of them): every step in flight then
-        scans its own pose batch, as consecutive MCTS roll-out batches do."""
+        scans its own pose batch, as consecutive MCTS roll-out batches do.
+        ``noise``: (std, seed, first global ray id of this rank's block) when the method adds range noise and the
+        block is scanned in MORE THAN ONE chunk: the noise is keyed by the global ray id, so every chunk call must
+        start at its own ray offset (``rl_set_noise`` in front of it) to reproduce the unchunked scan."""
         from . import _lib
         raw = _lib.raw("rl_calc_range_fan_device")
+        self._noise = None
+        if noise is not None and noise[0] > 0 and len(self.chunks) > 1:
+            self._noise = (_lib.raw("rl_set_noise"), float(noise[0]), int(noise[1]), int(noise[2]))
         B = self.num_rays
         ptrs = list(d_poses_ptr) if isinstance(d_poses_ptr, (list, tuple)) else [d_poses_ptr] * self.depth
         if len(ptrs) != self.depth:
@@ -223,6 +230,10 @@ class ShardedScan:
             sl.rcall = (pp, sl.local.data_ptr())
         self._bound = ("steer", _lib.raw("rl_calc_range_fan_device"), method._h, float(fov),
                        _lib.raw("rl_followgap_eval_device"), followgap._h, _lib.check)
+
+    def _chunk_noise(self, h, ci):
+        raw_noise, std, seed, base = self._noise
+        raw_noise(h, std, seed, base + self.chunks[ci][0] * self.num_rays)
 
     # the first slot's buffers (depth 1: the only ones)
     @property
@@ -269,7 +280,9 @@ class ShardedScan:
             return self._step_reduced(sl, compute)
         if compute is None and not self.gather:      # bound scan, nothing to exchange: the lean path
             raw, h, fov, check = self._bound
-            for pp, cnt, op in sl.calls:
+            for ci, (pp, cnt, op) in enumerate(sl.calls):
+                if self._noise is not None:
+                    self._chunk_noise(h, ci)
                 rc = raw(h, pp, cnt, fov, self.num_rays, op, None, None, sl.sptr)
                 if rc:
                     check(rc)
@@ -285,6 +298,8 @@ class ShardedScan:
                 if compute is None:
                     raw, hm, fov, check = self._bound
                     pp, cnt, op = sl.calls[ci]
+                    if self._noise is not None:
+                        self._chunk_noise(hm, ci)
                     rc = raw(hm, pp, cnt, fov, self.num_rays, op, None, None, sl.sptr)
                     if rc:
                         check(rc)

@@ -170,6 +170,7 @@ class _RangeMethod:
         _lib.check(_lib.lib().rl_method_create(omap._h, self.KIND, self.max_range_px,
                                                self.theta_disc, C.byref(self._h)))
         self._fan_raw = _lib.raw("rl_calc_range_many_fan")
+        self._fan_dense_raw = _lib.raw("rl_calc_range_fan")
 
     # -- the reference's entry point ----------------------------------------
     def calc_range_many(self, ins, outs, fov=None, num_rays=None):
@@ -297,7 +298,7 @@ class _RangeMethod:
             return self
         r = object.__new__(type(self))
         r.__dict__.update(omap=self.omap, max_range_px=self.max_range_px, theta_disc=self.theta_disc,
-                          _h=C.c_void_p(p), _fan_raw=self._fan_raw, _parent=self)   # (_parent: borrowed handle)
+                          _h=C.c_void_p(p), _fan_raw=self._fan_raw, _fan_dense_raw=self._fan_dense_raw, _parent=self)   # (_parent: borrowed handle)
         return r
 
     def set_noise(self, std, seed=0, ray_offset=0):

@@ -42,6 +42,7 @@ class ScanSimulator2D:
         self.output_vector_many = _lib.pinned_zeros(batch_size * self.num_rays, np.float32)
         self.input_vector_many = np.zeros((batch_size * self.num_rays, 3), dtype=np.float32)
         self._poses_many = np.zeros((batch_size, 3), dtype=np.float32)
+        self._many_addr = (None, None, 0, 0)
 
         self.hasMap = False
         self.scan_method = None
@@ -121,5 +122,15 @@ class ScanSimulator2D:
                 p[i, 1] = poses[i][1]
                 p[i, 2] = poses[i][2]
         self.input_vector_many[::n, :] = p       # reference-visible sparse layout
-        self.scan_method.calc_range_fan(p, self.output_vector_many, self.fov, n)
+        m = self.scan_method
+        if getattr(m, "_fan_dense_raw", None) is not None:
+            # the dense form of the same call on the cached vectors' addresses (no per-call ctypes objects or
+            # re-validation: ~2.5 us of the ~43 a 200-pose roll-out takes end to end)
+            if self._many_addr[0] is not p or self._many_addr[1] is not self.output_vector_many:
+                self._many_addr = (p, self.output_vector_many, p.ctypes.data, self.output_vector_many.ctypes.data)
+            rc = m._fan_dense_raw(m._h, self._many_addr[2], b, self.fov, n, self._many_addr[3], None, None)
+            if rc:
+                _lib.check(rc)
+        else:                                    # a foreign range_libc object: the public form
+            m.calc_range_fan(p, self.output_vector_many, self.fov, n)
         return self.output_vector_many.copy() if copy else self.output_vector_many

@@ -219,6 +219,24 @@ def test_bench_exchange_modes_two_ranks(gather):
     assert d["march_only"]["value"] > 0
 
 
+def test_bench_chunked_noisy_shard_two_ranks():
+    """cfg5's shape on the serial schedule: more than 32768 poses per rank are scanned in FOUR chunk calls per step
+    and the Gaussian noise is keyed by the global ray id — every chunk must start at its own ray offset or the
+    gathered ranges differ from the unchunked reference launch (a 2-rank cfg5 run once failed exactly so)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg5", "--poses", "33000",
+           "--steps", "3", "--warmup", "1", "--bursts", "3", "--same-device", "--backend", "gloo", "--no-cpu-baseline",
+           "--no-crash-line", "--no-extras"]
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "4 chunks per step" in d["config"]["gather"] and d["config"]["pipeline"].startswith("serial")
+    assert d["verified"] is True and d["verification"]["slots_equal_serial_launch"] is True
+    assert d["verification"]["gathered_equals_local"] is True
+
+
 def test_bench_single_rank_through_rccl():
     """The N>1 code path on real RCCL with the one GPU of the box: a one-rank process group, ranges
     all-gathered chunk by chunk through it on the pipelined streams (async collectives ordered against
