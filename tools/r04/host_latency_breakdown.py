@@ -6,6 +6,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pyracecarsimulator_amd import ScanSimulator2D, _lib, maps, range_libc, workloads
 
+if os.environ.get("SPIN") == "1":                       # hipSetDeviceFlags(hipDeviceScheduleSpin) before anything else
+    import torch  # noqa: F401  (the process must share torch's HIP runtime)
+    hip = C.CDLL("libamdhip64.so")
+    print("hipSetDeviceFlags(spin) ->", hip.hipSetDeviceFlags(C.c_uint(1)))
+
+
 def med(f, n=300, warm=30):
     for _ in range(warm): f()
     ts = []
