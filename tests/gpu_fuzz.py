@@ -122,6 +122,16 @@ def one_case(seed):
             out = np.empty(n, np.float32); m.calc_range_fan(poses, out, fov, B)
             assert np.array_equal(out, om2.rm_fan(poses, fov, B, 0.999)[0]), "after map update"
             m.close(); omap.update(occ)
+            if r.random() < 0.25:
+                # one handle over several devices (the box has one GPU: device 0 two or three times): the batch cut into
+                # pose blocks, ranges with noise-free parity against the oracle, crash indices global
+                multi = range_libc.PyOMap(g, device=[0] * int(r.integers(2, 4)))
+                mm = range_libc.PyRayMarchingGPU(multi, mrx); mm.set_option("multi_min_poses", int(r.choice([1, 16, 64])))
+                out = np.empty(n, np.float32); mm.calc_range_fan(poses, out, fov, B)
+                assert np.array_equal(out, rr), "multi-device fan"
+                assert mm.check_collision_many(poses, fov, B, edge, thr) == O.is_crashed(rr, B, P, edge, thr), "multi-device crash many"
+                assert mm.check_collision_groups(poses, grp, fov, B, edge, thr).tolist() == want, "multi-device crash groups"
+                mm.close(); multi.close()
             ins = poses[r.integers(0, P, 500)].copy(); ins[:, 2] = r.uniform(-9, 9, 500).astype(np.float32)
             outs = np.empty(500, np.float32)
             m = range_libc.PyRayMarching(omap, mrx); m.calc_range_many(ins, outs)

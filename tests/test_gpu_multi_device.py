@@ -107,6 +107,38 @@ def test_reference_call_forms_on_a_multi_device_handle(world, oracle_mod):
     m1.close()
 
 
+@pytest.mark.parametrize("cls,td", [(range_libc.PyCDDTCast, 108), (range_libc.PyGiantLUTCast, 180)])
+def test_table_methods_on_a_multi_device_map(world, oracle_mod, cls, td):
+    """The bandwidth-bound variants build their table on EVERY replica (lazily, on the first block a device gets)
+    and answer like the single-device handle and the oracle; options set on the handle reach every replica."""
+    g, one, multi = world
+    small = maps.make_maze(96, cell=12, wall=2, p=0.5, seed=3)
+    o1, om_ = range_libc.PyOMap(small, device=0), range_libc.PyOMap(small, device=[0, 0])
+    m1, mm = cls(o1, 60, td), cls(om_, 60, td)
+    mm.set_option("multi_min_poses", 8)
+    assert mm.get_info("multi_min_poses") == 8 and mm.get_info("n_devices") == 2 and m1.get_info("n_devices") == 1
+    mm.set_option("grid_mult", 5)
+    assert mm.replica(0).get_info("grid_mult") == 5 == mm.replica(1).get_info("grid_mult")
+    orc = oracle_mod.OracleMap.from_gridmap(small, 60)
+    poses = maps.sample_free_poses(small, 100, 8)
+    a, b = np.empty(100 * 360, np.float32), np.empty(100 * 360, np.float32)
+    m1.calc_range_fan(poses, a, 6.0, 360)
+    mm.calc_range_fan(poses, b, 6.0, 360)
+    want = orc.cddt_fan(td, poses, 6.0, 360) if cls is range_libc.PyCDDTCast else orc.lut_fan(orc.lut_build(td), poses, 6.0, 360)
+    assert np.array_equal(a, b) and np.array_equal(b, want)
+    assert mm.calc_range(float(poses[0, 0]), float(poses[0, 1]), 0.3) == m1.calc_range(float(poses[0, 0]), float(poses[0, 1]), 0.3)
+    # a map update reaches every replica's table
+    occ2 = small.occ.copy()
+    occ2[40:44, 10:80] = 1
+    o1.update(occ2)
+    om_.update(occ2)
+    m1.calc_range_fan(poses, a, 6.0, 360)
+    mm.calc_range_fan(poses, b, 6.0, 360)
+    assert np.array_equal(a, b)
+    for o in (mm, m1, om_, o1):
+        o.close()
+
+
 def test_noise_is_keyed_by_the_global_ray_id_across_device_blocks(world):
     g, one, multi = world
     m1, mm = range_libc.PyRayMarchingGPU(one, MRX), range_libc.PyRayMarchingGPU(multi, MRX)
