@@ -279,7 +279,9 @@ struct MultiPool {
     // becomes the caller's rl_last_error
     int run(std::vector<std::function<int()>> &jobs)
     {
-        const size_t k = std::min(jobs.size(), w.size() + 1);
+        if (jobs.size() > w.size() + 1)
+            return fail(RL_ERR_INVALID, "internal: %zu pose blocks for %zu devices", jobs.size(), w.size() + 1);
+        const size_t k = jobs.size();
         for (size_t i = 1; i < k; ++i) {
             Worker &x = *w[i - 1];
             std::lock_guard<std::mutex> lk(x.mu);
