@@ -52,8 +52,6 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
-XGMI_LINKS = 7               # fully connected 8-GPU node: one link per peer
-XGMI_LINK_GBS = 153.0 / 2    # ~153 GB/s per link both directions together -> per direction
 
 
 def parse_args():
@@ -296,7 +294,8 @@ def main():
     import torch
     import torch.distributed as dist
     from pyracecarsimulator_amd import _lib, range_libc, workloads
-    from pyracecarsimulator_amd.distributed import ShardedScan, broadcast_map
+    from pyracecarsimulator_amd.distributed import (ShardedScan, broadcast_map, XGMI_LINKS, XGMI_LINK_GBS,
+                                                    exchange_bytes as _exchange_bytes, scaling_model)
     from pyracecarsimulator_amd.pipeline import concurrent_streams
 
     if not torch.cuda.is_available():
@@ -715,11 +714,8 @@ def main():
     per_rank = n * B
 
     def exchange_bytes(md, wd):
-        """(bytes all GPUs send per step, bytes the busiest GPU RECEIVES per step) of mode md on wd GPUs with
-        this run's per-GPU batch."""
-        per = {"ranges": 4 * per_rank, "ranges_u16": 2 * per_rank, "root": 4 * per_rank, "crash": 4 * n_groups,
-               "steer": 4 * n, "none": 0}[md]
-        return per * wd, per * (wd - 1)
+        """(bytes all GPUs send per step, bytes the busiest GPU receives) of mode md on wd GPUs, this run's batch."""
+        return _exchange_bytes(md, wd, per_rank, n, n_groups)
 
     def side_leg(md, steps):
         """Mode md on this run's streams, batches and schedule: its own ShardedScan and timed loop."""
@@ -787,28 +783,20 @@ def main():
         # xGMI ingress of the mode's bytes is slower; the speed-up is against ONE GPU marching without exchange.
         base = legs.get("none", legs.get(mode))
         r_none = base["value"] / world                         # Mrays/s per GPU, march only
-        rays8 = per_rank if scaling == "weak" else per_rank * world // 8     # rays per GPU and step at 8 GPUs
-        peak8 = XGMI_LINKS * XGMI_LINK_GBS * 1e9
-        model = {}
-        for md in ("ranges", "ranges_u16", "root", "crash", "steer", "none"):
-            scale8 = rays8 / per_rank
-            ing8 = exchange_bytes(md, 8)[1] * scale8
-            floor_ms = ing8 / peak8 * 1e3
-            local = legs[md]["value"] / world if (md in ("crash", "steer") and md in legs) else r_none
-            xg = (rays8 / (floor_ms * 1e-3) / 1e6) if floor_ms > 0 else float("inf")
-            rate = min(local, xg)
-            model[md] = {"ingress_bytes_per_gpu_per_step_at_8": int(ing8), "xgmi_floor_ms": round(floor_ms, 5),
-                         "per_gpu_local_mrays_s": round(local, 1),
-                         "per_gpu_local_is": ("measured: %s leg of this run" % md) if (md in ("crash", "steer") and md in legs)
-                                             else "measured: march without exchange (this run)",
-                         "bound": "xgmi" if xg < local else "march",
-                         "modelled_speedup_8gpu": round(8.0 * rate / r_none, 2)}
+        scale8 = 1.0 if scaling == "weak" else world / 8.0     # the per-GPU batch at 8 GPUs (strong: global batch / 8)
+        model = scaling_model(r_none, {md: legs[md]["value"] / world for md in ("crash", "steer") if md in legs},
+                              int(per_rank * scale8), int(n * scale8), max(1, int(n_groups * scale8)))
+        for md, row in model.items():
+            row["per_gpu_local_is"] = ("measured: %s leg of this run" % md) if (md in ("crash", "steer") and md in legs) \
+                else "measured: march without exchange (this run)"
         out["scaling_model"] = {"modes": model, "per_gpu_march_mrays_s": round(r_none, 1),
-                                "rays_per_gpu_per_step_at_8": int(rays8),
-                                "xgmi_peak_gbs": round(peak8 / 1e9, 1),
+                                "rays_per_gpu_per_step_at_8": int(per_rank * scale8),
+                                "xgmi_peak_gbs": round(XGMI_LINKS * XGMI_LINK_GBS, 1),
                                 "speedup_is": "8 x min(per-GPU local rate of the mode, rays per step / xGMI ingress floor) "
                                               "/ per-GPU march rate; link rate assumed (%d x %.1f GB/s per direction), "
-                                              "local rates measured on %d GPU(s) in this run" % (XGMI_LINKS, XGMI_LINK_GBS, world),
+                                              "local rates measured on %d GPU(s) in this run%s" % (
+                                                  XGMI_LINKS, XGMI_LINK_GBS, world,
+                                                  " (same-device dry run over gloo: host-paced, not representative)" if a.same_device else ""),
                                 "reading": "`value` is the literal exchange BASELINE.json names (all-gather of every "
                                            "range): xGMI-bound at ~1x whatever the kernel does; crash / steer are what the "
                                            "reference's consumers read (scripts/mcts.py:237-245,262-267) and scale with the march"}

@@ -57,6 +57,45 @@ def broadcast_map(gmap_or_none, src=0, device=None):
                    (float(meta[3].item()), float(meta[4].item()), float(meta[5].item())), name)
 
 
+#: xGMI of a fully connected 8-GPU MI355X node: one link per peer, ~153 GB/s per link both directions together
+XGMI_LINKS = 7
+XGMI_LINK_GBS = 153.0 / 2
+
+EXCHANGE_MODES = ("ranges", "ranges_u16", "root", "crash", "steer", "none")
+
+
+def exchange_bytes(mode: str, world: int, rays_per_gpu: int, poses_per_gpu: int, groups_per_gpu: int):
+    """(bytes all GPUs send per step, bytes the busiest GPU RECEIVES per step) of an exchange mode on ``world``
+    GPUs: 4 B per ray (``ranges``, ``root``: into the one consumer), 2 B per ray (``ranges_u16``), 4 B per roll-out
+    (``crash``), 4 B per pose (``steer``)."""
+    per = {"ranges": 4 * rays_per_gpu, "ranges_u16": 2 * rays_per_gpu, "root": 4 * rays_per_gpu,
+           "crash": 4 * groups_per_gpu, "steer": 4 * poses_per_gpu, "none": 0}[mode]
+    return per * world, per * (world - 1)
+
+
+def scaling_model(march_mrays_per_gpu: float, local_mrays_per_gpu: dict, rays_per_gpu: int, poses_per_gpu: int,
+                  groups_per_gpu: int, target_world: int = 8, links: int = XGMI_LINKS,
+                  link_gbs: float = XGMI_LINK_GBS):
+    """What each exchange mode can reach on ``target_world`` GPUs of one node, from rates measured on the GPUs at
+    hand: a GPU computes at ``local_mrays_per_gpu[mode]`` (the per-GPU rate of the mode's LOCAL work; modes that only
+    move ranges overlap their exchange with the marches and compute at the march rate) unless the xGMI ingress of
+    the mode's bytes — into the busiest GPU, ``links`` links at ``link_gbs`` GB/s per direction — is slower; the
+    speed-up is against ONE GPU marching without exchange.  ``*_per_gpu`` are the per-GPU batch AT ``target_world``
+    GPUs.  Pure arithmetic (unit-tested on the CPU box); bench.py prints it on every N>1 line."""
+    peak = links * link_gbs * 1e9
+    out = {}
+    for md in EXCHANGE_MODES:
+        ingress = exchange_bytes(md, target_world, rays_per_gpu, poses_per_gpu, groups_per_gpu)[1]
+        floor_s = ingress / peak
+        local = float(local_mrays_per_gpu.get(md, march_mrays_per_gpu))
+        xg = (rays_per_gpu / floor_s / 1e6) if floor_s > 0 else float("inf")
+        out[md] = {"ingress_bytes_per_gpu_per_step_at_%d" % target_world: int(ingress),
+                   "xgmi_floor_ms": round(floor_s * 1e3, 5), "per_gpu_local_mrays_s": round(local, 1),
+                   "bound": "xgmi" if xg < local else "march",
+                   "modelled_speedup_%dgpu" % target_world: round(target_world * min(local, xg) / march_mrays_per_gpu, 2)}
+    return out
+
+
 def chunk_bounds(n_local: int, n_chunks: int):
     """Split a local block of ``n_local`` poses into <= n_chunks equal chunks (the last rank-
     uniform size is required by all_gather_into_tensor, so n_local must divide evenly or the
@@ -386,7 +425,8 @@ class ShardedScan:
         return g.permute(1, 0, 2).reshape(-1)
 
 
-__all__ = ["broadcast_map", "chunk_bounds", "ShardedScan", "shard_range", "BucketedIndexGather", "REDUCED_MODES"]
+__all__ = ["broadcast_map", "chunk_bounds", "ShardedScan", "shard_range", "BucketedIndexGather", "REDUCED_MODES",
+           "exchange_bytes", "scaling_model", "EXCHANGE_MODES", "XGMI_LINKS", "XGMI_LINK_GBS"]
 
 
 class BucketedIndexGather:

@@ -323,6 +323,32 @@ def test_sharded_scan_reduced_modes_world2(mode, depth, every, n_steps):
     assert (n_steps - 1) in res[0] and (n_steps - 1) in res[1]
 
 
+def test_scaling_model_arithmetic():
+    """bench.py's `scaling_model` (distributed.scaling_model) on cfg2's numbers: 4096 x 1081 rays per GPU, 167 Grays/s
+    per GPU marching, the fused crash test at 96 % and scan + FollowGap at 74 % of that: the literal all-gather of ranges
+    is xGMI-bound below 1x, half the bytes double it, the reduced modes scale with the march."""
+    from pyracecarsimulator_amd.distributed import exchange_bytes, scaling_model
+    rays, poses, groups = 4096 * 1081, 4096, 32
+    assert exchange_bytes("ranges", 8, rays, poses, groups) == (8 * 4 * rays, 7 * 4 * rays)
+    assert exchange_bytes("ranges_u16", 8, rays, poses, groups)[1] == 7 * 2 * rays
+    assert exchange_bytes("crash", 8, rays, poses, groups) == (8 * 4 * 32, 7 * 4 * 32)
+    assert exchange_bytes("steer", 2, rays, poses, groups) == (2 * 4 * 4096, 4 * 4096)
+    assert exchange_bytes("none", 8, rays, poses, groups) == (0, 0)
+    m = scaling_model(167000.0, {"crash": 160400.0, "steer": 124000.0}, rays, poses, groups)
+    assert set(m) == {"ranges", "ranges_u16", "root", "crash", "steer", "none"}
+    r = m["ranges"]
+    assert r["bound"] == "xgmi" and r["ingress_bytes_per_gpu_per_step_at_8"] == 7 * 4 * rays
+    assert r["xgmi_floor_ms"] == pytest.approx(7 * 4 * rays / (7 * 76.5e9) * 1e3, rel=1e-3)          # 0.2315 ms
+    assert r["modelled_speedup_8gpu"] == pytest.approx(8 * (rays / 0.2315e-3 / 1e6) / 167000.0, rel=2e-2)   # ~0.92
+    assert m["ranges_u16"]["modelled_speedup_8gpu"] == pytest.approx(2 * r["modelled_speedup_8gpu"], rel=2e-2)
+    assert m["root"]["modelled_speedup_8gpu"] == r["modelled_speedup_8gpu"]
+    assert m["crash"]["bound"] == "march" and m["crash"]["modelled_speedup_8gpu"] == pytest.approx(8 * 0.9605, rel=1e-2)
+    assert m["steer"]["bound"] == "march" and m["steer"]["modelled_speedup_8gpu"] == pytest.approx(8 * 0.7425, rel=1e-2)
+    assert m["none"]["modelled_speedup_8gpu"] == 8.0
+    # a slow enough march is not xGMI-bound even for the ranges (the 1 Grays/s BASELINE.md was written for)
+    assert scaling_model(1000.0, {}, rays, poses, groups)["ranges"]["bound"] == "march"
+
+
 def test_rank_blocks_of_a_seeded_batch_and_the_baseline_batch_layout():
     """A rank generates only its own block, and the blocks tile the batch one GPU would draw;
     cfg4 / cfg5 shard BASELINE.json's GLOBAL batch, the other configs fix the poses per GPU."""
