@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void followgap_kernel(const float *__restrict__
         float best_v = v0;
         int best_i = 0;
         // (the beams of a lane are loaded eight at a time before any of them is looked at: one memory round trip per
-        //  eight instead of one per beam — a wave used to spend 17 dependent L2 latencies, ~8 us, on a 1081-beam scan)
+        //  eight instead of one per beam; twenty at a time was slower)
         constexpr int LU = 8;
         for (int i0 = lane; i0 < size; i0 += 64 * LU) {
             float xs[LU];
@@ -79,24 +79,57 @@ __global__ __launch_bounds__(64) void followgap_kernel(const float *__restrict__
         const int C = (size + 63) >> 6;
         const int lo = lane * C, hi = min(lo + C, size);
         int first_zero = 0x7fffffff;
-        for (int i = lo; i < hi; ++i)
-            if (!(v[i] > 1.75f)) { first_zero = i; break; }
-        // exclusive suffix-min over lanes: next beam <= 1.75 after this lane's chunk
-        int nz = first_zero;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_down(nz, off);
-            if (lane + off < 64) nz = min(nz, o);
-        }
-        int next_zero = __shfl_down(nz, 1);
-        if (lane == 63) next_zero = 0x7fffffff;
-        next_zero = min(next_zero, size);
         int run_len = 0, run_start = 0;
-        for (int i = hi - 1; i >= lo; --i) {
-            if (!(v[i] > 1.75f)) { next_zero = i; continue; }
-            if (i == 0 || !(v[i - 1] > 1.75f)) {       // a run starts here
-                const int len = next_zero - i;
-                if (len >= run_len) { run_len = len; run_start = i; }   // walking backwards: ties -> smaller start
+        constexpr int CM = 20;                             // beams per lane held in registers (scans up to 1280 beams)
+        if (C <= CM) {
+            // the lane's chunk (and the beam in front of it) in ONE round of independent LDS reads; the two walks below
+            // are register arithmetic (they were ~3 C dependent LDS round trips per lane)
+            float w[CM];
+#pragma unroll
+            for (int u = 0; u < CM; ++u) w[u] = lo + u < hi ? v[lo + u] : 0.0f;
+            const float before = lo > 0 && lo < size ? v[lo - 1] : 0.0f;
+#pragma unroll
+            for (int u = CM - 1; u >= 0; --u)
+                if (lo + u < hi && !(w[u] > 1.75f)) first_zero = lo + u;
+            int nz = first_zero;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(nz, off);
+                if (lane + off < 64) nz = min(nz, o);
+            }
+            int next_zero = __shfl_down(nz, 1);
+            if (lane == 63) next_zero = 0x7fffffff;
+            next_zero = min(next_zero, size);
+#pragma unroll
+            for (int u = CM - 1; u >= 0; --u) {
+                const int i = lo + u;
+                if (i < hi) {
+                    if (!(w[u] > 1.75f)) next_zero = i;
+                    else if (i == 0 || !((u > 0 ? w[u > 0 ? u - 1 : 0] : before) > 1.75f)) {   // a run starts here
+                        const int len = next_zero - i;
+                        if (len >= run_len) { run_len = len; run_start = i; }   // walking backwards: ties -> smaller start
+                    }
+                }
+            }
+        } else {
+            for (int i = lo; i < hi; ++i)
+                if (!(v[i] > 1.75f)) { first_zero = i; break; }
+            // exclusive suffix-min over lanes: next beam <= 1.75 after this lane's chunk
+            int nz = first_zero;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(nz, off);
+                if (lane + off < 64) nz = min(nz, o);
+            }
+            int next_zero = __shfl_down(nz, 1);
+            if (lane == 63) next_zero = 0x7fffffff;
+            next_zero = min(next_zero, size);
+            for (int i = hi - 1; i >= lo; --i) {
+                if (!(v[i] > 1.75f)) { next_zero = i; continue; }
+                if (i == 0 || !(v[i - 1] > 1.75f)) {       // a run starts here
+                    const int len = next_zero - i;
+                    if (len >= run_len) { run_len = len; run_start = i; }   // walking backwards: ties -> smaller start
+                }
             }
         }
 #pragma unroll

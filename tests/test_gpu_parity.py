@@ -1109,7 +1109,7 @@ def test_followgap_kernel_reproduces_reference_build_vectors():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [10, 64, 65, 720, 1081, 4097])
+@pytest.mark.parametrize("size", [10, 64, 65, 720, 1081, 1217, 1280, 1281, 4097])
 def test_followgap_batches_equal_the_oracle(oracle_mod, size):
     from pyracecarsimulator_amd.followgap import PyFollowGap
     rng = np.random.default_rng(size)
