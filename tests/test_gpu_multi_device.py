@@ -5,7 +5,6 @@ scripts/racecar_simulator_v2.py:146-167, one Python process: scripts/mcts.py:237
 GPUs of the node.  The test box has ONE MI355X, so the device list names device 0 several times (N
 contexts, N worker threads, N streams on one GPU): every result must be bit-identical to the single-
 device call — ranges, noise (global ray ids), crash indices — and to the CPU oracle."""
-import ctypes as C
 
 import numpy as np
 import pytest
