@@ -86,7 +86,7 @@ int rl_map_create(const uint8_t *occ, int rows, int cols, float res, float ox, f
  * each; rl_method_create on that map returns a handle whose HOST-pointer entry points —
  * rl_calc_range_fan, rl_calc_range_many_fan, rl_calc_range_many, rl_check_collision_many,
  * rl_check_collision_groups, rl_car_rollout_check — cut the batch into contiguous pose blocks, one per
- * device (a device is brought in per `multi_min_poses` = 64 poses, option of the handle), run them
+ * device (a device is brought in per `multi_min_poses` = 512 poses, option of the handle), run them
  * concurrently (one worker thread per device, nothing is forked) and let every device write its block of
  * the results straight into the caller's buffer.  Results are bit-identical to the single-device call:
  * noise is keyed by the global ray id, crash indices are global.  With a result buffer from
@@ -141,7 +141,7 @@ int rl_calc_range_fan(rl_method *h, const float *poses_p3, int n_poses, float fo
 
 /* Optional: pinned host memory for result buffers.  A host-pointer scan whose `outs` lies inside a
  * block from rl_host_alloc is written by the kernel directly (no staging copy on the way back:
- * scanMany(200) 63 -> ~40 us).  ScanSimulator2D keeps its cached output vectors
+ * scanMany(200) 63 -> ~40 us) up to 2^21 rays per call and by DMA from HBM beyond that (faster from ~2000 poses up).  ScanSimulator2D keeps its cached output vectors
  * (scripts/scan_simulator.py:32-40) in such blocks.  rl_host_free waits for the device first.      */
 int rl_host_alloc(size_t bytes, void **out);
 int rl_host_free(void *p);
@@ -256,14 +256,15 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *              run theta-major: all poses against one table bin at a time), cddt_lds_sort
  *   binning    inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min,
  *              bin_generic, bin_ppw (poses per workgroup of the grid-wide binning kernels)
- *   launches   slice_log2 (pose slices below 2^n rays), pinned_max_rays (zero-copy host calls)
+ *   launches   slice_log2 (pose slices below 2^n rays), pinned_max_rays (zero-copy host calls), direct_max_rays (a result
+ *              buffer in a block of rl_host_alloc is written by the kernel itself up to this many rays, by DMA beyond)
  *              spec_drain / spec_stretch (one ray per lane: value-speculating drain loop from <= N live lanes,
  *              plain samples between attempts); drain_cap / drain_stretch (several rays per lane: a wave whose
  *              stream is dry compacts its last <= N rays (<= 64) into one ray per lane and finishes them with
  *              that loop)
  *   diagnosis  timing (1 launch sequence | 2 main kernel only), debug_stamps, drain_prio, lut_debug
  *   multi-device handles: every option goes to every device's replica; multi_min_poses (poses per device
- *              from which another device is brought in, default 64) belongs to the handle itself.
+ *              from which another device is brought in, default 512) belongs to the handle itself.
  * rl_method_get_info additionally answers n_devices, n_cu, clock_khz, last_grid, map_epoch and, for RL_CDDT
  * (builds the table if needed, synchronises): cddt_values, cddt_buckets, cddt_nonempty_buckets.          */
 int rl_method_set_option(rl_method *h, const char *name, int value);

@@ -331,8 +331,9 @@ struct rl_method {
     // the parent keeps kind / noise / options and owns no device memory
     std::vector<rl_method *> reps;
     std::unique_ptr<MultiPool> pool;
-    int multi_min_poses = 64;    // a device is only brought in for at least this many poses (a roll-out of 200 poses
-                                 // stays on one device: its 18-us march is cheaper than waking a second one)
+    int multi_min_poses = 512;   // a device is only brought in per this many poses: waking a worker costs ~18 us
+                                 // (profiles/r04/host_pointer_rate.txt: a 200-pose roll-out cut over three contexts 60 vs
+                                 // 42 us), a 512-pose block's transfer alone ~50 us — the reference's roll-out stays on one device
     rl_map *map = nullptr;
     int kind = 0;
     float max_range = 0;
@@ -409,6 +410,11 @@ struct rl_method {
     void *pin = nullptr;
     size_t pin_cap = 0;
     int pinned_max_rays = 262144; // 0 = always stage through device buffers
+    int direct_max_rays = 1 << 21; // a result buffer in a pinned block of rl_host_alloc is written by the kernel itself
+                                  // up to this many rays (a 200-pose roll-out: 41 vs 61 us, 1024 poses: 113 vs 132); larger
+                                  // batches go HBM -> DMA into the pinned block, which moves 4 B per ray faster than the
+                                  // kernel's stores over PCIe (4096 poses: 394 vs 449 us; a tie at 2048:
+                                  // profiles/r04/host_pointer_rate.txt)
     std::vector<double> edge_host; // the car-outline table last uploaded to `edge` (re-sent only when it changes)
     int *pin_flag = nullptr;       // pinned landing slot for the crash index
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
@@ -852,6 +858,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
     else if (!strcmp(name, "tiled")) h->tiled = value != 0;
     else if (!strcmp(name, "pinned_max_rays")) h->pinned_max_rays = value < 0 ? 0 : value;
+    else if (!strcmp(name, "direct_max_rays")) h->direct_max_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "inline_map_kb")) h->inline_map_kb = value < 0 ? 0 : value;
     else if (!strcmp(name, "stripe_max")) h->stripe_max = value < 0 ? 0 : value;
     else if (!strcmp(name, "order_inline")) h->order_inline = value != 0;
@@ -904,6 +911,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "bin_generic")) *value_out = h->bin_generic;
     else if (!strcmp(name, "tiled")) *value_out = h->tiled;
     else if (!strcmp(name, "pinned_max_rays")) *value_out = h->pinned_max_rays;
+    else if (!strcmp(name, "direct_max_rays")) *value_out = h->direct_max_rays;
     else if (!strcmp(name, "inline_map_kb")) *value_out = h->inline_map_kb;
     else if (!strcmp(name, "stripe_max")) *value_out = h->stripe_max;
     else if (!strcmp(name, "order_inline")) *value_out = h->order_inline;
@@ -1903,7 +1911,8 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     }
     // small calls: zero-copy through pinned host memory (scan() 45 -> ~25 us host-visible)
     // output buffer inside a pinned block of rl_host_alloc: the kernel writes the ranges straight into it
-    const bool direct_out = outs && !hits && !steps && in_host_block(outs, n_rays * sizeof(float), h->map->device);
+    const bool direct_out = outs && !hits && !steps && n_rays <= (size_t)h->direct_max_rays &&
+                            in_host_block(outs, n_rays * sizeof(float), h->map->device);
     const bool zc = !hits && !steps && (direct_out || n_rays <= (size_t)h->pinned_max_rays);
     const size_t off_out = ((size_t)n_poses * 3 * sizeof(float) + 255) & ~(size_t)255;
     const size_t off_end = off_out + (direct_out ? 0 : ((n_rays * sizeof(float) + 255) & ~(size_t)255));

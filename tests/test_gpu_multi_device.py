@@ -32,6 +32,12 @@ def world():
     one.close()
 
 
+def _split(m, per_device=64):
+    """A multi-device method that really cuts these (small) test batches: the default brings a device in per 512 poses."""
+    m.set_option("multi_min_poses", per_device)
+    return m
+
+
 def _edge():
     return RC.edge_distances(B, -FOV / 2.0, FOV / B, 0.275, RC.DEFAULT_CAR["width"], RC.DEFAULT_CAR["wb"])
 
@@ -48,9 +54,10 @@ def test_multi_map_shape_and_replicas(world):
 @pytest.mark.parametrize("cls", [range_libc.PyRayMarchingGPU, range_libc.PyRayMarching, range_libc.PyBresenhamsLine])
 def test_fan_blocks_equal_the_single_device_scan_and_the_oracle(world, oracle_mod, cls):
     g, one, multi = world
-    m1, mm = cls(one, MRX), cls(multi, MRX)
+    m1, mm = cls(one, MRX), _split(cls(multi, MRX))
     assert mm.n_devices == 3 and m1.n_devices == 1
     om = oracle_mod.OracleMap.from_gridmap(g, MRX)
+    assert mm.get_info("multi_min_poses") == 64 and cls(multi, MRX).get_info("multi_min_poses") == 512     # (default)
     for n in (1, 5, 63, 200, 1000):                      # below multi_min_poses x devices: fewer blocks (1, 1, 1, 3, 3)
         poses = maps.sample_free_poses(g, n, 100 + n)
         a, b = np.empty(n * B, np.float32), np.full(n * B, -7.0, np.float32)
@@ -79,7 +86,7 @@ def test_reference_call_forms_on_a_multi_device_handle(world, oracle_mod):
     """The fork's sparse 4-argument calc_range_many (pose p in row p * num_rays) and upstream's 2-argument
     per-ray form through a multi-device handle; pinned result blocks are written by every device directly."""
     g, one, multi = world
-    m1, mm = range_libc.PyRayMarchingGPU(one, MRX), range_libc.PyRayMarchingGPU(multi, MRX)
+    m1, mm = range_libc.PyRayMarchingGPU(one, MRX), _split(range_libc.PyRayMarchingGPU(multi, MRX))
     n = 700
     poses = maps.sample_free_poses(g, n, 4)
     ins = np.zeros((n * B, 3), np.float32)
@@ -140,7 +147,7 @@ def test_table_methods_on_a_multi_device_map(world, oracle_mod, cls, td):
 
 def test_noise_is_keyed_by_the_global_ray_id_across_device_blocks(world):
     g, one, multi = world
-    m1, mm = range_libc.PyRayMarchingGPU(one, MRX), range_libc.PyRayMarchingGPU(multi, MRX)
+    m1, mm = range_libc.PyRayMarchingGPU(one, MRX), _split(range_libc.PyRayMarchingGPU(multi, MRX))
     n = 640
     poses = maps.sample_free_poses(g, n, 11)
     for off in (0, 12345678901):
@@ -162,7 +169,7 @@ def test_noise_is_keyed_by_the_global_ray_id_across_device_blocks(world):
 def test_crash_indices_are_global(world, cls):
     g, one, multi = world
     args = (MRX, 108) if cls is range_libc.PyCDDTCast else (MRX,)
-    m1, mm = cls(one, *args), cls(multi, *args)
+    m1, mm = cls(one, *args), _split(cls(multi, *args))
     edge = _edge()
     rng = np.random.default_rng(5)
     n = 900
@@ -211,7 +218,7 @@ def test_rollout_chain_over_device_blocks(world):
     p1, s1, v1 = c1.rollout(states, actions)
     pm, sm, vm = cm.rollout(states, actions)
     assert np.array_equal(p1, pm) and np.array_equal(s1, sm) and np.array_equal(v1, vm)
-    m1, mm = range_libc.PyRayMarchingGPU(one, MRX), range_libc.PyRayMarchingGPU(multi, MRX)
+    m1, mm = range_libc.PyRayMarchingGPU(one, MRX), _split(range_libc.PyRayMarchingGPU(multi, MRX))
     edge = _edge()
     f1, o1, w1 = c1.rollout_check(m1, states, actions, FOV, B, edge, 0.001)
     fm, om_, wm = cm.rollout_check(mm, states, actions, FOV, B, edge, 0.001)
@@ -233,6 +240,8 @@ def test_scan_simulator_and_map_update_on_a_multi_device_map(world):
         sim = ScanSimulator2D(B, FOV, 0.01, batch_size=512)
         sim.setMap(omap, MRX, g.resolution, g.origin)
         sim.setRaytracingMethod("RMGPU")
+        if omap is multi:
+            _split(sim.scan_method)
         sims.append(sim)
     poses = maps.sample_free_poses(g, 512, 77)
     a = sims[0].scanMany(poses).copy()
@@ -260,7 +269,7 @@ def test_multi_device_handle_from_several_threads(world):
     scripts/ros_interface.py:115,142,189): calls serialise on the handle, results stay right."""
     import threading
     g, one, multi = world
-    m1, mm = range_libc.PyRayMarchingGPU(one, MRX), range_libc.PyRayMarchingGPU(multi, MRX)
+    m1, mm = range_libc.PyRayMarchingGPU(one, MRX), _split(range_libc.PyRayMarchingGPU(multi, MRX))
     poses = [maps.sample_free_poses(g, 400, 500 + t) for t in range(3)]
     want = [_scan(m1, p) for p in poses]
     errs = []
