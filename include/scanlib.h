@@ -257,11 +257,15 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *   binning    inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min,
  *              bin_generic, bin_ppw (poses per workgroup of the grid-wide binning kernels)
  *   launches   slice_log2 (pose slices below 2^n rays), pinned_max_rays (zero-copy host calls), direct_max_rays (a result
- *              buffer in a block of rl_host_alloc is written by the kernel itself up to this many rays, by DMA beyond)
+ *              buffer in a block of rl_host_alloc is written by the kernel itself up to this many rays, by DMA beyond),
+ *              overlap_min_rays (plain host-pointer scans of at least this many rays — default 2^24 — run as four pose
+ *              slices, the device-to-host copy of one overlapping the march of the next; 0 = never)
  *              spec_drain / spec_stretch (one ray per lane: value-speculating drain loop from <= N live lanes,
  *              plain samples between attempts); drain_cap / drain_stretch (several rays per lane: a wave whose
  *              stream is dry compacts its last <= N rays (<= 64) into one ray per lane and finishes them with
- *              that loop)
+ *              that loop); nt_store (1: the stream kernels' ranges leave with non-temporal stores — write-once data
+ *              that would otherwise displace the step map from the L2; set 0 when the next kernel on the stream
+ *              reads the ranges back at once, e.g. rl_followgap_eval_device)
  *   diagnosis  timing (1 launch sequence | 2 main kernel only), debug_stamps, drain_prio, lut_debug
  *   multi-device handles: every option goes to every device's replica; multi_min_poses (poses per device
  *              from which another device is brought in, default 512) belongs to the handle itself.

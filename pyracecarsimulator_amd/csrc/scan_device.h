@@ -117,6 +117,24 @@ __device__ __forceinline__ float hit_sqrtf(float x)
     return r;
 }
 
+// The range of a finished ray.  The stream kernels store it with one scattered 4-B store per lane, write-once and
+// never read back by the launch: a NON-TEMPORAL store keeps the 4 B per ray (17.7 MB per cfg2 launch, four launches
+// in flight) from displacing the band of the step map the XCD's L2 is supposed to hold — cfg2 serial +6 % (lone
+// kernel 44.3 -> 42.2 us), cfg3 RMGPU +2.8 %, cfg5 shard +2 %, cfg4 shard +1.3 %, cfg2 pipelined +0.8 %
+// (profiles/r04/nt_store_ab.txt; -DRL_PLAIN_STORE rebuilds the other side of the A/B).  A kernel that reads the ranges
+// back at once on the same stream (FollowGap: --gather steer -4.6 %) wants them in the L2: option nt_store 0.
+__device__ __forceinline__ void range_store(float *p, float r, int plain = 0)
+{
+#ifdef RL_PLAIN_STORE
+    *p = r;
+#else
+    if (plain)        // wave-uniform (a launch parameter)
+        *p = r;
+    else
+        __builtin_nontemporal_store(r, p);
+#endif
+}
+
 struct RayResult {
     float range_px;
     int hit_c, hit_r;

@@ -356,6 +356,7 @@ struct rl_method {
     int spec_stretch = 16;       //   ... after this many plain samples, and between two attempts whose first prediction failed
     int drain_cap = 64;          // several rays per lane: compact a wave's last rays into one slot from <= this many (<= 64)
     int drain_stretch = 8;       //   ... plain samples between two speculation attempts of the compacted rays
+    int nt_store = 1;            // ranges leave the stream kernels with non-temporal stores (0: plain — a consumer kernel reads them next)
     int wg_threads = 1024;       // stream kernel: workgroup size (256/512/1024) sharing one ray stream
     // GiantLUT (K3)
     DevBuf lut;
@@ -390,6 +391,9 @@ struct rl_method {
     int pad = 0, pstride = 0;    // pstride: elements per row (row-major) | M (tiled, see pdt_tiled_byte)
     uint64_t pdt_epoch = ~0ull;  // map epoch the padded copy was built from
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // big host-pointer calls: the D2H copy of pose slice k overlaps the march of slice k+1
+    hipEvent_t slice_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int overlap_min_rays = 1 << 24;      // ... from this many rays per call (0 = never); below ~16 k poses the slices cost more than they hide
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     DevBuf poses, outs, hits, steps, edge, flag;
@@ -785,6 +789,9 @@ extern "C" void rl_method_destroy(rl_method *h)
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->slice_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -851,6 +858,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "spec_stretch")) h->spec_stretch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
     else if (!strcmp(name, "drain_cap")) h->drain_cap = value < 1 ? 1 : (value > 64 ? 64 : value);
     else if (!strcmp(name, "drain_stretch")) h->drain_stretch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
+    else if (!strcmp(name, "nt_store")) h->nt_store = value != 0;
     else if (!strcmp(name, "timing")) h->timing = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
     else if (!strcmp(name, "bin_ppw")) h->bin_ppw = value < 256 ? 256 : (value > 8192 ? 8192 : value);
@@ -859,6 +867,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "tiled")) h->tiled = value != 0;
     else if (!strcmp(name, "pinned_max_rays")) h->pinned_max_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "direct_max_rays")) h->direct_max_rays = value < 0 ? 0 : value;
+    else if (!strcmp(name, "overlap_min_rays")) h->overlap_min_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "inline_map_kb")) h->inline_map_kb = value < 0 ? 0 : value;
     else if (!strcmp(name, "stripe_max")) h->stripe_max = value < 0 ? 0 : value;
     else if (!strcmp(name, "order_inline")) h->order_inline = value != 0;
@@ -904,6 +913,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "spec_stretch")) *value_out = h->spec_stretch;
     else if (!strcmp(name, "drain_cap")) *value_out = h->drain_cap;
     else if (!strcmp(name, "drain_stretch")) *value_out = h->drain_stretch;
+    else if (!strcmp(name, "nt_store")) *value_out = h->nt_store;
     else if (!strcmp(name, "timing")) *value_out = h->timing;
     else if (!strcmp(name, "bin_multi_min")) *value_out = h->bin_multi_min;
     else if (!strcmp(name, "bin_ppw")) *value_out = h->bin_ppw;
@@ -912,6 +922,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "tiled")) *value_out = h->tiled;
     else if (!strcmp(name, "pinned_max_rays")) *value_out = h->pinned_max_rays;
     else if (!strcmp(name, "direct_max_rays")) *value_out = h->direct_max_rays;
+    else if (!strcmp(name, "overlap_min_rays")) *value_out = h->overlap_min_rays;
     else if (!strcmp(name, "inline_map_kb")) *value_out = h->inline_map_kb;
     else if (!strcmp(name, "stripe_max")) *value_out = h->stripe_max;
     else if (!strcmp(name, "order_inline")) *value_out = h->order_inline;
@@ -1618,6 +1629,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.div_B = make_fastdiv((uint32_t)num_rays);
         sp.low_water = h->low_water >= 0 ? h->low_water : 12;
         sp.n_bands = pl.bands;
+        sp.plain_store = !h->nt_store;
         if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
         if (aux)
             hipLaunchKernelGGL((bl_fan_stream_kernel<true, 1024>), grid, block, lds, stream, m->mp, f, sp, h->blp, d_out,
@@ -1697,6 +1709,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.spec_stretch = h->spec_stretch;
         sp.drain_cap = h->drain_cap;
         sp.drain_stretch = h->drain_stretch;
+        sp.plain_store = !h->nt_store;
         sp.dbg = nullptr;
         const int waves_per_wg = pl.block / 64;
         if (h->debug_stamps) {
@@ -1953,6 +1966,38 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     float *d_out = (outs || !first_crashed)
                        ? (direct_out ? outs : zc ? (float *)((char *)h->pin + off_out) : (float *)h->outs.p)
                        : nullptr;
+    if (outs && !zc && !first_crashed && !hits && !steps && h->overlap_min_rays > 0 &&
+        n_rays >= (size_t)h->overlap_min_rays && n_poses >= 4 &&
+        (h->kind == RL_RM || h->kind == RL_RM_GPU || h->kind == RL_BRESENHAM)) {
+        // big plain scans are bound by the 4 B per ray going back over PCIe: four pose slices, the copy of slice k on
+        // a second stream while slice k+1 marches (the march of a 65536-pose batch is ~10 % of the call).  The table
+        // methods keep one launch: their kernels take 2-4 % of the call, and the theta-major CDDT search wants the
+        // whole batch (>= 32768 poses) in one launch
+        constexpr int S = 4;
+        if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        const int per = (n_poses + S - 1) / S;
+        const uint64_t base_off = h->ray_offset;
+        rc = RL_OK;
+        for (int k = 0, p0 = 0; p0 < n_poses && rc == RL_OK; ++k, p0 += per) {
+            const int np = std::min(per, n_poses - p0);
+            const size_t r0 = (size_t)p0 * num_rays, nr = (size_t)np * num_rays;
+            h->ray_offset = base_off + r0;               // noise stays keyed by the global ray id
+            rc = launch_fan(h, d_poses + (size_t)p0 * 3, np, fov, num_rays, d_out + r0, nullptr, nullptr, nullptr, h->stream);
+            if (rc) break;
+            if (!h->slice_ev[k] && hipEventCreateWithFlags(&h->slice_ev[k], hipEventDisableTiming) != hipSuccess) {
+                rc = fail(RL_ERR_HIP, "hipEventCreate failed");
+                break;
+            }
+            if (hipEventRecord(h->slice_ev[k], h->stream) != hipSuccess ||
+                hipStreamWaitEvent(h->copy_stream, h->slice_ev[k], 0) != hipSuccess ||
+                hipMemcpyAsync(outs + r0, d_out + r0, nr * sizeof(float), hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess)
+                rc = fail(RL_ERR_HIP, "sliced device-to-host copy failed");
+        }
+        h->ray_offset = base_off;
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->copy_stream);
+        return rc;
+    }
     rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_out,
                     hits ? (int32_t *)h->hits.p : nullptr, steps ? (uint16_t *)h->steps.p : nullptr,
                     first_crashed ? &cp : nullptr, h->stream);

@@ -75,6 +75,8 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "slots": 2, "inline_prep": 0, "bin_multi_min": 64, "xcd_bands": 3, "grid_mult": 2},
     {"variant": 1, "tiled": 0},                                 # row-major padded EDT (default: 4x8-cell tiles)
     {"variant": 1, "tiled": 0, "inline_prep": 0, "xcd_bands": 1},
+    {"variant": 1, "nt_store": 0},                              # plain range stores (default: non-temporal)
+    {"variant": 1, "nt_store": 0, "slots": 2},
 ])
 def test_every_kernel_schedule_is_bit_identical(oracle_mod, opts):
     g = maps.make_maze(400, cell=40, wall=3, p=0.45, seed=21, origin=(-7.0, 3.0, -0.4))
@@ -1235,6 +1237,38 @@ def test_pinned_result_vectors_are_written_directly(oracle_mod):
     del sim
     gc.collect()
     assert np.array_equal(keep, want)                      # the block lives as long as the array does
+
+
+@pytest.mark.gpu
+def test_big_host_calls_overlap_copy_and_march_in_pose_slices(oracle_mod):
+    """A plain host-pointer scan of >= overlap_min_rays rays is cut into four pose slices, the device-to-host copy of
+    one slice running on a second stream while the next slice marches: same bits as the unsliced call — pageable and
+    pinned result buffers, pose counts that do not divide by four, and noise keyed by the GLOBAL ray id."""
+    g = maps.load_colombia()
+    om = oracle_mod.OracleMap.from_gridmap(g, 300)
+    omap = range_libc.PyOMap(g)
+    m = range_libc.PyRayMarchingGPU(omap, 300)
+    assert m.get_info("overlap_min_rays") == 1 << 24
+    for n in (4, 7, 301):
+        poses = maps.sample_free_poses(g, n, 40 + n, dt=om.dt)
+        want = om.rm_fan(poses, 4.71, 1081, step_coeff=1.0, nthreads=4)[0]
+        for out in (np.zeros(n * 1081, np.float32), _lib.pinned_zeros(n * 1081, np.float32)):
+            m.set_option("direct_max_rays", 0)             # a pinned block takes the DMA path too
+            m.set_option("overlap_min_rays", 1)
+            m.calc_range_fan(poses, out, 4.71, 1081)
+            assert np.array_equal(out, want), n
+            m.set_option("overlap_min_rays", 0)
+            out[:] = 0
+            m.calc_range_fan(poses, out, 4.71, 1081)
+            assert np.array_equal(out, want), n
+    poses = maps.sample_free_poses(g, 301, 77, dt=om.dt)
+    m.set_noise(0.01, 6)
+    a, b = np.zeros(301 * 1081, np.float32), np.zeros(301 * 1081, np.float32)
+    m.set_option("overlap_min_rays", 1)
+    m.calc_range_fan(poses, a, 4.71, 1081)
+    m.set_option("overlap_min_rays", 0)
+    m.calc_range_fan(poses, b, 4.71, 1081)
+    assert np.array_equal(a, b) and a.std() > 0
 
 
 @pytest.mark.gpu

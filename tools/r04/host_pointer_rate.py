@@ -21,10 +21,13 @@ for n in (200, 512, 1024, 2048, 4096, 16384, 65536):
     row = []
     mm.set_option("multi_min_poses", 64)
     for meth, name, out, oname, direct in ((m, "one device", pageable, "pageable", None), (m, "one device", pinned, "pinned, kernel stores", 1 << 30),
-                                           (m, "one device", pinned, "pinned, DMA", 0), (mm, "3 contexts", pinned, "pinned, default", None)):
+                                           (m, "one device", pinned, "pinned, DMA", 0), (m, "one device", pinned, "pinned, DMA, no slice overlap", -1),
+                                           (mm, "3 contexts", pinned, "pinned, default", None)):
         if True:
+            if meth is m:
+                meth.set_option("overlap_min_rays", 0 if direct == -1 else 1 << 24)
             if direct is not None:
-                meth.set_option("direct_max_rays", direct)
+                meth.set_option("direct_max_rays", max(direct, 0))
             elif meth is m:
                 meth.set_option("direct_max_rays", 1 << 20)
             for _ in range(3): meth.calc_range_fan(poses, out, w.fov, B)
