@@ -70,7 +70,8 @@ def parse_args():
                     help="steps in flight: consecutive steps go round robin to this many concurrent "
                          "streams (1 = serial: step k+1 starts after step k's last ray; 0 = auto: 4, "
                          "except ray-marching batches above 32768 poses, which fill the machine on their "
-                         "own and lose L2 locality when two of them are co-resident)")
+                         "own and lose L2 locality when two of them are co-resident, and GiantLUT, whose lone "
+                         "launch runs at the HBM rate)")
     ap.add_argument("--grid-mult", type=int, default=0,
                     help="workgroups (x256 threads) per CU of one launch; 0 = 3 when pipelined (launches of "
                          "0.75 workgroups of 1024 per CU, two rays per lane: several launches co-resident on "
@@ -355,7 +356,9 @@ def main():
     # streams that really run concurrently (HIP maps streams onto a few hardware queues); a handle keeps
     # rl_launch_contexts() per-stream scratch sets — more streams than that would silently serialise
     n_ctx = int(_lib.lib().rl_launch_contexts())
-    P = a.pipeline if a.pipeline > 0 else (1 if (method in ("RM", "RMGPU", "BL") and n > 32768) else 4)
+    # (GiantLUT: a lone launch streams its rows at the HBM rate since they are read with non-temporal loads; launches
+    #  sharing the machine only get in each other's way: 838 serial, 771 / 726 Grays/s with 2 / 4 in flight)
+    P = a.pipeline if a.pipeline > 0 else (1 if ((method in ("RM", "RMGPU", "BL") and n > 32768) or method == "GLT") else 4)
     if P > n_ctx:
         print("bench.py: --pipeline %d clamped to the library's %d launch contexts" % (P, n_ctx), file=sys.stderr)
         P = n_ctx

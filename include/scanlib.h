@@ -266,7 +266,9 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *              that loop); nt_store (1: the stream kernels' ranges leave with non-temporal stores — write-once data
  *              that would otherwise displace the step map from the L2; set 0 when the next kernel on the stream
  *              reads the ranges back at once, e.g. rl_followgap_eval_device)
- *   diagnosis  timing (1 launch sequence | 2 main kernel only), debug_stamps, drain_prio, lut_debug
+ *   diagnosis  timing (1 launch sequence | 2 main kernel only), debug_stamps, drain_prio, lut_debug (bits: 1 skip the
+ *              gathers / searches, 2 skip the range stores, 8 non-temporal GiantLUT range stores, 16 PLAIN instead of
+ *              non-temporal GiantLUT row loads — the A/B partner of the default)
  *   multi-device handles: every option goes to every device's replica; multi_min_poses (poses per device
  *              from which another device is brought in, default 512) belongs to the handle itself.
  * rl_method_get_info additionally answers n_devices, n_cu, clock_khz, last_grid, map_epoch and, for RL_CDDT

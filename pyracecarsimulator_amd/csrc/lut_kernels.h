@@ -185,7 +185,17 @@ void lut_fan_lds_kernel(MapParams m, FanParams f, LutParams lp,
             int d = 2 * idx - b0;                              // chunk start relative to the first bin
             d = d < 0 ? d + lp.theta_disc : d;
             const bool need = all || d <= span || d >= lp.theta_disc - 7;
-            if (inb && idx < D && need) regs[n] = *reinterpret_cast<const uint4 *>(row + idx);
+            if (inb && idx < D && need) {
+                // NON-TEMPORAL: a row is read once per pose out of a table (11.5 GB at cfg3) that no cache holds —
+                // loads that do not allocate in the L2 / Infinity Cache: the lone launch 0.108 -> 0.089 ms,
+                // 677 -> 840 Grays/s (profiles/r04/lut_nt_ab.txt; lut_debug bit 4 = plain loads, the A/B partner)
+                if (!(lp.debug & 16)) {
+                    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(row + idx));
+                    regs[n] = make_uint4(v.x, v.y, v.z, v.w);
+                } else
+                    regs[n] = *reinterpret_cast<const uint4 *>(row + idx);
+            }
         }
     };
 

@@ -630,6 +630,11 @@ def test_giant_lut_fan_every_row_width_bit_equal_to_oracle(oracle_mod, td):
         m.calc_range_fan(poses, out, fov, B)
         want = om.lut_fan(lut0, poses, fov, B)
         assert np.array_equal(out, want), (td, B, fov, int((out != want).sum()))
+        m.set_option("lut_debug", 16)                       # plain instead of non-temporal row loads: same bits
+        out[:] = -1.0
+        m.calc_range_fan(poses, out, fov, B)
+        m.set_option("lut_debug", 0)
+        assert np.array_equal(out, want), (td, B, fov, "plain loads")
     # the last cell of the table: the row's 16-B tail loads stay inside the allocation
     corner = np.array([[g.origin[0], g.origin[1], 0.3]], np.float32)
     c, s_ = math.cos(g.origin[2]), math.sin(g.origin[2])
