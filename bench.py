@@ -405,8 +405,11 @@ def main():
     if mode == "steer" and fgap is None:
         raise SystemExit("--gather steer needs at least 10 beams per scan")
 
+    nt_default = meth.get_info("nt_store")          # (after --opt: the A/B of the non-temporal range stores)
+
     def make_scan(md):
         """A ShardedScan of this run's shape in exchange mode ``md``, bound to the method and the P batches."""
+        meth.set_option("nt_store", nt_default)     # (bind_steer clears it for its own mode)
         if md in ("crash", "steer"):
             sc = ShardedScan(n, B, dev, n_chunks=1, gather=True, streams=streams, gather_single_rank=a.dist_single,
                              mode=md, n_items=n_groups if md == "crash" else n, every=a.gather_every)

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NT) void bl_fan_stream_kernel(MapParams m, FanParam
                 }
                 float r = range * m.res;
                 if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + oidx);
-                range_store(out + oidx, r, sp.plain_store);
+                range_store(out, (uint32_t)oidx << 2, r, sp.plain_store);
                 if (AUX) {
                     if (hits) { hits[2 * (size_t)oidx] = hc; hits[2 * (size_t)oidx + 1] = hr; }
                     if (steps) steps[oidx] = (uint16_t)nstep;

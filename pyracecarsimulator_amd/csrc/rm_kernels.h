@@ -1394,7 +1394,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             }
             r *= pm.res;
             if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (s.oidx >> 2));
-            if (out) range_store(reinterpret_cast<float *>(reinterpret_cast<char *>(out) + s.oidx), r, sp.plain_store);
+            if (out) range_store(out, s.oidx, r, sp.plain_store);
             if (CRASH) crash_test(s, r);
             s.oidx = NO_RAY;
         };
@@ -1560,7 +1560,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 r *= pm.res;
                 if (f.noise_std > 0.0f)
                     r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + oidx);
-                if (out) range_store(reinterpret_cast<float *>(reinterpret_cast<char *>(out) + s1.oidx), r, sp.plain_store);
+                if (out) range_store(out, s1.oidx, r, sp.plain_store);
                 if (AUX) {
                     if (sp.dbg && t_drain && nstep - ns_drain > drain_samples) drain_samples = nstep - ns_drain;
                     if (hits) { hits[2 * (size_t)oidx] = hc; hits[2 * (size_t)oidx + 1] = hr; }

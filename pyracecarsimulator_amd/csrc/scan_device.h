@@ -123,15 +123,24 @@ __device__ __forceinline__ float hit_sqrtf(float x)
 // kernel 44.3 -> 42.2 us), cfg3 RMGPU +2.8 %, cfg5 shard +2 %, cfg4 shard +1.3 %, cfg2 pipelined +0.8 %
 // (profiles/r04/nt_store_ab.txt; -DRL_PLAIN_STORE rebuilds the other side of the A/B).  A kernel that reads the ranges
 // back at once on the same stream (FollowGap: --gather steer -4.6 %) wants them in the L2: option nt_store 0.
-__device__ __forceinline__ void range_store(float *p, float r, int plain = 0)
+__device__ __forceinline__ void range_store(float *base, uint32_t byte_off, float r, int plain = 0)
 {
+    // (base + 32-bit byte offset formed inside each branch: the store keeps its SGPR-base addressing)
 #ifdef RL_PLAIN_STORE
-    *p = r;
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = r;
 #else
-    if (plain)        // wave-uniform (a launch parameter)
-        *p = r;
-    else
-        __builtin_nontemporal_store(r, p);
+    if (plain) {      // wave-uniform (a launch parameter)
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = r;
+    } else {
+        // (the empty asm statements keep the two stores apart — hoisting and sinking both stop at them —: two stores
+        //  of one value to one address that differ only in their non-temporal hint become ONE PLAIN store in the
+        //  optimiser — the first build with this branch had no `nt` store left in it.  The store itself stays the
+        //  compiler's: written as inline asm it missed the wait states a VALU-written SGPR base needs in front of a
+        //  VMEM instruction, and faulted in the AUX kernels, which keep `out` in a spill lane)
+        asm volatile("" ::: "memory");
+        __builtin_nontemporal_store(r, reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off));
+        asm volatile("" ::: "memory");
+    }
 #endif
 }
 

@@ -233,7 +233,6 @@ class ShardedScan:
         for sl, pp in zip(self.slots, ptrs):
             base = sl.local.data_ptr()
             sl.calls = [(pp + lo * 12, hi - lo, base + lo * B * 4) for lo, hi in self.chunks]
-        method.set_option("nt_store", 1)       # (the default; bind_steer of an earlier ShardedScan on this method clears it)
         self._bound = (raw, method._h, float(fov), _lib.check)
 
     def bind_crash(self, method, d_poses_ptr, fov: float, group: int, d_edge_ptr: int, crash_thresh: float,
@@ -253,7 +252,6 @@ class ShardedScan:
         raw = _lib.raw("rl_check_collision_groups_device")
         for sl, pp in zip(self.slots, ptrs):
             sl.rcall = (pp, sl.local.data_ptr() if keep_ranges else None)
-        method.set_option("nt_store", 1)
         self._bound = ("crash", raw, method._h, float(fov), int(group), int(d_edge_ptr), float(crash_thresh), _lib.check)
 
     def bind_steer(self, method, followgap, d_poses_ptr, fov: float):
@@ -271,7 +269,7 @@ class ShardedScan:
             sl.rcall = (pp, sl.local.data_ptr())
         # FollowGap reads the scan back on the same stream at once: keep the ranges in the L2 (plain stores; the
         # default non-temporal stores cost this mode 4.6 %, profiles/r04/nt_store_ab.txt)
-        method.set_option("nt_store", 0)
+        method.set_option("nt_store", 0)       # (stays with the method: a caller that goes on to plain scans sets it back)
         self._bound = ("steer", _lib.raw("rl_calc_range_fan_device"), method._h, float(fov),
                        _lib.raw("rl_followgap_eval_device"), followgap._h, _lib.check)
 
