@@ -386,6 +386,9 @@ int rl_probe_gather_rate(int device, int active_lanes, double *lanes_per_clk_per
  * stores} in GB/s (copy counts read + write).  The practical ceiling next to the 8 TB/s spec of
  * bench.py's roofline (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy).                     */
 int rl_probe_hbm(int device, size_t bytes, double *gbs_out5);
+/* ... the same kernels with NON-TEMPORAL loads (what the GiantLUT row fetch uses): gbs_out3 = {read-only, copy, copy
+ * with non-temporal stores}.                                                                          */
+int rl_probe_hbm_nt(int device, size_t bytes, double *gbs_out3);
 
 #ifdef __cplusplus
 }

@@ -125,6 +125,7 @@ SYMBOLS = {
     "rl_method_last_plan": (C.c_int, [C.c_void_p, C.POINTER(LaunchPlan)]),
     "rl_launch_contexts": (C.c_int, []),
     "rl_probe_hbm": (C.c_int, [C.c_int, C.c_size_t, f64p]),
+    "rl_probe_hbm_nt": (C.c_int, [C.c_int, C.c_size_t, f64p]),
     "rl_ranges_to_u16_device": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),
     "rl_ranges_from_u16_device": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),
 }

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(1024) void gather_probe_kernel(const float *__restr
 // the practical ceiling the bandwidth-bound kernels (GiantLUT) are held against.  tools/hbm_probe.py measured
 // torch's elementwise kernels (copy 4.7, fill 6.8, sum 4.0 TB/s); MI355X_MICROARCH.md quotes 6.29 TB/s for a
 // float4 copy: these kernels are that copy (mode 0), a read-only sweep (1), a write-only fill (2), and the
-// copy / fill with non-temporal stores (3, 4).  Persistent grid (8 workgroups of 256 per CU), 4 x 16 B in
-// flight per lane.
+// copy / fill with non-temporal stores (3, 4); rl_probe_hbm_nt: the read-only sweep, the copy and the copy with
+// non-temporal stores, all three with NON-TEMPORAL loads (5, 6, 7) — what GiantLUT's row fetch uses since round 4.
+// Persistent grid (8 workgroups of 256 per CU), 4 x 16 B in flight per lane.
 // ------------------------------------------------------------------------------
 typedef unsigned int probe_v4u __attribute__((ext_vector_type(4)));   // (the non-temporal builtin wants a native vector)
 
@@ -43,6 +44,12 @@ __device__ __forceinline__ void nt_store16(uint4 *p, const uint4 &v)
 {
     probe_v4u w = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(w, reinterpret_cast<probe_v4u *>(p));
+}
+
+__device__ __forceinline__ uint4 nt_load16(const uint4 *p)
+{
+    const probe_v4u w = __builtin_nontemporal_load(reinterpret_cast<const probe_v4u *>(p));
+    return make_uint4(w.x, w.y, w.z, w.w);
 }
 
 __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
@@ -56,10 +63,13 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint4 *__restrict_
         uint4 a = fillv, b = fillv, c = fillv, d = fillv;
         if (mode == 0 || mode == 1 || mode == 3) {
             a = src[i]; b = src[i + stride]; c = src[i + 2 * stride]; d = src[i + 3 * stride];
+        } else if (mode >= 5) {       // 5: read-only, 6: copy, 7: copy with non-temporal stores — NON-TEMPORAL loads
+            a = nt_load16(src + i); b = nt_load16(src + i + stride); c = nt_load16(src + i + 2 * stride);
+            d = nt_load16(src + i + 3 * stride);
         }
-        if (mode == 1) {
+        if (mode == 1 || mode == 5) {
             acc ^= a.x ^ b.y ^ c.z ^ d.w;
-        } else if (mode == 3 || mode == 4) {
+        } else if (mode == 3 || mode == 4 || mode == 7) {
             nt_store16(dst + i, a);
             nt_store16(dst + i + stride, b);
             nt_store16(dst + i + 2 * stride, c);
@@ -70,8 +80,8 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint4 *__restrict_
     }
     for (; i < n16; i += stride) {
         uint4 a = fillv;
-        if (mode == 0 || mode == 1 || mode == 3) a = src[i];
-        if (mode == 1) acc ^= a.x;
+        if (mode == 0 || mode == 1 || mode == 3 || mode >= 5) a = src[i];
+        if (mode == 1 || mode == 5) acc ^= a.x;
         else dst[i] = a;
     }
     if (acc == 0x12345678u) sink[0] = acc;

@@ -2648,7 +2648,19 @@ extern "C" int rl_followgap_eval_device(rl_followgap *g, const float *d_scans, i
 }
 
 // ---------------------------------------------------------------- diagnostics: HBM stream probe
+static int probe_hbm_modes(int device, size_t bytes, double *gbs_out, int mode_lo, int mode_hi);
+
 extern "C" int rl_probe_hbm(int device, size_t bytes, double *gbs_out5)
+{
+    return probe_hbm_modes(device, bytes, gbs_out5, 0, 5);
+}
+
+extern "C" int rl_probe_hbm_nt(int device, size_t bytes, double *gbs_out3)
+{
+    return probe_hbm_modes(device, bytes, gbs_out3, 5, 8);
+}
+
+static int probe_hbm_modes(int device, size_t bytes, double *gbs_out5, int mode_lo, int mode_hi)
 {
     if (!gbs_out5) return fail(RL_ERR_INVALID, "rl_probe_hbm: null pointer");
     if (bytes < ((size_t)1 << 20)) return fail(RL_ERR_INVALID, "rl_probe_hbm: at least 1 MiB per buffer");
@@ -2671,7 +2683,7 @@ extern "C" int rl_probe_hbm(int device, size_t bytes, double *gbs_out5)
         rc = fail(RL_ERR_NOMEM, "rl_probe_hbm: setup failed (2 x %zu bytes)", n16 * 16);
     } else {
         const int grid = prop.multiProcessorCount * 8, reps = 10;
-        for (int mode = 0; mode < 5 && rc == RL_OK; ++mode) {
+        for (int mode = mode_lo; mode < mode_hi && rc == RL_OK; ++mode) {
             hipLaunchKernelGGL(hbm_probe_kernel, dim3(grid), dim3(256), 0, st, a, b, n16, mode, sink);     // warm
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < reps; ++r)
@@ -2682,8 +2694,8 @@ extern "C" int rl_probe_hbm(int device, size_t bytes, double *gbs_out5)
                 rc = fail(RL_ERR_HIP, "rl_probe_hbm: launch failed");
                 break;
             }
-            const double moved = (double)n16 * 16.0 * ((mode == 0 || mode == 3) ? 2.0 : 1.0);
-            gbs_out5[mode] = moved * reps / ((double)ms * 1e-3) / 1e9;
+            const double moved = (double)n16 * 16.0 * ((mode == 0 || mode == 3 || mode == 6 || mode == 7) ? 2.0 : 1.0);
+            gbs_out5[mode - mode_lo] = moved * reps / ((double)ms * 1e-3) / 1e9;
         }
     }
     if (a) (void)hipFree(a);

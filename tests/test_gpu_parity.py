@@ -1505,3 +1505,6 @@ def test_hbm_probe_reports_plausible_rates():
     out = (ctypes.c_double * 5)()
     _lib.check(_lib.lib().rl_probe_hbm(0, 512 << 20, out))
     assert all(1000.0 < v < 8000.0 for v in out), list(out)
+    out3 = (ctypes.c_double * 3)()
+    _lib.check(_lib.lib().rl_probe_hbm_nt(0, 512 << 20, out3))
+    assert all(1000.0 < v < 8000.0 for v in out3), list(out3)

@@ -42,3 +42,7 @@ out = (ctypes.c_double * 5)()
 _lib.check(_lib.lib().rl_probe_hbm(0, 2 << 30, out))
 for name, v in zip(("copy", "read only", "write only", "copy, non-temporal stores", "fill, non-temporal stores"), out):
     print("rl_probe_hbm %-26s: %.0f GB/s" % (name, v))
+out = (ctypes.c_double * 3)()
+_lib.check(_lib.lib().rl_probe_hbm_nt(0, 2 << 30, out))
+for name, v in zip(("read only, non-temporal loads", "copy, non-temporal loads", "copy, non-temporal loads + stores"), out):
+    print("rl_probe_hbm_nt %-34s: %.0f GB/s" % (name, v))
