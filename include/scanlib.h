@@ -250,7 +250,8 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
 /* tuning / diagnostics: integer options by name.  None changes a result bit; defaults are the
  * measured optima on MI355X.
  *   schedule   variant (1 stream kernel | 0 chunk-per-wave | 2 occ_fan_lds: unit steps on an LDS occupancy
- *              window, approximate), grid_mult, wg_threads, low_water (-1 auto), run_log2 (-1 auto), xcd_bands,
+ *              window, approximate | 3 audit mode of RL_RM / RL_RM_GPU: upstream-literal arithmetic, the ONE option
+ *              that changes result bits — onto the oracle's libm form, csrc/literal_kernels.h), grid_mult, wg_threads, low_water (-1 auto), run_log2 (-1 auto), xcd_bands,
  *              sort_poses, tiled (step-map layout), slots (rays per lane: 1 | 2 | 3 | 0 auto),
  *              cddt_bins (one look-up per pose and table bin), cddt_theta_min (poses from which the look-ups
  *              run theta-major: all poses against one table bin at a time), cddt_lds_sort
@@ -287,7 +288,9 @@ int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
  *                                  INTEGRATION.md), slice_log2 (only to force slicing in tests)
  *   thresholds of the planner      inline_max, inline_map_kb, stripe_max, bin_multi_min, cddt_theta_min, xcd_bands,
  *                                  low_water (-1 = automatic) — change them only with a sweep in hand
- *   kernel selection for A/B       variant (0 chunk kernel, 2 occ_fan_lds), tiled (0 = row-major step map; the
+ *   kernel selection for A/B       variant (0 chunk kernel, 2 occ_fan_lds, 3 the AUDIT mode: range_libc's CPU
+ *                                  arithmetic stated literally — glibc sinf / cosf per ray, un-fused products and
+ *                                  sums — bit-identical to the oracle's libm form, 3-5x slower), tiled (0 = row-major step map; the
  *                                  planner clears it by itself when the tiled geometry does not fit), cddt_bins
  *   diagnostics only               wg_threads, sort_poses, inline_prep, order_inline, bin_generic, run_log2,
  *                                  cddt_sort, lut_debug, debug_stamps
@@ -309,7 +312,8 @@ typedef enum rl_kernel_id {
     RL_K_LUT_FAN = 7,       /* lut_fan_kernel<CH>                                                         */
     RL_K_CDDT_BINS = 8,     /* cddt_fan_bins_kernel                                                       */
     RL_K_CDDT_RAYS = 9,     /* cddt_fan_kernel                                                            */
-    RL_K_CDDT_THETA = 10    /* cddt_theta_search_kernel + cddt_theta_fan_kernel (theta-major, large batches) */
+    RL_K_CDDT_THETA = 10,   /* cddt_theta_search_kernel + cddt_theta_fan_kernel (theta-major, large batches) */
+    RL_K_RM_LITERAL = 11    /* rm_literal_kernel<AUX, RAYS>: upstream-literal arithmetic, the audit mode (variant 3) */
 } rl_kernel_id;
 
 typedef enum rl_binning {
@@ -389,6 +393,10 @@ int rl_probe_hbm(int device, size_t bytes, double *gbs_out5);
 /* ... the same kernels with NON-TEMPORAL loads (what the GiantLUT row fetch uses): gbs_out3 = {read-only, copy, copy
  * with non-temporal stores}.                                                                          */
 int rl_probe_hbm_nt(int device, size_t bytes, double *gbs_out3);
+
+/* diagnostics: the audit mode's sinf / cosf (glibc's algorithm in double precision, csrc/literal_kernels.h) of n
+ * host floats, evaluated on the device — tests hold it against the host's libm.                        */
+int rl_probe_literal_sincosf(int device, const float *x, size_t n, float *sin_out, float *cos_out);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,10 @@ def lib():
         L.orc_rm_rays_libm.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, _f32p, _i32p, _u16p]
         L.orc_rm_fan_libm.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, C.c_float, C.c_int,
                                       _f32p, _i32p, _u16p]
+        L.orc_libm_sincosf.argtypes = [_f32p, C.c_long, _f32p, _f32p]
+        L.orc_lit_sincosf.argtypes = [_f32p, C.c_long, _f32p, _f32p]
+        L.orc_libm_restatement_check.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_long), C.c_int]
+        L.orc_libm_restatement_check.restype = C.c_long
         L.orc_bl_fan.argtypes = [mp, C.c_float, _f32p, C.c_int, C.c_float, C.c_int, _f32p, _i32p,
                                  _u16p, C.c_int]
         L.orc_bl_rays.argtypes = [mp, C.c_float, _f32p, C.c_int, _f32p, _i32p, _u16p, C.c_int]
@@ -328,6 +332,30 @@ class OracleMap:
         lib().orc_cddt_rays(C.byref(self._m), self._cddt_handle(theta_disc), self.max_range_px,
                             _p(ins, _f32p), ins.shape[0], _p(ranges, _f32p), nthreads)
         return ranges
+
+
+def libm_sincosf(x):
+    """(sinf, cosf) of a float32 array by THIS host's libm."""
+    x = np.ascontiguousarray(x, np.float32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().orc_libm_sincosf(_p(x, _f32p), x.size, _p(s, _f32p), _p(c, _f32p))
+    return s, c
+
+
+def lit_sincosf(x):
+    """(sinf, cosf) by the statement of glibc's algorithm that the product's audit mode runs on the device."""
+    x = np.ascontiguousarray(x, np.float32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().orc_lit_sincosf(_p(x, _f32p), x.size, _p(s, _f32p), _p(c, _f32p))
+    return s, c
+
+
+def libm_restatement_mismatches(first=0, step=1, nthreads=0):
+    """Float bit patterns first, first + step, ... (both signs): (sinf, cosf) inputs on which that statement and this
+    host's libm differ.  step 1 walks every finite float."""
+    bad_cos = C.c_long(0)
+    bad_sin = lib().orc_libm_restatement_check(first, step, C.byref(bad_cos), nthreads or max_threads())
+    return int(bad_sin), int(bad_cos.value)
 
 
 def edge_distances(num_rays, min_ang, inc, scan_dist_to_base, width, wheelbase):

@@ -340,6 +340,148 @@ void orc_rm_fan_libm(const orc_map *m, const float *dt, float max_range_px, floa
 }
 
 /* ------------------------------------------------------------------------ */
+/* The host libm's sinf / cosf, in bulk, and the statement of its algorithm that the product's AUDIT mode runs on
+ * the device (pyracecarsimulator_amd/csrc/literal_kernels.h: lit_sinf / lit_cosf).  glibc >= 2.28 (sysdeps/ieee754/
+ * flt-32/s_sinf.c, s_cosf.c, sincosf.h — ARM optimized routines): double-precision range reduction and
+ * polynomials, one rounding to float32 at the end; the x86-64 builds with FMA contract every multiply-add, written
+ * out as fma() here.  orc_libm_restatement_check walks float bit patterns and counts the inputs on which the
+ * statement and THIS host's libm differ: 0 over every finite float on glibc 2.35 / x86-64 with FMA — on such a host
+ * the device's audit mode is bit-identical to orc_rm_fan_libm / orc_rm_rays_libm above.                        */
+/* ------------------------------------------------------------------------ */
+void orc_libm_sincosf(const float *x, long n, float *s_out, float *c_out)
+{
+    for (long i = 0; i < n; ++i) {
+        s_out[i] = sinf(x[i]);
+        c_out[i] = cosf(x[i]);
+    }
+}
+
+static const double LIT_HPI_INV = 0x1.45F306DC9C883p+23, LIT_HPI = 0x1.921FB54442D18p0, LIT_PI63 = 0x1.921FB54442D18p-62;
+static const double LIT_C[5] = {0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5, -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16};
+static const double LIT_S[3] = {-0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13};
+static const uint32_t LIT_INV_PIO4[24] = {
+    0xa2u, 0xa2f9u, 0xa2f983u, 0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u, 0x4e441529u, 0x441529fcu, 0x1529fc27u,
+    0x29fc2757u, 0xfc2757d1u, 0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u, 0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u,
+    0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};
+
+static inline uint32_t lit_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline uint32_t lit_top12(float x) { return (lit_bits(x) >> 20) & 0x7ffu; }
+static inline int lit_flip(int q) { return ((q + 1) & 2) != 0; }               /* sign[] = {1, -1, -1, 1} */
+
+static inline float lit_poly(double x, double x2, int neg, int n)
+{
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = fma(x2, LIT_S[2], LIT_S[1]);
+        const double x7 = x3 * x2;
+        const double s = fma(x3, LIT_S[0], x);
+        return (float)fma(x7, s1, s);
+    }
+    const double sg = neg ? -1.0 : 1.0;
+    const double x4 = x2 * x2;
+    const double c2 = fma(x2, sg * LIT_C[4], sg * LIT_C[3]);
+    const double c1 = fma(x2, sg * LIT_C[1], sg * LIT_C[0]);
+    const double x6 = x4 * x2;
+    const double c = fma(x4, sg * LIT_C[2], c1);
+    return (float)fma(x6, c2, c);
+}
+
+static inline double lit_reduce_fast(double x, int *np)
+{
+    const double r = x * LIT_HPI_INV;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return fma(-(double)n, LIT_HPI, x);
+}
+
+static inline double lit_reduce_large(uint32_t xi, int *np)
+{
+    const uint32_t *arr = &LIT_INV_PIO4[(xi >> 26) & 15];
+    const int shift = (int)((xi >> 23) & 7);
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+    const uint64_t res1 = (uint64_t)xi * arr[4];
+    const uint64_t res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    *np = (int)n;
+    return (double)(int64_t)res0 * LIT_PI63;
+}
+
+static float lit_sinf(float y)
+{
+    double x = y;
+    int n;
+    if (lit_top12(y) < lit_top12(0x1.921FB6p-1f)) {
+        if (lit_top12(y) < lit_top12(0x1p-12f)) return y;
+        return lit_poly(x, x * x, 0, 0);
+    }
+    if (lit_top12(y) < lit_top12(120.0f)) {
+        x = lit_reduce_fast(x, &n);
+        return lit_poly(x * (lit_flip(n & 3) ? -1.0 : 1.0), x * x, (n & 2) != 0, n);
+    }
+    if (lit_top12(y) < lit_top12(INFINITY)) {
+        const uint32_t xi = lit_bits(y);
+        const int sign = (int)(xi >> 31);
+        x = lit_reduce_large(xi, &n);
+        return lit_poly(x * (lit_flip((n + sign) & 3) ? -1.0 : 1.0), x * x, ((n + sign) & 2) != 0, n);
+    }
+    return y - y;
+}
+
+static float lit_cosf(float y)
+{
+    double x = y;
+    int n;
+    if (lit_top12(y) < lit_top12(0x1.921FB6p-1f)) {
+        if (lit_top12(y) < lit_top12(0x1p-12f)) return 1.0f;
+        return lit_poly(x, x * x, 0, 1);
+    }
+    if (lit_top12(y) < lit_top12(120.0f))
+        x = lit_reduce_fast(x, &n);
+    else if (lit_top12(y) < lit_top12(INFINITY))
+        x = lit_reduce_large(lit_bits(y), &n);
+    else
+        return y - y;
+    return lit_poly(x * (lit_flip((n + 1) & 3) ? -1.0 : 1.0), x * x, ((n + 1) & 2) != 0, n ^ 1);
+}
+
+/* the statement above on an array (the GPU test compares the device's lit_sinf / lit_cosf with it as well) */
+void orc_lit_sincosf(const float *x, long n, float *s_out, float *c_out)
+{
+    for (long i = 0; i < n; ++i) {
+        s_out[i] = lit_sinf(x[i]);
+        c_out[i] = lit_cosf(x[i]);
+    }
+}
+
+/* float bit patterns first, first + step, ... below +inf, both signs: inputs on which the statement and the host's
+ * libm differ (sinf mismatches returned, cosf mismatches in *bad_cos).  step 1 = every finite float (~20 s on 8 cores). */
+long orc_libm_restatement_check(uint32_t first, uint32_t step, long *bad_cos, int nthreads)
+{
+    long bs = 0, bc = 0;
+    if (step == 0) step = 1;
+    const long count = ((long)0x7f800000u - (long)first + (long)step - 1) / (long)step;
+    (void)nthreads;
+#pragma omp parallel for reduction(+ : bs, bc) schedule(static) num_threads(nthreads > 1 ? nthreads : 1)
+    for (long k = 0; k < count; ++k) {
+        const uint32_t u = first + (uint32_t)k * step;
+        for (uint32_t sg = 0; sg < 2; ++sg) {
+            const uint32_t b = u | (sg << 31);
+            float x;
+            memcpy(&x, &b, 4);
+            if (lit_bits(sinf(x)) != lit_bits(lit_sinf(x))) ++bs;
+            if (lit_bits(cosf(x)) != lit_bits(lit_cosf(x))) ++bc;
+        }
+    }
+    if (bad_cos) *bad_cos = bc;
+    return bs;
+}
+
+/* ------------------------------------------------------------------------ */
 /* BresenhamsLine::calc_range (row a12)                    */
 /* ------------------------------------------------------------------------ */
 static inline float bl_cast(const orc_map *m, float max_range,

@@ -50,7 +50,7 @@ class LaunchPlan(C.Structure):
 
 
 KERNEL_IDS = {0: "none", 1: "rm_chunk", 2: "rm_stream", 3: "occ_lds", 4: "bl_stream", 5: "bl_lds", 6: "lut_lds",
-              7: "lut_fan", 8: "cddt_bins", 9: "cddt_rays", 10: "cddt_theta"}
+              7: "lut_fan", 8: "cddt_bins", 9: "cddt_rays", 10: "cddt_theta", 11: "rm_literal"}
 BINNINGS = {0: "none", 1: "small_keys", 2: "small_records", 3: "grid_sort", 4: "grid_unsorted", 5: "generic"}
 
 #: every symbol include/scanlib.h declares: name -> (restype, argtypes)
@@ -126,6 +126,7 @@ SYMBOLS = {
     "rl_launch_contexts": (C.c_int, []),
     "rl_probe_hbm": (C.c_int, [C.c_int, C.c_size_t, f64p]),
     "rl_probe_hbm_nt": (C.c_int, [C.c_int, C.c_size_t, f64p]),
+    "rl_probe_literal_sincosf": (C.c_int, [C.c_int, f32p, C.c_size_t, f32p, f32p]),
     "rl_ranges_to_u16_device": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),
     "rl_ranges_from_u16_device": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]),
 }

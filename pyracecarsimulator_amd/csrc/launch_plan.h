@@ -69,7 +69,7 @@ inline void default_opts(rl_plan_opts &o)
 inline rl_plan_opts sanitized(rl_plan_opts o)
 {
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    o.variant = clampi(o.variant, 0, 2);
+    o.variant = clampi(o.variant, 0, 3);
     o.grid_mult = clampi(o.grid_mult, 1, 64);
     o.wg_threads = o.wg_threads >= 1024 ? 1024 : (o.wg_threads >= 512 ? 512 : 256);
     o.low_water = o.low_water < 0 ? -1 : clampi(o.low_water, 0, 63);
@@ -252,6 +252,16 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     const long cpp = (num_rays + 63) / 64;
     const long n_chunks = (o.variant >= 1) ? (rays + 63) / 64 : (long)n_poses * cpp;
     const bool stream_ok = rays < (1L << 30);
+    if (o.variant == 3) {
+        // audit mode: upstream-literal arithmetic, one lane per ray (literal_kernels.h)
+        if (in.crash) return RL_ERR_UNSUPPORTED;
+        p->kernel = RL_K_RM_LITERAL;
+        p->grid = (int)std::max(1L, std::min((rays + WG - 1) / WG, (long)n_cu * o.grid_mult));
+        p->block = WG;
+        p->tiled = 0;
+        std::snprintf(p->name, sizeof p->name, "scan::rm_literal_kernel<%s, false>", tf(in.aux));
+        return RL_OK;
+    }
     if (o.variant == 2) {
         int R, ww;
         bool use_lds;

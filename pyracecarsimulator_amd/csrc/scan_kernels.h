@@ -24,6 +24,7 @@
 //   lut_kernels.h   K3   GiantLUT build + fan kernels
 //   bl_kernels.h    K2 / K2b Bresenham, occ_fan_lds
 //   cddt_kernels.h  K3b  CDDT table build, pose-major and theta-major fan kernels
+//   literal_kernels.h    the audit mode of the ray-marching methods: upstream-literal arithmetic with glibc's sinf / cosf
 #pragma once
 #include "scan_device.h"
 #include "edt_kernels.h"
@@ -31,3 +32,4 @@
 #include "lut_kernels.h"
 #include "bl_kernels.h"
 #include "cddt_kernels.h"
+#include "literal_kernels.h"

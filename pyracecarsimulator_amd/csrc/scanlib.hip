@@ -1518,6 +1518,18 @@ static int dispatch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, cons
 
 // enqueue the fan kernels on `stream`; all pointers are device pointers.  What is launched is decided by
 // plan::plan_fan (launch_plan.h); this function only executes the plan.
+// audit mode (variant 3): the per-map constants of range_libc's RangeMethod, double arithmetic with the host's libm
+// (as the CPU checker's upstream-literal statement computes them)
+static LiteralParams make_literal(const rl_map *m)
+{
+    LiteralParams lt;
+    const double wa = (double)m->mp.wa;
+    lt.rotation_const = (float)(-1.0 * wa - 3.0 * M_PI / 2.0);
+    lt.wsin = (float)sin(wa);
+    lt.wcos = (float)cos(wa);
+    return lt;
+}
+
 static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov, int num_rays,
                       float *d_out, int32_t *d_hits, uint16_t *d_steps, const CrashParams *crash,
                       hipStream_t stream)
@@ -1662,6 +1674,14 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         }
         break;
     }
+    case RL_K_RM_LITERAL: {
+        const LiteralParams lt = make_literal(m);
+        const long n_rays = (long)n_poses * num_rays;
+        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+        if (aux) hipLaunchKernelGGL((rm_literal_kernel<true, false>), grid, block, 0, stream, m->mp, f, lt, d_poses, n_rays, d_out, d_hits, d_steps);
+        else     hipLaunchKernelGGL((rm_literal_kernel<false, false>), grid, block, 0, stream, m->mp, f, lt, d_poses, n_rays, d_out, d_hits, d_steps);
+        break;
+    }
     case RL_K_RM_CHUNK: {
         CrashParams cp{nullptr, 0.0, nullptr, 1};
         if (crash) cp = *crash;
@@ -1754,6 +1774,13 @@ static int launch_rays(rl_method *h, const float *d_ins, long n, float *d_out, i
     } else if (h->kind == RL_BRESENHAM) {
         hipLaunchKernelGGL(bl_rays_kernel, dim3(grid), dim3(256), 0, stream, m->mp, f, d_ins, n,
                            d_out);
+    } else if (h->variant == 3) {
+        // audit mode: the upstream 2-argument form stated literally, one lane per row
+        const LiteralParams lt = make_literal(m);
+        if (d_hits || d_steps)
+            hipLaunchKernelGGL((rm_literal_kernel<true, true>), dim3(grid), dim3(256), 0, stream, m->mp, f, lt, d_ins, n, d_out, d_hits, d_steps);
+        else
+            hipLaunchKernelGGL((rm_literal_kernel<false, true>), dim3(grid), dim3(256), 0, stream, m->mp, f, lt, d_ins, n, d_out, d_hits, d_steps);
     } else if (h->variant >= 1 && n <= INT_MAX) {
         // a ray is a pose with one beam at alpha = 0: fan(num_rays = 1, fov = 0) gives exactly
         // (cos, sin) of the heading as direction, and the stream kernel packs 64 rays per block
@@ -2658,6 +2685,29 @@ extern "C" int rl_probe_hbm(int device, size_t bytes, double *gbs_out5)
 extern "C" int rl_probe_hbm_nt(int device, size_t bytes, double *gbs_out3)
 {
     return probe_hbm_modes(device, bytes, gbs_out3, 5, 8);
+}
+
+extern "C" int rl_probe_literal_sincosf(int device, const float *x, size_t n, float *sin_out, float *cos_out)
+{
+    if (!x || !sin_out || !cos_out) return fail(RL_ERR_INVALID, "rl_probe_literal_sincosf: null pointer");
+    int ndev = rl_device_count();
+    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    if (n == 0) return RL_OK;
+    HIPCHK(hipSetDevice(device));
+    float *d = nullptr;
+    if (hipMalloc((void **)&d, 3 * n * sizeof(float)) != hipSuccess) return fail(RL_ERR_NOMEM, "rl_probe_literal_sincosf: %zu floats", 3 * n);
+    int rc = RL_OK;
+    if (hipMemcpy(d, x, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RL_ERR_HIP, "upload failed");
+    if (rc == RL_OK) {
+        const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(literal_sincosf_kernel, dim3(grid), dim3(256), 0, nullptr, d, (long)n, d + n, d + 2 * n);
+        if (hipMemcpy(sin_out, d + n, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(cos_out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(RL_ERR_HIP, "rl_probe_literal_sincosf: kernel or download failed");
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 static int probe_hbm_modes(int device, size_t bytes, double *gbs_out5, int mode_lo, int mode_hi)

@@ -161,6 +161,88 @@ def test_device_fan_vs_upstream_literal_libm_form(oracle_mod):
     print("canonical (device) vs upstream-literal libm form — (map, coeff, rays with another hit cell, max |d| in cells):", seen)
 
 
+def test_audit_mode_trig_on_the_device_equals_this_hosts_libm(oracle_mod):
+    """The audit mode's sinf / cosf on the device (csrc/literal_kernels.h: glibc's algorithm in double precision) against
+    THIS host's libm, bit for bit: angles a scan can produce, every binade up to the largest float, denormals, zeros,
+    infinities and NaN — and against the oracle's own statement of that algorithm (which tests/test_oracle.py walks
+    over the float range against libm on the CPU box)."""
+    import ctypes
+    rng = np.random.default_rng(11)
+    x = np.concatenate([
+        rng.uniform(-13.0, 13.0, 400000).astype(np.float32),
+        (rng.uniform(-1.0, 1.0, 200000) * np.exp2(rng.uniform(-140.0, 127.9, 200000))).astype(np.float32),
+        rng.integers(0, 1 << 32, 400000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 120.0, -120.0, 0.78539816, 2.4414062e-4, 1e-45, 3.4028235e38],
+                 np.float32)])
+    s, c = np.empty_like(x), np.empty_like(x)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    _lib.check(_lib.lib().rl_probe_literal_sincosf(0, x.ctypes.data_as(f32p), x.size, s.ctypes.data_as(f32p),
+                                                   c.ctypes.data_as(f32p)))
+    for name, (ws, wc) in (("libm", oracle_mod.libm_sincosf(x)), ("statement", oracle_mod.lit_sincosf(x))):
+        for got, want, fn in ((s, ws, "sinf"), (c, wc, "cosf")):
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(got), nan), (name, fn)
+            bad = (got.view(np.uint32) != want.view(np.uint32)) & ~nan
+            assert not bad.any(), (name, fn, int(bad.sum()), x[bad][:5], got[bad][:5], want[bad][:5])
+
+
+def test_audit_mode_reproduces_the_upstream_literal_form_bit_for_bit(oracle_mod):
+    """variant 3 — range_libc's CPU arithmetic stated literally (libm trig per ray, un-fused products and sums,
+    calc_range(y, x, theta')) — against the oracle's libm forms: ranges, hit cells and sample counts of the fan form
+    on the three golden maps (both step coefficients) and a cfg2 subsample, the committed upstream-literal vectors
+    (tests/golden/rm_libm_forms.npz), the 2-argument per-ray form, and the poses that cannot be cast.  Where the
+    canonical default differs from upstream's literal arithmetic on <= 1e-4 of the rays, this mode does not differ."""
+    L = np.load(os.path.join(GOLD, "rm_libm_forms.npz"))
+    for name in ("rm_colombia", "rm_maze256", "rm_maze192_yaw"):
+        g, z = load_golden(name)
+        omap = range_libc.PyOMap(g)
+        om = oracle_mod.OracleMap.from_gridmap(g, int(z["max_range_px"]))
+        fov, B, mrx = float(z["fov"]), int(z["num_rays"]), int(z["max_range_px"])
+        poses = np.array(z["poses"], np.float32)
+        npz = int(L[name + "_n_poses"])
+        for tag, cls, sc in (("cpu", range_libc.PyRayMarching, 0.999), ("gpu", range_libc.PyRayMarchingGPU, 1.0)):
+            m = cls(omap, mrx)
+            m.set_option("variant", 3)
+            r, h, s_ = _fan(m, poses, fov, B)
+            assert m.last_plan()["kernel"] == "rm_literal"
+            rb, hb, sb = om.rm_fan_libm(poses, fov, B, step_coeff=sc)
+            assert np.array_equal(r, rb) and np.array_equal(h, hb) and np.array_equal(s_, sb), (name, tag)
+            n = npz * B
+            assert np.array_equal(r[:n], L["%s_ranges_%s" % (name, tag)]), (name, tag, "committed vectors")
+            assert np.array_equal(h[:n], L["%s_hits_%s" % (name, tag)].astype(np.int32).reshape(-1, 2))
+            assert np.array_equal(s_[:n], L["%s_steps_%s" % (name, tag)])
+            # ranges-only launch, and the upstream 2-argument form: one (x, y, theta) row per ray
+            r1 = np.empty_like(r)
+            m.calc_range_fan(poses, r1, fov, B)
+            assert np.array_equal(r1, rb)
+            ins = np.zeros((4000, 3), np.float32)
+            rng = np.random.default_rng(5)
+            pick = rng.integers(0, len(poses), len(ins))
+            ins[:, :2] = poses[pick, :2]
+            ins[:, 2] = rng.uniform(-12.0, 12.0, len(ins)).astype(np.float32)
+            ins[7] = [np.nan, 0.0, 0.0]
+            ins[8] = [1e6, -1e6, 1.0]
+            ins[9, 2] = 3e7                                  # (beyond the fast range reduction of libm's sinf)
+            ins[10, 2] = np.inf
+            o2 = np.empty(len(ins), np.float32)
+            m.calc_range_many(ins, o2)
+            assert np.array_equal(o2, om.rm_rays_libm(ins, step_coeff=sc)), (name, tag, "2-argument form")
+    w = workloads.cfg2()
+    g, B, mrx = w.gmap, w.num_rays, w.max_range_px
+    omap = range_libc.PyOMap(g)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    poses = workloads.make_poses(w, dt=om.dt)[np.linspace(0, w.n_poses - 1, 64).astype(np.int64)]
+    m = range_libc.PyRayMarchingGPU(omap, mrx)
+    m.set_option("variant", 3)
+    r, h, s_ = _fan(m, poses, w.fov, B)
+    rb, hb, sb = om.rm_fan_libm(poses, w.fov, B, step_coeff=1.0)
+    assert np.array_equal(r, rb) and np.array_equal(h, hb) and np.array_equal(s_, sb)
+    # the fused crash test has no literal form: refused, not silently served by another arithmetic
+    edge = oracle_mod.edge_distances(B, -w.fov / 2, w.fov / B, 0.275, 0.2032, 0.3302)
+    with pytest.raises(Exception):
+        m.check_collision_many(poses, w.fov, B, edge, 0.001)
+
+
 def test_pyomap_from_occupancy_grid_message_scans_like_the_oracle(oracle_mod):
     """Row a6 end to end: PyOMap(map_msg) with a quaternion origin (yaw != 0) and map_server data
     binarised as /root/reference/scripts/ros_interface.py:80-86 does -> ScanSimulator2D.scan."""

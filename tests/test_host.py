@@ -333,6 +333,18 @@ def test_launch_plan_survives_zeroed_and_out_of_range_options():
     assert _plan(_lib.RL_RM_GPU, 2049, 2049, 4096, 1081, slice_log2=99, grid_mult=-5, slots=7, run_log2=40)["grid"] >= 1
     assert _plan(_lib.RL_RM_GPU, 2049, 2049, 1 << 20, 1081, slice_log2=-3)["slices"] >= 1
     assert _plan(_lib.RL_BRESENHAM, 2049, 2049, 4096, 1081, grid_mult=0, xcd_bands=-1)["grid"] >= 1
+    # variant 3, the audit mode (upstream-literal arithmetic): one lane per ray, no binning pass, no fused crash test;
+    # the table methods and Bresenham keep their own kernels
+    pl = _plan(_lib.RL_RM, 2049, 2049, 4096, 1081, variant=3)
+    assert (pl["kernel"], pl["block"], pl["binning"], pl["name"]) == ("rm_literal", 256, "none", "scan::rm_literal_kernel<false, false>")
+    assert _plan(_lib.RL_RM_GPU, 435, 350, 7, 1081, variant=3, aux=True)["name"] == "scan::rm_literal_kernel<true, false>"
+    assert _plan(_lib.RL_RM_GPU, 2049, 2049, 4096, 1081, variant=9)["kernel"] == "rm_literal"        # (clamped)
+    assert _plan(_lib.RL_BRESENHAM, 2049, 2049, 4096, 1081, variant=3)["kernel"] == "bl_stream"
+    o = _lib.PlanOpts()
+    _lib.check(L.rl_plan_default_opts(C.byref(o)))
+    o.variant = 3
+    pl2 = _lib.LaunchPlan()
+    assert L.rl_plan_fan(_lib.RL_RM_GPU, 256, 2049, 2049, 300.0, 0, C.byref(o), 4096, 1081, 0, 1, C.byref(pl2)) == -4      # RL_ERR_UNSUPPORTED
 
 
 def test_launch_plan_falls_back_when_the_tiled_step_map_or_the_lds_does_not_fit():

@@ -10,6 +10,7 @@ import pytest
 
 from conftest import GOLD, ROOT, load_golden
 from oracle import np_statement as N
+from oracle import oracle as O
 from pyracecarsimulator_amd import maps
 
 
@@ -423,3 +424,16 @@ def test_followgap_restatement_equals_live_reference_build(oracle_mod):
         assert np.float32(got).tobytes() == np.float32(ref).tobytes() or (np.isnan(got) and np.isnan(ref))
         n += 1
     assert n == 300
+
+
+def test_audit_mode_trig_statement_equals_this_hosts_libm():
+    """The product's audit mode (variant 3, csrc/literal_kernels.h) evaluates glibc's sinf / cosf algorithm on the device.
+    The oracle holds the same statement in C; here it is walked against THIS host's libm over every 61st float bit
+    pattern of both signs (70 million inputs, ~2 s; step 1 — every finite float, 0 mismatches on glibc 2.35 / x86-64
+    with FMA — takes ~20 s on 8 cores: `python -c "from oracle import oracle as O; print(O.libm_restatement_mismatches())"`).
+    A host whose libm is another implementation fails here: the audit mode then reproduces glibc's arithmetic, not
+    that host's, and tests/test_gpu_parity.py::test_audit_mode_* say so too."""
+    assert O.libm_restatement_mismatches(first=0, step=61) == (0, 0)
+    assert O.libm_restatement_mismatches(first=0x3f000000, step=1 << 30) == (0, 0)      # (tiny call: argument handling)
+    x = np.array([0.3, -2.0, 11.0, 119.9, 120.0, 1e7, -3e38, 0.0, 1e-40], np.float32)
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(O.libm_sincosf(x), O.lit_sincosf(x)))
