@@ -88,6 +88,20 @@ def one_case(seed):
                         out2 = np.empty(n, np.float32); m.calc_range_fan(poses, out2, fov, B)
                         assert np.array_equal(out2, r0), "%s v%d ranges-only %s" % (name, variant, sched)
                     m.close()
+            # the audit mode (variant 3): upstream-literal arithmetic against the oracle's libm forms — the fan form
+            # with hit cells and sample counts, and the 2-argument per-ray form
+            if n <= 400000 or r.random() < 0.2:
+                for cls, sc in ((range_libc.PyRayMarching, 0.999), (range_libc.PyRayMarchingGPU, 1.0)):
+                    m = cls(omap, mrx); m.set_option("variant", 3)
+                    out = np.empty(n, np.float32); hits = np.empty((n, 2), np.int32); st = np.empty(n, np.uint16)
+                    m.calc_range_fan(poses, out, fov, B, hit_cells=hits, steps=st)
+                    r0, h0, s0 = om.rm_fan_libm(poses, fov, B, step_coeff=sc)
+                    assert np.array_equal(out, r0), "audit mode ranges %g" % sc
+                    assert np.array_equal(hits, h0) and np.array_equal(st, s0), "audit mode hits / steps %g" % sc
+                    ins = poses[: min(P, 3000)].copy()
+                    o2 = np.empty(len(ins), np.float32); m.calc_range_many(ins, o2)
+                    assert np.array_equal(o2, om.rm_rays_libm(ins, step_coeff=sc)), "audit mode rays %g" % sc
+                    m.close()
             if rows * cols <= 20000:
                 td = int(r.choice([2, 16, 112, 113, 360]))
                 m = range_libc.PyCDDTCast(omap, mrx, td)
