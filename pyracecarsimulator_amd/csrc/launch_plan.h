@@ -164,7 +164,9 @@ inline int plan_one(const In &in, rl_launch_plan *p)
                                            tiled_fit(in.rows, in.cols, in.max_range).ok);
     p->tiled = tiled_opt;
     if (in.kind == RL_GIANT_LUT) {
-        p->grid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4, (long)n_cu * o.grid_mult));
+        // (two generations of workgroups: the second fills in behind the first's ragged end — a lone cfg3 launch
+        //  0.0843 -> 0.0786 ms, 840 -> 901 Grays/s; a third generation adds nothing: profiles/r04/lut_grid_sweep.txt)
+        p->grid = (int)std::max(1L, std::min(((long)n_poses + 3) / 4, (long)n_cu * o.grid_mult * 2));
         p->block = 256;
         const int td = in.theta_disc;
         const int nl = (td / 2 + 255) / 256;                 // 16-B loads per lane for one row

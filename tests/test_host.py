@@ -243,7 +243,7 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
         "scan::rm_fan_stream_kernel<false, true, 1024, true, true, 2>"
     # cfg3: GiantLUT rows of 1442 bins = 3 x 16-B loads per lane, 17 chunks of 64 beams; and the CDDT variant
     p = _plan(GLT, 2000, 2000, 65536, 1081, theta_disc=1442)
-    assert (p["name"], p["grid"], p["block"], p["lds_bytes"]) == ("scan::lut_fan_lds_kernel<3, 17>", 2048, 256, 12288)
+    assert (p["name"], p["grid"], p["block"], p["lds_bytes"]) == ("scan::lut_fan_lds_kernel<3, 17>", 4096, 256, 12288)
     # cfg3's 65 536 poses run theta-major (all poses against one table bin at a time, bins pinned to XCDs;
     # the fan kernel takes 32 poses x 109 floats of LDS per pass); below cddt_theta_min pose-major:
     p = _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=108)
