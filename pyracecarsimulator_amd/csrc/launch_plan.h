@@ -192,7 +192,10 @@ inline int plan_one(const In &in, rl_launch_plan *p)
             while (ppb_log2 > 0 && ((in.theta_disc | 1) << ppb_log2) > 16384) --ppb_log2;
             p->kernel = RL_K_CDDT_THETA;
             p->block = 256;
-            p->grid = (int)std::max(1L, std::min((long)((in.theta_disc + 1) / 2) * ((n_poses + 127) / 128), (long)n_cu * 8));
+            // (eight generations of workgroups: the units are short and of uneven cost — bucket sizes —, later
+            //  generations level the end: cfg3 341 -> 364 Grays/s serial, ~350 -> 382-405 with four launches in
+            //  flight; 4 and 16 generations are 2-4 % behind: profiles/r04/cddt_grid_sweep.txt)
+            p->grid = (int)std::max(1L, std::min((long)((in.theta_disc + 1) / 2) * ((n_poses + 127) / 128), (long)n_cu * 64));
             p->bands = (p->grid >= o.xcd_bands && (in.theta_disc + 1) / 2 >= o.xcd_bands) ? std::max(o.xcd_bands, 1) : 1;
             p->ch = ppb_log2;
             p->nl = in.theta_disc | 1;                 // LDS row stride of the fan kernel
