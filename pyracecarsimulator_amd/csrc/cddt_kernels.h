@@ -750,8 +750,9 @@ __global__ __launch_bounds__(256) void cddt_theta_fan_kernel(MapParams m, FanPar
                                                              const float *__restrict__ R, float *__restrict__ out,
                                                              int ppb_log2, int stride)
 {
-    extern __shared__ float bin_range[];                 // ppb x stride floats (stride: theta_disc made odd)
+    extern __shared__ float bin_range[];                 // ppb x stride floats (stride: theta_disc made odd), then ppb headings
     const int td = cp.theta_disc, ppb = 1 << ppb_log2;
+    float *thg_l = bin_range + ((size_t)stride << ppb_log2);
     LutParams lp{};
     lp.theta_disc = td;
     lp.bins_per_rad = cp.bins_per_rad;
@@ -764,18 +765,48 @@ __global__ __launch_bounds__(256) void cddt_theta_fan_kernel(MapParams m, FanPar
             const int bin = i >> ppb_log2, q = i & (ppb - 1);
             if (q < np) bin_range[q * stride + bin] = R[(size_t)bin * f.n_poses + p0 + q];
         }
+        if ((int)threadIdx.x < np) thg_l[threadIdx.x] = poses[3 * (size_t)(p0 + (int)threadIdx.x) + 2] + m.wa;
         __syncthreads();
-        for (int q = 0; q < np; ++q) {
-            const int pose = p0 + q;
-            const float thg = poses[3 * (size_t)pose + 2] + m.wa;
-            const float *br = bin_range + (size_t)q * stride;
-            float *dst = out + (size_t)pose * f.num_rays;
-            for (int j = threadIdx.x; j < f.num_rays; j += 256) {
-                float r = br[lut_bin_fast(-(thg + fan_alpha(f, j)), lp, td_f, inv_td)];
-                if (f.noise_std > 0.0f)
-                    r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (size_t)pose * f.num_rays + j);
-                if (!(cp.debug & 2) || r == 123.456f) dst[j] = r;
+        // the group's ranges are ONE contiguous run of np x num_rays floats (pose-major output): written 16 B per
+        // lane — 1 KiB per wave instruction — when the run starts on a 16-B boundary (always for the planner's
+        // groups of >= 4 poses on an aligned buffer), else beam by beam.  (Round 4: the dword row stores of the
+        // first form ran at 4.7 TB/s, profiles/r04/write_probe.txt.)
+        const size_t run0 = (size_t)p0 * f.num_rays;
+        const uint32_t B = (uint32_t)f.num_rays, total = (uint32_t)np * B;
+        float *run = out + run0;
+        auto lookup = [&](uint32_t q, uint32_t j, uint32_t e) {
+            float r = bin_range[(size_t)q * stride + lut_bin_fast(-(thg_l[q] + fan_alpha(f, (int)j)), lp, td_f, inv_td)];
+            if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + run0 + e);
+            return r;
+        };
+        if ((reinterpret_cast<uintptr_t>(run) & 15) == 0 && !(cp.debug & 2)) {
+            const float inv_b = 1.0f / (float)B;
+            for (uint32_t c = threadIdx.x; c < (total >> 2); c += 256) {
+                const uint32_t e = c << 2;
+                uint32_t q = (uint32_t)(((float)e + 0.5f) * inv_b);          // e / B (e < 2^24: one correction step)
+                q -= (q * B > e) ? 1u : 0u;
+                q += ((q + 1u) * B <= e) ? 1u : 0u;
+                uint32_t j = e - q * B;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (j == B) { j = 0; ++q; }
+                    v[k] = lookup(q, j, e + (uint32_t)k);
+                    ++j;
+                }
+                *reinterpret_cast<float4 *>(run + e) = make_float4(v[0], v[1], v[2], v[3]);
             }
+            const uint32_t e = (total & ~3u) + threadIdx.x;                     // the run's last 0..3 floats
+            if (threadIdx.x < (total & 3u)) {
+                const uint32_t q = e / B;
+                run[e] = lookup(q, e - q * B, e);
+            }
+        } else {
+            for (uint32_t q = 0; q < (uint32_t)np; ++q)
+                for (uint32_t j = threadIdx.x; j < B; j += 256) {
+                    const float r = lookup(q, j, q * B + j);
+                    if (!(cp.debug & 2) || r == 123.456f) run[q * B + j] = r;
+                }
         }
         __syncthreads();
     }

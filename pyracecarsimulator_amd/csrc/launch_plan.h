@@ -199,7 +199,7 @@ inline int plan_one(const In &in, rl_launch_plan *p)
             p->bands = (p->grid >= o.xcd_bands && (in.theta_disc + 1) / 2 >= o.xcd_bands) ? std::max(o.xcd_bands, 1) : 1;
             p->ch = ppb_log2;
             p->nl = in.theta_disc | 1;                 // LDS row stride of the fan kernel
-            p->lds_bytes = (p->nl << ppb_log2) * (int)sizeof(float);
+            p->lds_bytes = ((p->nl + 1) << ppb_log2) * (int)sizeof(float);      // R rows of ppb poses + their headings
             std::snprintf(p->name, sizeof p->name, "scan::cddt_theta_search_kernel");
             return RL_OK;
         }
