@@ -62,7 +62,7 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *rl_last_error(void) { return g_err.c_str(); }
-extern "C" const char *rl_version(void) { return "scanlib-amd 0.4 (gfx950)"; }
+extern "C" const char *rl_version(void) { return "scanlib-amd 0.5 (gfx950)"; }
 
 extern "C" int rl_device_count(void)
 {
