@@ -1545,7 +1545,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
     rl_launch_plan pl;
     int rc = plan_for(h, n_poses, num_rays, aux, crash != nullptr, &pl);
     if (rc == RL_ERR_UNSUPPORTED)
-        return fail(rc, (h->variant == 2 && crash) ? "the fused crash test needs variant 0 or 1"
+        return fail(rc, (h->variant >= 2 && crash) ? "the fused crash test needs variant 0 or 1 (not the occupancy-window or the audit kernel)"
                         : h->variant == 2 ? "occupancy window of max_range %g does not fit LDS (num_rays %d)"
                                           : "the beam tables of max_range %g, num_rays %d exceed a workgroup's LDS (160 KB)",
                     h->max_range, num_rays);
