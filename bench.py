@@ -658,6 +658,34 @@ def main():
                 meth.set_noise(w.noise_std, w.noise_seed, lo * B)
             apply_schedule(True)
         extra = {}
+        if method in ("RM", "RMGPU") and not a.selftest_corrupt:
+            # parity on the record (range_libc is absent: the oracle is UNPINNED): the same subsample
+            # through the AUDIT mode (variant 3: upstream-literal arithmetic, glibc sinf / cosf on the device) must equal
+            # the oracle's libm form bit for bit, and the line states how far the canonical default is from it
+            sc = 1.0 if method == "RMGPU" else 0.999
+            lit_r, lit_h = np.empty(len(sub) * B, np.float32), np.empty((len(sub) * B, 2), np.int32)
+            can_h = np.empty_like(lit_h)
+            if w.noise_std > 0:
+                meth.set_noise(0.0, 0, 0)
+            try:
+                meth.calc_range_fan(poses, got, w.fov, B, hit_cells=can_h)
+                meth.set_option("variant", 3)
+                meth.calc_range_fan(poses, lit_r, w.fov, B, hit_cells=lit_h)
+            finally:
+                meth.set_option("variant", a.variant if a.variant >= 0 else 1)
+                if w.noise_std > 0:
+                    meth.set_noise(w.noise_std, w.noise_seed, lo * B)
+            ref_r, ref_h, _ = om.rm_fan_libm(poses, w.fov, B, step_coeff=sc)
+            if not (np.array_equal(lit_r, ref_r) and np.array_equal(lit_h, ref_h)):
+                return {"oracle_subsample": False, "audit_mode_differing_rays": int((lit_r != ref_r).sum())}
+            moved = (can_h != lit_h).any(axis=1)
+            extra["upstream_literal"] = {
+                "audit_mode": "variant 3 (range_libc's CPU arithmetic stated literally, glibc sinf / cosf) == the oracle's "
+                              "libm form on %d rays: ranges and hit cells bit-equal" % lit_r.size,
+                "canonical_default_vs_literal": {"rays": int(lit_r.size), "rays_with_another_hit_cell": int(moved.sum()),
+                                                 "max_range_difference_cells": round(float(np.abs(got - lit_r).max() / gmap.resolution), 4),
+                                                 "ranges_bit_equal": int((got == lit_r).sum())},
+                "oracle": "UNPINNED: range_libc is absent from the reference mount (restated from SURVEY.md Appendix A)"}
         if mode == "steer" and w.noise_std <= 0 and not a.selftest_corrupt:
             # the steering angles the timed loop left for batch 0 against FollowGap::eval restated on the CPU
             # (oracle/: bit-identical to the reference's compiled header) over the oracle's ranges
