@@ -1994,7 +1994,7 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
                        ? (direct_out ? outs : zc ? (float *)((char *)h->pin + off_out) : (float *)h->outs.p)
                        : nullptr;
     if (outs && !zc && !first_crashed && !hits && !steps && h->overlap_min_rays > 0 &&
-        n_rays >= (size_t)h->overlap_min_rays && n_poses >= 4 &&
+        n_rays >= (size_t)h->overlap_min_rays && n_poses >= 4 && !h->timing &&
         (h->kind == RL_RM || h->kind == RL_RM_GPU || h->kind == RL_BRESENHAM)) {
         // big plain scans are bound by the 4 B per ray going back over PCIe: four pose slices, the copy of slice k on
         // a second stream while slice k+1 marches (the march of a 65536-pose batch is ~10 % of the call).  The table
