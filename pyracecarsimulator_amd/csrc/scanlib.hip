@@ -2586,6 +2586,7 @@ struct rl_followgap {
     int device = 0;
     FollowGapParams P{};
     int window_size = 0;           // kept for the caller; FollowGap::eval never reads it
+    int n_cu = 256;                // (queried once: hipGetDeviceProperties costs the host tens of microseconds per call)
     hipStream_t stream = nullptr;
     DevBuf scans, angles;
     std::mutex mu;
@@ -2610,6 +2611,8 @@ extern "C" int rl_followgap_create(int device, int window_size, float max_distan
         delete g;
         return fail(RL_ERR_HIP, "stream creation failed");
     }
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) g->n_cu = n_cu;
     *out = g;
     return RL_OK;
 }
@@ -2635,9 +2638,7 @@ static int followgap_launch(rl_followgap *g, const float *d_scans, int n_scans, 
     if (n_scans == 0) return RL_OK;
     FollowGapParams p = g->P;
     p.size = size;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, g->device));
-    const int grid = std::min(n_scans, prop.multiProcessorCount * 32);
+    const int grid = std::min(n_scans, g->n_cu * 32);
     hipLaunchKernelGGL(followgap_kernel, dim3(grid), dim3(64), (size_t)size * sizeof(float), stream,
                        d_scans, n_scans, p, d_angles);
     HIPCHK(hipGetLastError());
