@@ -320,7 +320,7 @@ typedef enum rl_binning {
     RL_BIN_NONE = 0,          /* the march kernel derives the pose records of its own blocks (LDS)        */
     RL_BIN_SMALL_KEYS = 1,    /* pose_bin_small_kernel<true>: tile order only, one workgroup              */
     RL_BIN_SMALL_RECORDS = 2, /* pose_bin_small_kernel<false>: records in tile order, one workgroup       */
-    RL_BIN_GRID_SORT = 3,     /* pose_prep -> tile_scan_a -> tile_scan_b -> pose_scatter (grid-wide)      */
+    RL_BIN_GRID_SORT = 3,     /* pose_prep -> tile_scan_a -> pose_scatter (grid-wide)                    */
     RL_BIN_GRID_UNSORTED = 4, /* pose_prep only (caller's order kept)                                     */
     RL_BIN_GENERIC = 5        /* pose_bin_kernel: one workgroup, any size                                 */
 } rl_binning;

@@ -478,8 +478,8 @@ __device__ __forceinline__ uint32_t wg256_excl_scan(uint32_t v, uint32_t *part /
 }
 
 // The (tile, workgroup) counters of the grid-wide binning, hist_all[tile * n_wg + w], scanned by one
-// workgroup PER TILE in two small launches — (a) inside the tile's own run of n_wg counters (coalesced
-// 256-wide pieces, running carry) + the tile's total, (b) add the totals of the tiles in front — instead
+// workgroup PER TILE — inside the tile's own run of n_wg counters (coalesced 256-wide pieces, running carry) +
+// the tile's total; the totals of the tiles in front are added by the scatter kernel — instead
 // of one workgroup walking all tiles x workgroups counters with a lane-strided pattern (131 072 counters at
 // 262 144 poses: the single-workgroup scan was the longest of the three binning kernels).
 __global__ __launch_bounds__(256) void tile_scan_a_kernel(uint32_t *__restrict__ hist_all, int n_wg,
@@ -499,30 +499,39 @@ __global__ __launch_bounds__(256) void tile_scan_a_kernel(uint32_t *__restrict__
     if (threadIdx.x == 0) tile_total[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(256) void tile_scan_b_kernel(uint32_t *__restrict__ hist_all, int n_wg,
-                                                          const uint32_t *__restrict__ tile_total)
-{
-    __shared__ uint32_t part[4];
-    const int t = blockIdx.x;
-    uint32_t mine = 0;
-    for (int k = threadIdx.x; k < t; k += 256) mine += tile_total[k];
-    uint32_t base;
-    (void)wg256_excl_scan(mine, part, base);           // base = poses in the tiles in front of this one
-    uint32_t *row = hist_all + (size_t)t * n_wg;
-    for (int i = threadIdx.x; i < n_wg; i += 256) row[i] += base;
-}
-
+// (round 4: the scan of the tile totals — tile_scan_b_kernel, a launch of its own until then, ~4.6 us of launch
+//  latency for a microsecond of work — happens here: every scatter workgroup scans the <= 1024 totals itself)
 __global__ __launch_bounds__(256) void pose_scatter_kernel(int n, const PoseRec *__restrict__ rec,
                                                            const uint32_t *__restrict__ keys,
                                                            const uint32_t *__restrict__ base_all,
+                                                           const uint32_t *__restrict__ tile_total,
                                                            int n_wg, int n_tiles,
                                                            PoseRec *__restrict__ rec_sorted,
                                                            uint32_t *__restrict__ order, int poses_per_wg,
                                                            MapParams m, float *__restrict__ d0, float coeff)
 {
     extern __shared__ uint32_t cursor[];           // n_tiles
+    __shared__ uint32_t part[4];
     const int w = blockIdx.x;
-    for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) cursor[i] = base_all[(size_t)i * n_wg + w];
+    {
+        // cursor[tile] = slots of this tile in front of this workgroup's poses (tile_scan_a) + poses in the tiles
+        // in front of it (exclusive scan of the tile totals: each lane owns E consecutive tiles)
+        const int E = (n_tiles + 255) / 256;
+        uint32_t local = 0;
+        for (int e = 0; e < E; ++e) {
+            const int i = (int)threadIdx.x * E + e;
+            if (i < n_tiles) local += tile_total[i];
+        }
+        uint32_t tot;
+        uint32_t base = wg256_excl_scan(local, part, tot);
+        for (int e = 0; e < E; ++e) {
+            const int i = (int)threadIdx.x * E + e;
+            if (i < n_tiles) {
+                cursor[i] = base_all[(size_t)i * n_wg + w] + base;
+                base += tile_total[i];
+            }
+        }
+    }
     __syncthreads();
     const int p_end = min(n, (w + 1) * poses_per_wg);
     for (int p = w * poses_per_wg + threadIdx.x; p < p_end; p += blockDim.x) {

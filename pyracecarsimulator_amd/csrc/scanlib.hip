@@ -1320,11 +1320,9 @@ static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_po
             uint32_t *tile_total = (uint32_t *)cx.hist.p + n_ctr;
             hipLaunchKernelGGL(tile_scan_a_kernel, dim3(cnt), dim3(256), 0, stream, (uint32_t *)cx.hist.p, n_wg,
                                tile_total);
-            hipLaunchKernelGGL(tile_scan_b_kernel, dim3(cnt), dim3(256), 0, stream, (uint32_t *)cx.hist.p, n_wg,
-                               (const uint32_t *)tile_total);
             hipLaunchKernelGGL(pose_scatter_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,
                                n_poses, (const PoseRec *)cx.rec.p, (const uint32_t *)cx.keys.p,
-                               (const uint32_t *)cx.hist.p, n_wg, cnt, (PoseRec *)cx.rec_sorted.p,
+                               (const uint32_t *)cx.hist.p, (const uint32_t *)tile_total, n_wg, cnt, (PoseRec *)cx.rec_sorted.p,
                                (uint32_t *)cx.order.p, ppw, m->mp, d0, coeff);
         } else {
             // caller's order kept: one fully parallel pass, records land in place
