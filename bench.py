@@ -306,6 +306,12 @@ def main():
         if a.backend == "nccl":      # RCCL refuses two ranks on one device ("Duplicate GPU detected")
             print("bench.py: --same-device runs over gloo (RCCL needs one GPU per rank)", file=sys.stderr)
             a.backend = "gloo"
+    elif world > 1 and torch.cuda.device_count() < world:
+        # (device_count() does not initialise the GPU.)  One rank per GPU or nothing: a rank that silently shares a
+        # device would report an N-GPU number measured on fewer GPUs
+        raise SystemExit("bench.py --gpus %d: only %d device(s) visible — one GPU per rank is required "
+                         "(--same-device --backend gloo is the labelled dry run of the N>1 code path on one GPU)"
+                         % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or a.dist_single            # a process group exists
@@ -770,6 +776,14 @@ def main():
 
     if multi:
         out["rccl_world"] = world
+        # what the communicator itself reports, and which device every rank really used (gathered through it)
+        out["rccl_ranks"] = dist.get_world_size()
+        out["comm_backend"] = dist.get_backend()
+        dev_ids = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(world)]
+        dist.all_gather(dev_ids, torch.tensor([torch.cuda.current_device()], dtype=torch.int32, device=dev))
+        out["rank_devices"] = [int(t.item()) for t in dev_ids]
+        if world > 1 and not a.same_device:
+            assert len(set(out["rank_devices"])) == world, "ranks share a device: %r" % (out["rank_devices"],)
         gb, ingress = exchange_bytes(mode, world)
         out["gather_bytes_per_step"] = gb
         # xGMI: what one GPU must RECEIVE per step (the busiest one: every GPU for an all-gather, rank 0 for

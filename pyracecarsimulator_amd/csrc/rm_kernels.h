@@ -1065,6 +1065,14 @@ struct PadMap {
     float res;
 };
 
+// one ray in flight, as the hand-off passes it on: everything the march and the finish need (32 B, two 16-B stores)
+struct __attribute__((aligned(16))) LeftoverRec {
+    float gx, gy, dx, dy;    // grid origin, direction
+    float t, d_last;         // where the march stands, the step that took it there
+    uint32_t oidx;           // byte offset of the ray's range in `out`
+    uint32_t pose;           // pose id (fused crash test)
+};
+
 struct StreamParams {
     const PoseRec *rec;      // sorted order
     const uint32_t *order;   // sorted slot -> pose index | POSE_INVALID
@@ -1093,6 +1101,15 @@ struct StreamParams {
     int plain_store;         // 0: the ranges leave with non-temporal stores (range_store); 1: plain stores — for a caller
                              //   whose next kernel reads them back at once (FollowGap on the same stream: option nt_store 0)
     unsigned long long *dbg; // diagnostics (nullptr in production): 4 words per wave
+    // several rays per lane, HAND-OFF (round 5): a wave whose workgroup's stream is dry does not drain its last long
+    // rays in place — it writes them to `left_rec` (its own region of 2^left_cap_log2 records, no atomics), their
+    // number to left_cnt[wave], and leaves; rm_leftover_kernel, the next launch on the stream, finishes them.  A
+    // workgroup's slot is free ~2 us after its stream ran dry instead of ~14 us (its longest ray), so the slot goes
+    // to the next workgroup — of the next launch in flight, or of this launch's next generation (grids beyond the
+    // resident 2 workgroups per CU tile without a ragged end per generation).  nullptr: drain in place.
+    LeftoverRec *left_rec;
+    uint32_t *left_cnt;
+    int left_cap_log2;
 };
 
 
@@ -1395,6 +1412,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         static_assert(!(SLOTS >= 2) || !AUX, "multi-slot form: ranges (+ crash test), no diagnostics");
         Slot sa{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, NO_RAY, 0u, 0}, sb = sa, sc = sa;
         bool exhausted = total == 0;
+        uint32_t left_n = 0;              // rays this wave hands to rm_leftover_kernel
         auto finish = [&](Slot &s) {
             float r = f.max_range;
             if (s.d_last == PDT_HIT) {
@@ -1451,7 +1469,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                     const unsigned long long lc = SLOTS == 3 ? __ballot(sc.t < f.max_range) : 0ull;
                     const uint32_t na = (uint32_t)__popcll(la), nb2 = (uint32_t)__popcll(lb), nc = (uint32_t)__popcll(lc);
                     const uint32_t nlive = na + nb2 + nc;
-                    const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane(min(max(sp.drain_cap, 1), DRAIN_CAP));
+                    const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane(
+                        sp.left_rec ? min(max(sp.drain_cap, 1), 1 << sp.left_cap_log2) : min(max(sp.drain_cap, 1), DRAIN_CAP));
                     if (nlive > cap) {
                         // the plain loop until few rays are left
                         if (SLOTS == 3)
@@ -1470,6 +1489,27 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                         if (!(sa.t < f.max_range) && sa.oidx != NO_RAY) finish(sa);
                         if (!(sb.t < f.max_range) && sb.oidx != NO_RAY) finish(sb);
                         if (SLOTS == 3 && !(sc.t < f.max_range) && sc.oidx != NO_RAY) finish(sc);
+                        if (sp.left_rec) {
+                            // HAND-OFF: the live rays of every slot go to this wave's region of the leftover list
+                            // (ranks 0 .. nlive-1) and the wave leaves; rm_leftover_kernel finishes them
+                            const size_t gwv = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+                            LeftoverRec *dst = sp.left_rec + (gwv << sp.left_cap_log2);
+                            auto hand = [&](const Slot &s, uint32_t r) {
+                                uint4 *q = reinterpret_cast<uint4 *>(dst + r);
+                                q[0] = make_uint4(__builtin_bit_cast(uint32_t, s.gx), __builtin_bit_cast(uint32_t, s.gy),
+                                                  __builtin_bit_cast(uint32_t, s.dx), __builtin_bit_cast(uint32_t, s.dy));
+                                q[1] = make_uint4(__builtin_bit_cast(uint32_t, s.t), __builtin_bit_cast(uint32_t, s.d_last),
+                                                  s.oidx, CRASH ? s.pose : 0u);
+                            };
+                            if (sa.t < f.max_range)
+                                hand(sa, __builtin_amdgcn_mbcnt_hi((uint32_t)(la >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)la, 0u)));
+                            if (sb.t < f.max_range)
+                                hand(sb, na + __builtin_amdgcn_mbcnt_hi((uint32_t)(lb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lb, 0u)));
+                            if (SLOTS == 3 && sc.t < f.max_range)
+                                hand(sc, na + nb2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(lc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lc, 0u)));
+                            left_n = nlive;
+                            break;
+                        }
                         // compact the live rays of every slot into slot A, lanes 0 .. nlive-1, through LDS
                         auto put = [&](const Slot &s, uint32_t r) {
                             drain_scr[0 * DRAIN_CAP + r] = __builtin_bit_cast(uint32_t, s.gx);
@@ -1531,6 +1571,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                             sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
                             exhausted ? 0u : 2u * (uint32_t)sp.low_water);
         }
+        // (every wave of the grid writes its count, 0 included: the list needs no clearing between launches)
+        if (sp.left_cnt && lane == 0) sp.left_cnt[(size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)] = left_n;
         if (sp.dbg && lane == 0) {
             // diagnostics of the several-rays-per-lane form: absolute stamps {kernel entry, wave end, prologue done,
             // stream dry (0: never marched after exhaustion)} — tools/gpu_stamps_pipe.py
@@ -1642,6 +1684,59 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         sp.dbg[gw + 2] = ((unsigned long long)n_serv << 32) | ds_max;
         sp.dbg[gw + 3] = ((unsigned long long)(uint32_t)(t_drain ? t_drain - t_start : 0) << 32) |
                          ((unsigned long long)(K & 0xffffffu) << 8) | (uint32_t)(band & 0xff);
+    }
+}
+
+// ------------------------------------------------------------------------------
+// rm_leftover_kernel: the second launch of a hand-off march (StreamParams::left_rec).  Leftover wave w gathers the
+// records of 64 >> cap_log2 consecutive source waves (2^cap_log2 record slots each, left_cnt[] of them filled) —
+// one ray per lane — and finishes them with the one-ray-per-lane drain loops: a bounded stretch of the plain loop,
+// then the value-speculating loop (march_drain4), alternating.  Same arithmetic, same results: the t sequence of a
+// ray does not depend on which wave adds its steps.  No LDS, no workgroup-level state: 64..256-lane workgroups that
+// fit between the main kernels of the other streams.
+// ------------------------------------------------------------------------------
+template <bool CRASH>
+__global__ __launch_bounds__(256) void rm_leftover_kernel(PadMap pm, FanParams f, const LeftoverRec *__restrict__ rec,
+                                                          const uint32_t *__restrict__ cnt, int n_src, int cap_log2,
+                                                          int stretch, int plain_store, float *__restrict__ out,
+                                                          CrashParams cp)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t per_log2 = 6u - (uint32_t)cap_log2;
+    const uint32_t src = (w << per_log2) + (lane >> cap_log2), e = lane & ((1u << cap_log2) - 1u);
+    const bool has = src < (uint32_t)n_src && e < cnt[src];
+    float gx = 0.f, gy = 0.f, dx = 0.f, dy = 0.f, t = __builtin_inff(), d_last = 1.0f;
+    uint32_t oidx = NO_RAY, pose = 0;
+    int pc = 0, pr = 0;
+    if (has) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(rec + (((size_t)src << cap_log2) + e));
+        const uint4 a = q[0], b = q[1];
+        gx = __builtin_bit_cast(float, a.x); gy = __builtin_bit_cast(float, a.y);
+        dx = __builtin_bit_cast(float, a.z); dy = __builtin_bit_cast(float, a.w);
+        t = __builtin_bit_cast(float, b.x); d_last = __builtin_bit_cast(float, b.y);
+        oidx = b.z; pose = b.w;
+    }
+    if (!__ballot(has)) return;
+    while (__ballot(t < f.max_range)) {
+        march_loop_capped<true>(dx, dy, gx, gy, t, pc, pr, d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
+                                (uint32_t)stretch);
+        march_drain4<true>(dx, dy, gx, gy, t, pc, pr, d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range);
+    }
+    if (has) {
+        float r = f.max_range;
+        if (d_last == PDT_HIT) {
+            const float xd = (float)pc - gx, yd = (float)pr - gy;
+            r = hit_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+        }
+        r *= pm.res;
+        if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (oidx >> 2));
+        if (out) range_store(out, oidx, r, plain_store);
+        if (CRASH) {
+            // Car::isCrashed racecar/src/racecar.cpp:320 on this ray (beam index from the output offset)
+            const uint32_t jbeam = (oidx >> 2) - pose * (uint32_t)f.num_rays;
+            if (((double)r - cp.edge[jbeam]) < cp.thresh) crash_note(cp, pose);
+        }
     }
 }
 

@@ -172,6 +172,13 @@ struct rl_map {
     // occ / EDT / bit map.  A map callback thread and a scan thread may share the objects
     // (scripts/ros_interface.py:107-115).
     std::shared_mutex tables_mu;
+    // MULTI-DEVICE map only.  readers: the multi_* host-pointer entry points of every method of this map, for the
+    // whole batch (every device's block); writer: rl_map_update while it walks the replicas — so one batch is
+    // never scanned partly on the old and partly on the new occupancy.  `broken`: an update failed after some
+    // replicas had already taken the new cells; the handle then refuses every further call instead of answering
+    // from two different maps.
+    std::shared_mutex multi_mu;
+    std::atomic<bool> broken{false};
 };
 
 struct DevBuf {
@@ -210,10 +217,11 @@ struct LaunchCtx {
     bool bound = false;
     uint64_t last_use = 0;
     DevBuf rec, rec_sorted, order, keys, hist, pose_first, dbg, d0, cddt_r;   // cddt_r: theta-major CDDT, R[raw bin][pose]
+    DevBuf left_rec, left_cnt;     // hand-off march: the leftover list (rm_leftover_kernel), one region per wave of the main grid
     int crash_epoch = 0;           // mark value of the last per-pose crash launch (pose_marks)
     void release()
     {
-        for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg, &d0, &cddt_r}) b->release();
+        for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg, &d0, &cddt_r, &left_rec, &left_cnt}) b->release();
     }
 };
 constexpr int N_LAUNCH_CTX = 8;      // (HIP's default 4 hardware queues carry 4 concurrent streams; GPU_MAX_HW_QUEUES=8 carries 8)
@@ -356,6 +364,10 @@ struct rl_method {
     int spec_stretch = 16;       //   ... after this many plain samples, and between two attempts whose first prediction failed
     int drain_cap = 64;          // several rays per lane: compact a wave's last rays into one slot from <= this many (<= 64)
     int drain_stretch = 8;       //   ... plain samples between two speculation attempts of the compacted rays
+    int handoff = 0;             // several rays per lane, 1: a dry wave hands its last <= handoff_cap rays to rm_leftover_kernel (the
+                                 // next launch on the stream) instead of draining them in place (0: drain in place)
+    int handoff_cap = 16;        //   ... rays per wave handed over (8, 16, 32 or 64)
+    int handoff_wg = 256;        //   ... workgroup size of the leftover launch (64, 128 or 256)
     int nt_store = 1;            // ranges leave the stream kernels with non-temporal stores (0: plain — a consumer kernel reads them next)
     int wg_threads = 1024;       // stream kernel: workgroup size (256/512/1024) sharing one ray stream
     // GiantLUT (K3)
@@ -621,9 +633,22 @@ extern "C" int rl_map_update(rl_map *m, const uint8_t *occ)
     if (!m || !occ) return fail(RL_ERR_INVALID, "rl_map_update: null pointer");
     if (!m->reps.empty()) {
         std::lock_guard<std::mutex> lk(m->mu);
-        for (rl_map *r : m->reps) {
-            const int rc = rl_map_update(r, occ);
-            if (rc) return rc;
+        // exclusive against every multi_* call in progress: a batch sees ONE occupancy on all of its devices
+        std::unique_lock<std::shared_mutex> wl(m->multi_mu);
+        if (m->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
+        for (size_t i = 0; i < m->reps.size(); ++i) {
+            const int rc = rl_map_update(m->reps[i], occ);
+            if (rc) {
+                // replicas [0, i) hold the new cells, the others the old ones: no roll-back (the old cells are
+                // gone from the host) — the handle is marked and refuses further scans
+                if (i > 0) {
+                    m->broken.store(true);
+                    const std::string keep = g_err;
+                    return fail(rc, "rl_map_update failed on replica %zu of %zu after %zu replica(s) had been updated — "
+                                    "the multi-device map is now invalid: %s", i, m->reps.size(), i, keep.c_str());
+                }
+                return rc;
+            }
         }
         m->epoch++;
         return RL_OK;
@@ -857,6 +882,9 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "spec_drain")) h->spec_drain = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(name, "spec_stretch")) h->spec_stretch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
     else if (!strcmp(name, "drain_cap")) h->drain_cap = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (!strcmp(name, "handoff")) h->handoff = value != 0;
+    else if (!strcmp(name, "handoff_cap")) h->handoff_cap = value >= 64 ? 64 : (value >= 32 ? 32 : (value >= 16 ? 16 : 8));
+    else if (!strcmp(name, "handoff_wg")) h->handoff_wg = value >= 256 ? 256 : (value >= 128 ? 128 : 64);
     else if (!strcmp(name, "drain_stretch")) h->drain_stretch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
     else if (!strcmp(name, "nt_store")) h->nt_store = value != 0;
     else if (!strcmp(name, "timing")) h->timing = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -912,6 +940,9 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "spec_drain")) *value_out = h->spec_drain;
     else if (!strcmp(name, "spec_stretch")) *value_out = h->spec_stretch;
     else if (!strcmp(name, "drain_cap")) *value_out = h->drain_cap;
+    else if (!strcmp(name, "handoff")) *value_out = h->handoff;
+    else if (!strcmp(name, "handoff_cap")) *value_out = h->handoff_cap;
+    else if (!strcmp(name, "handoff_wg")) *value_out = h->handoff_wg;
     else if (!strcmp(name, "drain_stretch")) *value_out = h->drain_stretch;
     else if (!strcmp(name, "nt_store")) *value_out = h->nt_store;
     else if (!strcmp(name, "timing")) *value_out = h->timing;
@@ -1738,8 +1769,34 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.stripe = pl.record_source == 2 ? 1 : pl.record_source == 3 ? 2 : 0;
         sp.run_log2 = pl.run_log2;
         h->last_grid = pl.grid * waves_per_wg / WAVES_PER_WG;
-        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel alone
+        // hand-off march (several rays per lane on the tiled step map): dry waves leave their last rays in the launch
+        // context's leftover list — one region of handoff_cap records per wave of the main grid —, the second launch
+        // finishes them
+        const bool handoff = h->handoff && pl.slots >= 2 && pl.tiled && h->spec_drain > 0 && !h->debug_stamps;
+        int cap_log2 = 4;
+        const int n_src = pl.grid * waves_per_wg;
+        if (handoff) {
+            cap_log2 = h->handoff_cap >= 64 ? 6 : (h->handoff_cap >= 32 ? 5 : (h->handoff_cap >= 16 ? 4 : 3));
+            if ((rc = cx->left_rec.ensure(((size_t)n_src << cap_log2) * sizeof(LeftoverRec)))) return rc;
+            if ((rc = cx->left_cnt.ensure((size_t)n_src * sizeof(uint32_t)))) return rc;
+            sp.left_rec = (LeftoverRec *)cx->left_rec.p;
+            sp.left_cnt = (uint32_t *)cx->left_cnt.p;
+            sp.left_cap_log2 = cap_log2;
+            sp.drain_cap = std::min(sp.drain_cap, 1 << cap_log2);
+        }
+        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel(s) alone
         if ((rc = dispatch_rm_stream(pl, stream, pm, f, sp, d_out, d_hits, d_steps, cp))) return rc;
+        if (handoff) {
+            const int lw = h->handoff_wg / 64;                              // leftover waves per workgroup
+            const int n_lw = (n_src + (64 >> cap_log2) - 1) / (64 >> cap_log2);
+            const dim3 lgrid((unsigned)((n_lw + lw - 1) / lw)), lblock((unsigned)h->handoff_wg);
+            if (crash)
+                hipLaunchKernelGGL((rm_leftover_kernel<true>), lgrid, lblock, 0, stream, pm, f, (const LeftoverRec *)sp.left_rec,
+                                   (const uint32_t *)sp.left_cnt, n_src, cap_log2, h->drain_stretch, sp.plain_store, d_out, cp);
+            else
+                hipLaunchKernelGGL((rm_leftover_kernel<false>), lgrid, lblock, 0, stream, pm, f, (const LeftoverRec *)sp.left_rec,
+                                   (const uint32_t *)sp.left_cnt, n_src, cap_log2, h->drain_stretch, sp.plain_store, d_out, cp);
+        }
         break;
     }
     default:
@@ -2019,8 +2076,14 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
                 rc = fail(RL_ERR_HIP, "sliced device-to-host copy failed");
         }
         h->ray_offset = base_off;
-        (void)hipStreamSynchronize(h->stream);
-        (void)hipStreamSynchronize(h->copy_stream);
+        // (both streams are drained whatever happened; a kernel fault or a copy error that only surfaces here
+        //  must not come back as RL_OK with garbage in `outs`)
+        const hipError_t e_launch = hipGetLastError();
+        const hipError_t e_march = hipStreamSynchronize(h->stream);
+        const hipError_t e_copy = hipStreamSynchronize(h->copy_stream);
+        if (rc == RL_OK && (e_launch != hipSuccess || e_march != hipSuccess || e_copy != hipSuccess))
+            rc = fail(RL_ERR_HIP, "sliced host-pointer scan failed: launch %s, march stream %s, copy stream %s",
+                      hipGetErrorString(e_launch), hipGetErrorString(e_march), hipGetErrorString(e_copy));
         return rc;
     }
     rc = launch_fan(h, d_poses, n_poses, fov, num_rays, d_out,
@@ -2063,6 +2126,8 @@ static int multi_fan(rl_method *h, const float *poses, const float *rows3, int n
                      float *outs, int32_t *hits, uint16_t *steps)
 {
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->multi_mu);
+    if (h->map->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
     const int k = multi_parts(h, n_poses);
     const float nstd = h->noise_std;
     const uint64_t seed = h->noise_seed, off = h->ray_offset;
@@ -2087,6 +2152,8 @@ static int multi_fan(rl_method *h, const float *poses, const float *rows3, int n
 static int multi_rays(rl_method *h, const float *ins, float *outs, int n)
 {
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->multi_mu);
+    if (h->map->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
     const int k = (int)std::max<long>(1, std::min<long>((long)h->reps.size(), (long)n / (64L * std::max(h->multi_min_poses, 1) * 16)));
     const float nstd = h->noise_std;
     const uint64_t seed = h->noise_seed, off = h->ray_offset;
@@ -2109,6 +2176,8 @@ static int multi_crash(rl_method *h, const float *poses, int n_groups, int group
                        const double *edge, double thresh, int *first_crashed, float *ranges, bool single)
 {
     std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> ml(h->map->multi_mu);
+    if (h->map->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
     const long n_units = single ? group : n_groups;              // what is cut: poses of the one batch | roll-outs
     const long poses_per_unit = single ? 1 : group;
     const int k = (int)std::max<long>(1, std::min<long>(multi_parts(h, n_units * poses_per_unit), n_units));
@@ -2521,6 +2590,8 @@ extern "C" int rl_car_rollout_check(rl_car *c, rl_method *h, const double *state
             if (c->reps[i]->device != h->reps[i]->map->device)
                 return fail(RL_ERR_INVALID, "car and range method replicas live on different devices");
         std::scoped_lock lk(c->mu, h->mu);
+        std::shared_lock<std::shared_mutex> ml(h->map->multi_mu);
+        if (h->map->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
         const int k = (int)std::max<long>(1, std::min<long>(multi_parts(h, (long)R * n_steps), std::max(R, 1)));
         const size_t n_act = (size_t)(n_steps + every - 1) / every;
         const float nstd = h->noise_std;

@@ -269,13 +269,39 @@ class ShardedScan:
             sl.rcall = (pp, sl.local.data_ptr())
         # FollowGap reads the scan back on the same stream at once: keep the ranges in the L2 (plain stores; the
         # default non-temporal stores cost this mode 4.6 %, profiles/r04/nt_store_ab.txt)
-        method.set_option("nt_store", 0)       # (stays with the method: a caller that goes on to plain scans sets it back)
+        self._steer_method, self._steer_nt_store = method, int(method.get_info("nt_store"))
+        method.set_option("nt_store", 0)       # (unbind() / close() restores the method's own setting)
         self._bound = ("steer", _lib.raw("rl_calc_range_fan_device"), method._h, float(fov),
                        _lib.raw("rl_followgap_eval_device"), followgap._h, _lib.check)
 
     def _chunk_noise(self, h, ci):
+        """Key the next chunk call's noise at the chunk's own global ray id; after the LAST chunk of a step the
+        method is back at the block's offset (std, seed, base) the caller bound it with — a later direct scan
+        with the same method is keyed as if ShardedScan had never touched it."""
         raw_noise, std, seed, base = self._noise
-        raw_noise(h, std, seed, base + self.chunks[ci][0] * self.num_rays)
+        rc = raw_noise(h, std, seed, base + self.chunks[ci][0] * self.num_rays)
+        if rc:
+            from . import _lib
+            _lib.check(rc)
+
+    def _restore_noise(self, h):
+        raw_noise, std, seed, base = self._noise
+        rc = raw_noise(h, std, seed, base)
+        if rc:
+            from . import _lib
+            _lib.check(rc)
+
+    def unbind(self):
+        """Give the bound method back as it was handed over: ``bind_steer`` switches its range stores to plain
+        ones (``nt_store`` 0) for the FollowGap kernel that reads them next — a caller that goes on to plain scans
+        with the same method wants the non-temporal stores back."""
+        m = getattr(self, "_steer_method", None)
+        if m is not None:
+            m.set_option("nt_store", self._steer_nt_store)
+            self._steer_method = None
+        self._bound = None
+
+    close = unbind
 
     # the first slot's buffers (depth 1: the only ones)
     @property
@@ -328,6 +354,8 @@ class ShardedScan:
                 rc = raw(h, pp, cnt, fov, self.num_rays, op, None, None, sl.sptr)
                 if rc:
                     check(rc)
+            if self._noise is not None:
+                self._restore_noise(h)
             self.last = sl
             return sl
         with self._on(sl):
@@ -349,6 +377,8 @@ class ShardedScan:
                     compute(lo, hi, view, sl.sptr)
                 if self.gather:
                     sl.handles.append(self._exchange(sl, ci, view))
+            if compute is None and self._noise is not None:
+                self._restore_noise(self._bound[1])
         self.last = sl
         return sl
 
@@ -407,7 +437,9 @@ class ShardedScan:
 
     def results(self, slot=None):
         """Reduced modes: the slot's most recently exchanged bucket as a (world, steps, n_items) tensor
-        (call after ``finish()``); ``[:, s, :].reshape(-1)`` is step s of that bucket in global order."""
+        (call after ``finish()``, which also makes the CURRENT stream wait for the slot streams: kernels
+        enqueued on it afterwards see the exchanged bucket; a host read still needs a synchronisation);
+        ``[:, s, :].reshape(-1)`` is step s of that bucket in global order."""
         if not self.reduced:
             raise RuntimeError("results(): only for the reduced modes %r" % (REDUCED_MODES,))
         return (slot or self.last).bucket.latest()
@@ -522,9 +554,16 @@ class BucketedIndexGather:
             self.tick += self.every - slot
         for k in range(2):
             self._reuse(k)
+        # the waits above are enqueued on the producing stream (a torch side stream is non-blocking with respect to
+        # the default stream): order the CURRENT stream behind it, so that a reader enqueued there after flush()
+        # sees the exchanged bucket.  (A host read — .cpu(), .item() on another stream — still synchronises itself.)
+        if self.stream is not None and getattr(self.local[0], "is_cuda", False):
+            self.torch.cuda.current_stream(self.local[0].device).wait_stream(self.stream)
 
     def latest(self):
-        """(world, filled_steps, n_items) view of the most recently issued bucket (call after flush())."""
+        """(world, filled_steps, n_items) view of the most recently issued bucket.  Call after ``flush()``: it orders
+        the current stream behind the exchange; reading the view from the host or from a third stream needs that
+        stream's own synchronisation."""
         if self._last is None:
             return None
         k, filled = self._last

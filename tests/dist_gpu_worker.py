@@ -1,7 +1,9 @@
-"""Worker of tests/test_gpu_dist.py: launched by torch.distributed.run, every rank on cuda:0 over
-gloo (a 1-GPU box): map broadcast -> each rank scans its contiguous pose block with the PRODUCT
-(libscan_amd.so) -> chunked all-gather of the ranges, two steps in flight on two streams ->
-rank r saves what it gathered, in global pose order."""
+"""Worker of tests/test_gpu_dist.py: launched by torch.distributed.run.  With at least WORLD_SIZE visible
+devices every rank takes ITS OWN device (LOCAL_RANK) and the process group is RCCL ("nccl") — the real
+multi-GPU path; on a box with fewer devices (the 1-GPU gpurun box) every rank uses cuda:0 over gloo.
+Map broadcast -> each rank scans its contiguous pose block with the PRODUCT (libscan_amd.so) -> chunked
+all-gather of the ranges, two steps in flight on two streams -> rank r saves what it gathered, in global
+pose order, and a rank<r>_env.json saying which backend / device it ran on."""
 import os
 import sys
 
@@ -21,12 +23,23 @@ def main():
     from pyracecarsimulator_amd.pipeline import concurrent_streams
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo")
+    # (device_count() does not initialise the GPU; one device per rank whenever the box has them)
+    one_per_rank = torch.cuda.device_count() >= world and world > 1
+    di = int(os.environ.get("LOCAL_RANK", "0")) if one_per_rank else 0
+    torch.cuda.set_device(di)
+    dev = torch.device("cuda", di)
+    if one_per_rank:
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    assert dist.get_world_size() == world and dist.get_rank() == rank
+    import json
+    with open(os.path.join(out_dir, "rank%d_env.json" % rank), "w") as fh:
+        json.dump({"backend": dist.get_backend(), "device": di, "world": dist.get_world_size(),
+                   "visible_devices": torch.cuda.device_count()}, fh)
     g0 = maps.make_maze(512, cell=40, wall=3, p=0.45, seed=17, origin=(1.0, -2.0, 0.25)) if rank == 0 else None
     g = broadcast_map(g0, 0, dev)
-    omap = range_libc.PyOMap(g, device=0)
+    omap = range_libc.PyOMap(g, device=di)
     meth = range_libc.PyRayMarchingGPU(omap, 300)
     meth.set_noise(0.02, 99, 0)                              # noise keyed by the GLOBAL ray id
     fov = 4.71
@@ -77,7 +90,7 @@ def reduced_modes(out_dir, mode, rank, world, dev, meth, steps, lo, hi, B, fov, 
     meth.set_option("grid_mult", 3)
     edge = RC.edge_distances(B, -fov / 2.0, fov / B, 0.275, RC.DEFAULT_CAR["width"], RC.DEFAULT_CAR["wb"])
     d_edge = torch.from_numpy(edge).to(dev)
-    fg = PyFollowGap(10, 15.0, RC.DEFAULT_CAR["max_steer_ang"], 0.004, device=0)
+    fg = PyFollowGap(10, 15.0, RC.DEFAULT_CAR["max_steer_ang"], 0.004, device=dev.index)
     sc = ShardedScan(n, B, dev, n_chunks=1, gather=True, streams=streams if len(streams) == 2 else None, depth=2,
                      mode=mode, n_items=n // GROUP if mode == "crash" else n, every=2)
     ptrs = [steps[0][1].data_ptr(), steps[1][1].data_ptr()]          # slot k scans batch k

@@ -75,13 +75,20 @@ def one_case(seed):
                                  "bin_multi_min": int(r.choice([64, 8192])), "bin_ppw": int(r.choice([256, 512, 2048])), "pinned_max_rays": int(r.choice([0, 262144])),
                                  "slots": int(r.choice([1, 2, 3])), "spec_drain": int(r.choice([0, 8, 64])),
                                  "spec_stretch": int(r.choice([1, 4, 16])), "drain_cap": int(r.choice([1, 24, 64])),
-                                 "drain_stretch": int(r.choice([1, 8]))}
+                                 "drain_stretch": int(r.choice([1, 8])), "handoff": int(r.integers(0, 2)),
+                                 "handoff_cap": int(r.choice([8, 16, 32, 64])), "handoff_wg": int(r.choice([64, 128, 256]))}
                         for k_, v_ in sched.items():
                             m.set_option(k_, v_)
                     out = np.empty(n, np.float32); hits = np.empty((n, 2), np.int32); st = np.empty(n, np.uint16)
                     m.calc_range_fan(poses, out, fov, B, hit_cells=hits, steps=st)
                     r0, h0, s0 = ofun()
                     assert np.array_equal(out, r0), "%s v%d ranges %s" % (name, variant, sched)
+                    if name.startswith("RM") and variant == 1:
+                        # the ranges-only launch is its own instantiation (several rays per lane, drain compaction /
+                        # hand-off to rm_leftover_kernel): diagnostics force one ray per lane
+                        out2 = np.full(n, -3.0, np.float32)
+                        m.calc_range_fan(poses, out2, fov, B)
+                        assert np.array_equal(out2, r0), "%s v%d ranges-only %s" % (name, variant, sched)
                     assert np.array_equal(hits, h0), "%s v%d hits %s" % (name, variant, sched)
                     assert np.array_equal(st, s0), "%s v%d steps %s" % (name, variant, sched)
                     if sched:                      # ranges-only launch takes the non-diagnostic kernels
@@ -123,6 +130,7 @@ def one_case(seed):
             thr = 0.001
             rr = om.rm_fan(poses, fov, B, 1.0)[0]
             m = range_libc.PyRayMarchingGPU(omap, mrx); m.set_option("slots", int(r.choice([1, 2])))
+            m.set_option("handoff", int(r.integers(0, 2))); m.set_option("handoff_cap", int(r.choice([8, 64])))
             assert m.check_collision_many(poses, fov, B, edge, thr) == O.is_crashed(rr, B, P, edge, thr), "crash many"
             grp = next(k for k in (7, 5, 4, 3, 2, 1) if P % k == 0)
             want = [O.is_crashed(rr[k * grp * B:(k + 1) * grp * B], B, grp, edge, thr) for k in range(P // grp)]

@@ -1,7 +1,8 @@
-"""The N>1 path with the PRODUCT in it, on the one GPU of the test box: two ranks (cuda:0 each, gloo)
-scan their pose blocks with libscan_amd.so and all-gather the ranges; what every rank holds must be
-the oracle's scan of the whole batch in global pose order (SURVEY.md §8e "1-GPU output == N-GPU
-gathered output").  Also: ``bench.py --gpus 2`` started bare launches its own ranks."""
+"""The N>1 path with the PRODUCT in it: N ranks scan their pose blocks with libscan_amd.so and exchange the
+results; what every rank holds must be the oracle's scan of the whole batch in global pose order (SURVEY.md
+§8e "1-GPU output == N-GPU gathered output").  On a box with at least N visible devices the ranks take one
+device each and the group is RCCL (asserted: backend "nccl", N ranks, N distinct devices); on the 1-GPU
+test box every rank uses cuda:0 over gloo.  Also: ``bench.py --gpus 2`` started bare launches its own ranks."""
 import json
 import os
 import socket
@@ -30,6 +31,23 @@ def _free_port():
     return p
 
 
+def _visible_devices():
+    from pyracecarsimulator_amd import _lib
+    return _lib.lib().rl_device_count()
+
+
+def _check_rank_envs(tmp_path, world):
+    """What the workers report about themselves: with >= world visible devices the group must have been RCCL with
+    one distinct device per rank; otherwise gloo on device 0."""
+    envs = [json.load(open(os.path.join(str(tmp_path), "rank%d_env.json" % r))) for r in range(world)]
+    assert all(e["world"] == world for e in envs)
+    if _visible_devices() >= world:
+        assert all(e["backend"] == "nccl" for e in envs), envs
+        assert sorted(e["device"] for e in envs) == list(range(world)), envs
+    else:
+        assert all(e["backend"] == "gloo" and e["device"] == 0 for e in envs), envs
+
+
 def _env():
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -47,6 +65,7 @@ def test_ranks_gather_the_oracle_scan_in_global_pose_order(oracle_mod, tmp_path,
            os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(tmp_path), str(n_total), str(B), mode]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    _check_rank_envs(tmp_path, world)
     g = maps.make_maze(512, cell=40, wall=3, p=0.45, seed=17, origin=(1.0, -2.0, 0.25))
     om = oracle_mod.OracleMap.from_gridmap(g, 300)
     from pyracecarsimulator_amd import range_libc
@@ -93,6 +112,7 @@ def test_reduced_exchanges_equal_the_unsharded_result(oracle_mod, tmp_path, worl
            os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(tmp_path), str(n_total), str(B), mode]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    _check_rank_envs(tmp_path, world)
     g = maps.make_maze(512, cell=40, wall=3, p=0.45, seed=17, origin=(1.0, -2.0, 0.25))
     om = oracle_mod.OracleMap.from_gridmap(g, 300)
     omap = range_libc.PyOMap(g)
@@ -159,6 +179,8 @@ def test_bench_spawns_its_own_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    # the communicator's own rank count and the device every rank used are on the line (same-device dry run: 0, 0)
+    assert d["rccl_ranks"] == 2 and d["rank_devices"] == [0, 0] and d["comm_backend"] == "gloo"
     assert "all-gather ranges" in d["config"]["gather"]
     assert d["gather_bytes_per_step"] == 4 * 512 * 1081 * 2
     assert d["crash_mode"]["value"] > 0 and "steps in flight" in d["crash_mode"]["schedule"]
@@ -250,4 +272,26 @@ def test_bench_single_rank_through_rccl():
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and "all-gather ranges" in d["config"]["gather"] and d["value"] > 0
+    assert d["rccl_ranks"] == 1 and d["rank_devices"] == [0] and d["comm_backend"] == "nccl"
     assert d["verified"] is True and d["verification"]["gathered_equals_local"] is True
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`--gpus N` without --same-device needs N visible devices: a rank that silently shared a GPU would report an
+    N-GPU number measured on fewer.  (With N or more devices visible the run goes ahead on RCCL, one device per
+    rank, and says so on the line.)"""
+    nvis = _visible_devices()
+    world = 2
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2",
+           "--bursts", "3", "--poses", "256", "--no-cpu-baseline", "--no-crash-line", "--no-extras"]
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    if nvis < world:
+        assert r.returncode != 0 and "one GPU per rank is required" in r.stderr
+    else:
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["rccl_ranks"] == world and d["comm_backend"] == "nccl" and sorted(d["rank_devices"]) == list(range(world))
+        assert d["verified"] is True

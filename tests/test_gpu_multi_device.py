@@ -2,9 +2,11 @@
 host-pointer batch cut into contiguous pose blocks, one per device — what a drop-in caller of
 ScanSimulator2D.scanMany / checkCollisionMany (/root/reference/scripts/scan_simulator.py:113-135,
 scripts/racecar_simulator_v2.py:146-167, one Python process: scripts/mcts.py:237) needs to use the other
-GPUs of the node.  The test box has ONE MI355X, so the device list names device 0 several times (N
-contexts, N worker threads, N streams on one GPU): every result must be bit-identical to the single-
-device call — ranges, noise (global ray ids), crash indices — and to the CPU oracle."""
+GPUs of the node.  With ONE visible MI355X (the gpurun box) the device list names device 0 several times (N
+contexts, N worker threads, N streams on one GPU); with two or more visible devices the SAME tests run over
+DISTINCT devices (up to 8: ``_devs``) — hipSetDevice discipline, portable pinned blocks written by kernels of
+several devices, per-device worker threads — without a code change.  Every result must be bit-identical to the
+single-device call — ranges, noise (global ray ids), crash indices — and to the CPU oracle."""
 
 import numpy as np
 import pytest
@@ -17,6 +19,19 @@ pytestmark = pytest.mark.gpu
 FOV, B, MRX = 4.71, 1081, 300
 
 
+def _devs(k=3):
+    """Device list of a multi-device fixture: >= 2 visible devices -> distinct devices, min(visible, 8) of them for
+    the main fixture (k = 3) and min(visible, k) otherwise; one visible device -> device 0 named k times."""
+    n = _lib.lib().rl_device_count()
+    if n >= 2:
+        return list(range(min(n, 8 if k == 3 else k)))
+    return [0] * k
+
+
+def _distinct():
+    return _lib.lib().rl_device_count() >= 2
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _gpu(need_gpu):
     yield
@@ -26,7 +41,7 @@ def _gpu(need_gpu):
 def world():
     g = maps.make_maze(640, cell=40, wall=3, p=0.45, seed=23, origin=(-3.0, 2.0, 0.3))
     one = range_libc.PyOMap(g, device=0)
-    multi = range_libc.PyOMap(g, device=[0, 0, 0])
+    multi = range_libc.PyOMap(g, device=_devs(3))
     yield g, one, multi
     multi.close()
     one.close()
@@ -45,9 +60,12 @@ def _edge():
 def test_multi_map_shape_and_replicas(world):
     g, one, multi = world
     L = _lib.lib()
-    assert L.rl_map_n_devices(one._h) == 1 and L.rl_map_n_devices(multi._h) == 3
+    nd = len(_devs(3))
+    assert L.rl_map_n_devices(one._h) == 1 and L.rl_map_n_devices(multi._h) == nd
     assert L.rl_map_rows(multi._h) == g.rows and L.rl_map_cols(multi._h) == g.cols and L.rl_map_device(multi._h) == 0
-    assert L.rl_map_replica(multi._h, 3) is None and L.rl_map_replica(multi._h, 2) is not None
+    assert L.rl_map_replica(multi._h, nd) is None and L.rl_map_replica(multi._h, nd - 1) is not None
+    if _distinct():          # every replica lives on its own device
+        assert [L.rl_map_device(L.rl_map_replica(multi._h, i)) for i in range(nd)] == _devs(3)
     assert np.array_equal(multi.distance_transform(), one.distance_transform())
 
 
@@ -55,7 +73,7 @@ def test_multi_map_shape_and_replicas(world):
 def test_fan_blocks_equal_the_single_device_scan_and_the_oracle(world, oracle_mod, cls):
     g, one, multi = world
     m1, mm = cls(one, MRX), _split(cls(multi, MRX))
-    assert mm.n_devices == 3 and m1.n_devices == 1
+    assert mm.n_devices == len(_devs(3)) and m1.n_devices == 1
     om = oracle_mod.OracleMap.from_gridmap(g, MRX)
     assert mm.get_info("multi_min_poses") == 64 and cls(multi, MRX).get_info("multi_min_poses") == 512     # (default)
     for n in (1, 5, 63, 200, 1000):                      # below multi_min_poses x devices: fewer blocks (1, 1, 1, 3, 3)
@@ -106,7 +124,7 @@ def test_reference_call_forms_on_a_multi_device_handle(world, oracle_mod):
     with pytest.raises(_lib.ScanLibError) as e:
         mm.calc_range_fan_device(1, 1, FOV, B, 1)
     assert "rl_method_replica" in str(e.value)
-    assert mm.replica(2).n_devices == 1
+    assert mm.replica(len(_devs(3)) - 1).n_devices == 1
     with pytest.raises(IndexError):
         mm.replica(3)
     mm.close()
@@ -119,7 +137,7 @@ def test_table_methods_on_a_multi_device_map(world, oracle_mod, cls, td):
     and answer like the single-device handle and the oracle; options set on the handle reach every replica."""
     g, one, multi = world
     small = maps.make_maze(96, cell=12, wall=2, p=0.5, seed=3)
-    o1, om_ = range_libc.PyOMap(small, device=0), range_libc.PyOMap(small, device=[0, 0])
+    o1, om_ = range_libc.PyOMap(small, device=0), range_libc.PyOMap(small, device=_devs(2))
     m1, mm = cls(o1, 60, td), cls(om_, 60, td)
     mm.set_option("multi_min_poses", 8)
     assert mm.get_info("multi_min_poses") == 8 and mm.get_info("n_devices") == 2 and m1.get_info("n_devices") == 1
@@ -214,7 +232,7 @@ def test_rollout_chain_over_device_blocks(world):
     from pyracecarsimulator_amd import workloads as W
     w = W.Workload("t", g, 1, B, FOV, MRX, "RMGPU", 1)
     states, actions = W.rollout_inputs(w, 300, 3)
-    c1, cm = RC.CarBatch(device=0), RC.CarBatch(device=[0, 0, 0])
+    c1, cm = RC.CarBatch(device=0), RC.CarBatch(device=_devs(3))
     p1, s1, v1 = c1.rollout(states, actions)
     pm, sm, vm = cm.rollout(states, actions)
     assert np.array_equal(p1, pm) and np.array_equal(s1, sm) and np.array_equal(v1, vm)

@@ -77,6 +77,10 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "tiled": 0, "inline_prep": 0, "xcd_bands": 1},
     {"variant": 1, "nt_store": 0},                              # plain range stores (default: non-temporal)
     {"variant": 1, "nt_store": 0, "slots": 2},
+    {"variant": 1, "slots": 2, "handoff": 1},                   # dry waves hand their last rays to rm_leftover_kernel
+    {"variant": 1, "slots": 2, "handoff": 1, "handoff_cap": 8, "handoff_wg": 64, "inline_map_kb": 0, "stripe_max": 0},
+    {"variant": 1, "slots": 2, "handoff": 1, "handoff_cap": 64, "inline_prep": 0, "grid_mult": 2},
+    {"variant": 1, "slots": 3, "handoff": 1, "handoff_cap": 32, "handoff_wg": 128},
 ])
 def test_every_kernel_schedule_is_bit_identical(oracle_mod, opts):
     g = maps.make_maze(400, cell=40, wall=3, p=0.45, seed=21, origin=(-7.0, 3.0, -0.4))
@@ -1066,13 +1070,25 @@ def test_grouped_crash_device_api_fused_and_generic(oracle_mod):
     d_ranges = torch.zeros(400 * B, dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     m = range_libc.PyRayMarchingGPU(omap, mrx)
-    for ranges_ptr in (d_ranges.data_ptr(), 0):              # with and without storing the ranges
-        d_first.zero_()
-        m.check_collision_groups_device(d_poses.data_ptr(), 8, group, fov, B, d_edge.data_ptr(), 0.001,
-                                        d_first.data_ptr(), ranges_ptr, stream=st)
-        torch.cuda.synchronize()
-        assert d_first.cpu().tolist() == want
-    assert np.array_equal(d_ranges.cpu().numpy(), want_r)
+    # default schedule; two rays per lane draining in place; two rays per lane handing the last rays of a dry wave
+    # (and their crash test) to rm_leftover_kernel
+    for opts in ({}, {"slots": 2}, {"slots": 2, "handoff": 1, "handoff_cap": 8}, {"slots": 2, "handoff": 1, "handoff_cap": 64}):
+        for k, v in opts.items():
+            m.set_option(k, v)
+        for ranges_ptr in (d_ranges.data_ptr(), 0):              # with and without storing the ranges
+            d_first.zero_()
+            d_ranges.zero_()
+            m.check_collision_groups_device(d_poses.data_ptr(), 8, group, fov, B, d_edge.data_ptr(), 0.001,
+                                            d_first.data_ptr(), ranges_ptr, stream=st)
+            torch.cuda.synchronize()
+            assert d_first.cpu().tolist() == want, opts
+            if ranges_ptr:
+                assert np.array_equal(d_ranges.cpu().numpy(), want_r), opts
+    m.set_option("slots", 0)
+    m.set_option("handoff", 0)
+    m.check_collision_groups_device(d_poses.data_ptr(), 8, group, fov, B, d_edge.data_ptr(), 0.001,
+                                    d_first.data_ptr(), d_ranges.data_ptr(), stream=st)
+    torch.cuda.synchronize()
     assert any(w >= 0 for w in want) and any(w < 0 for w in want)
     assert m.check_collision_groups(poses, group, fov, B, edge, 0.001).tolist() == want
 
