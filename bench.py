@@ -97,6 +97,10 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed output verification (tuning sweeps)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the same-batch figure, the end-to-end host latencies and the gather-rate probe")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short verified side legs (cfg3 GiantLUT / CDDT, cfg2 crash / steer, a cfg5 shard) that "
+                         "the default 1-GPU cfg2 run appends to its line as `other_configs`")
+    ap.add_argument("--only-configs", default="", help="comma-separated subset of the side legs (tuning)")
     ap.add_argument("--selftest-corrupt", action="store_true",
                     help="flip one range of the last slot before the verification (tests that `verified` gates)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
@@ -284,6 +288,10 @@ def pmc_entry(workload, method, n, plan):
 
 def main():
     a = parse_args()
+    for kv in list(a.opt):                       # (`--opt variant=3` is `--variant 3`: the checker's statement follows it)
+        if kv.startswith("variant="):
+            a.variant = int(kv.split("=")[1])
+            a.opt.remove(kv)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
@@ -524,6 +532,7 @@ def main():
     verification = {}
     ok = True
     d_ref = None
+    literal_mode = {}           # the literal-arithmetic timing of the extras, quoted in verification.upstream_literal
 
     def reduced_reference(md, ranges):
         """The reduction of mode ``md`` over a (n*B,) float32 range tensor, independent of the fused path."""
@@ -630,7 +639,10 @@ def main():
             for pipelined in (True, False):
                 apply_schedule(pipelined)
                 meth.calc_range_fan(poses, got, w.fov, B)
-                if method in ("RM", "RMGPU"):
+                if method in ("RM", "RMGPU") and a.variant == 3:
+                    # --variant 3: the upstream-literal arithmetic is what is timed — its statement is the checker's libm form
+                    want = om.rm_fan_libm(poses, w.fov, B, step_coeff=1.0 if method == "RMGPU" else 0.999)[0]
+                elif method in ("RM", "RMGPU"):
                     want = om.rm_fan(poses, w.fov, B, step_coeff=1.0 if method == "RMGPU" else 0.999, nthreads=nthr,
                                      want_hits=False, want_steps=False)[0]
                 elif method == "BL":
@@ -664,7 +676,15 @@ def main():
                 meth.set_noise(w.noise_std, w.noise_seed, lo * B)
             apply_schedule(True)
         extra = {}
-        if method in ("RM", "RMGPU") and not a.selftest_corrupt:
+        if method in ("CDDT", "GLT", "BL"):
+            # the variants' tolerance is "<= 1 cell vs oracle RM" — the distribution of the timed
+            # method's error against EXACT ray marching on the same subsample goes on the line
+            import bench_legs
+            exact = om.rm_fan(poses, w.fov, B, step_coeff=1.0, nthreads=nthr, want_hits=False, want_steps=False)[0]
+            extra["vs_exact_rm"] = dict(bench_legs.error_stats_cells(got, exact, gmap.resolution),
+                                        what="|range - exact ray marching (oracle rm_fan, coefficient 1.0)| in cells, "
+                                             "%d poses x %d beams of batch 0" % (len(sub), B))
+        if method in ("RM", "RMGPU") and not a.selftest_corrupt and a.variant != 3:
             # parity on the record (range_libc is absent: the oracle is UNPINNED): the same subsample
             # through the AUDIT mode (variant 3: upstream-literal arithmetic, glibc sinf / cosf on the device) must equal
             # the oracle's libm form bit for bit, and the line states how far the canonical default is from it
@@ -688,6 +708,9 @@ def main():
             extra["upstream_literal"] = {
                 "audit_mode": "variant 3 (range_libc's CPU arithmetic stated literally, glibc sinf / cosf) == the oracle's "
                               "libm form on %d rays: ranges and hit cells bit-equal" % lit_r.size,
+                # the same schedule as `value` with the literal arithmetic (rm_fan_stream_kernel<.., LIT>), timed above
+                "audit_mode_mrays_s": literal_mode.get("value"), "audit_mode_vs_canonical": literal_mode.get("vs_canonical"),
+                "audit_mode_kernel": literal_mode.get("kernel"),
                 "canonical_default_vs_literal": {"rays": int(lit_r.size), "rays_with_another_hit_cell": int(moved.sum()),
                                                  "max_range_difference_cells": round(float(np.abs(got - lit_r).max() / gmap.resolution), 4),
                                                  "ranges_bit_equal": int((got == lit_r).sum())},
@@ -932,6 +955,21 @@ def main():
             out["same_batch"] = {"value": round(sb["value"], 2), "ms_per_step": round(sb["ms_per_step"], 4),
                                  "bursts": sb["bursts"],
                                  "what": "all %d steps in flight scan batch 0 (not the reported configuration)" % P}
+        if not a.no_extras and is_rm and a.variant < 0 and not scan.reduced and not a.selftest_corrupt:
+            # strict parity as a production mode: the SAME schedule — steps in flight, streams, pose
+            # batches — with the upstream-literal arithmetic (option variant 3 -> rm_fan_stream_kernel<.., LIT>)
+            meth.set_option("variant", 3)
+            try:
+                lm = summarise(timed_scan(scan, a.steps, min(a.warmup, 5), min(a.bursts, 9)), a.steps, rays_per_step)
+                lp = meth.last_plan()
+                literal_mode.update({"value": round(lm["value"], 2), "ms_per_step": round(lm["ms_per_step"], 4),
+                                     "vs_canonical": round(lm["value"] / out["value"], 4), "kernel": lp["name"],
+                                     "grid": lp["grid"], "bursts": lm["bursts"]})
+                out["literal_mode"] = dict(literal_mode, what="the timed schedule with option variant 3: range_libc's CPU "
+                                           "arithmetic stated literally (per-ray glibc sinf / cosf, un-fused march), bit-identical "
+                                           "to the checker's libm form (verification.upstream_literal)")
+            finally:
+                meth.set_option("variant", 1)
         if not a.no_extras and method in ("RM", "RMGPU"):
             # what the reference's callers see: numpy in -> numpy out through ScanSimulator2D
             # (scripts/scan_simulator.py:88-135), scan() = the sim tick, scanMany(200) = one MCTS roll-out
@@ -964,6 +1002,30 @@ def main():
     elif not a.no_verify:
         verification.setdefault("oracle_subsample", "not run (the oracle is loaded by the cpu_baseline leg only: "
                                                     "rank 0 of a 1-GPU run without --no-cpu-baseline)")
+    if (rank == 0 and world == 1 and not multi and a.workload == "cfg2" and not a.method and not a.poses and
+            mode == "none" and a.variant < 0 and not a.no_other_configs and not a.no_extras and not a.selftest_corrupt):
+        # ONE driver command, every single-GPU configuration: short verified legs of the other
+        # BASELINE.json configs and of the reduced modes, after the headline's measurement (bench_legs.py).  The oracle
+        # is the checker of those legs, loaded only when the cpu_baseline leg of this run loads it anyway.
+        import bench_legs
+        try:
+            scan = None
+            del d_poses
+            torch.cuda.empty_cache()
+        except Exception:                           # noqa: BLE001
+            pass
+        O_ = None
+        if not a.no_cpu_baseline and not a.no_verify:
+            from oracle import oracle as O_
+        only = set(x for x in a.only_configs.split(",") if x) or None
+        legs = bench_legs.other_configs(torch, dev, local_rank, O=O_, pmc_lookup=pmc_entry, only=only)
+        out["other_configs"] = legs
+        bad_legs = [k for k, v in legs.items() if v.get("verified") is False]
+        if not a.no_verify:
+            verification["other_configs_verified"] = not bad_legs
+            if bad_legs:
+                verification["other_configs_failed"] = bad_legs
+                ok = False
     if not a.no_verify:
         out["verified"] = bool(ok)
         out["verification"] = verification

@@ -313,7 +313,11 @@ typedef enum rl_kernel_id {
     RL_K_CDDT_BINS = 8,     /* cddt_fan_bins_kernel                                                       */
     RL_K_CDDT_RAYS = 9,     /* cddt_fan_kernel                                                            */
     RL_K_CDDT_THETA = 10,   /* cddt_theta_search_kernel + cddt_theta_fan_kernel (theta-major, large batches) */
-    RL_K_RM_LITERAL = 11    /* rm_literal_kernel<AUX, RAYS>: upstream-literal arithmetic, the audit mode (variant 3) */
+    RL_K_RM_LITERAL = 11,   /* rm_literal_kernel<AUX, RAYS>: upstream-literal arithmetic, one lane per ray — variant 3 with
+                               diagnostics (hit cells / sample counts), the 2-argument per-ray form, fans below 64 beams */
+    RL_K_RM_STREAM_LIT = 12 /* rm_fan_stream_kernel<false, CRASH, 1024, true, true, SLOTS, true>: variant 3 in production —
+                               the upstream-literal arithmetic on the stream kernel's schedule (ranges, fused crash test,
+                               noise; two rays per lane; batches above 8192 poses in pose slices)                 */
 } rl_kernel_id;
 
 typedef enum rl_binning {

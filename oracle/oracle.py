@@ -126,6 +126,11 @@ def lib():
         L.orc_cddt_fan.argtypes = [mp, C.c_void_p, C.c_float, _f32p, C.c_int, C.c_float, C.c_int,
                                    _f32p, C.c_int]
         L.orc_cddt_rays.argtypes = [mp, C.c_void_p, C.c_float, _f32p, C.c_int, _f32p, C.c_int]
+        L.orc_cddt_build_libm.argtypes = [mp, C.c_int]
+        L.orc_cddt_build_libm.restype = C.c_void_p
+        L.orc_cddt_rays_libm.argtypes = [mp, C.c_void_p, C.c_float, _f32p, C.c_int, _f32p]
+        L.orc_lut_build_libm.argtypes = [mp, _f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _u16p, C.c_int]
+        L.orc_lut_fan_rows_libm.argtypes = [mp, _u16p, C.c_int, C.c_float, _f32p, C.c_int, C.c_float, C.c_int, _f32p]
         L.orc_edge_distances.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                          C.c_double, _f64p]
         L.orc_is_crashed.argtypes = [_f32p, C.c_int, C.c_int, _f64p, C.c_double]
@@ -305,6 +310,24 @@ class OracleMap:
                                _p(ranges, _f32p))
         return ranges
 
+    def lut_build_libm(self, theta_disc, r0=0, r1=None, step_coeff=0.999, nthreads=0):
+        """Upstream-literal GiantLUT rows [r0, r1): libm cosf / sinf per bin, un-fused march from the cell corner."""
+        r1 = self.rows if r1 is None else r1
+        lut = np.empty((r1 - r0, self.cols, theta_disc), dtype=np.uint16)
+        lib().orc_lut_build_libm(C.byref(self._m), _p(self.dt, _f32p), self.max_range_px, step_coeff, theta_disc, r0, r1,
+                                 _p(lut, _u16p), nthreads or lib().orc_max_threads())
+        return lut
+
+    def lut_fan_rows_libm(self, pose_rows, poses, fov, num_rays):
+        """Fan query on literal rows: un-fused world->grid, per-ray float32 angles, fmod + roundf bin rule."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        pose_rows = np.ascontiguousarray(pose_rows, dtype=np.uint16)
+        assert pose_rows.shape[0] == poses.shape[0]
+        ranges = np.empty(poses.shape[0] * num_rays, dtype=np.float32)
+        lib().orc_lut_fan_rows_libm(C.byref(self._m), _p(pose_rows, _u16p), pose_rows.shape[1], self.max_range_px,
+                                    _p(poses, _f32p), poses.shape[0], fov, num_rays, _p(ranges, _f32p))
+        return ranges
+
     def lut_rays(self, lut, ins, nthreads=1):
         ins = np.ascontiguousarray(ins, dtype=np.float32).reshape(-1, 3)
         ranges = np.empty(ins.shape[0], dtype=np.float32)
@@ -324,6 +347,18 @@ class OracleMap:
         lib().orc_cddt_fan(C.byref(self._m), self._cddt_handle(theta_disc), self.max_range_px,
                            _p(poses, _f32p), poses.shape[0], fov, num_rays, _p(ranges, _f32p),
                            nthreads)
+        return ranges
+
+    def cddt_rays_libm(self, theta_disc, ins):
+        """The 2-argument per-ray query on the upstream-literal table (libm trig per bin, un-fused projection,
+        fmod + roundf bin rule) — what scripts/two_player/scan.py:57-70 feeds: per-ray float32 thetas."""
+        key = ("libm", theta_disc)
+        if key not in self._cddt:
+            self._cddt[key] = lib().orc_cddt_build_libm(C.byref(self._m), theta_disc)
+        ins = np.ascontiguousarray(ins, dtype=np.float32).reshape(-1, 3)
+        ranges = np.empty(ins.shape[0], dtype=np.float32)
+        lib().orc_cddt_rays_libm(C.byref(self._m), self._cddt[key], self.max_range_px, _p(ins, _f32p), ins.shape[0],
+                                 _p(ranges, _f32p))
         return ranges
 
     def cddt_rays(self, theta_disc, ins, nthreads=1):

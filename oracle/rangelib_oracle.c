@@ -601,6 +601,19 @@ static inline int lut_bin(float th, int theta_disc)
     return b < 0 ? b + theta_disc : b;
 }
 
+/* upstream's discretize_theta stated literally (as recalled, [UPSTREAM-RECALL]): fmod into [0, 2pi), then
+ * roundf(theta * theta_disc / 2pi) (halves away from zero), wrapped */
+static inline int lut_bin_libm(float th, int theta_disc)
+{
+    const float two_pi = 6.283185307179586f;
+    if (!(th > -1e9f && th < 1e9f)) return 0;
+    float t = fmodf(th, two_pi);
+    if (t < 0.0f) t += two_pi;
+    volatile float scaled = t * (float)theta_disc;
+    int b = (int)roundf(scaled / two_pi) % theta_disc;
+    return b < 0 ? b + theta_disc : b;
+}
+
 static inline uint16_t lut_quant(float r_px, float max_range)
 {
     float q = rintf(fminf(r_px, max_range) * (65535.0f / max_range));
@@ -718,13 +731,23 @@ static int cmp_float(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
-/* per-bin geometry shared by build and query */
-static void cddt_bin_geometry(const orc_map *m, int theta_disc, int a,
+/* per-bin geometry shared by build and query.
+ * lit (the *_libm statements): upstream's literal arithmetic as recalled (SURVEY row a13,
+ * [UPSTREAM-RECALL]) — the bin angle from a double-precision product rounded once (`M_2PI * i / theta_discretization`
+ * with a double constant), libm cosf / sinf, every product and sum its own float32 rounding (no fma).  The canonical
+ * form (lit = 0) is what the device builds bit for bit; the literal form measures how far that is from a libm build. */
+static void cddt_bin_geometry(const orc_map *m, int theta_disc, int a, int lit,
                               float *cosv, float *sinv, int *width, float *translation)
 {
-    float ang = (float)a * (6.283185307179586f / (float)theta_disc);
     float s, c;
-    orc_sincosf(ang, &s, &c);
+    if (lit) {
+        float ang = (float)(6.283185307179586 * (double)a / (double)theta_disc);
+        c = cosf(ang);
+        s = sinf(ang);
+    } else {
+        float ang = (float)a * (6.283185307179586f / (float)theta_disc);
+        orc_sincosf(ang, &s, &c);
+    }
     *cosv = c;
     *sinv = s;
     float W = (float)m->cols, H = (float)m->rows;
@@ -732,7 +755,8 @@ static void cddt_bin_geometry(const orc_map *m, int theta_disc, int a,
     float rotated_height = fabsf(W * s) + fabsf(H * c);
     *width = (int)ceilf(rotated_height - CDDT_EPS) + 1;
     /* lowest rotated corner -> translation making every bucket index >= 0 */
-    float lt = H * c, rt = fmaf(W, s, H * c), rb = W * s;
+    volatile float ws = W * s, hc = H * c;                 /* (volatile: the literal sum stays un-fused) */
+    float lt = H * c, rt = lit ? ws + hc : fmaf(W, s, H * c), rb = W * s;
     float mn = fminf(lt, fminf(rt, rb));
     *translation = fmaxf(0.0f, -mn - CDDT_EPS);
 }
@@ -747,16 +771,27 @@ static inline int is_edge(const orc_map *m, int r, int c)
            !m->occ[(size_t)r * m->cols + c - 1] || !m->occ[(size_t)r * m->cols + c + 1];
 }
 
-/* lut-space projection of a point for bin a */
-static inline void cddt_project(float c, float s, float tr, float x, float y, float *lx, float *ly)
+/* lut-space projection of a point for bin a (lit: un-fused products, as upstream's x*cos - y*sin) */
+static inline void cddt_project(int lit, float c, float s, float tr, float x, float y, float *lx, float *ly)
 {
+    if (lit) {
+        volatile float xc = x * c, ys = y * s, xs = x * s, yc = y * c;
+        *lx = xc - ys;
+        *ly = (xs + yc) + tr;
+        return;
+    }
     *lx = fmaf(x, c, -(y * s));
     *ly = fmaf(x, s, y * c) + tr;
 }
 
-orc_cddt *orc_cddt_build(const orc_map *m, int theta_disc)
+static orc_cddt *cddt_build(const orc_map *m, int theta_disc, int lit);
+orc_cddt *orc_cddt_build(const orc_map *m, int theta_disc) { return cddt_build(m, theta_disc, 0); }
+orc_cddt *orc_cddt_build_libm(const orc_map *m, int theta_disc) { return cddt_build(m, theta_disc, 1); }
+
+static orc_cddt *cddt_build(const orc_map *m, int theta_disc, int lit)
 {
     orc_cddt *cd = (orc_cddt *)calloc(1, sizeof(orc_cddt));
+    cd->literal = lit;
     int nb = (theta_disc + 1) / 2;
     cd->theta_disc = theta_disc;
     cd->n_bins = nb;
@@ -767,7 +802,7 @@ orc_cddt *orc_cddt_build(const orc_map *m, int theta_disc)
     cd->bucket_off = (int64_t *)malloc((nb + 1) * sizeof(int64_t));
     int64_t nbk = 0;
     for (int a = 0; a < nb; ++a) {
-        cddt_bin_geometry(m, theta_disc, a, &cd->cosv[a], &cd->sinv[a], &cd->lut_width[a],
+        cddt_bin_geometry(m, theta_disc, a, lit, &cd->cosv[a], &cd->sinv[a], &cd->lut_width[a],
                           &cd->lut_translation[a]);
         cd->bucket_off[a] = nbk;
         nbk += cd->lut_width[a];
@@ -793,7 +828,7 @@ orc_cddt *orc_cddt_build(const orc_map *m, int theta_disc)
                     float cs = cd->cosv[a], sn = cd->sinv[a];
                     float half = (fabsf(sn) + fabsf(cs)) * 0.5f;
                     float lx, ly;
-                    cddt_project(cs, sn, cd->lut_translation[a], px, py, &lx, &ly);
+                    cddt_project(lit, cs, sn, cd->lut_translation[a], px, py, &lx, &ly);
                     int upper = (int)((ly + half) - CDDT_EPS);
                     int lower = (int)((ly - half) + CDDT_EPS);
                     if (lower < 0) lower = 0;
@@ -836,12 +871,12 @@ static inline float cddt_query(const orc_map *m, const orc_cddt *cd, float max_r
     /* CDDTCast::discretize_theta(-heading): nearest bin of -th in [0, theta_disc);
      * bins >= theta_disc/2 use the bin half a turn away, searching backwards      */
     int td = cd->theta_disc;
-    int b = lut_bin(-th, td);
+    int b = cd->literal ? lut_bin_libm(-th, td) : lut_bin(-th, td);
     int flipped = 0;
     if (b >= cd->n_bins) { b -= td / 2; flipped = 1; }
     if (b >= cd->n_bins) b = cd->n_bins - 1;           /* odd theta_disc guard */
     float lx, ly;
-    cddt_project(cd->cosv[b], cd->sinv[b], cd->lut_translation[b], gx, gy, &lx, &ly);
+    cddt_project(cd->literal, cd->cosv[b], cd->sinv[b], cd->lut_translation[b], gx, gy, &lx, &ly);
     float out = max_range;
     if (ly >= 0.0f && ly < (float)cd->lut_width[b]) {
         int64_t bk = cd->bucket_off[b] + (int)ly;
@@ -874,6 +909,84 @@ void orc_cddt_fan(const orc_map *m, const orc_cddt *c, float max_range_px,
         for (int j = 0; j < num_rays; ++j)
             ranges[(size_t)p * num_rays + j] =
                 cddt_query(m, c, max_range_px, gx, gy, thg + fan_alpha(fov, num_rays, j));
+    }
+}
+
+/* world pose -> grid as RangeMethod::numpy_calc_range states it (rm_cast_libm above): un-fused rotation with the
+ * double-precision sin / cos of the world angle rounded once */
+static inline void world_to_grid_libm(const orc_map *m, float xw, float yw, float thw, float *gx, float *gy, float *thg)
+{
+    const float wsin = (float)sin((double)m->wa), wcos = (float)cos((double)m->wa);
+    float x = (xw - m->ox) * m->inv_res;
+    float y = (yw - m->oy) * m->inv_res;
+    volatile float a = wcos * x, b = wsin * y, c = wsin * x, d = wcos * y;
+    *gx = a - b;
+    *gy = c + d;
+    *thg = thw + m->wa;
+}
+
+/* the 2-argument per-ray form on a literal table (what scripts/two_player/scan.py:57-70 feeds: per-ray float32 thetas) */
+void orc_cddt_rays_libm(const orc_map *m, const orc_cddt *c, float max_range_px, const float *ins, int n, float *ranges)
+{
+    for (int i = 0; i < n; ++i) {
+        float gx, gy, thg;
+        world_to_grid_libm(m, ins[3 * i], ins[3 * i + 1], ins[3 * i + 2], &gx, &gy, &thg);
+        ranges[i] = cddt_query(m, c, max_range_px, gx, gy, thg);
+    }
+}
+
+/* GiantLUT, literal statement: one libm ray-marching cast per (cell, bin) from the cell's integer corner along
+ * (cosf, sinf) of the bin angle (double product rounded once), un-fused march (rm_cast_libm's arithmetic in grid
+ * coordinates), the same quantisation; rows [r0, r1) */
+void orc_lut_build_libm(const orc_map *m, const float *dt, float max_range_px, float step_coeff, int theta_disc,
+                        int r0, int r1, uint16_t *lut, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 1 ? nthreads : 1)
+    for (int r = r0; r < r1; ++r)
+        for (int c = 0; c < m->cols; ++c) {
+            uint16_t *row = lut + ((size_t)(r - r0) * m->cols + c) * theta_disc;
+            for (int b = 0; b < theta_disc; ++b) {
+                const float ang = (float)(6.283185307179586 * (double)b / (double)theta_disc);
+                const float dx = cosf(ang), dy = sinf(ang);
+                const float x0 = (float)c, y0 = (float)r;
+                float t = 0.0f, out = max_range_px;
+                while (t < max_range_px) {
+                    volatile float ax = dx * t, ay = dy * t;
+                    const int px = (int)(x0 + ax), py = (int)(y0 + ay);
+                    if (px < 0 || py < 0 || px >= m->cols || py >= m->rows) break;
+                    const float d = dt[(size_t)py * m->cols + px];
+                    if (d <= 0.0f) {
+                        volatile float xd = (float)px - x0, yd = (float)py - y0;
+                        volatile float xx = xd * xd, yy = yd * yd;
+                        out = sqrtf(xx + yy);
+                        break;
+                    }
+                    const float st = d * step_coeff;
+                    t += st > 1.0f ? st : 1.0f;
+                }
+                row[b] = lut_quant(out, max_range_px);
+            }
+        }
+}
+
+/* fan query on literal rows (one theta row per pose, as orc_lut_fan_rows): literal world->grid and bin rule */
+void orc_lut_fan_rows_libm(const orc_map *m, const uint16_t *pose_rows, int theta_disc, float max_range_px,
+                           const float *poses, int n_poses, float fov, int num_rays, float *ranges)
+{
+    const float fcols = (float)m->cols, frows = (float)m->rows;
+    const float amin = -0.5f * fov, inc = fov / (float)num_rays;
+    for (int p = 0; p < n_poses; ++p) {
+        float gx, gy, thg;
+        world_to_grid_libm(m, poses[3 * p], poses[3 * p + 1], poses[3 * p + 2], &gx, &gy, &thg);
+        const int in = gx >= 0.0f && gx < fcols && gy >= 0.0f && gy < frows;
+        const uint16_t *row = pose_rows + (size_t)p * theta_disc;
+        for (int j = 0; j < num_rays; ++j) {
+            volatile float aj = (float)j * inc;
+            const float th = thg + (amin + aj);
+            ranges[(size_t)p * num_rays + j] = in ? lut_dequant(row[lut_bin_libm(th, theta_disc)], max_range_px) * m->res
+                                                  : max_range_px * m->res;
+        }
     }
 }
 

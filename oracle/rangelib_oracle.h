@@ -118,8 +118,18 @@ typedef struct orc_cddt {
     int64_t *offsets;        /* CSR: bucket -> [start,end) in xs                        */
     float *xs;               /* sorted unique lut-space x of edge-cell centres          */
     int64_t n_buckets, n_xs;
+    int literal;             /* 1: built by orc_cddt_build_libm (libm trig, un-fused projection, upstream's bin rule) */
 } orc_cddt;
 orc_cddt *orc_cddt_build(const orc_map *m, int theta_disc);
+/* upstream-literal statements of the table methods (libm cosf / sinf per bin, un-fused projection, roundf bin rule):
+ * how far the canonical tables (== the device's, bit for bit) are from a libm build — tests/test_oracle.py,
+ * tests/golden/table_libm_forms.npz, tests/test_gpu_parity.py::test_device_tables_vs_upstream_literal_libm_forms */
+orc_cddt *orc_cddt_build_libm(const orc_map *m, int theta_disc);
+void orc_cddt_rays_libm(const orc_map *m, const orc_cddt *c, float max_range_px, const float *ins, int n, float *ranges);
+void orc_lut_build_libm(const orc_map *m, const float *dt, float max_range_px, float step_coeff, int theta_disc,
+                        int r0, int r1, uint16_t *lut, int nthreads);
+void orc_lut_fan_rows_libm(const orc_map *m, const uint16_t *pose_rows, int theta_disc, float max_range_px,
+                           const float *poses, int n_poses, float fov, int num_rays, float *ranges);
 void orc_cddt_free(orc_cddt *c);
 void orc_cddt_fan(const orc_map *m, const orc_cddt *c, float max_range_px,
                   const float *poses, int n_poses, float fov, int num_rays,

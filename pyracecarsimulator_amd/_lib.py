@@ -50,7 +50,7 @@ class LaunchPlan(C.Structure):
 
 
 KERNEL_IDS = {0: "none", 1: "rm_chunk", 2: "rm_stream", 3: "occ_lds", 4: "bl_stream", 5: "bl_lds", 6: "lut_lds",
-              7: "lut_fan", 8: "cddt_bins", 9: "cddt_rays", 10: "cddt_theta", 11: "rm_literal"}
+              7: "lut_fan", 8: "cddt_bins", 9: "cddt_rays", 10: "cddt_theta", 11: "rm_literal", 12: "rm_stream_literal"}
 BINNINGS = {0: "none", 1: "small_keys", 2: "small_records", 3: "grid_sort", 4: "grid_unsorted", 5: "generic"}
 
 #: every symbol include/scanlib.h declares: name -> (restype, argtypes)

@@ -23,6 +23,7 @@ constexpr int STRIPE_BINS = 64;
 constexpr int STRIPE_MAX_PER_LANE = 8;
 constexpr int INLINE_LDS_BUDGET = 72 * 1024;   // LDS an INLINE workgroup may use (two 1024-lane workgroups per CU)
 constexpr int INLINE_REC_BYTES = 32;     // one BlockRec per owned 64-ray block (rm_kernels.h)
+constexpr int LIT_SLICE_POSES = 4096;    // upstream-literal stream form: poses per slice of a batch too large for one INLINE launch
 constexpr int DRAIN_CAP = 64, DRAIN_FIELDS = 7;   // several rays per lane: per-wave compaction scratch of the drain phase
                                                   // (7 dwords per ray, 9 with the fused crash test)
 
@@ -258,7 +259,25 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     const long n_chunks = (o.variant >= 1) ? (rays + 63) / 64 : (long)n_poses * cpp;
     const bool stream_ok = rays < (1L << 30);
     if (o.variant == 3) {
-        // audit mode: upstream-literal arithmetic, one lane per ray (literal_kernels.h)
+        // upstream-literal arithmetic.  Production form: the stream kernel's schedule with per-ray libm directions at
+        // claim time (template argument LIT) — whenever the records can be derived in LDS (INLINE: every batch of up to
+        // 8192 poses and fans of >= 64 beams; plan_fan cuts larger batches into pose slices) on the tiled step map and no
+        // diagnostics are asked for.  Everything else: the one-lane-per-ray kernel (literal_kernels.h).
+        if (!in.aux && tiled_opt) {
+            In as_stream = in;
+            as_stream.o.variant = 1;
+            if (as_stream.o.slots == 3) as_stream.o.slots = 2;
+            rl_launch_plan q;
+            std::memset(&q, 0, sizeof q);
+            if (plan_one(as_stream, &q) == RL_OK && q.kernel == RL_K_RM_STREAM && q.record_source != 0 && q.tiled &&
+                q.block == 1024 && q.slots <= 2) {
+                *p = q;
+                p->kernel = RL_K_RM_STREAM_LIT;
+                std::snprintf(p->name, sizeof p->name, "scan::rm_fan_stream_kernel<false, %s, 1024, true, true, %d, true>",
+                              tf(in.crash), q.slots);
+                return RL_OK;
+            }
+        }
         if (in.crash) return RL_ERR_UNSUPPORTED;
         p->kernel = RL_K_RM_LITERAL;
         p->grid = (int)std::max(1L, std::min((rays + WG - 1) / WG, (long)n_cu * o.grid_mult));
@@ -402,6 +421,25 @@ inline int plan_fan(const In &in_raw, rl_launch_plan *p)
     // the stream kernels index rays with 32-bit byte offsets: batches of 2^30 rays or more go
     // through in pose slices, each its own launch sequence
     const long slice_rays = 1L << in.o.slice_log2;
+    if (in.o.variant == 3 && !in.aux && in.n_poses > LIT_SLICE_POSES && in.num_rays >= 64 &&
+        (in.kind == RL_RM || in.kind == RL_RM_GPU)) {
+        // upstream-literal mode: the stream form derives its records in LDS — batches the planner cannot take that way
+        // in one launch (beyond the keys-only binning's 8191 poses on a big map, or beyond the LDS budget) run as pose
+        // slices of 4096, one launch sequence each (launch_fan; a fused crash test marks poses, so its slices only shift
+        // the mark array)
+        int rc = plan_one(in, p);
+        if (rc == RL_OK && p->kernel == RL_K_RM_STREAM_LIT) return rc;
+        In first = in;
+        first.n_poses = LIT_SLICE_POSES;
+        std::memset(p, 0, sizeof *p);
+        rc = plan_one(first, p);
+        if (rc == RL_OK && p->kernel == RL_K_RM_STREAM_LIT) {
+            p->slices = (in.n_poses + LIT_SLICE_POSES - 1) / LIT_SLICE_POSES;
+            p->slice_poses = LIT_SLICE_POSES;
+            return rc;
+        }
+        std::memset(p, 0, sizeof *p);
+    }
     if ((long)in.n_poses * in.num_rays >= slice_rays && in.o.variant >= 1 && !in.crash && in.n_poses > 1) {
         const int per = (int)std::max(1L, (slice_rays - 1) / in.num_rays);
         In first = in;

@@ -3,6 +3,7 @@
 // the persistent stream kernel rm_fan_stream_kernel.  Part of scan_kernels.h.
 #pragma once
 #include "scan_device.h"
+#include "literal_math.h"
 
 namespace scan {
 
@@ -259,6 +260,35 @@ __device__ __forceinline__ uint32_t pose_record(const MapParams &m, const float 
         return ((uint32_t)n_tiles - 1) | POSE_INVALID;
     }
     return (uint32_t)(((int)r.gy >> tile_shift) * tiles_x + ((int)r.gx >> tile_shift));
+}
+
+// The record of a pose in the UPSTREAM-LITERAL arithmetic (variant 3, stream kernel template argument LIT):
+// RangeMethod::numpy_calc_range's world -> grid with un-fused products and the double-precision sin / cos of the world
+// angle rounded once (the checker's rm_cast_libm; literal_kernels.h::literal_cast).  calc_range(y, x, theta') marches
+// (row, col): the record keeps the COLUMN coordinate in gx and the ROW coordinate in gy, as every loop here expects,
+// and the pose's world heading in ct — the direction is computed per RAY at claim time (libm sinf / cosf of
+// theta_p + alpha_j).  A pose the literal march would leave before its first sample (outside the map, non-finite) is
+// flagged like the canonical one: every beam a miss.
+__device__ __forceinline__ uint32_t pose_record_lit(const MapParams &m, const LiteralParams &lp, const float *__restrict__ poses,
+                                                    int p, PoseRec &r)
+{
+    const float xw = poses[3 * (size_t)p], yw = poses[3 * (size_t)p + 1], thw = poses[3 * (size_t)p + 2];
+    float x = (xw - m.ox) * m.inv_res;
+    float y = (yw - m.oy) * m.inv_res;
+    const float temp = x;
+    x = lp.wcos * x - lp.wsin * y;
+    y = lp.wsin * temp + lp.wcos * y;
+    r.gx = x;
+    r.gy = y;
+    r.ct = thw;
+    r.st = 0.0f;
+    const bool fin = (thw - thw) == 0.0f;
+    const bool inb = x > -1.0f && x < m.fcols && y > -1.0f && y < m.frows;       // (int) truncation: (-1, 0) is cell 0
+    if (!(fin && inb)) {
+        r.gx = 0.0f; r.gy = 0.0f; r.ct = 0.0f;
+        return POSE_INVALID;
+    }
+    return 0u;
 }
 
 __global__ __launch_bounds__(1024) void pose_bin_kernel(MapParams m, const float *__restrict__ poses,
@@ -565,6 +595,19 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f)
     return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
+
+// position of a sample: (origin + direction x t) for both coordinates.  Canonical form: ONE packed fma (both halves
+// IEEE-fused: the CPU statement's fmaf).  LIT (upstream-literal arithmetic, variant 3: range_libc computes x0 + dx * t with the
+// product and the sum each rounded to float32): packed multiply, then packed add — one VALU instruction more per sample.
+// Operands as register-pair strings: D <- DIR(hi, lo crossed by op_sel) x T(lo, lo) [+] ORG.
+#define RM_POS(D, DIR, T, ORG)                                                                             \
+    ".if %[lit]\n\t"                                                                                       \
+    "v_pk_mul_f32 " D ", " DIR ", " T " op_sel:[1,0] op_sel_hi:[0,0]\n\t"                                    \
+    "v_pk_add_f32 " D ", " D ", " ORG "\n\t"                                                                 \
+    ".else\n\t"                                                                                            \
+    "v_pk_fma_f32 " D ", " DIR ", " T ", " ORG " op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"                        \
+    ".endif\n\t"
+
 // ------------------------------------------------------------------------------
 // The march loop of K1b, hand-scheduled for gfx950.  EXEC holds the live lanes
 // (v_cmpx drops a lane the moment its t reaches max_range, hits, or leaves the map),
@@ -576,7 +619,7 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f)
 //   d  = step map at (r, c)              = max(dt*coeff, 1) | +inf (occupied) | 3e38 (border)
 //   t += d                               => a hit / leaving the map pushes t past max_range
 // ------------------------------------------------------------------------------
-template <bool AUX, bool TILED>
+template <bool AUX, bool TILED, bool LIT = false>
 __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float gy, float &t, int &c,
                                            int &r, float &d, uint32_t &nstep, const float *pdt,
                                            int stride, int nstride, uint32_t k4, float max_range,
@@ -596,7 +639,7 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
         "s_mov_b64 %[save], exec\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v20\n"
         "L_march_%=:\n\t"
-        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[26:27]", "v[22:23]", "v[20:21]", "v[24:25]")
         "v_cvt_i32_f32_e32 %[c], v26\n\t"
         "v_cvt_i32_f32_e32 %[r], v27\n\t"
         ".if %[tiled]\n\t"
@@ -622,14 +665,14 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
           [save] "=&s"(save), [n] "=&s"(n)
         : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy),
           [mx] "s"(max_range), [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4),
-          [base] "s"(pdt), [low] "s"(low), [aux] "n"(AUX ? 1 : 0), [tiled] "n"(TILED ? 1 : 0)
+          [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), [low] "s"(low), [aux] "n"(AUX ? 1 : 0), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "vcc", "scc", "memory");
 }
 
 
 // march_loop with an iteration cap (drain phase: a bounded stretch of the plain loop between two attempts of
 // the speculating loop).  Leaves when no lane is live or after `iters` samples per lane.
-template <bool TILED>
+template <bool TILED, bool LIT = false>
 __device__ __forceinline__ void march_loop_capped(float dx, float dy, float gx, float gy, float &t, int &c, int &r,
                                                   float &d, const float *pdt, int stride, int nstride, uint32_t k4,
                                                   float max_range, uint32_t iters)
@@ -641,7 +684,7 @@ __device__ __forceinline__ void march_loop_capped(float dx, float dy, float gx, 
         "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
         "s_cbranch_execz L_cap_done_%=\n"
         "L_cap_%=:\n\t"
-        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[26:27]", "v[22:23]", "v[20:21]", "v[24:25]")
         "v_cvt_i32_f32_e32 %[c], v26\n\t"
         "v_cvt_i32_f32_e32 %[r], v27\n\t"
         ".if %[tiled]\n\t"
@@ -664,7 +707,7 @@ __device__ __forceinline__ void march_loop_capped(float dx, float dy, float gx, 
         "s_mov_b64 exec, %[save]\n\t"
         : [t] "+{v20}"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [save] "=&s"(save), [n] "+s"(n)
         : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy), [mx] "s"(max_range),
-          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [tiled] "n"(TILED ? 1 : 0)
+          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "vcc", "scc", "memory");
 }
 
@@ -685,7 +728,7 @@ __device__ __forceinline__ void march_loop_capped(float dx, float dy, float gx, 
 // samples 0 and 3 in v42 / v43 — exactly the fixed registers of slots B and C of the several-rays-per-lane
 // kernels, which are dead when this loop runs there (no register beyond theirs).
 // ------------------------------------------------------------------------------
-template <bool TILED>
+template <bool TILED, bool LIT = false>
 __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float gy, float &t, int &c, int &r,
                                              float &d, const float *pdt, int stride, int nstride, uint32_t k4,
                                              float max_range)
@@ -707,7 +750,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "v_add_f32_e32 v30, v28, v29\n\t"
         "v_add_f32_e32 v32, v30, v29\n\t"
         // sample 0 (every live lane)
-        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[26:27]", "v[22:23]", "v[20:21]", "v[24:25]")
         "v_cvt_i32_f32_e32 v26, v26\n\t"
         "v_cvt_i32_f32_e32 v27, v27\n\t"
         "v_mad_i32_i24 v27, v27, %[stride], %[k4]\n\t"
@@ -716,7 +759,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "global_load_dword v42, v26, %[base]\n\t"
         // sample 1 where t1 is still inside the range window
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
-        "v_pk_fma_f32 v[34:35], v[22:23], v[28:29], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[34:35]", "v[22:23]", "v[28:29]", "v[24:25]")
         "v_cvt_i32_f32_e32 v34, v34\n\t"
         "v_cvt_i32_f32_e32 v35, v35\n\t"
         "v_mad_i32_i24 v35, v35, %[stride], %[k4]\n\t"
@@ -725,7 +768,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "global_load_dword v31, v34, %[base]\n\t"
         // sample 2
         "v_cmpx_gt_f32_e32 %[mx], v30\n\t"
-        "v_pk_fma_f32 v[36:37], v[22:23], v[30:31], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[36:37]", "v[22:23]", "v[30:31]", "v[24:25]")
         "v_cvt_i32_f32_e32 v36, v36\n\t"
         "v_cvt_i32_f32_e32 v37, v37\n\t"
         "v_mad_i32_i24 v37, v37, %[stride], %[k4]\n\t"
@@ -734,7 +777,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "global_load_dword v33, v36, %[base]\n\t"
         // sample 3
         "v_cmpx_gt_f32_e32 %[mx], v32\n\t"
-        "v_pk_fma_f32 v[38:39], v[22:23], v[32:33], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[38:39]", "v[22:23]", "v[32:33]", "v[24:25]")
         "v_cvt_i32_f32_e32 v38, v38\n\t"
         "v_cvt_i32_f32_e32 v39, v39\n\t"
         "v_mad_i32_i24 v39, v39, %[stride], %[k4]\n\t"
@@ -779,7 +822,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "L_drain_out_%=:\n\t"
         // cell of the last consumed sample of every ray that went through this loop
         "s_mov_b64 exec, %[ent]\n\t"
-        "v_pk_fma_f32 v[26:27], v[22:23], v[40:41], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[26:27]", "v[22:23]", "v[40:41]", "v[24:25]")
         "v_cvt_i32_f32_e32 %[c], v26\n\t"
         "v_cvt_i32_f32_e32 %[r], v27\n"
         "L_drain_done_%=:\n\t"
@@ -787,11 +830,174 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         : [t] "+{v20}"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [save] "=&s"(save), [ent] "=&s"(ent),
           [live] "=&s"(live), [hit] "=&s"(hit)
         : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy), [mx] "s"(max_range),
-          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt)
+          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0)
         : "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40",
           "v41", "v42", "v43", "vcc", "scc", "memory");
 }
 
+
+// ------------------------------------------------------------------------------
+// The GROUP drain loop (round 5): 2 or 4 lanes per ray, 8 / 16 samples of one ray in flight.
+// The last rays of a dry wave are single long chains whose steps repeat (rays of 48..80 samples: 80 % of the steps
+// equal their predecessor, from 80 samples up 91 %: tools replay in profiles/r05/drain_depth_model.txt), and each
+// dependent sample is a memory round trip.  march_drain4 speculates 4 deep because one lane has no registers for
+// more; once a wave holds <= 32 / <= 16 live rays it has LANES to spare: the rays are laid out L = 2 / 4 lanes per ray
+// (every lane of a group holds the ray's state), lane j of a group starts 4 j steps ahead — t advanced by 4 j
+// SEQUENTIAL additions of the last step g, the same roundings the march itself would make — and runs the 4-deep
+// speculation body of march_drain4 from there.  A lane's samples count only if every lane in front of it in the
+// group found four repeats (its start is then bit for bit where the march arrived); the ray's new state is the state
+// of the first lane whose chain broke (or of the last lane), broadcast to the group with ds_bpermute.  Same t
+// sequence, same cells, same results as march_loop — up to 4 L samples per round trip.  Every iteration speculates
+// (no plain stretch in between: the SIMD has nothing else to do, a failed prediction costs issue slots nobody wants).
+// Leaves when at most `low_lanes` lanes are live.  lm1 = L - 1.
+// Registers: exactly those of march_drain4 (the lane's place in its group is re-derived from the lane id in registers
+// that are dead at that point: a single VGPR more in this block's footprint made the compiler spill ray state around the
+// hot loops of the kernel, which sits at its 64-VGPR occupancy limit).
+// ------------------------------------------------------------------------------
+template <bool TILED, bool LIT = false>
+__device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, float gy, float &t, int &c, int &r,
+                                                  float &d, const float *pdt, int stride, int nstride, uint32_t k4,
+                                                  float max_range, uint32_t lm1, uint32_t low_lanes)
+{
+    static_assert(TILED, "the speculative drain loops exist for the tiled step map only");
+    unsigned long long save, ent0, live, ent, am;
+    uint32_t n;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_mov_b64 %[ent0], exec\n\t"
+        "s_mov_b64 %[live], exec\n\t"
+        "s_cbranch_execz L_grp_done_%=\n"
+        "L_grp_%=:\n\t"
+        "v_mov_b32_e32 v29, %[d]\n\t"                       // g
+        // lane j of a group starts 4 j steps ahead: sequential additions, the march's own roundings
+        "v_mbcnt_lo_u32_b32 v26, -1, 0\n\t"
+        "v_mbcnt_hi_u32_b32 v26, -1, v26\n\t"
+        "v_and_b32_e32 v27, %[lm1], v26\n\t"               // j = lane & (L - 1)
+        "v_cmpx_lt_u32_e32 0, v27\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_cmpx_lt_u32_e32 1, v27\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_cmpx_lt_u32_e32 2, v27\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "v_add_f32_e32 v20, v20, v29\n\t"
+        "s_mov_b64 exec, %[live]\n\t"
+        // lanes whose start is still inside the range window take part (lane 0 of a live group always does)
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_mov_b64 %[ent], exec\n\t"
+        "v_add_f32_e32 v28, v20, v29\n\t"                   // t1, t2, t3
+        "v_add_f32_e32 v30, v28, v29\n\t"
+        "v_add_f32_e32 v32, v30, v29\n\t"
+        // sample 0
+        RM_POS("v[26:27]", "v[22:23]", "v[20:21]", "v[24:25]")
+        "v_cvt_i32_f32_e32 v26, v26\n\t"
+        "v_cvt_i32_f32_e32 v27, v27\n\t"
+        "v_mad_i32_i24 v27, v27, %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v27, %[nstride], v27\n\t"
+        "v_lshl_add_u32 v26, v26, 4, v27\n\t"
+        "global_load_dword v42, v26, %[base]\n\t"
+        // sample 1 where t1 is still inside the range window
+        "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
+        RM_POS("v[34:35]", "v[22:23]", "v[28:29]", "v[24:25]")
+        "v_cvt_i32_f32_e32 v34, v34\n\t"
+        "v_cvt_i32_f32_e32 v35, v35\n\t"
+        "v_mad_i32_i24 v35, v35, %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v35, %[nstride], v35\n\t"
+        "v_lshl_add_u32 v34, v34, 4, v35\n\t"
+        "global_load_dword v31, v34, %[base]\n\t"
+        // sample 2
+        "v_cmpx_gt_f32_e32 %[mx], v30\n\t"
+        RM_POS("v[36:37]", "v[22:23]", "v[30:31]", "v[24:25]")
+        "v_cvt_i32_f32_e32 v36, v36\n\t"
+        "v_cvt_i32_f32_e32 v37, v37\n\t"
+        "v_mad_i32_i24 v37, v37, %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v37, %[nstride], v37\n\t"
+        "v_lshl_add_u32 v36, v36, 4, v37\n\t"
+        "global_load_dword v33, v36, %[base]\n\t"
+        // sample 3
+        "v_cmpx_gt_f32_e32 %[mx], v32\n\t"
+        RM_POS("v[38:39]", "v[22:23]", "v[32:33]", "v[24:25]")
+        "v_cvt_i32_f32_e32 v38, v38\n\t"
+        "v_cvt_i32_f32_e32 v39, v39\n\t"
+        "v_mad_i32_i24 v39, v39, %[stride], %[k4]\n\t"
+        "v_and_b32_e32 v39, %[nstride], v39\n\t"
+        "v_lshl_add_u32 v38, v38, 4, v39\n\t"
+        "global_load_dword v43, v38, %[base]\n\t"
+        // stage 0: the sample at the lane's start (real for lane 0; for lane j > 0 if the lanes in front all repeated)
+        "s_mov_b64 exec, %[ent]\n\t"
+        "s_waitcnt vmcnt(3)\n\t"
+        "v_mov_b32_e32 v40, v20\n\t"
+        "v_mov_b32_e32 %[d], v42\n\t"
+        "v_add_f32_e32 v20, v20, v42\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "v_cmpx_eq_f32_e32 v42, v29\n\t"
+        // stage 1
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_mov_b32_e32 v40, v20\n\t"
+        "v_mov_b32_e32 %[d], v31\n\t"
+        "v_add_f32_e32 v20, v20, v31\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "v_cmpx_eq_f32_e32 v31, v29\n\t"
+        // stage 2
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_mov_b32_e32 v40, v20\n\t"
+        "v_mov_b32_e32 %[d], v33\n\t"
+        "v_add_f32_e32 v20, v20, v33\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "v_cmpx_eq_f32_e32 v33, v29\n\t"
+        // stage 3
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_mov_b32_e32 v40, v20\n\t"
+        "v_mov_b32_e32 %[d], v43\n\t"
+        "v_add_f32_e32 v20, v20, v43\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "v_cmpx_eq_f32_e32 v43, v29\n\t"
+        "s_mov_b64 %[am], exec\n\t"                         // four repeats and still marching: the next lane's start is real
+        // the group's new state: the first lane whose chain broke, or the last lane
+        "s_mov_b64 exec, %[save]\n\t"
+        "v_mbcnt_lo_u32_b32 v28, -1, 0\n\t"
+        "v_mbcnt_hi_u32_b32 v28, -1, v28\n\t"
+        "v_and_b32_e32 v30, %[lm1], v28\n\t"
+        "v_sub_u32_e32 v28, v28, v30\n\t"                  // first lane of my group
+        "v_lshrrev_b64 v[26:27], v28, %[am]\n\t"           // my group's all-match bits from bit 0 up
+        "v_not_b32_e32 v26, v26\n\t"
+        "v_ffbl_b32_e32 v26, v26\n\t"
+        "v_min_u32_e32 v26, %[lm1], v26\n\t"               // the tail lane: first one whose chain broke, or the last
+        "v_add_lshl_u32 v26, v26, v28, 2\n\t"
+        "ds_bpermute_b32 v20, v26, v20\n\t"
+        "ds_bpermute_b32 %[d], v26, %[d]\n\t"
+        "ds_bpermute_b32 v40, v26, v40\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        // who is still marching
+        "s_mov_b64 exec, %[live]\n\t"
+        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
+        "s_mov_b64 %[live], exec\n\t"
+        "s_bcnt1_i32_b64 %[n], exec\n\t"
+        "s_cmp_gt_u32 %[n], %[low]\n\t"
+        "s_cbranch_scc1 L_grp_%=\n\t"
+        // cell of the last consumed sample of every ray that went through this loop
+        "s_mov_b64 exec, %[ent0]\n\t"
+        RM_POS("v[26:27]", "v[22:23]", "v[40:41]", "v[24:25]")
+        "v_cvt_i32_f32_e32 %[c], v26\n\t"
+        "v_cvt_i32_f32_e32 %[r], v27\n"
+        "L_grp_done_%=:\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        : [t] "+{v20}"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [save] "=&s"(save), [ent0] "=&s"(ent0),
+          [live] "=&s"(live), [ent] "=&s"(ent), [am] "=&s"(am), [n] "=&s"(n)
+        : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy), [mx] "s"(max_range),
+          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), [lm1] "s"(lm1),
+          [low] "s"(low_lanes)
+        : "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40",
+          "v41", "v42", "v43", "vcc", "scc", "memory");
+}
 
 // Two rays per lane (SLOTS = 2 of the stream kernel): slot A and slot B of a lane are two independent
 // rays with their own live masks.  The wave alternates EXEC between the masks — switching is scalar
@@ -800,7 +1006,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
 // siblings on its SIMD.  (Round 1 tried two slots with per-slot predication on the row-major layout:
 // the extra VALU per sample made it 6 % slower.)  Registers are fixed as in march_loop: slot A
 // t v20 / dir v[22:23] / origin v[24:25] / scratch v[26:27], slot B t v28 / v[30:31] / v[32:33] / v[34:35].
-template <bool TILED>
+template <bool TILED, bool LIT = false>
 __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, float gyA, float &tA, int &cA, int &rA,
                                             float &dA, float dxB, float dyB, float gxB, float gyB, float &tB,
                                             int &cB, int &rB, float &dB, const float *pdt, int stride, int nstride,
@@ -818,7 +1024,7 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         // (decoupled slots: a slot's next load is issued as soon as ITS previous one has returned — not after both
         //  have — so the two dependent chains only share the instruction stream, not each other's latency)
         "s_mov_b64 exec, %[mA]\n\t"
-        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[26:27]", "v[22:23]", "v[20:21]", "v[24:25]")
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
         "v_cvt_i32_f32_e32 %[rA], v27\n\t"
         ".if %[tiled]\n\t"
@@ -831,7 +1037,7 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         ".endif\n\t"
         "global_load_dword %[dA], v26, %[base]\n\t"
         "s_mov_b64 exec, %[mB]\n\t"
-        "v_pk_fma_f32 v[34:35], v[30:31], v[28:29], v[32:33] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[34:35]", "v[30:31]", "v[28:29]", "v[32:33]")
         "v_cvt_i32_f32_e32 %[cB], v34\n\t"
         "v_cvt_i32_f32_e32 %[rB], v35\n\t"
         ".if %[tiled]\n\t"
@@ -849,7 +1055,7 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "v_add_f32_e32 v20, v20, %[dA]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
         "s_mov_b64 %[mA], exec\n\t"
-        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[26:27]", "v[22:23]", "v[20:21]", "v[24:25]")
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
         "v_cvt_i32_f32_e32 %[rA], v27\n\t"
         ".if %[tiled]\n\t"
@@ -866,7 +1072,7 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "v_add_f32_e32 v28, v28, %[dB]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         "s_mov_b64 %[mB], exec\n\t"
-        "v_pk_fma_f32 v[34:35], v[30:31], v[28:29], v[32:33] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[34:35]", "v[30:31]", "v[28:29]", "v[32:33]")
         "v_cvt_i32_f32_e32 %[cB], v34\n\t"
         "v_cvt_i32_f32_e32 %[rB], v35\n\t"
         ".if %[tiled]\n\t"
@@ -900,7 +1106,7 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
           [n2] "=&s"(n2)
         : [dyA] "{v22}"(dyA), [dxA] "{v23}"(dxA), [gxA] "{v24}"(gxA), [gyA] "{v25}"(gyA), [dyB] "{v30}"(dyB),
           [dxB] "{v31}"(dxB), [gxB] "{v32}"(gxB), [gyB] "{v33}"(gyB), [mx] "s"(max_range), [stride] "s"(stride),
-          [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
+          [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "v34", "v35", "vcc", "scc", "memory");
 }
 
@@ -910,7 +1116,7 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
 // (Tried and dropped, no measurable change at cfg2 / 32 k poses: a drain-phase form that branches over
 //  a slot whose rays have all finished instead of issuing its 9 VALU with EXEC = 0, and a 24-bit
 //  multiply for the output index in the claim.)
-template <bool TILED>
+template <bool TILED, bool LIT = false>
 __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, float gyA, float &tA, int &cA, int &rA,
                                             float &dA, float dxB, float dyB, float gxB, float gyB, float &tB,
                                             int &cB, int &rB, float &dB, float dxC, float dyC, float gxC, float gyC,
@@ -931,7 +1137,7 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "s_mov_b64 %[mC], exec\n"
         // (decoupled slots, like march_loop2: a slot's next load goes out as soon as its own previous one is back)
         "s_mov_b64 exec, %[mA]\n\t"
-        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[26:27]", "v[22:23]", "v[20:21]", "v[24:25]")
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
         "v_cvt_i32_f32_e32 %[rA], v27\n\t"
         ".if %[tiled]\n\t"
@@ -944,7 +1150,7 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         ".endif\n\t"
         "global_load_dword %[dA], v26, %[base]\n\t"
         "s_mov_b64 exec, %[mB]\n\t"
-        "v_pk_fma_f32 v[34:35], v[30:31], v[28:29], v[32:33] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[34:35]", "v[30:31]", "v[28:29]", "v[32:33]")
         "v_cvt_i32_f32_e32 %[cB], v34\n\t"
         "v_cvt_i32_f32_e32 %[rB], v35\n\t"
         ".if %[tiled]\n\t"
@@ -957,7 +1163,7 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         ".endif\n\t"
         "global_load_dword %[dB], v34, %[base]\n\t"
         "s_mov_b64 exec, %[mC]\n\t"
-        "v_pk_fma_f32 v[42:43], v[38:39], v[36:37], v[40:41] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[42:43]", "v[38:39]", "v[36:37]", "v[40:41]")
         "v_cvt_i32_f32_e32 %[cC], v42\n\t"
         "v_cvt_i32_f32_e32 %[rC], v43\n\t"
         ".if %[tiled]\n\t"
@@ -975,7 +1181,7 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "v_add_f32_e32 v20, v20, %[dA]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
         "s_mov_b64 %[mA], exec\n\t"
-        "v_pk_fma_f32 v[26:27], v[22:23], v[20:21], v[24:25] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[26:27]", "v[22:23]", "v[20:21]", "v[24:25]")
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
         "v_cvt_i32_f32_e32 %[rA], v27\n\t"
         ".if %[tiled]\n\t"
@@ -992,7 +1198,7 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "v_add_f32_e32 v28, v28, %[dB]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         "s_mov_b64 %[mB], exec\n\t"
-        "v_pk_fma_f32 v[34:35], v[30:31], v[28:29], v[32:33] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[34:35]", "v[30:31]", "v[28:29]", "v[32:33]")
         "v_cvt_i32_f32_e32 %[cB], v34\n\t"
         "v_cvt_i32_f32_e32 %[rB], v35\n\t"
         ".if %[tiled]\n\t"
@@ -1009,7 +1215,7 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         "v_add_f32_e32 v36, v36, %[dC]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v36\n\t"
         "s_mov_b64 %[mC], exec\n\t"
-        "v_pk_fma_f32 v[42:43], v[38:39], v[36:37], v[40:41] op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+        RM_POS("v[42:43]", "v[38:39]", "v[36:37]", "v[40:41]")
         "v_cvt_i32_f32_e32 %[cC], v42\n\t"
         "v_cvt_i32_f32_e32 %[rC], v43\n\t"
         ".if %[tiled]\n\t"
@@ -1051,7 +1257,7 @@ __device__ __forceinline__ void march_loop3(float dxA, float dyA, float gxA, flo
         : [dyA] "{v22}"(dyA), [dxA] "{v23}"(dxA), [gxA] "{v24}"(gxA), [gyA] "{v25}"(gyA), [dyB] "{v30}"(dyB),
           [dxB] "{v31}"(dxB), [gxB] "{v32}"(gxB), [gyB] "{v33}"(gyB), [dyC] "{v38}"(dyC), [dxC] "{v39}"(dxC),
           [gxC] "{v40}"(gxC), [gyC] "{v41}"(gyC), [mx] "s"(max_range), [stride] "s"(stride),
-          [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
+          [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "v34", "v35", "v42", "v43", "vcc", "scc", "memory");
 }
 
@@ -1093,6 +1299,8 @@ struct StreamParams {
     int drain_cap;           // several rays per lane, stream dry: compact the wave's live rays into ONE slot once at most
                              //   this many are left (<= DRAIN_CAP)
     int drain_stretch;       //   ... and the plain stretch between two speculation attempts there
+    int group_drain;         //   ... and from 32 / 16 live rays down 2 / 4 lanes per ray, 8 / 16 samples per round trip (march_drain_group)
+    LiteralParams lit;       // LIT only (variant 3 in the stream kernel): rotation constant, sin / cos of the world angle
     int run_log2;            // a workgroup's stream interleaves RUNS of 2^run_log2 consecutive 64-ray blocks
     int stripe;              // INLINE only, where the band's pose ids come from: 0 = the caller's order
                              //   (band = index range), 1 = row stripes of the map compacted by every
@@ -1248,11 +1456,15 @@ constexpr uint32_t NO_RAY = 0xffffffffu;       // output index of a slot that ho
 constexpr int DRAIN_CAP = 64;                  // capacity; the threshold is StreamParams::drain_cap <= DRAIN_CAP
 constexpr int DRAIN_FIELDS = 7;                // gx, gy, dx, dy, t, last step, output offset (+ 2 with the crash test)
 
-template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED, int SLOTS = 1>
+template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED, int SLOTS = 1, bool LIT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
 void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__restrict__ out,
                           int32_t *__restrict__ hits, uint16_t *__restrict__ steps, CrashParams cp)
 {
+    // LIT: the upstream-literal arithmetic (variant 3) on this kernel's schedule — per-ray libm directions at claim time,
+    // un-fused position (packed multiply + packed add in the march loops), un-fused hit range, records in (row, col)
+    // naming: bit-identical to the checker's orc_rm_fan_libm.  Records come from the INLINE prologue only.
+    static_assert(!LIT || (INLINE && TILED && !AUX), "literal stream form: INLINE records, tiled step map, no diagnostics");
     extern __shared__ __attribute__((aligned(32))) float lds_f[];
     const unsigned long long t_entry = sp.dbg ? wall_clock64() : 0ull;   // diagnostics
     uint32_t *q_next = reinterpret_cast<uint32_t *>(lds_f);     // shared slot counter
@@ -1322,7 +1534,8 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 const uint32_t pid = sp.stripe == 1 ? list[p0]
                                    : sp.stripe == 2 ? (sp.order[seg_lo + p0] & ~POSE_INVALID) : seg_lo + p0;
                 PoseRec r;
-                const uint32_t kf = pose_record(mp, sp.raw_poses, (int)pid, 0, 1, 1, r);
+                const uint32_t kf = LIT ? pose_record_lit(mp, sp.lit, sp.raw_poses, (int)pid, r)
+                                        : pose_record(mp, sp.raw_poses, (int)pid, 0, 1, 1, r);
                 br.gx = r.gx; br.gy = r.gy; br.ct = r.ct; br.st = r.st;
                 br.d0 = pose_first_step(mp, r.gx, r.gy, kf, f.step_coeff);
                 br.obase = (pid * (uint32_t)f.num_rays + j0) << 2;
@@ -1360,12 +1573,23 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             const uint32_t l = q & 63u;
             const bool valid = l < (rb.z >> 16);
             const uint32_t j = (rb.z & 0xffffu) + l;
-            const float2 cs = fan_cs[j];
-            const float ct = __builtin_bit_cast(float, ra.z), st = __builtin_bit_cast(float, ra.w);
             s.gx = __builtin_bit_cast(float, ra.x);
             s.gy = __builtin_bit_cast(float, ra.y);
-            s.dx = __builtin_fmaf(ct, cs.x, -(st * cs.y));
-            s.dy = __builtin_fmaf(st, cs.x, ct * cs.y);
+            if (LIT) {
+                // beam j of the pose at theta_p + (-fov/2 + j * (fov / B)), the product and both sums rounded to float32;
+                // theta' = -theta + (-world_angle - 3 pi / 2); calc_range(y, x, theta') marches rows along cosf, columns
+                // along sinf (glibc's algorithm, literal_math.h)
+                const float aj = (float)j * f.inc;
+                const float th = __builtin_bit_cast(float, ra.z) + (f.amin + aj);
+                const float thp = -th + sp.lit.rotation_const;
+                s.dy = lit_cosf(thp);
+                s.dx = lit_sinf(thp);
+            } else {
+                const float2 cs = fan_cs[j];
+                const float ct = __builtin_bit_cast(float, ra.z), st = __builtin_bit_cast(float, ra.w);
+                s.dx = __builtin_fmaf(ct, cs.x, -(st * cs.y));
+                s.dy = __builtin_fmaf(st, cs.x, ct * cs.y);
+            }
             s.oidx = valid ? rb.y + (l << 2) : NO_RAY;
             if (CRASH) {
                 s.pose = rb.w;
@@ -1417,7 +1641,12 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             float r = f.max_range;
             if (s.d_last == PDT_HIT) {
                 const float xd = (float)s.pc - s.gx, yd = (float)s.pr - s.gy;
-                r = hit_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+                if (LIT) {                       // sqrtf(xd * xd + yd * yd): every product and the sum its own rounding
+                    const float xx = xd * xd, yy = yd * yd;
+                    r = hit_sqrtf(yy + xx);
+                } else {
+                    r = hit_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+                }
             }
             r *= pm.res;
             if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + (s.oidx >> 2));
@@ -1474,11 +1703,11 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                     if (nlive > cap) {
                         // the plain loop until few rays are left
                         if (SLOTS == 3)
-                            march_loop3<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx,
+                            march_loop3<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx,
                                         sb.gy, sb.t, sb.pc, sb.pr, sb.d_last, sc.dx, sc.dy, sc.gx, sc.gy, sc.t, sc.pc, sc.pr,
                                         sc.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range, cap);
                         else
-                            march_loop2<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx,
+                            march_loop2<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx,
                                         sb.gy, sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4,
                                         f.max_range, cap);
                         continue;
@@ -1550,11 +1779,57 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                         // ... and finish them with the one-ray-per-lane drain loops (value speculation on the step).
                         // Nothing of slots B / C is needed any more: the wave leaves from here (the drain loops use
                         // the registers of those slots as scratch).
-                        while (__ballot(sa.t < f.max_range)) {
-                            march_loop_capped<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt,
-                                                     pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)sp.drain_stretch);
-                            march_drain4<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt, pm.stride,
-                                                pm.nstride, pm.k4, f.max_range);
+                        // From 32 / 16 live rays down the wave has lanes to spare: the rays are laid out 2 / 4 lanes per ray
+                        // and marched 8 / 16 samples per round trip (march_drain_group) — the launch ends with its longest
+                        // chain, and a chain of 100 samples is ~39 round trips 4 deep, ~14 at 16 deep.
+                        uint32_t L = 1;                       // lanes per ray (every lane of a group holds the ray's state;
+                                                              //  only the first carries the output offset)
+                        for (;;) {
+                            const unsigned long long lv = __ballot(sa.t < f.max_range);
+                            if (!lv) break;
+                            const uint32_t nl = (uint32_t)__popcll(lv) / L;
+                            // (group_drain = N: 4 lanes per ray from N live rays down, 2 lanes per ray from 2 N; N <= 16)
+                            const uint32_t gdn = (uint32_t)sp.group_drain;
+                            const uint32_t want = gdn ? (nl <= gdn ? 4u : (nl <= 2u * gdn ? 2u : 1u)) : 1u;
+                            if (want > L) {
+                                // rays that have finished leave first; the live ones are re-ranked through LDS
+                                if (!(sa.t < f.max_range) && sa.oidx != NO_RAY) finish(sa);
+                                const bool lead = sa.t < f.max_range && (lane & (L - 1u)) == 0u;
+                                const unsigned long long lb2 = __ballot(lead);
+                                if (lead)
+                                    put(sa, __builtin_amdgcn_mbcnt_hi((uint32_t)(lb2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lb2, 0u)));
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                L = want;
+                                const uint32_t ri = lane / L;
+                                sa.t = INF;
+                                sa.oidx = NO_RAY;
+                                if (ri < nl) {
+                                    sa.gx = __builtin_bit_cast(float, drain_scr[0 * DRAIN_CAP + ri]);
+                                    sa.gy = __builtin_bit_cast(float, drain_scr[1 * DRAIN_CAP + ri]);
+                                    sa.dx = __builtin_bit_cast(float, drain_scr[2 * DRAIN_CAP + ri]);
+                                    sa.dy = __builtin_bit_cast(float, drain_scr[3 * DRAIN_CAP + ri]);
+                                    sa.t = __builtin_bit_cast(float, drain_scr[4 * DRAIN_CAP + ri]);
+                                    sa.d_last = __builtin_bit_cast(float, drain_scr[5 * DRAIN_CAP + ri]);
+                                    if ((lane & (L - 1u)) == 0u) sa.oidx = drain_scr[6 * DRAIN_CAP + ri];
+                                    if (CRASH) {
+                                        sa.pose = drain_scr[7 * DRAIN_CAP + ri];
+                                        sa.jbeam = (int)drain_scr[8 * DRAIN_CAP + ri];
+                                    }
+                                }
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (reads done before the next re-ranking writes)
+                                continue;
+                            }
+                            if (L == 1u) {
+                                march_loop_capped<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt,
+                                                         pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)sp.drain_stretch);
+                                march_drain4<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt, pm.stride,
+                                                    pm.nstride, pm.k4, f.max_range);
+                            } else {
+                                // (2 lanes per ray: until 16 rays are left — 32 lanes —, then 4 lanes per ray to the end)
+                                march_drain_group<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt,
+                                                         pm.stride, pm.nstride, pm.k4, f.max_range, L - 1u,
+                                                         L == 2u ? 2u * gdn : 0u);
+                            }
                         }
                         if (sa.oidx != NO_RAY) finish(sa);
                         break;
@@ -1562,12 +1837,12 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 }
             }
             if (SLOTS == 3)
-                march_loop3<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
+                march_loop3<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
                             sb.t, sb.pc, sb.pr, sb.d_last, sc.dx, sc.dy, sc.gx, sc.gy, sc.t, sc.pc, sc.pr, sc.d_last,
                             pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
                             exhausted ? 0u : 3u * (uint32_t)sp.low_water);
             else
-                march_loop2<TILED>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
+                march_loop2<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
                             sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
                             exhausted ? 0u : 2u * (uint32_t)sp.low_water);
         }
@@ -1606,7 +1881,12 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                     hc = s1.pc;
                     hr = s1.pr;
                     const float xd = (float)hc - s1.gx, yd = (float)hr - s1.gy;
-                    r = hit_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+                    if (LIT) {
+                        const float xx = xd * xd, yy = yd * yd;
+                        r = hit_sqrtf(yy + xx);
+                    } else {
+                        r = hit_sqrtf(__builtin_fmaf(xd, xd, yd * yd));
+                    }
                 }
                 r *= pm.res;
                 if (f.noise_std > 0.0f)
@@ -1655,20 +1935,20 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             // drain phase: the plain loop while more than a handful of lanes are live, then the
             // value-speculating loop for the last long rays (march_drain4)
             if (exhausted && sp.spec_drain > 0) {
-                march_loop<AUX, TILED>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, nstep, pm.pdt,
+                march_loop<AUX, TILED, LIT>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, nstep, pm.pdt,
                                        pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)sp.spec_drain);
                 // what is still marching after a stretch of the plain loop is a long chain: speculate on it
                 // while that pays, fall back to the plain loop for a stretch when it does not
                 while (__ballot(s1.t < f.max_range)) {
-                    march_loop_capped<TILED>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, pm.pdt,
+                    march_loop_capped<TILED, LIT>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, pm.pdt,
                                              pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)sp.spec_stretch);
-                    march_drain4<TILED>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, pm.pdt, pm.stride,
+                    march_drain4<TILED, LIT>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, pm.pdt, pm.stride,
                                         pm.nstride, pm.k4, f.max_range);
                 }
                 continue;
             }
         }
-        march_loop<AUX, TILED>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, nstep, pm.pdt, pm.stride,
+        march_loop<AUX, TILED, LIT>(s1.dx, s1.dy, s1.gx, s1.gy, s1.t, s1.pc, s1.pr, s1.d_last, nstep, pm.pdt, pm.stride,
                                pm.nstride, pm.k4, f.max_range, exhausted ? 0u : (uint32_t)sp.low_water);
     }
     uint32_t ds_max = 0;

@@ -1,21 +1,10 @@
 // scan_kernels.h — gfx950 kernels of the lidar scan path.
 //
-//   K0  edt_*            exact Euclidean distance transform of the occupancy grid
-//                        (range_libc DistanceTransform)
-//   K1  rm_fan_kernel    fan-expanding sphere tracing on the float32 EDT
-//                        (RayMarching / RayMarchingGPU, rows a8-a11); bit-exact
-//       rm_rays_kernel   one (x,y,theta) row per ray (upstream 2-arg API)
-//
-// Work decomposition of K1 (wave64-first, not a warp-shaped port of kernels.cu's
-// thread-per-ray 1024x256 grid): the unit of work is a CHUNK = 64 consecutive
-// beams of one pose, owned by one wavefront, so the 64 lanes of a wave march 64
-// neighbouring beams (angular spacing fov/num_rays ~ 0.25 deg): their samples
-// fall in the same few EDT cache lines, their step counts are similar (less
-// divergence), and the wave leaves the march loop as soon as every lane has hit
-// or left the map (exec-mask early termination).  The per-beam (cos a_j, sin a_j)
-// fan table is computed once per workgroup and kept in LDS; per-pose constants are
-// wave-uniform.  Waves are persistent and take chunks round-robin, so a launch
-// has 256 CUs x 8 workgroups regardless of the batch size.
+// Product path of the ray-marching methods: K1b, rm_fan_stream_kernel (rm_kernels.h) — a persistent grid of 1024-lane
+// workgroups, each draining ONE stream of 64-ray blocks through an LDS counter with lane refill, two rays per lane, the
+// tile-ordered pose list cut into one band per XCD, a hand-scheduled gfx950 march loop on the 4x8-cell-tiled step map
+// (DESIGN.md section 4).  K1 (rm_fan_kernel: a chunk of 64 consecutive beams per wave, no refill) is variant 0, the
+// round-1 shape kept as an A/B partner and for launches the stream kernel cannot index (>= 2^30 rays without slicing).
 //
 // The kernels live in one header per family:
 //   edt_kernels.h   K0   exact EDT

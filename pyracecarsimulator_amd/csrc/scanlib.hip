@@ -364,6 +364,7 @@ struct rl_method {
     int spec_stretch = 16;       //   ... after this many plain samples, and between two attempts whose first prediction failed
     int drain_cap = 64;          // several rays per lane: compact a wave's last rays into one slot from <= this many (<= 64)
     int drain_stretch = 8;       //   ... plain samples between two speculation attempts of the compacted rays
+    int group_drain = 0;         //   ... and from 2 N / N live rays down 2 / 4 lanes per ray, 8 / 16 samples per round trip (N <= 16; 0: off)
     int handoff = 0;             // several rays per lane, 1: a dry wave hands its last <= handoff_cap rays to rm_leftover_kernel (the
                                  // next launch on the stream) instead of draining them in place (0: drain in place)
     int handoff_cap = 16;        //   ... rays per wave handed over (8, 16, 32 or 64)
@@ -882,6 +883,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "spec_drain")) h->spec_drain = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(name, "spec_stretch")) h->spec_stretch = value < 1 ? 1 : (value > 4096 ? 4096 : value);
     else if (!strcmp(name, "drain_cap")) h->drain_cap = value < 1 ? 1 : (value > 64 ? 64 : value);
+    else if (!strcmp(name, "group_drain")) h->group_drain = value < 0 ? 0 : (value > 16 ? 16 : value);
     else if (!strcmp(name, "handoff")) h->handoff = value != 0;
     else if (!strcmp(name, "handoff_cap")) h->handoff_cap = value >= 64 ? 64 : (value >= 32 ? 32 : (value >= 16 ? 16 : 8));
     else if (!strcmp(name, "handoff_wg")) h->handoff_wg = value >= 256 ? 256 : (value >= 128 ? 128 : 64);
@@ -940,6 +942,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "spec_drain")) *value_out = h->spec_drain;
     else if (!strcmp(name, "spec_stretch")) *value_out = h->spec_stretch;
     else if (!strcmp(name, "drain_cap")) *value_out = h->drain_cap;
+    else if (!strcmp(name, "group_drain")) *value_out = h->group_drain;
     else if (!strcmp(name, "handoff")) *value_out = h->handoff;
     else if (!strcmp(name, "handoff_cap")) *value_out = h->handoff_cap;
     else if (!strcmp(name, "handoff_wg")) *value_out = h->handoff_wg;
@@ -1492,7 +1495,7 @@ static int ensure_step_map(rl_method *h, hipStream_t stream)
 }
 
 // the stream-kernel instantiation a plan names
-template <bool A, bool C, int N, bool I, bool T, int S>
+template <bool A, bool C, int N, bool I, bool T, int S, bool L = false>
 static void launch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, const PadMap &pm, const FanParams &f,
                              const StreamParams &sp, float *d_out, int32_t *d_hits, uint16_t *d_steps,
                              const CrashParams &cp)
@@ -1500,9 +1503,9 @@ static void launch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, const
     // (more dynamic LDS than HIP's default cap — fans of several thousand beams, with the crash table —: opt in,
     //  as the BL / occ / CDDT kernels do; the attribute is sticky per function and device, the call is cheap)
     if (pl.lds_bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rm_fan_stream_kernel<A, C, N, I, T, S>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rm_fan_stream_kernel<A, C, N, I, T, S, L>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_bytes);
-    hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, N, I, T, S>), dim3(pl.grid), dim3(N), (size_t)pl.lds_bytes, stream,
+    hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, N, I, T, S, L>), dim3(pl.grid), dim3(N), (size_t)pl.lds_bytes, stream,
                        pm, f, sp, d_out, d_hits, d_steps, cp);
 }
 
@@ -1513,7 +1516,12 @@ static int dispatch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, cons
     const bool inl = pl.record_source != 0, tiled = pl.tiled != 0, aux = pl.aux != 0, crash = pl.crash != 0;
     const int nt = pl.block;
 #define RM_ARGS pl, stream, pm, f, sp, d_out, d_hits, d_steps, cp
-    if (pl.slots == 3) {                       // three rays per lane: plain ranges, 1024 lanes
+    if (pl.kernel == RL_K_RM_STREAM_LIT) {     // upstream-literal arithmetic (variant 3): INLINE records, tiled step map
+        if (pl.slots >= 2) { if (crash) launch_rm_stream<false, true, 1024, true, true, 2, true>(RM_ARGS);
+                             else launch_rm_stream<false, false, 1024, true, true, 2, true>(RM_ARGS); }
+        else               { if (crash) launch_rm_stream<false, true, 1024, true, true, 1, true>(RM_ARGS);
+                             else launch_rm_stream<false, false, 1024, true, true, 1, true>(RM_ARGS); }
+    } else if (pl.slots == 3) {                // three rays per lane: plain ranges, 1024 lanes
         if (!inl) launch_rm_stream<false, false, 1024, false, true, 3>(RM_ARGS);
         else if (tiled) launch_rm_stream<false, false, 1024, true, true, 3>(RM_ARGS);
         else launch_rm_stream<false, false, 1024, true, false, 3>(RM_ARGS);
@@ -1581,6 +1589,9 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
     if (rc) return fail(rc, "launch planning failed");
     if (pl.slices > 1) {
         // pose slices below 2^slice_log2 rays, each its own launch sequence
+        if (crash && crash->group != 0)
+            return fail(RL_ERR_UNSUPPORTED, "a fused crash test over %d poses in the upstream-literal mode needs the per-pose "
+                                            "mark form (rl_check_collision_groups*), not one roll-out of that length", n_poses);
         const int per = pl.slice_poses;
         const uint64_t base_off = h->ray_offset;
         // one event pair around the whole sliced sequence (the per-slice pairs would leave the
@@ -1593,9 +1604,16 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             const int np = std::min(per, n_poses - p0);
             const size_t r0 = (size_t)p0 * num_rays;
             h->ray_offset = base_off + r0;               // noise stays keyed by the global ray id
+            // (a fused crash test reaches a sliced launch only in per-pose-mark form — the upstream-literal mode's
+            //  slices: slice k marks poses p0 .. p0 + np - 1 through a shifted mark array)
+            CrashParams cps{nullptr, 0.0, nullptr, 1, 0};
+            if (crash) {
+                cps = *crash;
+                cps.first_crashed = crash->first_crashed + p0;
+            }
             rc = launch_fan(h, d_poses + (size_t)p0 * 3, np, fov, num_rays, d_out ? d_out + r0 : nullptr,
                             d_hits ? d_hits + 2 * r0 : nullptr, d_steps ? d_steps + r0 : nullptr,
-                            nullptr, stream);
+                            crash ? &cps : nullptr, stream);
         }
         h->ray_offset = base_off;
         h->timing = timing;
@@ -1721,6 +1739,7 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
 #undef LAUNCH_CHUNK
         break;
     }
+    case RL_K_RM_STREAM_LIT:
     case RL_K_RM_STREAM: {
         // (1) per-pose records + tile-ordered permutation, (2) banded lane-refill march
         CrashParams cp{nullptr, 0.0, nullptr, 1};
@@ -1758,6 +1777,8 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         sp.spec_stretch = h->spec_stretch;
         sp.drain_cap = h->drain_cap;
         sp.drain_stretch = h->drain_stretch;
+        sp.group_drain = h->group_drain;
+        if (pl.kernel == RL_K_RM_STREAM_LIT) sp.lit = make_literal(m);
         sp.plain_store = !h->nt_store;
         sp.dbg = nullptr;
         const int waves_per_wg = pl.block / 64;
@@ -1772,7 +1793,8 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
         // hand-off march (several rays per lane on the tiled step map): dry waves leave their last rays in the launch
         // context's leftover list — one region of handoff_cap records per wave of the main grid —, the second launch
         // finishes them
-        const bool handoff = h->handoff && pl.slots >= 2 && pl.tiled && h->spec_drain > 0 && !h->debug_stamps;
+        const bool handoff = h->handoff && pl.slots >= 2 && pl.tiled && h->spec_drain > 0 && !h->debug_stamps &&
+                             pl.kernel == RL_K_RM_STREAM;      // (the leftover kernel marches the canonical arithmetic)
         int cap_log2 = 4;
         const int n_src = pl.grid * waves_per_wg;
         if (handoff) {

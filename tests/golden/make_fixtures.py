@@ -17,6 +17,7 @@ Run in the build container only (reads /root/reference; the GPU box never does):
 * golden/rm_*.npz         GOLD-A/B: ranges, hit cells, step counts of the C oracle on seeded
                           poses (cross-checked here against the independent NumPy statement
                           before being written).
+* golden/table_libm_forms.npz  CDDT / GiantLUT queries of the same poses through the upstream-literal TABLE statements
 * golden/rm_libm_forms.npz  the same poses (first 16 per map) through the upstream-literal libm
                           form of the oracle: what the canonical form's deviation is gated against.
 """
@@ -301,6 +302,54 @@ def libm_forms(n_poses=16):
     print("rm_libm_forms", os.path.getsize(os.path.join(GOLD, "rm_libm_forms.npz")) // 1024, "KiB")
 
 
+def table_libm_forms(n_poses=8):
+    """The TABLE methods in the upstream-literal form (orc_cddt_build_libm / orc_cddt_rays_libm,
+    orc_lut_build_libm / orc_lut_fan_rows_libm: libm cosf / sinf per bin of a double-precision bin angle, un-fused
+    projection and world->grid, fmod + roundf bin rule) for the first ``n_poses`` poses of every rm_*.npz:
+    * CDDT theta_disc 112 (the reference's, scripts/two_player/rcs_two_player.py:121) and 360, queried the way the
+      reference's only CDDT user does — the 2-argument per-ray form with host-built float32 thetas
+      (scripts/two_player/scan.py:57-70);
+    * GiantLUT theta_disc 180: the literal theta rows of the sampled poses' cells + the literal fan query on them.
+    The GPU tests gate the device tables' distance to these numbers
+    (tests/test_gpu_parity.py::test_device_tables_vs_upstream_literal_libm_forms).  Generated with this container's
+    glibc; the arrays are committed data."""
+    out = {}
+    for name in ("rm_colombia", "rm_maze256", "rm_maze192_yaw"):
+        z = dict(np.load(os.path.join(GOLD, name + ".npz")))
+        rows, cols = (int(v) for v in z["shape"])
+        occ = np.ascontiguousarray(np.unpackbits(z["occ_packed"], axis=1)[:, :cols].astype(np.uint8))
+        g = maps.GridMap(occ, float(z["resolution"]), tuple(float(v) for v in z["origin"]), name)
+        mrx = int(z["max_range_px"])
+        om = O.OracleMap.from_gridmap(g, mrx)
+        poses = np.ascontiguousarray(z["poses"][:n_poses])
+        fov, B = float(z["fov"]), int(z["num_rays"])
+        ins = table_ray_rows(poses, fov, B)
+        for td in (112, 360):
+            out["%s_cddt%d" % (name, td)] = om.cddt_rays_libm(td, ins)
+        td = 180
+        rr, cc = om.lut_pose_cells(poses)
+        pose_rows = np.zeros((len(poses), td), np.uint16)
+        for i, (r_, c_) in enumerate(zip(rr, cc)):
+            if r_ >= 0:
+                pose_rows[i] = om.lut_build_libm(td, int(r_), int(r_) + 1, nthreads=1)[0, int(c_)]
+        out[name + "_lut180_rows"] = pose_rows
+        out[name + "_lut180_fan"] = om.lut_fan_rows_libm(pose_rows, poses, fov, B)
+        out[name + "_n_poses"] = np.int32(len(poses))
+    np.savez_compressed(os.path.join(GOLD, "table_libm_forms.npz"), **out)
+    print("table_libm_forms", os.path.getsize(os.path.join(GOLD, "table_libm_forms.npz")) // 1024, "KiB")
+
+
+def table_ray_rows(poses, fov, B):
+    """(x, y, theta) rows of the 2-argument form for the fans of ``poses``: theta = heading + the float32 np.arange
+    angle row scripts/two_player/scan.py:57-62 builds on the host."""
+    ang = (np.float32(-0.5) * np.float32(fov) + np.arange(B, dtype=np.float32) * (np.float32(fov) / np.float32(B))).astype(np.float32)
+    ins = np.zeros((len(poses) * B, 3), np.float32)
+    for p in range(len(poses)):
+        ins[p * B:(p + 1) * B, :2] = poses[p, :2]
+        ins[p * B:(p + 1) * B, 2] = poses[p, 2] + ang
+    return ins
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     colombia()
@@ -313,6 +362,7 @@ def main():
                        origin=(-3.0, 2.5, 0.6))           # rotated origin (yaw != 0)
     rm_golden("rm_maze192_yaw", g, 16, 103, mrx=120, fov=6.0, num_rays=360)
     libm_forms()
+    table_libm_forms()
     followgap_ref()
 
 

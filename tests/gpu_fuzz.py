@@ -19,6 +19,8 @@ def run(seconds, seed):
 
 def one_case(seed):
     if True:
+        if os.environ.get("FUZZ_TRACE"):
+            print("case", seed, flush=True)
         r = np.random.default_rng(seed)
         rows, cols = int(r.integers(1, 400)), int(r.integers(1, 400))
         kind = r.integers(0, 4)
@@ -75,10 +77,16 @@ def one_case(seed):
                                  "bin_multi_min": int(r.choice([64, 8192])), "bin_ppw": int(r.choice([256, 512, 2048])), "pinned_max_rays": int(r.choice([0, 262144])),
                                  "slots": int(r.choice([1, 2, 3])), "spec_drain": int(r.choice([0, 8, 64])),
                                  "spec_stretch": int(r.choice([1, 4, 16])), "drain_cap": int(r.choice([1, 24, 64])),
-                                 "drain_stretch": int(r.choice([1, 8])), "handoff": int(r.integers(0, 2)),
+                                 "drain_stretch": int(r.choice([1, 8])), "handoff": int(r.integers(0, 2)), "group_drain": int(r.choice([0, 2, 16])),
                                  "handoff_cap": int(r.choice([8, 16, 32, 64])), "handoff_wg": int(r.choice([64, 128, 256]))}
+                        if os.environ.get("FUZZ_NO_GROUP"):
+                            sched["group_drain"] = 0
+                        if os.environ.get("FUZZ_NO_HANDOFF"):
+                            sched["handoff"] = 0
                         for k_, v_ in sched.items():
                             m.set_option(k_, v_)
+                        if os.environ.get("FUZZ_TRACE"):
+                            print("  ", name, variant, sched, flush=True)
                     out = np.empty(n, np.float32); hits = np.empty((n, 2), np.int32); st = np.empty(n, np.uint16)
                     m.calc_range_fan(poses, out, fov, B, hit_cells=hits, steps=st)
                     r0, h0, s0 = ofun()
@@ -130,7 +138,9 @@ def one_case(seed):
             thr = 0.001
             rr = om.rm_fan(poses, fov, B, 1.0)[0]
             m = range_libc.PyRayMarchingGPU(omap, mrx); m.set_option("slots", int(r.choice([1, 2])))
-            m.set_option("handoff", int(r.integers(0, 2))); m.set_option("handoff_cap", int(r.choice([8, 64])))
+            m.set_option("handoff", 0 if os.environ.get("FUZZ_NO_HANDOFF") else int(r.integers(0, 2))); m.set_option("handoff_cap", int(r.choice([8, 64])))
+            if os.environ.get("FUZZ_NO_GROUP"):
+                m.set_option("group_drain", 0)
             assert m.check_collision_many(poses, fov, B, edge, thr) == O.is_crashed(rr, B, P, edge, thr), "crash many"
             grp = next(k for k in (7, 5, 4, 3, 2, 1) if P % k == 0)
             want = [O.is_crashed(rr[k * grp * B:(k + 1) * grp * B], B, grp, edge, thr) for k in range(P // grp)]

@@ -153,6 +153,24 @@ def test_bench_default_line_is_verified_and_complete():
     assert d["end_to_end"]["scan_us"] > 0 and d["end_to_end"]["scanMany_200_us"] > 0
     assert d["same_batch"]["value"] > 0
     assert "4 distinct seeded batches" in d["config"]["pose_batches"]
+    # ONE driver command, every single-GPU configuration: the short verified side legs (bench_legs.py)
+    oc = d["other_configs"]
+    assert set(oc) == {"cfg3_glt", "cfg3_cddt", "cfg3_cddt_theta108", "cfg2_crash", "cfg2_steer", "cfg5_shard"}
+    for name, leg in oc.items():
+        assert "error" not in leg and "skipped" not in leg, (name, leg)
+        assert leg["verified"] is True and leg["verification"]["slots_equal_serial_launch"] is True, (name, leg)
+        assert leg["verification"]["oracle_subsample"] is True, (name, leg)
+        assert leg["mrays_s"] > 0 and leg["ms_per_step"] > 0 and 0 < leg["frac"], (name, leg)
+        assert "frac_hbm" in leg and leg["config"]["kernel"].startswith("scan::")
+    assert d["verification"]["other_configs_verified"] is True
+    assert "theta_disc 112" in oc["cfg3_cddt"]["config"]["method"]          # the reference's bin count
+    # the table methods carry their error against exact ray marching on the line (cells)
+    for name in ("cfg3_glt", "cfg3_cddt", "cfg3_cddt_theta108"):
+        e = oc[name]["vs_exact_rm"]
+        assert e["rays"] >= 16 * 1081 and 0 <= e["median"] <= e["p90"] <= e["p99"] <= e["max"]
+    assert oc["cfg3_glt"]["vs_exact_rm"]["median"] < 1.0
+    assert "vs_exact_rm" not in oc["cfg5_shard"] and oc["cfg5_shard"]["mean_samples_per_ray"] > 1
+    assert "Car::isCrashed" in oc["cfg2_crash"]["config"]["reduce"] and oc["cfg2_steer"]["verification"]["oracle_followgap"] is True
 
 
 def test_bench_verification_gate():

@@ -77,6 +77,9 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "tiled": 0, "inline_prep": 0, "xcd_bands": 1},
     {"variant": 1, "nt_store": 0},                              # plain range stores (default: non-temporal)
     {"variant": 1, "nt_store": 0, "slots": 2},
+    {"variant": 1, "slots": 2, "group_drain": 16},              # the last 32 / 16 rays of a wave on 2 / 4 lanes per ray (default: off)
+    {"variant": 1, "slots": 3, "group_drain": 4, "drain_cap": 24},
+    {"variant": 1, "slots": 2, "group_drain": 16, "drain_cap": 8, "drain_stretch": 1},   # straight into 4 lanes per ray
     {"variant": 1, "slots": 2, "handoff": 1},                   # dry waves hand their last rays to rm_leftover_kernel
     {"variant": 1, "slots": 2, "handoff": 1, "handoff_cap": 8, "handoff_wg": 64, "inline_map_kb": 0, "stripe_max": 0},
     {"variant": 1, "slots": 2, "handoff": 1, "handoff_cap": 64, "inline_prep": 0, "grid_mult": 2},
@@ -165,6 +168,76 @@ def test_device_fan_vs_upstream_literal_libm_form(oracle_mod):
     print("canonical (device) vs upstream-literal libm form — (map, coeff, rays with another hit cell, max |d| in cells):", seen)
 
 
+def _ray_rows(poses, fov, B):
+    """(x, y, theta) rows of the 2-argument form: heading + the float32 np.arange angle row of scripts/two_player/scan.py:57-62"""
+    ang = (np.float32(-0.5) * np.float32(fov) + np.arange(B, dtype=np.float32) * (np.float32(fov) / np.float32(B))).astype(np.float32)
+    ins = np.zeros((len(poses) * B, 3), np.float32)
+    for q in range(len(poses)):
+        ins[q * B:(q + 1) * B, :2] = poses[q, :2]
+        ins[q * B:(q + 1) * B, 2] = poses[q, 2] + ang
+    return ins
+
+
+def test_device_tables_vs_upstream_literal_libm_forms():
+    """The TABLE methods against upstream's literal arithmetic (range_libc absent: PARITY UNPINNED; the closest
+    available statement is oracle/rangelib_oracle.c's *_libm table forms — libm cosf / sinf per bin of a
+    double-precision bin angle, un-fused projection and world->grid, fmod + roundf bin rule).  The device builds the
+    CANONICAL tables bit for bit (test_cddt_* / test_giant_lut_*); this gate pins their distance to the literal form on
+    the committed vectors (tests/golden/table_libm_forms.npz, make_fixtures.py::table_libm_forms), queried the way
+    the reference's only CDDT user queries (2-argument per-ray form, scripts/two_player/scan.py:57-70):
+    CDDT theta_disc 112 (scripts/two_player/rcs_two_player.py:121) and 360: every ray within 1e-3 cell, no ray in
+    another bucket; GiantLUT theta_disc 180: every range within one table code of the literal fan query."""
+    L = np.load(os.path.join(GOLD, "table_libm_forms.npz"))
+    seen = []
+    for name in ("rm_colombia", "rm_maze256", "rm_maze192_yaw"):
+        g, z = load_golden(name)
+        omap = range_libc.PyOMap(g)
+        fov, B, mrx = float(z["fov"]), int(z["num_rays"]), int(z["max_range_px"])
+        n = int(L[name + "_n_poses"])
+        poses = np.ascontiguousarray(z["poses"][:n])
+        ins = _ray_rows(poses, fov, B)
+        for td in (112, 360):
+            m = range_libc.PyCDDTCast(omap, mrx, td)
+            got = np.empty(len(ins), np.float32)
+            m.calc_range_many(ins, got)
+            e = np.abs(got - L["%s_cddt%d" % (name, td)]) / g.resolution
+            seen.append((name, "cddt%d" % td, float((e == 0).mean()), float(e.max())))
+            assert e.max() <= 1e-3, (name, td, float(e.max()), int((e > 1e-3).sum()))
+            m.close()
+        m = range_libc.PyGiantLUTCast(omap, mrx, 180)
+        fan = np.empty(n * B, np.float32)
+        m.calc_range_fan(poses, fan, fov, B)
+        code = mrx / 65535.0
+        e = np.abs(fan - L[name + "_lut180_fan"]) / g.resolution
+        seen.append((name, "lut180", float((e == 0).mean()), float(e.max())))
+        assert (e > 1.01 * code).mean() <= 1e-3 and np.median(e) == 0.0, (name, float(e.max()))
+        m.close()
+    print("device tables vs upstream-literal libm table forms — (map, method, share of rays bit-equal, max |d| in cells):", seen)
+
+
+def _exact_rm_gate(err_cells, theta_disc, mean_range_cells, origin_cells, what):
+    """K2 / K3 ranges "<= 1 cell vs oracle RM".  One cell is what the METHODS' conventions allow
+    on most rays, not on all of them, so the gate is the distribution (recorded on bench.py's line as vs_exact_rm):
+      * floor, whatever theta_disc: exact ray marching reports the distance to the hit cell's INTEGER corner, the table
+        methods the distance to the wall's edge-cell geometry (CDDT) / a cast from the pose cell's corner (GiantLUT,
+        + origin_cells = sqrt(2)/2 on average) — both within a cell of the wall, median difference ~0.6 cell, p90 ~1.5;
+      * angular term: the ray's angle is rounded to the nearest of theta_disc bins, half a bin at most:
+        E = (pi / theta_disc) x mean range; at unit incidence slope it shifts the hit by E;
+      * tails: a ray that grazes a corner in one statement and passes it in the other differs by up to the range
+        window — p99 and max are recorded and bounded by the window only.
+    Gates: median <= 0.75 + 0.1 E, p90 <= 1.75 + 0.6 E (+ origin term), >= 65 % of the rays within one cell."""
+    E = math.pi / theta_disc * mean_range_cells
+    med, p90, p99, mx = (float(np.median(err_cells)), float(np.percentile(err_cells, 90)),
+                         float(np.percentile(err_cells, 99)), float(err_cells.max()))
+    within = float((err_cells <= 1.0).mean())
+    print("%s vs exact ray marching (cells): median %.3f p90 %.3f p99 %.2f max %.1f, within one cell %.4f; E = %.3f"
+          % (what, med, p90, p99, mx, within, E))
+    assert med <= 0.75 + 0.1 * E + 0.25 * origin_cells, (what, med)
+    assert p90 <= 1.75 + 0.6 * E + origin_cells, (what, p90)
+    assert within >= 0.65, (what, within)
+    return med, p90, p99, mx, within
+
+
 def test_audit_mode_trig_on_the_device_equals_this_hosts_libm(oracle_mod):
     """The audit mode's sinf / cosf on the device (csrc/literal_kernels.h: glibc's algorithm in double precision) against
     THIS host's libm, bit for bit: angles a scan can produce, every binade up to the largest float, denormals, zeros,
@@ -219,6 +292,8 @@ def test_audit_mode_reproduces_the_upstream_literal_form_bit_for_bit(oracle_mod)
             r1 = np.empty_like(r)
             m.calc_range_fan(poses, r1, fov, B)
             assert np.array_equal(r1, rb)
+            # (ranges only: the production form — the stream kernel's schedule with the literal arithmetic)
+            assert m.last_plan()["kernel"] == "rm_stream_literal", m.last_plan()
             ins = np.zeros((4000, 3), np.float32)
             rng = np.random.default_rng(5)
             pick = rng.integers(0, len(poses), len(ins))
@@ -241,10 +316,88 @@ def test_audit_mode_reproduces_the_upstream_literal_form_bit_for_bit(oracle_mod)
     r, h, s_ = _fan(m, poses, w.fov, B)
     rb, hb, sb = om.rm_fan_libm(poses, w.fov, B, step_coeff=1.0)
     assert np.array_equal(r, rb) and np.array_equal(h, hb) and np.array_equal(s_, sb)
-    # the fused crash test has no literal form: refused, not silently served by another arithmetic
+    # the fused crash test in the literal arithmetic: Car::isCrashed (oracle._ref-pinned restatement) over the LITERAL ranges
     edge = oracle_mod.edge_distances(B, -w.fov / 2, w.fov / B, 0.275, 0.2032, 0.3302)
-    with pytest.raises(Exception):
-        m.check_collision_many(poses, w.fov, B, edge, 0.001)
+    assert m.check_collision_many(poses, w.fov, B, edge, 0.001) == oracle_mod.is_crashed(rb, B, len(poses), edge, 0.001)
+    assert m.last_plan()["kernel"] == "rm_stream_literal" and m.last_plan()["crash"] == 1
+
+
+def test_upstream_literal_mode_in_production_shape(oracle_mod):
+    """variant 3 as a PRODUCTION mode: the upstream-literal arithmetic — per-ray theta_p +
+    (-fov/2 + j * inc) in float32, glibc sinf / cosf at claim time, un-fused position and hit range, calc_range(y, x,
+    theta') — on the stream kernel's schedule (rm_fan_stream_kernel<.., LIT>): two rays per lane, pipelined, noise, the
+    fused crash test per roll-out (what scripts/racecar_simulator_v2.py:146-167 consumes), batches beyond one INLINE
+    launch in pose slices.  Everything bit-identical to the checker's orc_rm_fan_libm, isCrashed over ITS ranges."""
+    torch = pytest.importorskip("torch")
+    from pyracecarsimulator_amd import racecar as RC
+    w = workloads.cfg2()
+    g, B, mrx = w.gmap, w.num_rays, w.max_range_px
+    omap = range_libc.PyOMap(g)
+    om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+    all_poses = workloads.make_poses(w, dt=om.dt)
+    edge = RC.edge_distances(B, -w.fov / 2.0, w.fov / B, 0.275, RC.DEFAULT_CAR["width"], RC.DEFAULT_CAR["wb"])
+    for cls, sc in ((range_libc.PyRayMarchingGPU, 1.0), (range_libc.PyRayMarching, 0.999)):
+        m = cls(omap, mrx)
+        m.set_option("variant", 3)
+        for n, opts in ((200, {}), (600, {"slots": 2}), (600, {"slots": 2, "group_drain": 8}), (1000, {"slots": 1}),
+                        (1000, {"slots": 2, "inline_map_kb": 0, "stripe_max": 0}), (1000, {"slots": 2, "grid_mult": 3})):
+            for k, v in opts.items():
+                m.set_option(k, v)
+            poses = np.ascontiguousarray(all_poses[:n])
+            poses[3] = [np.nan, 0.0, 0.0]
+            poses[5] = [1e6, -1e6, 1.0]
+            poses[7, 2] = np.inf
+            want = om.rm_fan_libm(poses, w.fov, B, step_coeff=sc)[0]
+            got = np.full(n * B, -1.0, np.float32)
+            m.calc_range_fan(poses, got, w.fov, B)
+            assert m.last_plan()["kernel"] == "rm_stream_literal", (n, opts, m.last_plan())
+            assert np.array_equal(got, want), (cls.__name__, n, opts, int((got != want).sum()))
+            # fused crash test, roll-outs of 100 poses: indices of Car::isCrashed over the literal ranges
+            grp = 100
+            first = m.check_collision_groups(poses, grp, w.fov, B, edge, 0.001)
+            ref = [oracle_mod.is_crashed(want[q * grp * B:(q + 1) * grp * B], B, grp, edge, 0.001) for q in range(n // grp)]
+            assert first.tolist() == ref, (cls.__name__, n, opts)
+        m.close()
+    # a batch beyond one INLINE launch: pose slices of 4096, noise keyed by the global ray id, crash marks shifted per slice
+    m = range_libc.PyRayMarchingGPU(omap, mrx)
+    m.set_option("variant", 3)
+    n, Bs = 9000, 96
+    poses = np.ascontiguousarray(workloads.make_poses(w, dt=om.dt, n_poses=n, seed=77))
+    want = om.rm_fan_libm(poses, 2.0, Bs, step_coeff=1.0)[0]
+    got = np.empty(n * Bs, np.float32)
+    m.calc_range_fan(poses, got, 2.0, Bs)
+    pl = m.plan_fan(n, Bs)                      # (last_plan() is the last SLICE's launch)
+    assert pl["kernel"] == "rm_stream_literal" and pl["slices"] == 3 and pl["slice_poses"] == 4096, pl
+    assert m.last_plan()["kernel"] == "rm_stream_literal"
+    assert np.array_equal(got, want)
+    edge96 = np.full(Bs, 0.3)
+    first = m.check_collision_groups(poses, 90, 2.0, Bs, edge96, 0.001)
+    assert first.tolist() == [oracle_mod.is_crashed(want[q * 90 * Bs:(q + 1) * 90 * Bs], Bs, 90, edge96, 0.001) for q in range(100)]
+    # noise: the sliced literal launch and the one-lane-per-ray kernel (diagnostics force it) draw the same noise
+    m.set_noise(0.01, 5, 1000)
+    a, b, hb = np.empty(n * Bs, np.float32), np.empty(n * Bs, np.float32), np.empty((n * Bs, 2), np.int32)
+    m.calc_range_fan(poses, a, 2.0, Bs)
+    m.calc_range_fan(poses, b, 2.0, Bs, hit_cells=hb)
+    assert m.last_plan()["kernel"] == "rm_literal" and np.array_equal(a, b)
+    assert 0.009 < float((a - want).std()) < 0.011
+    # device-resident, four launches in flight on four streams (the shape bench.py --opt variant=3 times)
+    m.set_noise(0.0, 0, 0)
+    m.set_option("slots", 2)
+    m.set_option("grid_mult", 3)
+    from pyracecarsimulator_amd.pipeline import concurrent_streams
+    streams = concurrent_streams(4)
+    n = 4096
+    batches = [np.ascontiguousarray(workloads.make_poses(w, dt=om.dt, n_poses=n, seed=900 + k)) for k in range(len(streams))]
+    d_p = [torch.from_numpy(b).cuda() for b in batches]
+    d_o = [torch.empty(n * B, dtype=torch.float32, device="cuda") for _ in batches]
+    for rep in range(3):
+        for k, st in enumerate(streams):
+            m.calc_range_fan_device(d_p[k].data_ptr(), n, w.fov, B, d_o[k].data_ptr(), stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    sub = np.linspace(0, n - 1, 24).astype(np.int64)
+    for k in range(len(streams)):
+        want = om.rm_fan_libm(batches[k][sub], w.fov, B, step_coeff=1.0)[0]
+        assert np.array_equal(d_o[k].view(n, B)[torch.from_numpy(sub).cuda()].reshape(-1).cpu().numpy(), want), k
 
 
 def test_pyomap_from_occupancy_grid_message_scans_like_the_oracle(oracle_mod):
@@ -880,6 +1033,8 @@ def test_cfg3_giant_lut_full_size(oracle_mod):
     pick = (sub[:, None] * B + np.arange(B)[None, :]).ravel()
     err = np.abs(out[pick] - np.minimum(rm, mrx * g.resolution)) / g.resolution
     assert np.median(err) < 1.0 and (err < 2.0).mean() > 0.9
+    # ... as the distribution SURVEY section 8(c)'s one-cell tolerance means (thresholds derived in _exact_rm_gate)
+    _exact_rm_gate(err, td, float(np.minimum(rm, mrx * g.resolution).mean() / g.resolution), 0.71, "GiantLUT theta_disc %d, cfg3" % td)
 
 
 # ---------------------------------------------------------------- configs 4 and 5: one GPU's shard
@@ -1596,6 +1751,19 @@ def test_cfg3_cddt_full_size(oracle_mod):
     rm = om.rm_fan(poses[sub], w.fov, B, nthreads=oracle_mod.max_threads(), want_hits=False, want_steps=False)[0]
     err = np.abs(want - np.minimum(rm, mrx * g.resolution)) / g.resolution
     assert np.median(err) < 2.0
+    # ... as the distribution SURVEY section 8(c)'s one-cell tolerance means (thresholds derived in _exact_rm_gate), at
+    # 108, at the reference's own theta_disc 112 (scripts/two_player/rcs_two_player.py:121) and at the beam spacing
+    rbar = float(np.minimum(rm, mrx * g.resolution).mean() / g.resolution)
+    _exact_rm_gate(err, 108, rbar, 0.0, "CDDT theta_disc 108, cfg3")
+    m.set_option("cddt_bins", 1)
+    for td2 in (112, 1442):
+        m2 = range_libc.PyCDDTCast(omap, mrx, td2)
+        o4 = np.empty(len(sub) * B, np.float32)
+        m2.calc_range_fan(poses[sub], o4, w.fov, B)
+        assert np.array_equal(o4, om.cddt_fan(td2, poses[sub], w.fov, B, nthreads=oracle_mod.max_threads()))
+        _exact_rm_gate(np.abs(o4 - np.minimum(rm, mrx * g.resolution)) / g.resolution, td2, rbar, 0.0,
+                       "CDDT theta_disc %d, cfg3" % td2)
+        m2.close()
 
 
 def test_hbm_probe_reports_plausible_rates():

@@ -335,16 +335,31 @@ def test_launch_plan_survives_zeroed_and_out_of_range_options():
     assert _plan(_lib.RL_BRESENHAM, 2049, 2049, 4096, 1081, grid_mult=0, xcd_bands=-1)["grid"] >= 1
     # variant 3, the audit mode (upstream-literal arithmetic): one lane per ray, no binning pass, no fused crash test;
     # the table methods and Bresenham keep their own kernels
+    # (round 5: in PRODUCTION shape — the stream kernel's schedule with the literal arithmetic — whenever the records can
+    #  be derived in LDS and no diagnostics are asked for; the one-lane-per-ray kernel otherwise)
     pl = _plan(_lib.RL_RM, 2049, 2049, 4096, 1081, variant=3)
-    assert (pl["kernel"], pl["block"], pl["binning"], pl["name"]) == ("rm_literal", 256, "none", "scan::rm_literal_kernel<false, false>")
+    assert (pl["kernel"], pl["block"], pl["binning"], pl["slots"], pl["name"]) == (
+        "rm_stream_literal", 1024, "small_keys", 2, "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, true>")
+    pl = _plan(_lib.RL_RM_GPU, 2049, 2049, 200, 1081, variant=3, crash=True)              # the reference's roll-out batch
+    assert (pl["kernel"], pl["crash"], pl["name"]) == ("rm_stream_literal", 1, "scan::rm_fan_stream_kernel<false, true, 1024, true, true, 1, true>")
+    pl = _plan(_lib.RL_RM_GPU, 2049, 2049, 65536, 1081, variant=3)                        # beyond one INLINE launch: pose slices
+    assert (pl["kernel"], pl["slices"], pl["slice_poses"]) == ("rm_stream_literal", 16, 4096)
+    assert _plan(_lib.RL_RM_GPU, 435, 350, 100000, 1081, variant=3)["kernel"] == "rm_stream_literal"   # small map
+    pl = _plan(_lib.RL_RM, 2049, 2049, 4096, 1081, variant=3, aux=True)                   # diagnostics: one lane per ray
+    assert (pl["kernel"], pl["block"], pl["binning"], pl["name"]) == ("rm_literal", 256, "none", "scan::rm_literal_kernel<true, false>")
     assert _plan(_lib.RL_RM_GPU, 435, 350, 7, 1081, variant=3, aux=True)["name"] == "scan::rm_literal_kernel<true, false>"
-    assert _plan(_lib.RL_RM_GPU, 2049, 2049, 4096, 1081, variant=9)["kernel"] == "rm_literal"        # (clamped)
+    assert _plan(_lib.RL_RM_GPU, 2049, 2049, 4096, 32, variant=3)["kernel"] == "rm_literal"            # fans below 64 beams
+    assert _plan(_lib.RL_RM_GPU, 2049, 2049, 4096, 1081, variant=9)["kernel"] == "rm_stream_literal"  # (clamped to 3)
     assert _plan(_lib.RL_BRESENHAM, 2049, 2049, 4096, 1081, variant=3)["kernel"] == "bl_stream"
     o = _lib.PlanOpts()
     _lib.check(L.rl_plan_default_opts(C.byref(o)))
     o.variant = 3
     pl2 = _lib.LaunchPlan()
-    assert L.rl_plan_fan(_lib.RL_RM_GPU, 256, 2049, 2049, 300.0, 0, C.byref(o), 4096, 1081, 0, 1, C.byref(pl2)) == -4      # RL_ERR_UNSUPPORTED
+    # the fused crash test in the literal arithmetic: served by the stream form; refused (RL_ERR_UNSUPPORTED) only where
+    # that form cannot run — fans below 64 beams go to the one-lane-per-ray kernel, which has no crash test
+    assert L.rl_plan_fan(_lib.RL_RM_GPU, 256, 2049, 2049, 300.0, 0, C.byref(o), 4096, 1081, 0, 1, C.byref(pl2)) == 0
+    assert pl2.as_dict()["kernel"] == "rm_stream_literal" and pl2.crash == 1
+    assert L.rl_plan_fan(_lib.RL_RM_GPU, 256, 2049, 2049, 300.0, 0, C.byref(o), 4096, 32, 0, 1, C.byref(pl2)) == -4       # RL_ERR_UNSUPPORTED
 
 
 def test_launch_plan_falls_back_when_the_tiled_step_map_or_the_lds_does_not_fit():

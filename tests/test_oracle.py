@@ -244,6 +244,55 @@ def test_committed_upstream_literal_vectors_match_this_hosts_libm(oracle_mod):
             assert mism.sum() <= 2 and np.abs(a - gr).max() <= 1.5 * g.resolution
 
 
+def test_committed_table_literal_vectors_match_this_hosts_libm(oracle_mod):
+    """tests/golden/table_libm_forms.npz — CDDT (theta_disc 112, the reference's, and 360; the 2-argument per-ray form
+    scripts/two_player/scan.py:57-70 uses) and GiantLUT (theta_disc 180) in the upstream-literal statement (libm cosf /
+    sinf per bin, un-fused projection, fmod + roundf bin rule) — recomputed on this host: equal to the committed arrays
+    (bit for bit unless this host's libm rounds a cosf / sinf differently: then within 1e-3 cell), and the CANONICAL
+    statement (what the device builds bit for bit) stays inside the gate the GPU test applies to the device:
+    every ray within 1e-3 cell of the literal form, GiantLUT codes identical."""
+    import importlib.util
+    import os
+    from conftest import GOLD
+    spec = importlib.util.spec_from_file_location("make_fixtures", os.path.join(GOLD, "make_fixtures.py"))
+    L = np.load(os.path.join(GOLD, "table_libm_forms.npz"))
+    # (table_ray_rows restated: importing make_fixtures would pull the reference-side generators in)
+    def ray_rows(poses, fov, B):
+        ang = (np.float32(-0.5) * np.float32(fov) + np.arange(B, dtype=np.float32) * (np.float32(fov) / np.float32(B))).astype(np.float32)
+        ins = np.zeros((len(poses) * B, 3), np.float32)
+        for q in range(len(poses)):
+            ins[q * B:(q + 1) * B, :2] = poses[q, :2]
+            ins[q * B:(q + 1) * B, 2] = poses[q, 2] + ang
+        return ins
+    assert spec is not None
+    for name in ("rm_colombia", "rm_maze256", "rm_maze192_yaw"):
+        g, z = load_golden(name)
+        mrx = int(z["max_range_px"])
+        om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+        n = int(L[name + "_n_poses"])
+        poses, fov, B = np.ascontiguousarray(z["poses"][:n]), float(z["fov"]), int(z["num_rays"])
+        ins = ray_rows(poses, fov, B)
+        for td in (112, 360):
+            want = L["%s_cddt%d" % (name, td)]
+            lit = om.cddt_rays_libm(td, ins)
+            assert np.abs(lit - want).max() <= 1e-3 * g.resolution, (name, td)
+            can = om.cddt_rays(td, ins)
+            assert np.abs(can - want).max() <= 1e-3 * g.resolution, (name, td, float(np.abs(can - want).max()))
+        td = 180
+        rr, cc = om.lut_pose_cells(poses)
+        lit_rows, can_rows = np.zeros((n, td), np.uint16), np.zeros((n, td), np.uint16)
+        for i, (r_, c_) in enumerate(zip(rr, cc)):
+            if r_ >= 0:
+                lit_rows[i] = om.lut_build_libm(td, int(r_), int(r_) + 1, nthreads=1)[0, int(c_)]
+                can_rows[i] = om.lut_build(td, int(r_), int(r_) + 1, nthreads=1)[0, int(c_)]
+        assert np.abs(lit_rows.astype(np.int32) - L[name + "_lut180_rows"].astype(np.int32)).max() <= 1
+        assert np.abs(can_rows.astype(np.int32) - L[name + "_lut180_rows"].astype(np.int32)).max() <= 1
+        assert np.abs(om.lut_fan_rows_libm(lit_rows, poses, fov, B) - L[name + "_lut180_fan"]).max() <= 1e-3 * g.resolution
+        # canonical fan query on canonical rows against the literal answer: the same bins except at exact ties
+        can_fan = om.lut_fan_rows(can_rows, poses, fov, B)
+        assert (np.abs(can_fan - L[name + "_lut180_fan"]) > 1e-3 * g.resolution).mean() <= 1e-3
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_other_casters_c_oracle_equals_numpy_statements(oracle_mod, seed):
     """Rows a12-a14: BresenhamsLine, GiantLUTCast queries and CDDTCast (table + queries) of the C
