@@ -34,12 +34,12 @@ def error_stats_cells(got_m, want_m, resolution):
 
 LEGS = (
     # name, workload, method, theta_disc, poses, pipeline, reduce, steps, bursts
-    ("cfg3_glt", "cfg3", "GLT", 1442, 65536, 1, None, 6, 5),
-    ("cfg3_cddt", "cfg3", "CDDT", 112, 65536, 4, None, 8, 5),
-    ("cfg3_cddt_theta108", "cfg3", "CDDT", 108, 65536, 4, None, 8, 5),
-    ("cfg2_crash", "cfg2", "RMGPU", 0, 4096, 4, "crash", 20, 7),
-    ("cfg2_steer", "cfg2", "RMGPU", 0, 4096, 4, "steer", 20, 7),
-    ("cfg5_shard", "cfg5", "RMGPU", 0, 32768, 4, None, 8, 5),
+    ("cfg3_glt", "cfg3", "GLT", 1442, 65536, 1, None, 8, 5),
+    ("cfg3_cddt", "cfg3", "CDDT", 112, 65536, 4, None, 24, 5),
+    ("cfg3_cddt_theta108", "cfg3", "CDDT", 108, 65536, 4, None, 24, 5),
+    ("cfg2_crash", "cfg2", "RMGPU", 0, 4096, 4, "crash", 80, 7),
+    ("cfg2_steer", "cfg2", "RMGPU", 0, 4096, 4, "steer", 80, 7),
+    ("cfg5_shard", "cfg5", "RMGPU", 0, 32768, 4, None, 24, 5),
 )
 
 
@@ -54,7 +54,7 @@ def _alg_bytes(method, mean_steps, B, nbar):
     return 4.0 * probes + 8.0 + 4.0 + pose
 
 
-def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=0, cache=None):
+def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=0, cache=None, streams=None):
     from pyracecarsimulator_amd import range_libc, workloads, racecar as RC
     from pyracecarsimulator_amd.followgap import PyFollowGap
     from pyracecarsimulator_amd.pipeline import concurrent_streams
@@ -72,7 +72,11 @@ def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=
         meth = range_libc.PyRayMarchingGPU(omap, w.max_range_px)
     is_rm = method == "RMGPU"
     dt = omap.distance_transform()
-    streams = concurrent_streams(P) if P > 1 else [torch.cuda.current_stream()]
+    # (the caller's set of concurrently running streams when it has one: every new set costs a probe of 16 candidates)
+    if P > 1:
+        streams = list(streams[:P]) if (streams and len(streams) >= P) else concurrent_streams(P)
+    else:
+        streams = [torch.cuda.current_stream()]
     P = len(streams)
     default_gm = meth.get_info("grid_mult")
 
@@ -90,7 +94,6 @@ def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=
         have.append(workloads.make_poses(w, dt=dt, n_poses=n, seed=w.pose_seed + 7919 * len(have) + seed_shift))
     batches = have[:P]
     d_poses = [torch.from_numpy(b).to(dev) for b in batches]
-    outs = [torch.empty(n * B, dtype=torch.float32, device=dev) for _ in range(P)]
     if w.noise_std > 0:
         meth.set_noise(w.noise_std, w.noise_seed, 0)
     group = next(g for g in range(min(200, n), 0, -1) if n % g == 0)
@@ -98,41 +101,45 @@ def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=
     edge = RC.edge_distances(B, -w.fov / 2.0, w.fov / B, 0.275, RC.DEFAULT_CAR["width"], RC.DEFAULT_CAR["wb"])
     d_edge = torch.from_numpy(edge).to(dev)
     THRESH = 0.001
-    red = None
+    # the PRODUCT's own pipeline object runs the steps (ShardedScan: one prepared C call per step and slot — a Python
+    # wrapper call per step costs the host more than a 26-us step leaves it)
+    from pyracecarsimulator_amd.distributed import ShardedScan
     fg = None
+    pose_ptrs = [t.data_ptr() for t in d_poses]
     if reduce_ == "crash":
-        red = [torch.zeros(n_groups, dtype=torch.int32, device=dev) for _ in range(P)]
+        sc = ShardedScan(n, B, dev, n_chunks=1, gather=True, streams=streams, mode="crash", n_items=n_groups, every=8)
+        sc.bind_crash(meth, pose_ptrs, w.fov, group, d_edge.data_ptr(), THRESH)
     elif reduce_ == "steer":
         fg = PyFollowGap(10, 15.0, RC.DEFAULT_CAR["max_steer_ang"], 0.004, device=device_index)
-        red = [torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(P)]
-        meth.set_option("nt_store", 0)          # FollowGap reads the scan back at once (as ShardedScan.bind_steer does)
-    sptr = [s.cuda_stream for s in streams]
-
-    def step(i):
-        k = i % P
-        if reduce_ == "crash":
-            meth.check_collision_groups_device(d_poses[k].data_ptr(), n_groups, group, w.fov, B, d_edge.data_ptr(), THRESH,
-                                               red[k].data_ptr(), outs[k].data_ptr(), stream=sptr[k])
-        else:
-            meth.calc_range_fan_device(d_poses[k].data_ptr(), n, w.fov, B, outs[k].data_ptr(), stream=sptr[k])
-            if reduce_ == "steer":
-                fg.eval_many_device(outs[k].data_ptr(), n, B, red[k].data_ptr(), stream=sptr[k])
+        sc = ShardedScan(n, B, dev, n_chunks=1, gather=True, streams=streams, mode="steer", n_items=n, every=8)
+        sc.bind_steer(meth, fg, pose_ptrs, w.fov)
+    else:
+        sc = ShardedScan(n, B, dev, n_chunks=1, gather=False, streams=streams, mode="ranges",
+                         max_range_m=w.max_range_px * w.gmap.resolution)
+        sc.bind(meth, pose_ptrs, w.fov)
+    outs = [sl.local for sl in sc.slots]
 
     schedule(True)
-    for i in range(max(P, 3)):
-        step(i)
+    for _ in range(max(P, 3)):
+        sc.step()
+    sc.finish()
     torch.cuda.synchronize()
     plan = meth.last_plan()
     walls = []
     for _ in range(bursts):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
+        for _i in range(steps):
+            sc.step()
+        sc.finish()
         torch.cuda.synchronize()
         walls.append((time.perf_counter() - t0) / steps)
     ms = float(np.median(walls)) * 1e3
     rays = n * B
+    red = None
+    if reduce_:
+        # the last reduced result of every slot (slot k always scans batch k)
+        red = [sc.results(sl)[0, -1].clone() for sl in sc.slots]
 
     # ---- verification
     ver = {}
@@ -231,6 +238,8 @@ def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=
                 "leg_seconds": None})
     if is_rm:
         out["mean_samples_per_ray"] = round(mean_steps, 3)
+    sc.unbind()
+    del sc
     if fg is not None:
         del fg
     meth.close()
@@ -239,7 +248,7 @@ def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=
     return out
 
 
-def other_configs(torch, dev, device_index, O=None, pmc_lookup=None, only=None, budget_s=40.0):
+def other_configs(torch, dev, device_index, O=None, pmc_lookup=None, only=None, budget_s=40.0, streams=None):
     """Run the side legs; one that raises is reported as {"error": ...} (not a verification failure), one that runs
     and mismatches carries verified: false — bench.py gates its exit code on that."""
     res = {}
@@ -252,7 +261,7 @@ def other_configs(torch, dev, device_index, O=None, pmc_lookup=None, only=None, 
             res[spec[0]] = {"skipped": "time budget of %.0f s for the side legs used up" % budget_s}
             continue
         try:
-            res[spec[0]] = run_leg(spec, torch, dev, device_index, O=O, pmc_lookup=pmc_lookup, cache=cache)
+            res[spec[0]] = run_leg(spec, torch, dev, device_index, O=O, pmc_lookup=pmc_lookup, cache=cache, streams=streams)
         except Exception as e:                      # noqa: BLE001 — a side leg must not take the headline down
             res[spec[0]] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()

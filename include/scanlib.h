@@ -90,8 +90,10 @@ int rl_map_create(const uint8_t *occ, int rows, int cols, float res, float ox, f
  * concurrently (one worker thread per device, nothing is forked) and let every device write its block of
  * the results straight into the caller's buffer.  Results are bit-identical to the single-device call:
  * noise is keyed by the global ray id, crash indices are global.  With a result buffer from
- * rl_host_alloc every device stores over its own PCIe link (4 B per ray), so the host-pointer scan
- * scales with the number of links and never touches xGMI; the crash forms return 4 B per roll-out.
+ * rl_host_alloc every device stores over its own PCIe link (4 B per ray) and nothing touches xGMI, so the
+ * host-pointer scan is EXPECTED to scale with the number of links — modelled, not measured: the pool's boxes have one
+ * GPU, the tests name device 0 several times there (and distinct devices wherever more are visible); the crash forms
+ * return 4 B per roll-out.
  * The *_device entry points take device memory of ONE device: call them with rl_method_replica(h, i)
  * (a borrowed per-device handle; rl_map_replica likewise).  rl_map_update updates every replica.        */
 int rl_map_create_multi(const uint8_t *occ, int rows, int cols, float res, float ox, float oy, float oyaw,
@@ -250,8 +252,10 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
 /* tuning / diagnostics: integer options by name.  None changes a result bit; defaults are the
  * measured optima on MI355X.
  *   schedule   variant (1 stream kernel | 0 chunk-per-wave | 2 occ_fan_lds: unit steps on an LDS occupancy
- *              window, approximate | 3 audit mode of RL_RM / RL_RM_GPU: upstream-literal arithmetic, the ONE option
- *              that changes result bits — onto the oracle's libm form, csrc/literal_kernels.h), grid_mult, wg_threads, low_water (-1 auto), run_log2 (-1 auto), xcd_bands,
+ *              window, approximate | 3 the UPSTREAM-LITERAL arithmetic of RL_RM / RL_RM_GPU — range_libc's CPU
+ *              statement: per-ray glibc sinf / cosf, un-fused products and sums —, the ONE option that changes result
+ *              bits: onto the checker's libm form.  A production mode since round 5: same entry points, same stream
+ *              kernel schedule, fused crash test and noise included, ~0.93x the default's rate), grid_mult, wg_threads, low_water (-1 auto), run_log2 (-1 auto), xcd_bands,
  *              sort_poses, tiled (step-map layout), slots (rays per lane: 1 | 2 | 3 | 0 auto),
  *              cddt_bins (one look-up per pose and table bin), cddt_theta_min (poses from which the look-ups
  *              run theta-major: all poses against one table bin at a time), cddt_lds_sort
@@ -288,9 +292,11 @@ int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
  *                                  INTEGRATION.md), slice_log2 (only to force slicing in tests)
  *   thresholds of the planner      inline_max, inline_map_kb, stripe_max, bin_multi_min, cddt_theta_min, xcd_bands,
  *                                  low_water (-1 = automatic) — change them only with a sweep in hand
- *   kernel selection for A/B       variant (0 chunk kernel, 2 occ_fan_lds, 3 the AUDIT mode: range_libc's CPU
- *                                  arithmetic stated literally — glibc sinf / cosf per ray, un-fused products and
- *                                  sums — bit-identical to the oracle's libm form, 3-5x slower), tiled (0 = row-major step map; the
+ *   arithmetic                     variant 3: range_libc's CPU arithmetic stated literally — glibc sinf / cosf per ray,
+ *                                  un-fused products and sums — bit-identical to the checker's libm form; the stream
+ *                                  kernel's schedule (rm_fan_stream_kernel<.., LIT>), 0.93x the default's rate
+ *   kernel selection for A/B       variant (0 chunk kernel, 2 occ_fan_lds), group_drain, handoff (round 5's measured and
+ *                                  rejected drain forms), cddt_search (0 = round 4's search kernel), tiled (0 = row-major step map; the
  *                                  planner clears it by itself when the tiled geometry does not fit), cddt_bins
  *   diagnostics only               wg_threads, sort_poses, inline_prep, order_inline, bin_generic, run_log2,
  *                                  cddt_sort, lut_debug, debug_stamps
@@ -298,7 +304,10 @@ int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
 typedef struct rl_plan_opts {
     int variant, grid_mult, wg_threads, low_water, sort_poses, xcd_bands, slots, tiled;
     int inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min, bin_generic;
-    int run_log2, cddt_bins, cddt_sort, lut_debug, debug_stamps, slice_log2, cddt_theta_min, reserved[2];
+    int run_log2, cddt_bins, cddt_sort, lut_debug, debug_stamps, slice_log2, cddt_theta_min;
+    int cddt_search;     /* theta-major CDDT search kernel: 1 = look-ups prepared once per pose, picked up by the 8-lane groups
+                            (cddt_theta_search2_kernel, round 5: default), 0 = every group prepares its own (round 4)      */
+    int reserved[1];
 } rl_plan_opts;
 
 typedef enum rl_kernel_id {
@@ -312,7 +321,7 @@ typedef enum rl_kernel_id {
     RL_K_LUT_FAN = 7,       /* lut_fan_kernel<CH>                                                         */
     RL_K_CDDT_BINS = 8,     /* cddt_fan_bins_kernel                                                       */
     RL_K_CDDT_RAYS = 9,     /* cddt_fan_kernel                                                            */
-    RL_K_CDDT_THETA = 10,   /* cddt_theta_search_kernel + cddt_theta_fan_kernel (theta-major, large batches) */
+    RL_K_CDDT_THETA = 10,   /* cddt_theta_search[2]_kernel + cddt_theta_fan_kernel (theta-major, large batches) */
     RL_K_RM_LITERAL = 11,   /* rm_literal_kernel<AUX, RAYS>: upstream-literal arithmetic, one lane per ray — variant 3 with
                                diagnostics (hit cells / sample counts), the 2-argument per-ray form, fans below 64 beams */
     RL_K_RM_STREAM_LIT = 12 /* rm_fan_stream_kernel<false, CRASH, 1024, true, true, SLOTS, true>: variant 3 in production —

@@ -32,7 +32,7 @@ class PlanOpts(C.Structure):
         "variant", "grid_mult", "wg_threads", "low_water", "sort_poses", "xcd_bands", "slots", "tiled",
         "inline_prep", "inline_max", "inline_map_kb", "stripe_max", "order_inline", "bin_multi_min",
         "bin_generic", "run_log2", "cddt_bins", "cddt_sort", "lut_debug", "debug_stamps", "slice_log2",
-        "cddt_theta_min")] + [("reserved", C.c_int * 2)]
+        "cddt_theta_min", "cddt_search")] + [("reserved", C.c_int * 1)]
 
 
 class LaunchPlan(C.Structure):

@@ -745,6 +745,134 @@ void cddt_theta_search_kernel(MapParams m, FanParams f, CddtParams cp, const flo
     }
 }
 
+// Round 5: the same look-ups with the per-look-up PREPARATION done once instead of eight times.  The kernel above is
+// VALU-bound (~18 wave instructions per look-up, 66 M per cfg3 launch = 107 us of issue in a 118-us kernel,
+// profiles/r04/kt_cfg3_cddt): all 8 lanes of a group — and every lane for all four look-ups of its group — repeat the
+// projection, the fan-run test, the bucket header fetch and its decoding.  Here lane i of a wave prepares look-up i
+// (pose p0 + i: one coalesced 1-KiB record read per wave, one projection, ONE header gather per look-up), and the
+// 8-lane groups pick their look-up's three words {lx, first line, count | flags} from the preparing lane with
+// ds_bpermute: 64 look-ups per wave iteration in two rounds of 8 groups x CDDT_TK.  Same arithmetic, same table
+// lines, same insertion points: bit-identical.  A unit = (table bin, 256 poses).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(88), amdgpu_waves_per_eu(8, 8)))
+void cddt_theta_search2_kernel(MapParams m, FanParams f, CddtParams cp, const float *__restrict__ poses,
+                               const float4 *__restrict__ prep, float *__restrict__ R, int n_xcd)
+{
+    const int td = cp.theta_disc, half = td / 2;
+    const float INF = __builtin_inff();
+    constexpr int PB = 256;
+    const int n_pb = (f.n_poses + PB - 1) / PB;
+    const int x = (int)(blockIdx.x % (unsigned)n_xcd), g = (int)(blockIdx.x / (unsigned)n_xcd);
+    const int G = ((int)gridDim.x - x + n_xcd - 1) / n_xcd;
+    const int t_lo = (int)((long)cp.n_bins * x / n_xcd), t_hi = (int)((long)cp.n_bins * (x + 1) / n_xcd);
+    const uint32_t u1 = (uint32_t)(t_hi - t_lo) * (uint32_t)n_pb;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int c = lane & 7, grp = lane >> 3;
+    const float4 *tab4 = reinterpret_cast<const float4 *>(cp.tab);
+    const bool dbg_off = !(cp.debug & 1);
+    static_assert(CDDT_TK == 4, "the reductions below are written for four look-ups per group");
+    for (uint32_t u = (uint32_t)g; u < u1; u += (uint32_t)G) {
+        const uint32_t ut = u / (uint32_t)n_pb;
+        const int t = t_lo + (int)ut, p0 = (int)(u - ut * (uint32_t)n_pb) * PB + wave * 64;
+        if (p0 >= f.n_poses) continue;                         // (wave-uniform: this wave's 64 poses do not exist)
+        const float cs = cp.cosv[t], sn = cp.sinv[t], tr = cp.trans[t], wdt = (float)cp.width[t];
+        const uint32_t boff = cp.bucket_off[t];
+        const int rb = t + half;
+        const bool has_b = rb >= cp.n_bins && rb < td;
+        // ---- preparation: lane i <-> pose p0 + i
+        const int pose = p0 + lane;
+        const float4 pr = prep[min(pose, f.n_poses - 1)];
+        const int first = __builtin_bit_cast(int, pr.z), cnt = __builtin_bit_cast(int, pr.w);
+        int df = t - first, db = rb - first;
+        df += df < 0 ? td : 0;
+        db += db < 0 ? td : 0;
+        const bool live = (pose < f.n_poses) & dbg_off;
+        const bool nf = live & (df < cnt), nbk = live & has_b & (db < cnt);
+        const float my_lx = __builtin_fmaf(pr.x, cs, -(pr.y * sn));
+        const float ly = __builtin_fmaf(pr.x, sn, pr.y * cs) + tr;
+        const bool inside = (nf | nbk) & (ly >= 0.0f) & (ly < wdt);
+        uint2 hd = cp.hdr[inside ? boff + (uint32_t)(int)ly : 0u];
+        hd.y = inside ? hd.y : 0u;                             // (nothing stored: both ranges stay max_range)
+        const bool my_slow = ((hd.y + 31u) >> 5) > 32u;        // several separator lines: the general look-up below
+        // the three words a group needs of its look-up: lx, first line, count | need flags (counts stay below 2^29)
+        const int w_lx = __builtin_bit_cast(int, my_lx), w_line = (int)hd.x;
+        const int w_cnt = (int)((my_slow ? 0u : hd.y) | (nf ? 0x80000000u : 0u) | (nbk ? 0x40000000u : 0u) |
+                                (my_slow ? 0x20000000u : 0u));
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            float lx[CDDT_TK];
+            uint32_t line0[CDDT_TK], nval[CDDT_TK], flg[CDDT_TK];
+#pragma unroll
+            for (int k = 0; k < CDDT_TK; ++k) {
+                const int src = (r * 32 + k * 8 + grp) << 2;   // the lane that prepared this group's look-up k
+                lx[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, w_lx));
+                line0[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, w_line);
+                const uint32_t wc = (uint32_t)__builtin_amdgcn_ds_bpermute(src, w_cnt);
+                nval[k] = wc & 0x1fffffffu;
+                flg[k] = wc >> 29;                             // bit 2 need_f, bit 1 need_b, bit 0 slow
+            }
+            float4 sq[CDDT_TK];
+            uint32_t nleaf[CDDT_TK];
+            bool seps[CDDT_TK];
+#pragma unroll
+            for (int k = 0; k < CDDT_TK; ++k) {
+                nleaf[k] = (nval[k] + 31u) >> 5;
+                seps[k] = nleaf[k] > 1u;
+                sq[k] = tab4[seps[k] ? (size_t)line0[k] * 8 + c : (size_t)c];
+            }
+            uint32_t cn[CDDT_TK];
+            float fs[CDDT_TK];
+#pragma unroll
+            for (int k = 0; k < CDDT_TK; ++k) {
+                cn[k] = count_le(sq[k], lx[k]);
+                fs[k] = first_gt(sq[k], lx[k], INF);
+            }
+            red8_add_min_x4(cn[0], fs[0], cn[1], fs[1], cn[2], fs[2], cn[3], fs[3]);
+            float4 lq[CDDT_TK];
+            bool have_leaf[CDDT_TK];
+#pragma unroll
+            for (int k = 0; k < CDDT_TK; ++k) {
+                fs[k] = seps[k] ? fs[k] : INF;
+                have_leaf[k] = (nval[k] != 0u) & (!seps[k] | (cn[k] > 0u));
+                const uint32_t leaf = seps[k] ? min(cn[k], nleaf[k]) - 1u : 0u;
+                lq[k] = tab4[have_leaf[k] ? ((size_t)line0[k] + (seps[k] ? 1u : 0u) + leaf) * 8 + c : (size_t)c];
+            }
+            float f4[CDDT_TK], b4[CDDT_TK];
+#pragma unroll
+            for (int k = 0; k < CDDT_TK; ++k) {
+                f4[k] = first_ge(lq[k], lx[k], INF);
+                b4[k] = last_le(lq[k], lx[k], -INF);
+            }
+            red8_min_max_x4(f4[0], b4[0], f4[1], b4[1], f4[2], b4[2], f4[3], b4[3]);
+            float my_f = 0.0f, my_b = 0.0f;
+            uint32_t my_flg = 0;
+#pragma unroll
+            for (int k = 0; k < CDDT_TK; ++k) {
+                const float x_ = lx[k];
+                const float rf = vmin((have_leaf[k] ? vmin(fs[k], f4[k]) : fs[k]) - x_, f.max_range);
+                const float rbk = vmin(x_ - (have_leaf[k] ? b4[k] : -INF), f.max_range);
+                const bool mine = c == k;                      // lane k of the group stores look-up k
+                my_f = mine ? rf : my_f;
+                my_b = mine ? rbk : my_b;
+                my_flg = mine ? flg[k] : my_flg;
+            }
+            // the round's 32 look-ups are the poses p0 + r * 32 + k * 8 + grp: lanes (grp, c = k < 4) write one 128-B line
+            const int pq = p0 + r * 32 + c * 8 + grp;
+            if (c < CDDT_TK && (my_flg & 1u) == 0u) {
+                if (my_flg & 4u) R[(size_t)t * f.n_poses + pq] = my_f * m.res;
+                if (my_flg & 2u) R[(size_t)rb * f.n_poses + pq] = my_b * m.res;
+            }
+        }
+        // buckets beyond 1024 values (several separator lines; a long straight wall along the bin's direction): the
+        // general one-lane look-up, by the lane that prepared the pose
+        if (my_slow && (nf | nbk)) {
+            float rf, rbk;
+            cddt_query_pair(cp, f.max_range, pr.x, pr.y, t, rf, rbk);
+            if (nf) R[(size_t)t * f.n_poses + pose] = rf * m.res;
+            if (nbk) R[(size_t)rb * f.n_poses + pose] = rbk * m.res;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cddt_theta_fan_kernel(MapParams m, FanParams f, CddtParams cp,
                                                              const float *__restrict__ poses,
                                                              const float *__restrict__ R, float *__restrict__ out,

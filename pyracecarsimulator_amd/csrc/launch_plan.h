@@ -58,6 +58,7 @@ inline void default_opts(rl_plan_opts &o)
     o.cddt_bins = 1;
     o.cddt_sort = 0;
     o.cddt_theta_min = 32768;
+    o.cddt_search = 1;
     o.lut_debug = 0;
     o.debug_stamps = 0;
     o.slice_log2 = 30;
@@ -89,6 +90,7 @@ inline rl_plan_opts sanitized(rl_plan_opts o)
     o.cddt_bins = o.cddt_bins != 0;
     o.cddt_sort = o.cddt_sort != 0;
     o.cddt_theta_min = clampi(o.cddt_theta_min, 0, 1 << 30);
+    o.cddt_search = o.cddt_search != 0;
     o.slice_log2 = clampi(o.slice_log2, 8, 30);
     return o;
 }
@@ -196,12 +198,14 @@ inline int plan_one(const In &in, rl_launch_plan *p)
             // (eight generations of workgroups: the units are short and of uneven cost — bucket sizes —, later
             //  generations level the end: cfg3 341 -> 364 Grays/s serial, ~350 -> 382-405 with four launches in
             //  flight; 4 and 16 generations are 2-4 % behind: profiles/r04/cddt_grid_sweep.txt)
-            p->grid = (int)std::max(1L, std::min((long)((in.theta_disc + 1) / 2) * ((n_poses + 127) / 128), (long)n_cu * 64));
+            // (a unit of work = one table bin x 128 poses; 256 poses with the round-5 search kernel, whose waves take 64 each)
+            const int unit_poses = o.cddt_search ? 256 : 128;
+            p->grid = (int)std::max(1L, std::min((long)((in.theta_disc + 1) / 2) * ((n_poses + unit_poses - 1) / unit_poses), (long)n_cu * 64));
             p->bands = (p->grid >= o.xcd_bands && (in.theta_disc + 1) / 2 >= o.xcd_bands) ? std::max(o.xcd_bands, 1) : 1;
             p->ch = ppb_log2;
             p->nl = in.theta_disc | 1;                 // LDS row stride of the fan kernel
             p->lds_bytes = ((p->nl + 1) << ppb_log2) * (int)sizeof(float);      // R rows of ppb poses + their headings
-            std::snprintf(p->name, sizeof p->name, "scan::cddt_theta_search_kernel");
+            std::snprintf(p->name, sizeof p->name, o.cddt_search ? "scan::cddt_theta_search2_kernel" : "scan::cddt_theta_search_kernel");
             return RL_OK;
         }
         if (o.cddt_bins && in.theta_disc <= num_rays && in.theta_disc <= 8192) {

@@ -1787,7 +1787,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                         for (;;) {
                             const unsigned long long lv = __ballot(sa.t < f.max_range);
                             if (!lv) break;
-                            const uint32_t nl = (uint32_t)__popcll(lv) / L;
+                            const uint32_t nl = (uint32_t)__popcll(lv) >> (L >> 1);        // (L = 1, 2, 4: a shift, not a division)
                             // (group_drain = N: 4 lanes per ray from N live rays down, 2 lanes per ray from 2 N; N <= 16)
                             const uint32_t gdn = (uint32_t)sp.group_drain;
                             const uint32_t want = gdn ? (nl <= gdn ? 4u : (nl <= 2u * gdn ? 2u : 1u)) : 1u;
@@ -1800,7 +1800,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                                     put(sa, __builtin_amdgcn_mbcnt_hi((uint32_t)(lb2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lb2, 0u)));
                                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                                 L = want;
-                                const uint32_t ri = lane / L;
+                                const uint32_t ri = lane >> (L >> 1);
                                 sa.t = INF;
                                 sa.oidx = NO_RAY;
                                 if (ri < nl) {

@@ -391,6 +391,7 @@ struct rl_method {
                                  // 0 = auto (launch_plan.h: 2 from 2^23 rays per launch up, from 2^20 on maps beyond the
                                  // small-map bound; callers that keep several launches in flight set 2: +15..30 %)
     int cddt_theta_min = 32768;                            // poses per launch from which the CDDT look-ups run theta-major (0: never)
+    int cddt_search = 1;                                   // theta-major search kernel: 1 = look-ups prepared once per pose (round 5), 0 = round 4's
     int cddt_sort = 0;                                     // per-bin fan kernel walks the poses in map-tile order, XCD bands
                                                            // (measured: -13 % at 4096 poses - the binning launch and no
                                                            // reuse at that density -, +3 % at 32768: off by default)
@@ -909,6 +910,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
     else if (!strcmp(name, "slots")) h->slots = value >= 3 ? 3 : (value == 2 ? 2 : (value == 1 ? 1 : 0));
     else if (!strcmp(name, "cddt_bins")) h->cddt_bins_kernel = value != 0;
+    else if (!strcmp(name, "cddt_search")) h->cddt_search = value != 0;
     else if (!strcmp(name, "cddt_sort")) h->cddt_sort = value != 0;
     else if (!strcmp(name, "cddt_theta_min")) h->cddt_theta_min = value < 0 ? 0 : value;
     else if (!strcmp(name, "cddt_lds_sort")) {
@@ -968,6 +970,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "xcd_bands")) *value_out = h->xcd_bands;
     else if (!strcmp(name, "slots")) *value_out = h->slots;
     else if (!strcmp(name, "cddt_bins")) *value_out = h->cddt_bins_kernel;
+    else if (!strcmp(name, "cddt_search")) *value_out = h->cddt_search;
     else if (!strcmp(name, "cddt_sort")) *value_out = h->cddt_sort;
     else if (!strcmp(name, "cddt_theta_min")) *value_out = h->cddt_theta_min;
     else if (!strcmp(name, "cddt_lds_sort")) *value_out = h->cddt_lds_sort;
@@ -1422,6 +1425,7 @@ static rl_plan_opts opts_of(const rl_method *h)
     o.cddt_bins = h->cddt_bins_kernel;
     o.cddt_sort = h->cddt_sort;
     o.cddt_theta_min = h->cddt_theta_min;
+    o.cddt_search = h->cddt_search;
     o.lut_debug = h->lut_debug;
     o.debug_stamps = h->debug_stamps;
     o.slice_log2 = h->slice_log2;
@@ -1569,6 +1573,307 @@ static LiteralParams make_literal(const rl_map *m)
 
 static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov, int num_rays,
                       float *d_out, int32_t *d_hits, uint16_t *d_steps, const CrashParams *crash,
+                      hipStream_t stream);
+
+// what a method family's launch function needs: the call's arguments, the plan, the launch context
+struct FanLaunch {
+    rl_method *h;
+    const rl_map *m;
+    const rl_launch_plan &pl;
+    LaunchCtx *cx;
+    FanParams f;
+    const float *d_poses;
+    int n_poses;
+    float fov;
+    int num_rays;
+    float *d_out;
+    int32_t *d_hits;
+    uint16_t *d_steps;
+    const CrashParams *crash;
+    hipStream_t stream;
+    bool aux;
+};
+#define FAN_LAUNCH_LOCALS                                                                                              \
+    rl_method *h = L.h; const rl_map *m = L.m; const rl_launch_plan &pl = L.pl; LaunchCtx *cx = L.cx;                   \
+    const FanParams &f = L.f; const float *d_poses = L.d_poses; const int n_poses = L.n_poses; const float fov = L.fov; \
+    const int num_rays = L.num_rays; float *d_out = L.d_out; int32_t *d_hits = L.d_hits; uint16_t *d_steps = L.d_steps; \
+    const CrashParams *crash = L.crash; hipStream_t stream = L.stream; const bool aux = L.aux;                          \
+    const dim3 grid(pl.grid), block(pl.block); const size_t lds = (size_t)pl.lds_bytes; int rc = RL_OK;                \
+    (void)h; (void)m; (void)cx; (void)f; (void)d_poses; (void)n_poses; (void)fov; (void)num_rays; (void)d_out;           \
+    (void)d_hits; (void)d_steps; (void)crash; (void)stream; (void)aux; (void)grid; (void)block; (void)lds; (void)rc
+
+// RL_K_LUT_LDS, RL_K_LUT_FAN
+static int launch_lut(const FanLaunch &L)
+{
+    FAN_LAUNCH_LOCALS;
+    if ((rc = ensure_lut(h, stream))) return rc;
+    if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+#define LAUNCH_LL(N, C) hipLaunchKernelGGL((lut_fan_lds_kernel<N, C>), grid, block, lds, stream, m->mp, f, h->lp, d_poses, d_out)
+    if (pl.kernel == RL_K_LUT_LDS) {
+        if (pl.ch == 12) { if (pl.nl == 1) LAUNCH_LL(1, 12); else if (pl.nl == 2) LAUNCH_LL(2, 12); else LAUNCH_LL(3, 12); }
+        else             { if (pl.nl == 1) LAUNCH_LL(1, 17); else if (pl.nl == 2) LAUNCH_LL(2, 17); else LAUNCH_LL(3, 17); }
+    } else if (pl.ch == 12)
+        hipLaunchKernelGGL((lut_fan_kernel<12>), grid, block, 0, stream, m->mp, f, h->lp, d_poses, d_out);
+    else
+        hipLaunchKernelGGL((lut_fan_kernel<17>), grid, block, 0, stream, m->mp, f, h->lp, d_poses, d_out);
+#undef LAUNCH_LL
+    return RL_OK;
+}
+
+// RL_K_CDDT_BINS
+static int launch_cddt_bins(const FanLaunch &L)
+{
+    FAN_LAUNCH_LOCALS;
+    if ((rc = ensure_cddt(h, stream))) return rc;
+    // tile-ordered poses in XCD bands: neighbouring origins hit neighbouring buckets (L2 reuse)
+    const uint32_t *d_order = nullptr;
+    if (pl.binning != RL_BIN_NONE) {
+        if ((rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, pl.binning))) return rc;
+        d_order = (const uint32_t *)cx->order.p;
+    }
+    if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+    hipLaunchKernelGGL(cddt_fan_bins_kernel, grid, block, lds, stream, m->mp, f, h->cdp, d_poses, d_out, d_order,
+                       pl.bands, pl.nl, pl.ch);
+    return RL_OK;
+}
+
+// RL_K_CDDT_THETA
+static int launch_cddt_theta(const FanLaunch &L)
+{
+    FAN_LAUNCH_LOCALS;
+    if ((rc = ensure_cddt(h, stream))) return rc;
+    // scratch of the launch context: R[raw bin][pose] behind the per-pose records {gx, gy, first bin, bins}
+    const size_t prep_bytes = (((size_t)n_poses * 16) + 255) & ~(size_t)255;
+    if ((rc = cx->cddt_r.ensure(prep_bytes + (size_t)h->cdp.theta_disc * (size_t)n_poses * sizeof(float)))) return rc;
+    float4 *d_prep = (float4 *)cx->cddt_r.p;
+    float *d_r = (float *)((char *)cx->cddt_r.p + prep_bytes);
+    if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+    hipLaunchKernelGGL(cddt_theta_prep_kernel, dim3((unsigned)std::max(1, std::min((n_poses + 255) / 256, m->n_cu * 8))),
+                       dim3(256), 0, stream, m->mp, f, h->cdp, d_poses, d_prep);
+    if (h->cddt_search)
+        hipLaunchKernelGGL(cddt_theta_search2_kernel, grid, block, 0, stream, m->mp, f, h->cdp, d_poses,
+                           (const float4 *)d_prep, d_r, pl.bands);
+    else
+        hipLaunchKernelGGL(cddt_theta_search_kernel, grid, block, 0, stream, m->mp, f, h->cdp, d_poses,
+                           (const float4 *)d_prep, d_r, pl.bands);
+    const int n_grp = (n_poses + (1 << pl.ch) - 1) >> pl.ch;
+    hipLaunchKernelGGL(cddt_theta_fan_kernel, dim3((unsigned)std::max(1, std::min(n_grp, m->n_cu * 8))), block, lds,
+                       stream, m->mp, f, h->cdp, d_poses, (const float *)d_r, d_out, pl.ch, pl.nl);
+    return RL_OK;
+}
+
+// RL_K_CDDT_RAYS
+static int launch_cddt_rays(const FanLaunch &L)
+{
+    FAN_LAUNCH_LOCALS;
+    if ((rc = ensure_cddt(h, stream))) return rc;
+    if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+    hipLaunchKernelGGL(cddt_fan_kernel, grid, block, 0, stream, m->mp, f, h->cdp, d_poses, d_out);
+    return RL_OK;
+}
+
+// RL_K_BL_STREAM
+static int launch_bl_stream(const FanLaunch &L)
+{
+    FAN_LAUNCH_LOCALS;
+    // K2b: stream schedule on the cache-resident bit map
+    if ((rc = ensure_blpad(h, stream))) return rc;
+    if ((rc = bin_poses(h, *cx, d_poses, n_poses, 1, stream, pl.binning))) return rc;
+    StreamParams sp{};
+    sp.rec = (const PoseRec *)cx->rec_sorted.p;
+    sp.order = (const uint32_t *)cx->order.p;
+    sp.div_B = make_fastdiv((uint32_t)num_rays);
+    sp.low_water = h->low_water >= 0 ? h->low_water : 12;
+    sp.n_bands = pl.bands;
+    sp.plain_store = !h->nt_store;
+    if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+    if (aux)
+        hipLaunchKernelGGL((bl_fan_stream_kernel<true, 1024>), grid, block, lds, stream, m->mp, f, sp, h->blp, d_out,
+                           d_hits, d_steps);
+    else
+        hipLaunchKernelGGL((bl_fan_stream_kernel<false, 1024>), grid, block, lds, stream, m->mp, f, sp, h->blp, d_out,
+                           d_hits, d_steps);
+    return RL_OK;
+}
+
+// RL_K_BL_LDS, RL_K_OCC_LDS
+static int launch_bl_lds(const FanLaunch &L)
+{
+    FAN_LAUNCH_LOCALS;
+    size_t lds_bl = 0;
+    BlParams bp = make_bl(h, num_rays, lds_bl);
+    if (lds_bl > 48 * 1024) {          // more dynamic LDS than the default cap: opt in
+        const void *fa = pl.kernel == RL_K_BL_LDS ? reinterpret_cast<const void *>(&bl_fan_kernel<true>)
+                                                  : reinterpret_cast<const void *>(&occ_fan_lds_kernel<true>);
+        const void *fb = pl.kernel == RL_K_BL_LDS ? reinterpret_cast<const void *>(&bl_fan_kernel<false>)
+                                                  : reinterpret_cast<const void *>(&occ_fan_lds_kernel<false>);
+        HIPCHK(hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
+        HIPCHK(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
+    }
+    if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+    if (pl.kernel == RL_K_BL_LDS) {
+        if (aux) hipLaunchKernelGGL((bl_fan_kernel<true>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+        else     hipLaunchKernelGGL((bl_fan_kernel<false>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+    } else {
+        // occ_fan_lds: unit-step march on an LDS-resident occupancy window (A/B partner, approximate)
+        if (aux) hipLaunchKernelGGL((occ_fan_lds_kernel<true>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+        else     hipLaunchKernelGGL((occ_fan_lds_kernel<false>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
+    }
+    return RL_OK;
+}
+
+// RL_K_RM_LITERAL
+static int launch_rm_literal(const FanLaunch &L)
+{
+    FAN_LAUNCH_LOCALS;
+    const LiteralParams lt = make_literal(m);
+    const long n_rays = (long)n_poses * num_rays;
+    if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+    if (aux) hipLaunchKernelGGL((rm_literal_kernel<true, false>), grid, block, 0, stream, m->mp, f, lt, d_poses, n_rays, d_out, d_hits, d_steps);
+    else     hipLaunchKernelGGL((rm_literal_kernel<false, false>), grid, block, 0, stream, m->mp, f, lt, d_poses, n_rays, d_out, d_hits, d_steps);
+    return RL_OK;
+}
+
+// RL_K_RM_CHUNK
+static int launch_rm_chunk(const FanLaunch &L)
+{
+    FAN_LAUNCH_LOCALS;
+    CrashParams cp{nullptr, 0.0, nullptr, 1};
+    if (crash) cp = *crash;
+    if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
+#define LAUNCH_CHUNK(A, C) hipLaunchKernelGGL((rm_fan_kernel<A, C>), grid, block, lds, stream, m->mp, f, d_poses, d_out, d_hits, d_steps, cp)
+    if (crash) { if (aux) LAUNCH_CHUNK(true, true); else LAUNCH_CHUNK(false, true); }
+    else       { if (aux) LAUNCH_CHUNK(true, false); else LAUNCH_CHUNK(false, false); }
+#undef LAUNCH_CHUNK
+    return RL_OK;
+}
+
+// RL_K_RM_STREAM_LIT, RL_K_RM_STREAM
+static int launch_rm_stream_family(const FanLaunch &L)
+{
+    FAN_LAUNCH_LOCALS;
+    // (1) per-pose records + tile-ordered permutation, (2) banded lane-refill march
+    CrashParams cp{nullptr, 0.0, nullptr, 1};
+    if (crash) cp = *crash;
+    if ((rc = cx->rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
+    if ((rc = cx->order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
+    if ((rc = cx->keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure_step_map(h, stream))) return rc;
+    if (pl.binning != RL_BIN_NONE &&
+        (rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, pl.binning)))
+        return rc;
+    PadMap pm{};
+    pm.pdt = (const float *)((const char *)h->pdt.p + h->pdt_base_off);
+    pm.stride = h->pstride;
+    pm.nstride = (int)h->pdt_mask;
+    pm.pad = h->pad;
+    pm.k4 = h->pdt_k4;
+    pm.div_stride = make_fastdiv((uint32_t)h->pstride);
+    pm.res = m->res;
+    StreamParams sp{};
+    sp.rec = (const PoseRec *)cx->rec_sorted.p;
+    sp.order = (const uint32_t *)cx->order.p;
+    sp.d0 = (const float *)cx->d0.p;
+    if ((rc = ensure_fan_table(h, f, fov, stream, &sp.fan_tab))) return rc;
+    sp.div_B = make_fastdiv((uint32_t)num_rays);
+    sp.low_water = h->low_water >= 0 ? h->low_water : ((pl.record_source != 0 && pl.slots >= 2) ? 20 : 12);
+    sp.n_bands = pl.bands;
+    sp.raw_poses = d_poses;
+    sp.map = m->d_mp;
+    sp.k_max = pl.k_max;
+    sp.cpp = (uint32_t)((num_rays + 63) / 64);
+    sp.div_cpp = make_fastdiv(sp.cpp);
+    sp.drain_prio = h->drain_prio;
+    sp.spec_drain = h->spec_drain;
+    sp.spec_stretch = h->spec_stretch;
+    sp.drain_cap = h->drain_cap;
+    sp.drain_stretch = h->drain_stretch;
+    sp.group_drain = h->group_drain;
+    if (pl.kernel == RL_K_RM_STREAM_LIT) sp.lit = make_literal(m);
+    sp.plain_store = !h->nt_store;
+    sp.dbg = nullptr;
+    const int waves_per_wg = pl.block / 64;
+    if (h->debug_stamps) {
+        if ((rc = cx->dbg.ensure((size_t)pl.grid * waves_per_wg * 4 * sizeof(uint64_t)))) return rc;
+        sp.dbg = (unsigned long long *)cx->dbg.p;
+        h->last_dbg = cx->dbg.p;
+    }
+    sp.stripe = pl.record_source == 2 ? 1 : pl.record_source == 3 ? 2 : 0;
+    sp.run_log2 = pl.run_log2;
+    h->last_grid = pl.grid * waves_per_wg / WAVES_PER_WG;
+    // hand-off march (several rays per lane on the tiled step map): dry waves leave their last rays in the launch
+    // context's leftover list — one region of handoff_cap records per wave of the main grid —, the second launch
+    // finishes them
+    const bool handoff = h->handoff && pl.slots >= 2 && pl.tiled && h->spec_drain > 0 && !h->debug_stamps &&
+                         pl.kernel == RL_K_RM_STREAM;      // (the leftover kernel marches the canonical arithmetic)
+    int cap_log2 = 4;
+    const int n_src = pl.grid * waves_per_wg;
+    if (handoff) {
+        cap_log2 = h->handoff_cap >= 64 ? 6 : (h->handoff_cap >= 32 ? 5 : (h->handoff_cap >= 16 ? 4 : 3));
+        if ((rc = cx->left_rec.ensure(((size_t)n_src << cap_log2) * sizeof(LeftoverRec)))) return rc;
+        if ((rc = cx->left_cnt.ensure((size_t)n_src * sizeof(uint32_t)))) return rc;
+        sp.left_rec = (LeftoverRec *)cx->left_rec.p;
+        sp.left_cnt = (uint32_t *)cx->left_cnt.p;
+        sp.left_cap_log2 = cap_log2;
+        sp.drain_cap = std::min(sp.drain_cap, 1 << cap_log2);
+    }
+    if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel(s) alone
+    if ((rc = dispatch_rm_stream(pl, stream, pm, f, sp, d_out, d_hits, d_steps, cp))) return rc;
+    if (handoff) {
+        const int lw = h->handoff_wg / 64;                              // leftover waves per workgroup
+        const int n_lw = (n_src + (64 >> cap_log2) - 1) / (64 >> cap_log2);
+        const dim3 lgrid((unsigned)((n_lw + lw - 1) / lw)), lblock((unsigned)h->handoff_wg);
+        if (crash)
+            hipLaunchKernelGGL((rm_leftover_kernel<true>), lgrid, lblock, 0, stream, pm, f, (const LeftoverRec *)sp.left_rec,
+                               (const uint32_t *)sp.left_cnt, n_src, cap_log2, h->drain_stretch, sp.plain_store, d_out, cp);
+        else
+            hipLaunchKernelGGL((rm_leftover_kernel<false>), lgrid, lblock, 0, stream, pm, f, (const LeftoverRec *)sp.left_rec,
+                               (const uint32_t *)sp.left_cnt, n_src, cap_log2, h->drain_stretch, sp.plain_store, d_out, cp);
+    }
+    return RL_OK;
+}
+
+// a batch cut into pose slices (plan: slices > 1), each its own launch sequence on the stream
+static int launch_fan_sliced(rl_method *h, const rl_launch_plan &pl, const float *d_poses, int n_poses, float fov,
+                             int num_rays, float *d_out, int32_t *d_hits, uint16_t *d_steps, const CrashParams *crash,
+                             hipStream_t stream)
+{
+    int rc = RL_OK;
+    // pose slices below 2^slice_log2 rays, each its own launch sequence
+    if (crash && crash->group != 0)
+        return fail(RL_ERR_UNSUPPORTED, "a fused crash test over %d poses in the upstream-literal mode needs the per-pose "
+                                        "mark form (rl_check_collision_groups*), not one roll-out of that length", n_poses);
+    const int per = pl.slice_poses;
+    const uint64_t base_off = h->ray_offset;
+    // one event pair around the whole sliced sequence (the per-slice pairs would leave the
+    // last slice only)
+    const int timing = h->timing;
+    h->timing = 0;
+    if (timing) HIPCHK(hipEventRecord(h->ev0, stream));
+    rc = RL_OK;
+    for (int p0 = 0; p0 < n_poses && rc == RL_OK; p0 += per) {
+        const int np = std::min(per, n_poses - p0);
+        const size_t r0 = (size_t)p0 * num_rays;
+        h->ray_offset = base_off + r0;               // noise stays keyed by the global ray id
+        // (a fused crash test reaches a sliced launch only in per-pose-mark form — the upstream-literal mode's
+        //  slices: slice k marks poses p0 .. p0 + np - 1 through a shifted mark array)
+        CrashParams cps{nullptr, 0.0, nullptr, 1, 0};
+        if (crash) {
+            cps = *crash;
+            cps.first_crashed = crash->first_crashed + p0;
+        }
+        rc = launch_fan(h, d_poses + (size_t)p0 * 3, np, fov, num_rays, d_out ? d_out + r0 : nullptr,
+                        d_hits ? d_hits + 2 * r0 : nullptr, d_steps ? d_steps + r0 : nullptr,
+                        crash ? &cps : nullptr, stream);
+    }
+    h->ray_offset = base_off;
+    h->timing = timing;
+    if (timing && rc == RL_OK) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
+    return rc;
+}
+
+static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov, int num_rays,
+                      float *d_out, int32_t *d_hits, uint16_t *d_steps, const CrashParams *crash,
                       hipStream_t stream)
 {
     if (n_poses == 0) return RL_OK;
@@ -1587,243 +1892,48 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
                                           : "the beam tables of max_range %g, num_rays %d exceed a workgroup's LDS (160 KB)",
                     h->max_range, num_rays);
     if (rc) return fail(rc, "launch planning failed");
-    if (pl.slices > 1) {
-        // pose slices below 2^slice_log2 rays, each its own launch sequence
-        if (crash && crash->group != 0)
-            return fail(RL_ERR_UNSUPPORTED, "a fused crash test over %d poses in the upstream-literal mode needs the per-pose "
-                                            "mark form (rl_check_collision_groups*), not one roll-out of that length", n_poses);
-        const int per = pl.slice_poses;
-        const uint64_t base_off = h->ray_offset;
-        // one event pair around the whole sliced sequence (the per-slice pairs would leave the
-        // last slice only)
-        const int timing = h->timing;
-        h->timing = 0;
-        if (timing) HIPCHK(hipEventRecord(h->ev0, stream));
-        rc = RL_OK;
-        for (int p0 = 0; p0 < n_poses && rc == RL_OK; p0 += per) {
-            const int np = std::min(per, n_poses - p0);
-            const size_t r0 = (size_t)p0 * num_rays;
-            h->ray_offset = base_off + r0;               // noise stays keyed by the global ray id
-            // (a fused crash test reaches a sliced launch only in per-pose-mark form — the upstream-literal mode's
-            //  slices: slice k marks poses p0 .. p0 + np - 1 through a shifted mark array)
-            CrashParams cps{nullptr, 0.0, nullptr, 1, 0};
-            if (crash) {
-                cps = *crash;
-                cps.first_crashed = crash->first_crashed + p0;
-            }
-            rc = launch_fan(h, d_poses + (size_t)p0 * 3, np, fov, num_rays, d_out ? d_out + r0 : nullptr,
-                            d_hits ? d_hits + 2 * r0 : nullptr, d_steps ? d_steps + r0 : nullptr,
-                            crash ? &cps : nullptr, stream);
-        }
-        h->ray_offset = base_off;
-        h->timing = timing;
-        if (timing && rc == RL_OK) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
-        return rc;
-    }
+    if (pl.slices > 1) return launch_fan_sliced(h, pl, d_poses, n_poses, fov, num_rays, d_out, d_hits, d_steps, crash, stream);
     LaunchCtx *cx = nullptr;
     if ((rc = acquire_ctx(h, stream, &cx))) return rc;
     h->last_plan = pl;
     FanParams f = make_fan(h, n_poses, fov, num_rays);
-    const dim3 grid(pl.grid), block(pl.block);
-    const size_t lds = (size_t)pl.lds_bytes;
     if (h->timing == 1) HIPCHK(hipEventRecord(h->ev0, stream));
+    const FanLaunch L{h, m, pl, cx, f, d_poses, n_poses, fov, num_rays, d_out, d_hits, d_steps, crash, stream, aux};
     switch (pl.kernel) {
     case RL_K_LUT_LDS:
-    case RL_K_LUT_FAN: {
-        if ((rc = ensure_lut(h, stream))) return rc;
-        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
-#define LAUNCH_LL(N, C) hipLaunchKernelGGL((lut_fan_lds_kernel<N, C>), grid, block, lds, stream, m->mp, f, h->lp, d_poses, d_out)
-        if (pl.kernel == RL_K_LUT_LDS) {
-            if (pl.ch == 12) { if (pl.nl == 1) LAUNCH_LL(1, 12); else if (pl.nl == 2) LAUNCH_LL(2, 12); else LAUNCH_LL(3, 12); }
-            else             { if (pl.nl == 1) LAUNCH_LL(1, 17); else if (pl.nl == 2) LAUNCH_LL(2, 17); else LAUNCH_LL(3, 17); }
-        } else if (pl.ch == 12)
-            hipLaunchKernelGGL((lut_fan_kernel<12>), grid, block, 0, stream, m->mp, f, h->lp, d_poses, d_out);
-        else
-            hipLaunchKernelGGL((lut_fan_kernel<17>), grid, block, 0, stream, m->mp, f, h->lp, d_poses, d_out);
-#undef LAUNCH_LL
+    case RL_K_LUT_FAN:
+        rc = launch_lut(L);
         break;
-    }
-    case RL_K_CDDT_BINS: {
-        if ((rc = ensure_cddt(h, stream))) return rc;
-        // tile-ordered poses in XCD bands: neighbouring origins hit neighbouring buckets (L2 reuse)
-        const uint32_t *d_order = nullptr;
-        if (pl.binning != RL_BIN_NONE) {
-            if ((rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, pl.binning))) return rc;
-            d_order = (const uint32_t *)cx->order.p;
-        }
-        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
-        hipLaunchKernelGGL(cddt_fan_bins_kernel, grid, block, lds, stream, m->mp, f, h->cdp, d_poses, d_out, d_order,
-                           pl.bands, pl.nl, pl.ch);
+    case RL_K_CDDT_BINS:
+        rc = launch_cddt_bins(L);
         break;
-    }
-    case RL_K_CDDT_THETA: {
-        if ((rc = ensure_cddt(h, stream))) return rc;
-        // scratch of the launch context: R[raw bin][pose] behind the per-pose records {gx, gy, first bin, bins}
-        const size_t prep_bytes = (((size_t)n_poses * 16) + 255) & ~(size_t)255;
-        if ((rc = cx->cddt_r.ensure(prep_bytes + (size_t)h->cdp.theta_disc * (size_t)n_poses * sizeof(float)))) return rc;
-        float4 *d_prep = (float4 *)cx->cddt_r.p;
-        float *d_r = (float *)((char *)cx->cddt_r.p + prep_bytes);
-        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
-        hipLaunchKernelGGL(cddt_theta_prep_kernel, dim3((unsigned)std::max(1, std::min((n_poses + 255) / 256, m->n_cu * 8))),
-                           dim3(256), 0, stream, m->mp, f, h->cdp, d_poses, d_prep);
-        hipLaunchKernelGGL(cddt_theta_search_kernel, grid, block, 0, stream, m->mp, f, h->cdp, d_poses,
-                           (const float4 *)d_prep, d_r, pl.bands);
-        const int n_grp = (n_poses + (1 << pl.ch) - 1) >> pl.ch;
-        hipLaunchKernelGGL(cddt_theta_fan_kernel, dim3((unsigned)std::max(1, std::min(n_grp, m->n_cu * 8))), block, lds,
-                           stream, m->mp, f, h->cdp, d_poses, (const float *)d_r, d_out, pl.ch, pl.nl);
+    case RL_K_CDDT_THETA:
+        rc = launch_cddt_theta(L);
         break;
-    }
     case RL_K_CDDT_RAYS:
-        if ((rc = ensure_cddt(h, stream))) return rc;
-        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
-        hipLaunchKernelGGL(cddt_fan_kernel, grid, block, 0, stream, m->mp, f, h->cdp, d_poses, d_out);
+        rc = launch_cddt_rays(L);
         break;
-    case RL_K_BL_STREAM: {
-        // K2b: stream schedule on the cache-resident bit map
-        if ((rc = ensure_blpad(h, stream))) return rc;
-        if ((rc = bin_poses(h, *cx, d_poses, n_poses, 1, stream, pl.binning))) return rc;
-        StreamParams sp{};
-        sp.rec = (const PoseRec *)cx->rec_sorted.p;
-        sp.order = (const uint32_t *)cx->order.p;
-        sp.div_B = make_fastdiv((uint32_t)num_rays);
-        sp.low_water = h->low_water >= 0 ? h->low_water : 12;
-        sp.n_bands = pl.bands;
-        sp.plain_store = !h->nt_store;
-        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
-        if (aux)
-            hipLaunchKernelGGL((bl_fan_stream_kernel<true, 1024>), grid, block, lds, stream, m->mp, f, sp, h->blp, d_out,
-                               d_hits, d_steps);
-        else
-            hipLaunchKernelGGL((bl_fan_stream_kernel<false, 1024>), grid, block, lds, stream, m->mp, f, sp, h->blp, d_out,
-                               d_hits, d_steps);
+    case RL_K_BL_STREAM:
+        rc = launch_bl_stream(L);
         break;
-    }
     case RL_K_BL_LDS:
-    case RL_K_OCC_LDS: {
-        size_t lds_bl = 0;
-        BlParams bp = make_bl(h, num_rays, lds_bl);
-        if (lds_bl > 48 * 1024) {          // more dynamic LDS than the default cap: opt in
-            const void *fa = pl.kernel == RL_K_BL_LDS ? reinterpret_cast<const void *>(&bl_fan_kernel<true>)
-                                                      : reinterpret_cast<const void *>(&occ_fan_lds_kernel<true>);
-            const void *fb = pl.kernel == RL_K_BL_LDS ? reinterpret_cast<const void *>(&bl_fan_kernel<false>)
-                                                      : reinterpret_cast<const void *>(&occ_fan_lds_kernel<false>);
-            HIPCHK(hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
-            HIPCHK(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bl));
-        }
-        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
-        if (pl.kernel == RL_K_BL_LDS) {
-            if (aux) hipLaunchKernelGGL((bl_fan_kernel<true>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
-            else     hipLaunchKernelGGL((bl_fan_kernel<false>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
-        } else {
-            // occ_fan_lds: unit-step march on an LDS-resident occupancy window (A/B partner, approximate)
-            if (aux) hipLaunchKernelGGL((occ_fan_lds_kernel<true>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
-            else     hipLaunchKernelGGL((occ_fan_lds_kernel<false>), grid, block, lds_bl, stream, m->mp, f, bp, d_poses, d_out, d_hits, d_steps);
-        }
+    case RL_K_OCC_LDS:
+        rc = launch_bl_lds(L);
         break;
-    }
-    case RL_K_RM_LITERAL: {
-        const LiteralParams lt = make_literal(m);
-        const long n_rays = (long)n_poses * num_rays;
-        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
-        if (aux) hipLaunchKernelGGL((rm_literal_kernel<true, false>), grid, block, 0, stream, m->mp, f, lt, d_poses, n_rays, d_out, d_hits, d_steps);
-        else     hipLaunchKernelGGL((rm_literal_kernel<false, false>), grid, block, 0, stream, m->mp, f, lt, d_poses, n_rays, d_out, d_hits, d_steps);
+    case RL_K_RM_LITERAL:
+        rc = launch_rm_literal(L);
         break;
-    }
-    case RL_K_RM_CHUNK: {
-        CrashParams cp{nullptr, 0.0, nullptr, 1};
-        if (crash) cp = *crash;
-        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
-#define LAUNCH_CHUNK(A, C) hipLaunchKernelGGL((rm_fan_kernel<A, C>), grid, block, lds, stream, m->mp, f, d_poses, d_out, d_hits, d_steps, cp)
-        if (crash) { if (aux) LAUNCH_CHUNK(true, true); else LAUNCH_CHUNK(false, true); }
-        else       { if (aux) LAUNCH_CHUNK(true, false); else LAUNCH_CHUNK(false, false); }
-#undef LAUNCH_CHUNK
+    case RL_K_RM_CHUNK:
+        rc = launch_rm_chunk(L);
         break;
-    }
     case RL_K_RM_STREAM_LIT:
-    case RL_K_RM_STREAM: {
-        // (1) per-pose records + tile-ordered permutation, (2) banded lane-refill march
-        CrashParams cp{nullptr, 0.0, nullptr, 1};
-        if (crash) cp = *crash;
-        if ((rc = cx->rec.ensure((size_t)n_poses * sizeof(PoseRec)))) return rc;
-        if ((rc = cx->order.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
-        if ((rc = cx->keys.ensure((size_t)n_poses * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure_step_map(h, stream))) return rc;
-        if (pl.binning != RL_BIN_NONE &&
-            (rc = bin_poses(h, *cx, d_poses, n_poses, 0, stream, pl.binning)))
-            return rc;
-        PadMap pm{};
-        pm.pdt = (const float *)((const char *)h->pdt.p + h->pdt_base_off);
-        pm.stride = h->pstride;
-        pm.nstride = (int)h->pdt_mask;
-        pm.pad = h->pad;
-        pm.k4 = h->pdt_k4;
-        pm.div_stride = make_fastdiv((uint32_t)h->pstride);
-        pm.res = m->res;
-        StreamParams sp{};
-        sp.rec = (const PoseRec *)cx->rec_sorted.p;
-        sp.order = (const uint32_t *)cx->order.p;
-        sp.d0 = (const float *)cx->d0.p;
-        if ((rc = ensure_fan_table(h, f, fov, stream, &sp.fan_tab))) return rc;
-        sp.div_B = make_fastdiv((uint32_t)num_rays);
-        sp.low_water = h->low_water >= 0 ? h->low_water : ((pl.record_source != 0 && pl.slots >= 2) ? 20 : 12);
-        sp.n_bands = pl.bands;
-        sp.raw_poses = d_poses;
-        sp.map = m->d_mp;
-        sp.k_max = pl.k_max;
-        sp.cpp = (uint32_t)((num_rays + 63) / 64);
-        sp.div_cpp = make_fastdiv(sp.cpp);
-        sp.drain_prio = h->drain_prio;
-        sp.spec_drain = h->spec_drain;
-        sp.spec_stretch = h->spec_stretch;
-        sp.drain_cap = h->drain_cap;
-        sp.drain_stretch = h->drain_stretch;
-        sp.group_drain = h->group_drain;
-        if (pl.kernel == RL_K_RM_STREAM_LIT) sp.lit = make_literal(m);
-        sp.plain_store = !h->nt_store;
-        sp.dbg = nullptr;
-        const int waves_per_wg = pl.block / 64;
-        if (h->debug_stamps) {
-            if ((rc = cx->dbg.ensure((size_t)pl.grid * waves_per_wg * 4 * sizeof(uint64_t)))) return rc;
-            sp.dbg = (unsigned long long *)cx->dbg.p;
-            h->last_dbg = cx->dbg.p;
-        }
-        sp.stripe = pl.record_source == 2 ? 1 : pl.record_source == 3 ? 2 : 0;
-        sp.run_log2 = pl.run_log2;
-        h->last_grid = pl.grid * waves_per_wg / WAVES_PER_WG;
-        // hand-off march (several rays per lane on the tiled step map): dry waves leave their last rays in the launch
-        // context's leftover list — one region of handoff_cap records per wave of the main grid —, the second launch
-        // finishes them
-        const bool handoff = h->handoff && pl.slots >= 2 && pl.tiled && h->spec_drain > 0 && !h->debug_stamps &&
-                             pl.kernel == RL_K_RM_STREAM;      // (the leftover kernel marches the canonical arithmetic)
-        int cap_log2 = 4;
-        const int n_src = pl.grid * waves_per_wg;
-        if (handoff) {
-            cap_log2 = h->handoff_cap >= 64 ? 6 : (h->handoff_cap >= 32 ? 5 : (h->handoff_cap >= 16 ? 4 : 3));
-            if ((rc = cx->left_rec.ensure(((size_t)n_src << cap_log2) * sizeof(LeftoverRec)))) return rc;
-            if ((rc = cx->left_cnt.ensure((size_t)n_src * sizeof(uint32_t)))) return rc;
-            sp.left_rec = (LeftoverRec *)cx->left_rec.p;
-            sp.left_cnt = (uint32_t *)cx->left_cnt.p;
-            sp.left_cap_log2 = cap_log2;
-            sp.drain_cap = std::min(sp.drain_cap, 1 << cap_log2);
-        }
-        if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel(s) alone
-        if ((rc = dispatch_rm_stream(pl, stream, pm, f, sp, d_out, d_hits, d_steps, cp))) return rc;
-        if (handoff) {
-            const int lw = h->handoff_wg / 64;                              // leftover waves per workgroup
-            const int n_lw = (n_src + (64 >> cap_log2) - 1) / (64 >> cap_log2);
-            const dim3 lgrid((unsigned)((n_lw + lw - 1) / lw)), lblock((unsigned)h->handoff_wg);
-            if (crash)
-                hipLaunchKernelGGL((rm_leftover_kernel<true>), lgrid, lblock, 0, stream, pm, f, (const LeftoverRec *)sp.left_rec,
-                                   (const uint32_t *)sp.left_cnt, n_src, cap_log2, h->drain_stretch, sp.plain_store, d_out, cp);
-            else
-                hipLaunchKernelGGL((rm_leftover_kernel<false>), lgrid, lblock, 0, stream, pm, f, (const LeftoverRec *)sp.left_rec,
-                                   (const uint32_t *)sp.left_cnt, n_src, cap_log2, h->drain_stretch, sp.plain_store, d_out, cp);
-        }
+    case RL_K_RM_STREAM:
+        rc = launch_rm_stream_family(L);
         break;
-    }
     default:
         return fail(RL_ERR_INVALID, "launch plan names no kernel");
     }
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     if (h->timing) { HIPCHK(hipEventRecord(h->ev1, stream)); h->timed = true; }
     return RL_OK;

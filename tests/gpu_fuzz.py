@@ -122,6 +122,7 @@ def one_case(seed):
                 m = range_libc.PyCDDTCast(omap, mrx, td)
                 m.set_option("cddt_bins", int(r.integers(0, 2))); m.set_option("cddt_lds_sort", int(r.choice([128, 16384]))); m.set_option("cddt_sort", int(r.integers(0, 2)))
                 m.set_option("cddt_theta_min", int(r.choice([0, 1, 32768])))      # pose-major | theta-major | by size
+                m.set_option("cddt_search", int(r.integers(0, 2)))
                 out = np.empty(n, np.float32); m.calc_range_fan(poses, out, fov, B)
                 assert np.array_equal(out, om.cddt_fan(td, poses, fov, B)), "CDDT td=%d" % td
                 m.close()

@@ -937,10 +937,14 @@ def test_cddt_fan_searches_only_the_bins_the_fan_touches(oracle_mod):
             assert np.array_equal(out, want), (td, fov, B)
             if td <= B:                                   # the theta-major pair of kernels on the same fans
                 m.set_option("cddt_theta_min", 1)
-                out[:] = -1.0
-                m.calc_range_fan(poses, out, fov, B)
-                assert m.last_plan()["kernel"] == "cddt_theta"
-                assert np.array_equal(out, want), ("theta-major", td, fov, B)
+                for search in (1, 0):                     # round 5's search kernel (look-ups prepared once per pose) and round 4's
+                    m.set_option("cddt_search", search)
+                    out[:] = -1.0
+                    m.calc_range_fan(poses, out, fov, B)
+                    assert m.last_plan()["kernel"] == "cddt_theta"
+                    assert m.last_plan()["name"] == ("scan::cddt_theta_search2_kernel" if search else "scan::cddt_theta_search_kernel")
+                    assert np.array_equal(out, want), ("theta-major", search, td, fov, B)
+                m.set_option("cddt_search", 1)
                 m.set_option("cddt_theta_min", 32768)
 
 
@@ -971,9 +975,12 @@ def test_cddt_long_walls_fill_large_buckets(oracle_mod, lds_sort):
             assert np.array_equal(out, want), (td, bins)
         m.set_option("cddt_bins", 1)
         m.set_option("cddt_theta_min", 1)                 # theta-major (buckets beyond 1024 values: several separator lines)
-        out = np.empty(len(poses) * 1081, np.float32)
-        m.calc_range_fan(poses, out, 4.71, 1081)
-        assert m.last_plan()["kernel"] == "cddt_theta" and np.array_equal(out, want), td
+        for search in (1, 0):
+            m.set_option("cddt_search", search)
+            out = np.empty(len(poses) * 1081, np.float32)
+            m.calc_range_fan(poses, out, 4.71, 1081)
+            assert m.last_plan()["kernel"] == "cddt_theta" and np.array_equal(out, want), (td, search)
+        m.set_option("cddt_search", 1)
         m.set_option("cddt_theta_min", 32768)
         # a rebuild (map update) goes through the same enqueue-only path again
         occ2 = occ.copy()
@@ -1723,6 +1730,12 @@ def test_cfg3_cddt_full_size(oracle_mod):
     m.calc_range_fan(poses, out, w.fov, B)
     assert m.last_plan()["kernel"] == "cddt_theta"
     assert out.min() >= 0.0 and out.max() <= mrx * g.resolution
+    m.set_option("cddt_search", 0)                                    # round 4's search kernel on the same batch
+    old = np.empty_like(out)
+    m.calc_range_fan(poses, old, w.fov, B)
+    assert m.last_plan()["name"] == "scan::cddt_theta_search_kernel" and np.array_equal(old, out)
+    del old
+    m.set_option("cddt_search", 1)
     m.set_option("cddt_theta_min", 0)                                 # the pose-major kernel on the same batch
     pm = np.empty_like(out)
     m.calc_range_fan(poses, pm, w.fov, B)

@@ -247,8 +247,10 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
     # cfg3's 65 536 poses run theta-major (all poses against one table bin at a time, bins pinned to XCDs;
     # the fan kernel takes 32 poses x 109 floats of LDS per pass); below cddt_theta_min pose-major:
     p = _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=108)
-    assert (p["kernel"], p["block"], p["grid"], p["bands"], p["ch"], p["nl"], p["lds_bytes"]) == \
-        ("cddt_theta", 256, 16384, 8, 5, 109, 32 * 110 * 4)
+    assert (p["kernel"], p["block"], p["grid"], p["bands"], p["ch"], p["nl"], p["lds_bytes"], p["name"]) == \
+        ("cddt_theta", 256, 54 * 256, 8, 5, 109, 32 * 110 * 4, "scan::cddt_theta_search2_kernel")   # units of 256 poses
+    p4 = _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=108, cddt_search=0)                      # round 4's kernel: 128
+    assert (p4["grid"], p4["name"]) == (16384, "scan::cddt_theta_search_kernel")
     assert _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=720)["ch"] == 4      # 16 poses x 721 floats
     assert _plan(CDDT, 2000, 2000, 65536, 1081, theta_disc=108, cddt_theta_min=0)["kernel"] == "cddt_bins"
     p = _plan(CDDT, 2000, 2000, 3, 1081, theta_disc=4, cddt_theta_min=1)

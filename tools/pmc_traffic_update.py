@@ -9,11 +9,13 @@ note = sys.argv[5] if len(sys.argv) > 5 else None
 summ = json.load(open(os.path.join(ROOT, prof, "pmc_summary.json")))
 path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 doc = json.load(open(path))
-MAIN = ("rm_fan_stream_kernel", "lut_fan_lds_kernel", "bl_fan_stream_kernel", "cddt_fan_bins_kernel", "cddt_theta_search_kernel")
+MAIN = ("rm_fan_stream_kernel", "lut_fan_lds_kernel", "bl_fan_stream_kernel", "cddt_fan_bins_kernel", "cddt_theta_search_kernel", "cddt_theta_search2_kernel")
 for key, v in summ.items():
     if not any(key.startswith(m) for m in MAIN) or v.get("_dispatches", 0) < 4 or "FETCH_SIZE" not in v:
         continue
     name, grid = key.rsplit(" [grid ", 1)
+    if name.endswith(", false>") and name.startswith("rm_fan_stream_kernel"):     # (the plan names the literal form only)
+        name = name[:-len(", false>")] + ">"
     grid = int(grid.rstrip("]"))
     e = {"workload": workload, "method": method, "poses": poses, "kernel": "scan::" + name, "grid": grid,
          "bytes": int(round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024))}
