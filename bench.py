@@ -946,19 +946,6 @@ def main():
                                     "frac": round(floor_ms / wall_ms, 5),
                                     "lanes_per_valu_inst": pe.get("lanes_per_valu"),
                                     "source": pe["profile"] + " (SQ_INSTS_VALU; not measured in this run)"}
-        if pe and pe.get("tcp_line_accesses") and not a.no_extras:
-            # the CU's L1 (TCP) looks up ONE 128-B line per clock: a wave-wide gather of unrelated cells costs one look-up
-            # per distinct line of each 16-lane quad (TCP_TOTAL_CACHE_ACCESSES of exactly this launch shape, committed) —
-            # the floor the ray-marching kernels actually run against
-            prop = torch.cuda.get_device_properties(dev)
-            clk_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
-            floor_ms = pe["tcp_line_accesses"] / (prop.multi_processor_count * clk_hz) * 1e3
-            out["roofline_tcp"] = {"line_accesses_per_launch": pe["tcp_line_accesses"], "floor_ms": round(floor_ms, 5),
-                                   "frac": round(floor_ms / wall_ms, 5),
-                                   "lines_per_wave_load": round(pe["tcp_line_accesses"] / max(pe.get("wave_loads", 0), 1), 2),
-                                   "peak_is": "one L1 tag look-up per clock per CU (%d CUs x %.2f GHz)" % (
-                                       prop.multi_processor_count, clk_hz / 1e9),
-                                   "source": pe["profile"] + " (TCP_TOTAL_CACHE_ACCESSES_sum; not measured in this run)"}
         if not a.no_extras and P > 1 and not scan.reduced:
             # the same schedule with every step in flight scanning the SAME batch (what round 2 measured):
             # quantifies what identical cache lines in identical order are worth

@@ -236,6 +236,10 @@ def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=
                 "steps": steps, "bursts": bursts, "algorithmic_bytes_per_ray": round(bpr, 3),
                 "traffic_source": pe["profile"] if pe else None,
                 "leg_seconds": None})
+    if method == "CDDT":
+        # (SURVEY section 8(d) prices a per-RAY bisection; the theta-major kernels answer one look-up per (pose, table bin)
+        #  and ~B / theta_disc beams share it, so frac exceeds 1 by construction: frac_hbm is the figure to read)
+        out["frac_is"] = "algorithmic bytes of a per-ray bisection / time / HBM peak: > 1 because ~%d beams share one look-up; read frac_hbm" % max(1, B // max(1, theta or 108))
     if is_rm:
         out["mean_samples_per_ray"] = round(mean_steps, 3)
     sc.unbind()

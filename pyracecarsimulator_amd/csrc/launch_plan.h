@@ -340,14 +340,21 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     // auto: two rays per lane from 2^23 rays up, and from 2^20 on maps beyond the small-map bound (long rays:
     // +6 % on a lone 2049^2 launch of 1024 ... 16 384 poses since dry waves compact their last rays; colombia's
     // short rays lose 3 % — profiles/r03/sweep_serial_slots.txt)
-    int slots_req = o.slots ? o.slots : ((rays >= (1L << 23) || (rays >= (1L << 20) && !small_map)) ? 2 : 1);
+    // (round 5, tools/r05/small_batch_sweep.py: since dry waves compact their last rays, two rays per lane win at EVERY
+    //  batch size on maps beyond the small-map bound — one scan 13.5 -> 12.7 us, the reference's 200-pose roll-out
+    //  20.5 -> 18.8 us, 1024 poses 26.4 -> 24.2 us on 2049^2; 200 poses 21.9 -> 19.4 us, 4096 poses 54 -> 48.6 us on
+    //  4096^2 —, and still lose 3..8 % on colombia below 4096 poses)
+    int slots_req = o.slots ? o.slots : ((rays >= (1L << 23) || !small_map) ? 2 : 1);
     // (a fan whose tables leave no room for the scratch of 16 waves marches one ray per lane)
     if (slots_req >= 2 && (in.aux || !tiled_opt || tables_b + 16 * drain_wave > (size_t)INLINE_LDS_BUDGET)) slots_req = 1;
     const bool multi = slots_req >= 2;                                // <=> the launch takes 2 or 3 rays per lane
     auto drain_bytes = [&](int nthreads) { return multi ? (size_t)(nthreads / 64) * drain_wave : (size_t)0; };
-    const size_t inl_tables = tables_b + drain_bytes(1024);
+    // (INLINE launches: 1024-lane workgroups; 512 with wg_threads = 512 — an A/B of round 5: half the waves wait for the
+    //  slowest wave of their workgroup, twice the workgroups share a band's stream)
+    const int inl_nt = (o.wg_threads == 512 && slots_req == 2 && !in.crash && !in.aux) ? 512 : 1024;
+    const size_t inl_tables = tables_b + drain_bytes(inl_nt);
     if (inl) {
-        nt = 1024;
+        nt = inl_nt;
         const long g_min = std::max(1L, std::min((n_blocks_inl + 15) / 16, (long)n_cu * o.grid_mult * WG / nt) / bands);
         const long seg_chunks_max = (((long)n_poses + bands - 1) / bands) * cpp;
         const long grid_i = std::max((long)bands, std::min((n_blocks_inl + 15) / 16, std::max((long)n_cu * o.grid_mult * WG / nt, 1L)));
@@ -401,7 +408,7 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     p->kernel = RL_K_RM_STREAM;
     p->slots = s;
     p->tiled = t;
-    p->block = inl ? 1024 : nt;
+    p->block = inl ? (s == 2 ? inl_nt : 1024) : nt;
     // (several rays per lane: the compaction scratch sits between the tables and the block records)
     p->lds_bytes = (int)(inl ? inl_tables + (size_t)k_max * INLINE_REC_BYTES + lds_extra
                              : (s >= 2 ? tables_b + drain_bytes(p->block)

@@ -1537,7 +1537,8 @@ static int dispatch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, cons
         else if (nt == 512) launch_rm_stream<false, C, 512, false, true, 2>(RM_ARGS);   \
         else launch_rm_stream<false, C, 256, false, true, 2>(RM_ARGS);               \
     } while (0)
-        if (crash) RM_S2(true); else RM_S2(false);
+        if (inl && nt == 512 && !crash) launch_rm_stream<false, false, 512, true, true, 2>(RM_ARGS);   // (A/B: wg_threads 512)
+        else if (crash) RM_S2(true); else RM_S2(false);
 #undef RM_S2
     } else {
 #define RM_S1(A, C, T)                                                               \

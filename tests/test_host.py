@@ -343,7 +343,7 @@ def test_launch_plan_survives_zeroed_and_out_of_range_options():
     assert (pl["kernel"], pl["block"], pl["binning"], pl["slots"], pl["name"]) == (
         "rm_stream_literal", 1024, "small_keys", 2, "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, true>")
     pl = _plan(_lib.RL_RM_GPU, 2049, 2049, 200, 1081, variant=3, crash=True)              # the reference's roll-out batch
-    assert (pl["kernel"], pl["crash"], pl["name"]) == ("rm_stream_literal", 1, "scan::rm_fan_stream_kernel<false, true, 1024, true, true, 1, true>")
+    assert (pl["kernel"], pl["crash"], pl["name"]) == ("rm_stream_literal", 1, "scan::rm_fan_stream_kernel<false, true, 1024, true, true, 2, true>")
     pl = _plan(_lib.RL_RM_GPU, 2049, 2049, 65536, 1081, variant=3)                        # beyond one INLINE launch: pose slices
     assert (pl["kernel"], pl["slices"], pl["slice_poses"]) == ("rm_stream_literal", 16, 4096)
     assert _plan(_lib.RL_RM_GPU, 435, 350, 100000, 1081, variant=3)["kernel"] == "rm_stream_literal"   # small map
