@@ -164,7 +164,7 @@ def build(force: bool = False) -> str:
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO)
                                              for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "../libscan_amd.so"]
+        subprocess.check_call(["make", "-j4", "-C", os.path.join(_HERE, "csrc"), "../libscan_amd.so"]
                               + (["-B"] if force else []))
     return _SO
 

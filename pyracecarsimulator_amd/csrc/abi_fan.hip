@@ -1,722 +1,18 @@
-// scanlib.hip — host side of libscan_amd.so (C ABI declared in include/scanlib.h).
+// abi_fan.hip — the method handle of libscan_amd.so (C ABI: include/scanlib.h): options, derived tables, launch planning,
+// every fan / ray launch, the device-pointer entry points, the single-device host-pointer paths, the fused crash test.
 //
-// Replaces, for the scan path only, range_libc's PyOMap / PyRayMarching /
-// PyRayMarchingGPU / PyCDDTCast objects that the reference builds at
-// scripts/scan_simulator.py:72-76, scripts/ros_interface.py:210 and
+// Replaces, for the scan path only, range_libc's PyRayMarching / PyRayMarchingGPU / PyBresenhamsLine / PyCDDTCast /
+// PyGiantLUTCast objects that the reference builds at scripts/scan_simulator.py:72-76, scripts/ros_interface.py:210 and
 // scripts/two_player/scan.py:45-46.  There is no CPU fallback in this library.
-#include "../../include/scanlib.h"
+#include "abi_internal.h"
 #include "scan_kernels.h"
-#include "car_kernels.h"
-#include "consumer_kernels.h"
-#include "probe_kernels.h"
+#include "crash_kernels.h"
 #include "launch_plan.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <climits>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <atomic>
-#include <condition_variable>
-#include <functional>
-#include <memory>
-#include <mutex>
-#include <shared_mutex>
-#include <new>
-#include <string>
-#include <thread>
-#include <vector>
-
-using namespace scan;
 
 static_assert(plan::WG == scan::WG && plan::STREAM_HDR == scan::STREAM_HDR && plan::STRIPE_BINS == scan::STRIPE_BINS &&
                   plan::STRIPE_MAX_PER_LANE == scan::STRIPE_MAX_PER_LANE && plan::DRAIN_CAP == scan::DRAIN_CAP &&
                   plan::DRAIN_FIELDS == scan::DRAIN_FIELDS && plan::INLINE_REC_BYTES == (int)sizeof(scan::BlockRec),
               "launch_plan.h and rm_kernels.h disagree about the stream kernels' LDS layout");
-
-// ------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------
-static thread_local std::string g_err = "";
-
-static int fail(int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
-
-#define HIPCHK(expr)                                                                      \
-    do {                                                                                  \
-        hipError_t e_ = (expr);                                                           \
-        if (e_ != hipSuccess)                                                             \
-            return fail(RL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                              \
-    } while (0)
-
-extern "C" const char *rl_last_error(void) { return g_err.c_str(); }
-extern "C" const char *rl_version(void) { return "scanlib-amd 0.5 (gfx950)"; }
-
-extern "C" int rl_device_count(void)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
-
-// ------------------------------------------------------------------------------
-// pinned host blocks handed to callers (rl_host_alloc): a scan whose output buffer lies in one of
-// them is written by the kernel directly — no staging copy on the way back
-// ------------------------------------------------------------------------------
-static std::mutex g_host_mu;
-struct HostBlock {
-    char *p;
-    size_t bytes;
-    uint64_t devices;      // devices that may have work in flight on the block: where it was allocated and
-};                         // every device a scan was launched from with its output inside the block
-static std::vector<HostBlock> g_host_blocks;
-
-// is [p, p+bytes) inside a block of rl_host_alloc?  `device` >= 0: a launch on that device is about to write it
-static bool in_host_block(const void *p, size_t bytes, int device = -1)
-{
-    std::lock_guard<std::mutex> lk(g_host_mu);
-    for (auto &b : g_host_blocks)
-        if ((const char *)p >= b.p && (const char *)p + bytes <= b.p + b.bytes) {
-            if (device >= 0 && device < 64) b.devices |= 1ull << device;
-            return true;
-        }
-    return false;
-}
-
-extern "C" int rl_host_alloc(size_t bytes, void **out)
-{
-    if (!out || bytes == 0) return fail(RL_ERR_INVALID, "rl_host_alloc: bad arguments");
-    if (rl_device_count() <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available");
-    void *p = nullptr;
-    // (portable + mapped: every device of a multi-device handle writes its pose block's ranges straight into it)
-    if (hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess)
-        return fail(RL_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
-    memset(p, 0, bytes);
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    {
-        std::lock_guard<std::mutex> lk(g_host_mu);
-        g_host_blocks.push_back(HostBlock{(char *)p, bytes, (cur >= 0 && cur < 64) ? 1ull << cur : 0ull});
-    }
-    *out = p;
-    return RL_OK;
-}
-
-extern "C" int rl_host_free(void *p)
-{
-    if (!p) return RL_OK;
-    uint64_t devices = 0;
-    {
-        std::lock_guard<std::mutex> lk(g_host_mu);
-        auto it = std::find_if(g_host_blocks.begin(), g_host_blocks.end(),
-                               [&](const HostBlock &b) { return b.p == (char *)p; });
-        if (it == g_host_blocks.end()) return fail(RL_ERR_INVALID, "rl_host_free: not a block of rl_host_alloc");
-        devices = it->devices;
-        g_host_blocks.erase(it);
-    }
-    // a kernel may still be writing into it: wait for the devices that were handed the block — not for every
-    // visible device (a rank of an N-GPU job would create contexts on, and stall, its neighbours' GPUs)
-    int ndev = 0, cur = 0;
-    if (hipGetDeviceCount(&ndev) == hipSuccess && hipGetDevice(&cur) == hipSuccess) {
-        for (int d = 0; d < ndev && d < 64; ++d)
-            if (((devices >> d) & 1ull) && hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
-        (void)hipSetDevice(cur);
-    }
-    HIPCHK(hipHostFree(p));
-    return RL_OK;
-}
-
-// ------------------------------------------------------------------------------
-// handles
-// ------------------------------------------------------------------------------
-struct rl_map {
-    // a MULTI-DEVICE map (rl_map_create_multi) owns no device memory itself: it holds one ordinary map per
-    // device in `reps` (the same device may appear several times) and its own fields describe the shape only
-    std::vector<rl_map *> reps;
-    int device = 0;
-    int clock_khz = 0;
-    int rows = 0, cols = 0;
-    float res = 0, ox = 0, oy = 0, oyaw = 0;
-    uint8_t *d_occ = nullptr;
-    int *d_g = nullptr;          // EDT pass-1 scratch
-    float *d_dt = nullptr;
-    uint32_t *d_bits = nullptr;
-    int bits_stride = 0;
-    hipStream_t stream = nullptr;
-    std::atomic<uint64_t> epoch{0};   // bumped by rl_map_update; derived tables rebuild lazily
-    MapParams mp{};
-    MapParams *d_mp = nullptr;   // device copy (kernels that take the map by pointer)
-    // edge cells (occupied with a free 4-neighbour), the input of every CDDT table of this map: built
-    // with the other map tables once a CDDT method exists, so that a table rebuild knows the count on
-    // the host without a read-back of its own (rl_map_update synchronises anyway)
-    bool want_edges = false;
-    uint32_t *d_edges = nullptr, *d_n_edges = nullptr;
-    uint32_t *pin_n_edges = nullptr;
-    uint32_t n_edges = 0;
-    int n_cu = 256;
-    std::mutex mu;
-    // readers: every launch path of every method of this map (held for the whole call, i.e. until
-    // the results of a host-pointer call have landed); writer: rl_map_update while it rewrites
-    // occ / EDT / bit map.  A map callback thread and a scan thread may share the objects
-    // (scripts/ros_interface.py:107-115).
-    std::shared_mutex tables_mu;
-    // MULTI-DEVICE map only.  readers: the multi_* host-pointer entry points of every method of this map, for the
-    // whole batch (every device's block); writer: rl_map_update while it walks the replicas — so one batch is
-    // never scanned partly on the old and partly on the new occupancy.  `broken`: an update failed after some
-    // replicas had already taken the new cells; the handle then refuses every further call instead of answering
-    // from two different maps.
-    std::shared_mutex multi_mu;
-    std::atomic<bool> broken{false};
-};
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes)
-    {
-        if (bytes <= cap) return RL_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) return fail(RL_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want,
-                                         hipGetErrorString(e));
-        cap = want;
-        return RL_OK;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-// Per-launch scratch of a method (pose records, tile order, binning histograms, crash marks) is
-// kept PER STREAM: a *_device call only enqueues work, so a second call on another stream may run
-// concurrently with the first on the GPU (bench.py pipelines consecutive batches on two streams so
-// that batch k+1 fills the CUs batch k's tail leaves idle).  Calls on one stream reuse one context
-// in stream order.  More distinct streams than contexts: the least recently used context is handed
-// over after a device synchronisation (rare, and needs no handle of the old stream, which the
-// caller may have destroyed).
-struct LaunchCtx {
-    hipStream_t stream = nullptr;
-    bool bound = false;
-    uint64_t last_use = 0;
-    DevBuf rec, rec_sorted, order, keys, hist, pose_first, dbg, d0, cddt_r;   // cddt_r: theta-major CDDT, R[raw bin][pose]
-    DevBuf left_rec, left_cnt;     // hand-off march: the leftover list (rm_leftover_kernel), one region per wave of the main grid
-    int crash_epoch = 0;           // mark value of the last per-pose crash launch (pose_marks)
-    void release()
-    {
-        for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg, &d0, &cddt_r, &left_rec, &left_cnt}) b->release();
-    }
-};
-constexpr int N_LAUNCH_CTX = 8;      // (HIP's default 4 hardware queues carry 4 concurrent streams; GPU_MAX_HW_QUEUES=8 carries 8)
-
-// A derived table (step map, GiantLUT, CDDT) is built lazily on the stream of the call that needs
-// it first; launches on OTHER streams must not start before the build has finished.
-struct TableDep {
-    hipEvent_t ev = nullptr;
-    hipStream_t built_on = nullptr;
-    bool pending = false;
-};
-
-
-// ------------------------------------------------------------------------------
-// Several devices behind one handle (rl_map_create_multi): a single-process caller — the reference's
-// scanMany / checkCollisionMany callers are ONE Python process (scripts/mcts.py:237,
-// scripts/scan_simulator.py:113-135) — hands over one pose batch and every device scans a contiguous
-// block of it.  One persistent worker thread per device (bound to it with hipSetDevice once) runs the
-// ordinary single-device entry point on that device's replica handle; job 0 runs on the calling thread.
-// Threads and streams only: nothing is forked or re-executed after the GPU has been initialised.
-// ------------------------------------------------------------------------------
-struct MultiPool {
-    struct Worker {
-        std::thread th;
-        std::mutex mu;
-        std::condition_variable cv;
-        std::function<int()> job;
-        bool has = false, done = false, stop = false;
-        int rc = 0;
-        std::string err;
-        int device = 0;
-    };
-    std::vector<std::unique_ptr<Worker>> w;
-
-    void start(const std::vector<int> &devices)
-    {
-        for (size_t i = 1; i < devices.size(); ++i) {       // (block 0 is the caller's)
-            auto wk = std::make_unique<Worker>();
-            wk->device = devices[i];
-            Worker *raw = wk.get();
-            wk->th = std::thread([raw]() {
-                (void)hipSetDevice(raw->device);
-                std::unique_lock<std::mutex> lk(raw->mu);
-                for (;;) {
-                    raw->cv.wait(lk, [raw]() { return raw->has || raw->stop; });
-                    if (raw->stop) return;
-                    raw->has = false;
-                    lk.unlock();
-                    const int rc = raw->job();
-                    std::string msg = rc ? g_err : std::string();
-                    lk.lock();
-                    raw->rc = rc;
-                    raw->err = std::move(msg);
-                    raw->done = true;
-                    raw->cv.notify_all();
-                }
-            });
-            w.push_back(std::move(wk));
-        }
-    }
-
-    // jobs[0] on the caller, jobs[i] on worker i-1; the first failure (lowest block) is reported, its message
-    // becomes the caller's rl_last_error
-    int run(std::vector<std::function<int()>> &jobs)
-    {
-        if (jobs.size() > w.size() + 1)
-            return fail(RL_ERR_INVALID, "internal: %zu pose blocks for %zu devices", jobs.size(), w.size() + 1);
-        const size_t k = jobs.size();
-        for (size_t i = 1; i < k; ++i) {
-            Worker &x = *w[i - 1];
-            std::lock_guard<std::mutex> lk(x.mu);
-            x.job = std::move(jobs[i]);
-            x.has = true;
-            x.done = false;
-            x.cv.notify_all();
-        }
-        int rc = jobs.empty() ? RL_OK : jobs[0]();
-        std::string err = rc ? g_err : std::string();
-        for (size_t i = 1; i < k; ++i) {
-            Worker &x = *w[i - 1];
-            std::unique_lock<std::mutex> lk(x.mu);
-            x.cv.wait(lk, [&x]() { return x.done; });
-            if (rc == RL_OK && x.rc != RL_OK) {
-                rc = x.rc;
-                err = x.err;
-            }
-        }
-        if (rc) g_err = err;
-        return rc;
-    }
-
-    ~MultiPool()
-    {
-        for (auto &x : w) {
-            {
-                std::lock_guard<std::mutex> lk(x->mu);
-                x->stop = true;
-                x->cv.notify_all();
-            }
-            if (x->th.joinable()) x->th.join();
-        }
-    }
-};
-
-// contiguous block of `rank` when n items are cut into `parts` (the same split as workloads.shard_range)
-static inline void block_of(long n, int rank, int parts, long &lo, long &hi)
-{
-    const long base = n / parts, rem = n % parts;
-    lo = rank * base + std::min<long>(rank, rem);
-    hi = lo + base + (rank < rem ? 1 : 0);
-}
-
-struct rl_method {
-    // multi-device method (created on a multi-device map): one ordinary method per device + the worker pool;
-    // the parent keeps kind / noise / options and owns no device memory
-    std::vector<rl_method *> reps;
-    std::unique_ptr<MultiPool> pool;
-    int multi_min_poses = 512;   // a device is only brought in per this many poses: waking a worker costs ~18 us
-                                 // (profiles/r04/host_pointer_rate.txt: a 200-pose roll-out cut over three contexts 60 vs
-                                 // 42 us), a 512-pose block's transfer alone ~50 us — the reference's roll-out stays on one device
-    rl_map *map = nullptr;
-    int kind = 0;
-    float max_range = 0;
-    float step_coeff = 0.999f;
-    int theta_disc = 0;
-    float noise_std = 0;
-    uint64_t noise_seed = 0, ray_offset = 0;
-    int variant = 1;             // 0: chunk kernel (K1); 1: binned + banded + lane-refill stream kernel (K1b)
-    int grid_mult = 8;           // workgroups per CU for the persistent launches (8 resident: <= 80 SGPRs, <= 64 VGPRs)
-    int low_water = -1;          // stream kernel: refill when <= this many lanes (per ray slot) still march.  -1 = auto: 12, and 20
-                                 // for the several-rays-per-lane launches that derive their records in LDS (small and mid-size
-                                 // batches: +3 % with four in flight; big batches lose 3-6 % above 12: profiles/r03/ab_low_water.txt)
-    int sort_poses = 1;          // stream kernel: order poses by map tile
-    int xcd_bands = 8;           // stream kernel: bands of the sorted list, one per XCD
-    int timing = 0;              // 1: HIP events around every launch sequence (rl_last_kernel_ms);
-                                 // 2: around the march kernel only (pose binning excluded)
-    int lut_debug = 0;
-    int drain_prio = 0;
-    int spec_drain = 8;          // one ray per lane: value-speculating drain loop once <= this many lanes are live (0 = off)
-    int spec_stretch = 16;       //   ... after this many plain samples, and between two attempts whose first prediction failed
-    int drain_cap = 64;          // several rays per lane: compact a wave's last rays into one slot from <= this many (<= 64)
-    int drain_stretch = 8;       //   ... plain samples between two speculation attempts of the compacted rays
-    int group_drain = 0;         //   ... and from 2 N / N live rays down 2 / 4 lanes per ray, 8 / 16 samples per round trip (N <= 16; 0: off)
-    int handoff = 0;             // several rays per lane, 1: a dry wave hands its last <= handoff_cap rays to rm_leftover_kernel (the
-                                 // next launch on the stream) instead of draining them in place (0: drain in place)
-    int handoff_cap = 16;        //   ... rays per wave handed over (8, 16, 32 or 64)
-    int handoff_wg = 256;        //   ... workgroup size of the leftover launch (64, 128 or 256)
-    int nt_store = 1;            // ranges leave the stream kernels with non-temporal stores (0: plain — a consumer kernel reads them next)
-    int wg_threads = 1024;       // stream kernel: workgroup size (256/512/1024) sharing one ray stream
-    // GiantLUT (K3)
-    DevBuf lut;
-    uint64_t lut_epoch = ~0ull;
-    LutParams lp{};
-    // CDDT (K3b)
-    DevBuf cd_cos, cd_sin, cd_trans, cd_width, cd_boff, cd_offsets, cd_xs2, cd_cursor, cd_tmp, cd_hdr, cd_tab;
-    uint64_t cddt_epoch = ~0ull;
-    CddtParams cdp{};
-    uint32_t cd_buckets = 0;
-    std::vector<float> cd_h_cos, cd_h_sin, cd_h_trans;     // per-bin constants (host copies stay alive:
-    std::vector<int> cd_h_width;                           //  their uploads are asynchronous)
-    std::vector<uint32_t> cd_h_boff;
-    int cd_geom_rows = -1, cd_geom_cols = -1;              // map shape the constants were made for
-    bool cd_sort_attr = false;
-    bool cd_counts_clean = false;                          // bucket counters are all zero (see ensure_cddt)
-    int slots = 0;               // stream kernel: rays per lane; 2 (3: inline form only) = plain-range launches on the tiled step
-                                 // map keep two loads in flight per lane and compact a dry wave's last rays into one slot;
-                                 // 0 = auto (launch_plan.h: 2 from 2^23 rays per launch up, from 2^20 on maps beyond the
-                                 // small-map bound; callers that keep several launches in flight set 2: +15..30 %)
-    int cddt_theta_min = 32768;                            // poses per launch from which the CDDT look-ups run theta-major (0: never)
-    int cddt_search = 1;                                   // theta-major search kernel: 1 = look-ups prepared once per pose (round 5), 0 = round 4's
-    int cddt_sort = 0;                                     // per-bin fan kernel walks the poses in map-tile order, XCD bands
-                                                           // (measured: -13 % at 4096 poses - the binning launch and no
-                                                           // reuse at that density -, +3 % at 32768: off by default)
-    int cddt_lds_sort = (int)CDDT_LDS_SORT;                // buckets up to this size are sorted in LDS (diagnostics: lower it)
-    int cddt_bins_kernel = 1;                              // 1: one query per (pose, theta bin); 0: per ray
-    DevBuf blpad;                // K2b: padded normal + transposed bit maps (bl_pad_bits_kernel)
-    BlPad blp{};
-    uint64_t blpad_epoch = ~0ull;
-    TableDep blpad_dep;
-    DevBuf pdt;                  // EDT with a border of `pad` cells of -1 (stream kernel)
-    int pad = 0, pstride = 0;    // pstride: elements per row (row-major) | M (tiled, see pdt_tiled_byte)
-    uint64_t pdt_epoch = ~0ull;  // map epoch the padded copy was built from
-    hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;   // big host-pointer calls: the D2H copy of pose slice k overlaps the march of slice k+1
-    hipEvent_t slice_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int overlap_min_rays = 1 << 24;      // ... from this many rays per call (0 = never); below ~16 k poses the slices cost more than they hide
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    DevBuf poses, outs, hits, steps, edge, flag;
-    LaunchCtx ctx[N_LAUNCH_CTX];
-    uint64_t use_clock = 0;
-    TableDep pdt_dep, lut_dep, cddt_dep;
-    // beam-direction tables (cos, sin per beam) of the fans this handle has been called with
-    struct FanTab {
-        uint32_t fov_bits = 0;
-        int num_rays = 0;
-        uint64_t last_use = 0;
-        DevBuf tab;
-        TableDep dep;
-    } fan_tabs[4];
-    uint64_t fan_clock = 0;
-    // small host calls (scan(): one pose, scanMany(): a roll-out): poses and ranges go through ONE
-    // pinned, device-mapped host buffer the kernels read / write directly — no staging copies
-    void *pin = nullptr;
-    size_t pin_cap = 0;
-    int pinned_max_rays = 262144; // 0 = always stage through device buffers
-    int direct_max_rays = 1 << 21; // a result buffer in a pinned block of rl_host_alloc is written by the kernel itself
-                                  // up to this many rays (a 200-pose roll-out: 41 vs 61 us, 1024 poses: 113 vs 132); larger
-                                  // batches go HBM -> DMA into the pinned block, which moves 4 B per ray faster than the
-                                  // kernel's stores over PCIe (4096 poses: 394 vs 449 us; a tie at 2048:
-                                  // profiles/r04/host_pointer_rate.txt)
-    std::vector<double> edge_host; // the car-outline table last uploaded to `edge` (re-sent only when it changes)
-    int *pin_flag = nullptr;       // pinned landing slot for the crash index
-    int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
-    int bin_ppw = POSES_PER_WG;  // ... poses per workgroup of those kernels
-    int order_inline = 1;        // big maps, stripe_max..8192 poses: keys-only binning launch + INLINE march
-    int stripe_max = 1536;       // big maps, inline_max..stripe_max poses: no binning launch, workgroups compact
-                                 // their own row-stripe band of the pose list (0 = off)
-    int inline_map_kb = 2048;    // maps up to this size (f32 cells) never take the binning launch while the records fit LDS
-    int run_log2 = -1;           // stream interleave granularity: runs of 2^run_log2 blocks; -1 = by batch size
-    int tiled = 1;               // step map with 4 rows interleaved (a 128-B line = 4x8 cells); 0 = row-major
-    int pdt_tiled = -1;          // layout the padded copy was built with
-    uint32_t pdt_k4 = 0, pdt_mask = 0;
-    size_t pdt_base_off = 0;     // tiled: the column bias (pad << 4 bytes) folded into the base address
-    int slice_log2 = 30;         // launches are cut into pose slices below 2^slice_log2 rays
-    int bin_generic = 0;         // diagnostics: force the generic single-workgroup binning kernel
-    int inline_prep = 1;         // tiny batches: no binning launch, workgroups derive their own records
-    int inline_max = 512;        //   ... below this many poses (measured: wins below ~512, loses above)
-    int debug_stamps = 0;        // diagnostics: per-wave start/end stamps of the stream kernel
-    int last_grid = 0;
-    void *last_dbg = nullptr;    // stamps buffer of the last launch (in its context)
-    rl_launch_plan last_plan{};  // what the last fan launch of this handle was planned as (plan::plan_fan)
-    std::vector<float> h_poses;
-    std::mutex mu;
-};
-
-static int set_device(const rl_map *m)
-{
-    HIPCHK(hipSetDevice(m->device));
-    return RL_OK;
-}
-
-// ------------------------------------------------------------------------------
-// map
-// ------------------------------------------------------------------------------
-static void host_sincosf(float x, float &s, float &c)
-{
-    // host twin of scan::det_sincosf (same operations; this TU is built with
-    // -ffp-contract=off and fmaf is a single rounding on the host too)
-    const float TWO_OVER_PI = 0x1.45f306p-1f;
-    const float P1 = 0x1.921fb6p+0f, P2 = -0x1.777a5cp-25f, P3 = -0x1.ee59dap-50f;
-    float k = rintf(x * TWO_OVER_PI);
-    float r = fmaf(-k, P1, x);
-    r = fmaf(-k, P2, r);
-    r = fmaf(-k, P3, r);
-    float z = r * r;
-    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = fmaf(z, ps, -1.6666654611e-1f);
-    float sr = fmaf(r * z, ps, r);
-    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = fmaf(z, pc, 4.166664568298827e-2f);
-    float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
-    int q = ((int)k) & 3;
-    float ss = (q & 1) ? cr : sr;
-    float cc = (q & 1) ? sr : cr;
-    if (q == 1 || q == 2) cc = -cc;
-    if (q >= 2) ss = -ss;
-    s = ss;
-    c = cc;
-}
-
-static int map_build_tables(rl_map *m)
-{
-    // K0: exact EDT + bit-packed occupancy, all on the device
-    const int rows = m->rows, cols = m->cols;
-    hipLaunchKernelGGL(edt_cols_kernel, dim3((cols + 63) / 64), dim3(1024), 0, m->stream,
-                       m->d_occ, rows, cols, m->d_g);
-    hipLaunchKernelGGL(edt_rows_kernel, dim3(rows), dim3(256), (size_t)cols * sizeof(int),
-                       m->stream, m->d_g, rows, cols, m->d_dt);
-    hipLaunchKernelGGL(pack_bits_kernel, dim3((m->bits_stride + 255) / 256, rows), dim3(256), 0,
-                       m->stream, m->d_occ, rows, cols, m->bits_stride, m->d_bits);
-    if (m->want_edges) {
-        if (!m->d_edges) {
-            HIPCHK(hipMalloc((void **)&m->d_edges, (size_t)rows * cols * sizeof(uint32_t)));
-            HIPCHK(hipMalloc((void **)&m->d_n_edges, 256));
-            HIPCHK(hipHostMalloc((void **)&m->pin_n_edges, 64, hipHostMallocDefault));
-        }
-        HIPCHK(hipMemsetAsync(m->d_n_edges, 0, 4, m->stream));
-        hipLaunchKernelGGL(cddt_edges_kernel, dim3((cols + 255) / 256, (rows + EDGE_ROWS_PER_WG - 1) / EDGE_ROWS_PER_WG),
-                           dim3(256), 0, m->stream,
-                           m->d_occ, rows, cols, m->d_n_edges, m->d_edges);
-        HIPCHK(hipMemcpyAsync(m->pin_n_edges, m->d_n_edges, 4, hipMemcpyDeviceToHost, m->stream));
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(m->stream));
-    if (m->want_edges) m->n_edges = *m->pin_n_edges;
-    return RL_OK;
-}
-
-extern "C" int rl_map_create(const uint8_t *occ, int rows, int cols, float res, float ox,
-                             float oy, float oyaw, int device, rl_map **out)
-{
-    if (!occ || !out) return fail(RL_ERR_INVALID, "rl_map_create: null pointer");
-    if (rows <= 0 || cols <= 0 || rows > 16384 || cols > 16384)
-        return fail(RL_ERR_INVALID, "rl_map_create: rows/cols must be in [1,16384] (got %dx%d)",
-                    rows, cols);
-    if (!(res > 0.0f)) return fail(RL_ERR_INVALID, "rl_map_create: resolution must be > 0");
-    int ndev = rl_device_count();
-    if (ndev <= 0)
-        return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= ndev)
-        return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
-    rl_map *m = new (std::nothrow) rl_map();
-    if (!m) return fail(RL_ERR_NOMEM, "out of host memory");
-    m->device = device;
-    m->rows = rows;
-    m->cols = cols;
-    m->res = res;
-    m->ox = ox;
-    m->oy = oy;
-    m->oyaw = oyaw;
-    m->bits_stride = (cols + 31) / 32;
-    auto bail = [&](int code) {
-        rl_map_destroy(m);
-        return code;
-    };
-    if (hipSetDevice(device) != hipSuccess) return bail(fail(RL_ERR_HIP, "hipSetDevice failed"));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
-        m->n_cu = prop.multiProcessorCount;
-        m->clock_khz = prop.clockRate;
-    }
-    const size_t n = (size_t)rows * cols;
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&m->d_occ, n) != hipSuccess ||
-        hipMalloc((void **)&m->d_g, n * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&m->d_dt, n * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&m->d_bits, (size_t)rows * m->bits_stride * sizeof(uint32_t)) !=
-            hipSuccess)
-        return bail(fail(RL_ERR_NOMEM, "device allocation for a %dx%d map failed", rows, cols));
-    if (hipMemcpyAsync(m->d_occ, occ, n, hipMemcpyHostToDevice, m->stream) != hipSuccess)
-        return bail(fail(RL_ERR_HIP, "map upload failed"));
-    int rc = map_build_tables(m);
-    if (rc != RL_OK) return bail(rc);
-
-    MapParams &p = m->mp;
-    p.dt = m->d_dt;
-    p.bits = m->d_bits;
-    p.bits_stride = m->bits_stride;
-    p.rows = rows;
-    p.cols = cols;
-    p.frows = (float)rows;
-    p.fcols = (float)cols;
-    p.res = res;
-    p.inv_res = (float)(1.0 / (double)res);
-    p.ox = ox;
-    p.oy = oy;
-    p.wa = -oyaw;                                   // PyOMap: world_angle = -yaw
-    host_sincosf(p.wa, p.wa_sin, p.wa_cos);
-    if (hipMalloc((void **)&m->d_mp, sizeof(MapParams)) != hipSuccess ||
-        hipMemcpy(m->d_mp, &m->mp, sizeof(MapParams), hipMemcpyHostToDevice) != hipSuccess)
-        return bail(fail(RL_ERR_NOMEM, "map parameter upload failed"));
-    *out = m;
-    return RL_OK;
-}
-
-extern "C" int rl_map_create_multi(const uint8_t *occ, int rows, int cols, float res, float ox, float oy,
-                                   float oyaw, const int *devices, int n_devices, rl_map **out)
-{
-    if (!occ || !out || !devices) return fail(RL_ERR_INVALID, "rl_map_create_multi: null pointer");
-    if (n_devices < 1 || n_devices > 64) return fail(RL_ERR_INVALID, "rl_map_create_multi: 1..64 devices (got %d)", n_devices);
-    rl_map *m = new (std::nothrow) rl_map();
-    if (!m) return fail(RL_ERR_NOMEM, "out of host memory");
-    for (int i = 0; i < n_devices; ++i) {
-        rl_map *r = nullptr;
-        const int rc = rl_map_create(occ, rows, cols, res, ox, oy, oyaw, devices[i], &r);
-        if (rc) {
-            const std::string keep = g_err;
-            rl_map_destroy(m);
-            g_err = keep;
-            return rc;
-        }
-        m->reps.push_back(r);
-    }
-    const rl_map *r0 = m->reps[0];
-    m->device = r0->device;
-    m->rows = rows;
-    m->cols = cols;
-    m->res = res;
-    m->ox = ox;
-    m->oy = oy;
-    m->oyaw = oyaw;
-    m->n_cu = r0->n_cu;
-    m->clock_khz = r0->clock_khz;
-    m->mp = r0->mp;
-    *out = m;
-    return RL_OK;
-}
-
-extern "C" int rl_map_n_devices(const rl_map *m) { return m ? (m->reps.empty() ? 1 : (int)m->reps.size()) : 0; }
-
-extern "C" rl_map *rl_map_replica(rl_map *m, int i)
-{
-    if (!m) return nullptr;
-    if (m->reps.empty()) return i == 0 ? m : nullptr;
-    return (i >= 0 && i < (int)m->reps.size()) ? m->reps[i] : nullptr;
-}
-
-extern "C" int rl_map_update(rl_map *m, const uint8_t *occ)
-{
-    if (!m || !occ) return fail(RL_ERR_INVALID, "rl_map_update: null pointer");
-    if (!m->reps.empty()) {
-        std::lock_guard<std::mutex> lk(m->mu);
-        // exclusive against every multi_* call in progress: a batch sees ONE occupancy on all of its devices
-        std::unique_lock<std::shared_mutex> wl(m->multi_mu);
-        if (m->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
-        for (size_t i = 0; i < m->reps.size(); ++i) {
-            const int rc = rl_map_update(m->reps[i], occ);
-            if (rc) {
-                // replicas [0, i) hold the new cells, the others the old ones: no roll-back (the old cells are
-                // gone from the host) — the handle is marked and refuses further scans
-                if (i > 0) {
-                    m->broken.store(true);
-                    const std::string keep = g_err;
-                    return fail(rc, "rl_map_update failed on replica %zu of %zu after %zu replica(s) had been updated — "
-                                    "the multi-device map is now invalid: %s", i, m->reps.size(), i, keep.c_str());
-                }
-                return rc;
-            }
-        }
-        m->epoch++;
-        return RL_OK;
-    }
-    std::lock_guard<std::mutex> lk(m->mu);
-    // exclusive: no host-pointer call of any method of this map is in progress; the device
-    // synchronisation covers launches the asynchronous *_device entry points left in flight
-    std::unique_lock<std::shared_mutex> wl(m->tables_mu);
-    int rc = set_device(m);
-    if (rc) return rc;
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyAsync(m->d_occ, occ, (size_t)m->rows * m->cols, hipMemcpyHostToDevice,
-                          m->stream));
-    rc = map_build_tables(m);
-    if (rc) return rc;
-    m->epoch++;
-    return RL_OK;
-}
-
-extern "C" void rl_map_destroy(rl_map *m)
-{
-    if (!m) return;
-    if (!m->reps.empty()) {
-        for (rl_map *r : m->reps) rl_map_destroy(r);
-        delete m;
-        return;
-    }
-    (void)hipSetDevice(m->device);
-    if (m->d_occ) (void)hipFree(m->d_occ);
-    if (m->d_g) (void)hipFree(m->d_g);
-    if (m->d_dt) (void)hipFree(m->d_dt);
-    if (m->d_bits) (void)hipFree(m->d_bits);
-    if (m->d_mp) (void)hipFree(m->d_mp);
-    if (m->d_edges) (void)hipFree(m->d_edges);
-    if (m->d_n_edges) (void)hipFree(m->d_n_edges);
-    if (m->pin_n_edges) (void)hipHostFree(m->pin_n_edges);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
-    delete m;
-}
-
-extern "C" int rl_map_rows(const rl_map *m) { return m ? m->rows : 0; }
-extern "C" int rl_map_cols(const rl_map *m) { return m ? m->cols : 0; }
-extern "C" int rl_map_device(const rl_map *m) { return m ? m->device : -1; }
-
-extern "C" int rl_map_get_dt(rl_map *m, float *dt_out)
-{
-    if (!m || !dt_out) return fail(RL_ERR_INVALID, "rl_map_get_dt: null pointer");
-    if (!m->reps.empty()) return rl_map_get_dt(m->reps[0], dt_out);
-    std::lock_guard<std::mutex> lk(m->mu);
-    int rc = set_device(m);
-    if (rc) return rc;
-    HIPCHK(hipMemcpy(dt_out, m->d_dt, (size_t)m->rows * m->cols * sizeof(float),
-                     hipMemcpyDeviceToHost));
-    return RL_OK;
-}
-
-extern "C" int rl_map_get_occ(rl_map *m, uint8_t *occ_out)
-{
-    if (!m || !occ_out) return fail(RL_ERR_INVALID, "rl_map_get_occ: null pointer");
-    if (!m->reps.empty()) return rl_map_get_occ(m->reps[0], occ_out);
-    std::lock_guard<std::mutex> lk(m->mu);
-    int rc = set_device(m);
-    if (rc) return rc;
-    HIPCHK(hipMemcpy(occ_out, m->d_occ, (size_t)m->rows * m->cols, hipMemcpyDeviceToHost));
-    return RL_OK;
-}
 
 // ------------------------------------------------------------------------------
 // method
@@ -745,9 +41,9 @@ extern "C" int rl_method_create(rl_map *m, int kind, float max_range_px, int the
             rl_method *r = nullptr;
             const int rc = rl_method_create(rm, kind, max_range_px, theta_disc, &r);
             if (rc) {
-                const std::string keep = g_err;
+                const std::string keep = last_error();
                 rl_method_destroy(h);
-                g_err = keep;
+                set_last_error(keep);
                 return rc;
             }
             h->reps.push_back(r);
@@ -837,7 +133,7 @@ extern "C" rl_method *rl_method_replica(rl_method *h, int i)
 static int cddt_table_stats(rl_method *h, const char *name, int64_t *value_out);
 
 // how many devices of a multi-device handle a batch of n_poses is cut over
-static int multi_parts(const rl_method *h, long n_poses)
+int multi_parts(const rl_method *h, long n_poses)
 {
     const long by_size = n_poses / std::max(h->multi_min_poses, 1);
     return (int)std::max<long>(1, std::min<long>((long)h->reps.size(), by_size));
@@ -997,7 +293,7 @@ static FanParams make_fan(const rl_method *h, int n_poses, float fov, int num_ra
     return f;
 }
 
-static int check_fan_args(const rl_method *h, int n_poses, float fov, int num_rays)
+int check_fan_args(const rl_method *h, int n_poses, float fov, int num_rays)
 {
     if (!h) return fail(RL_ERR_INVALID, "null method handle");
     if (n_poses < 0) return fail(RL_ERR_INVALID, "n_poses must be >= 0");
@@ -2112,7 +1408,7 @@ static int pin_ensure(rl_method *h, size_t bytes)
 }
 
 // car-outline table -> h->edge, re-sent only when its contents changed since the last call
-static int upload_edge(rl_method *h, const double *edge, int num_rays)
+int upload_edge(rl_method *h, const double *edge, int num_rays)
 {
     const size_t cap_before = h->edge.cap;
     int rc = h->edge.ensure((size_t)num_rays * sizeof(double));
@@ -2126,7 +1422,7 @@ static int upload_edge(rl_method *h, const double *edge, int num_rays)
     return RL_OK;
 }
 
-static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, int num_rays,
+int fan_host(rl_method *h, const float *poses, int n_poses, float fov, int num_rays,
                     float *outs, int32_t *hits, uint16_t *steps, const double *edge,
                     double crash_thresh, int *first_crashed)
 {
@@ -2248,158 +1544,10 @@ static int fan_host(rl_method *h, const float *poses, int n_poses, float fov, in
     return RL_OK;
 }
 
-// ------------------------------------------------------------------------------
-// multi-device forms of the host-pointer entry points: contiguous pose blocks, one per device, each
-// device writing its block of the results straight into the caller's buffer (in a pinned block of
-// rl_host_alloc the kernels write it directly: 4 B per ray over that device's own PCIe link).  Noise
-// stays keyed by the GLOBAL ray id (the replica's ray offset is the parent's + the block's first ray),
-// crash indices are global: the result is bit-identical to the single-device call.
-// ------------------------------------------------------------------------------
-static int multi_fan(rl_method *h, const float *poses, const float *rows3, int n_poses, float fov, int num_rays,
-                     float *outs, int32_t *hits, uint16_t *steps)
-{
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::shared_lock<std::shared_mutex> ml(h->map->multi_mu);
-    if (h->map->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
-    const int k = multi_parts(h, n_poses);
-    const float nstd = h->noise_std;
-    const uint64_t seed = h->noise_seed, off = h->ray_offset;
-    std::vector<std::function<int()>> jobs;
-    for (int i = 0; i < k; ++i) {
-        long lo, hi;
-        block_of(n_poses, i, k, lo, hi);
-        rl_method *r = h->reps[i];
-        const size_t r0 = (size_t)lo * num_rays;
-        jobs.push_back([=]() {
-            int rc = rl_set_noise(r, nstd, seed, off + r0);
-            if (rc) return rc;
-            if (rows3)          // the fork's sparse 4-argument layout: pose p in row p * num_rays
-                return rl_calc_range_many_fan(r, rows3 + r0 * 3, outs + r0, (int)(hi - lo) * num_rays, fov, num_rays);
-            return rl_calc_range_fan(r, poses + 3 * lo, (int)(hi - lo), fov, num_rays, outs + r0,
-                                     hits ? hits + 2 * r0 : nullptr, steps ? steps + r0 : nullptr);
-        });
-    }
-    return h->pool->run(jobs);
-}
 
-static int multi_rays(rl_method *h, const float *ins, float *outs, int n)
+// rl_calc_range_many on one device: (x, y, theta) rows in, ranges out
+int rays_host(rl_method *h, const float *ins, float *outs, int n)
 {
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::shared_lock<std::shared_mutex> ml(h->map->multi_mu);
-    if (h->map->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
-    const int k = (int)std::max<long>(1, std::min<long>((long)h->reps.size(), (long)n / (64L * std::max(h->multi_min_poses, 1) * 16)));
-    const float nstd = h->noise_std;
-    const uint64_t seed = h->noise_seed, off = h->ray_offset;
-    std::vector<std::function<int()>> jobs;
-    for (int i = 0; i < k; ++i) {
-        long lo, hi;
-        block_of(n, i, k, lo, hi);
-        rl_method *r = h->reps[i];
-        jobs.push_back([=]() {
-            int rc = rl_set_noise(r, nstd, seed, off + (uint64_t)lo);
-            if (rc) return rc;
-            return rl_calc_range_many(r, ins + 3 * lo, outs + lo, (int)(hi - lo));
-        });
-    }
-    return h->pool->run(jobs);
-}
-
-// groups of `group` poses (group == n_poses, n_groups == 1 with `single`: rl_check_collision_many's one index)
-static int multi_crash(rl_method *h, const float *poses, int n_groups, int group, float fov, int num_rays,
-                       const double *edge, double thresh, int *first_crashed, float *ranges, bool single)
-{
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::shared_lock<std::shared_mutex> ml(h->map->multi_mu);
-    if (h->map->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
-    const long n_units = single ? group : n_groups;              // what is cut: poses of the one batch | roll-outs
-    const long poses_per_unit = single ? 1 : group;
-    const int k = (int)std::max<long>(1, std::min<long>(multi_parts(h, n_units * poses_per_unit), n_units));
-    const float nstd = h->noise_std;
-    const uint64_t seed = h->noise_seed, off = h->ray_offset;
-    std::vector<int> part(k, 0);
-    std::vector<long> los(k, 0), his(k, 0);
-    std::vector<std::function<int()>> jobs;
-    for (int i = 0; i < k; ++i) {
-        long lo, hi;
-        block_of(n_units, i, k, lo, hi);
-        los[i] = lo;
-        his[i] = hi;
-        rl_method *r = h->reps[i];
-        const size_t p0 = (size_t)lo * poses_per_unit, r0 = p0 * num_rays;
-        int *res = single ? &part[i] : first_crashed + lo;
-        jobs.push_back([=]() {
-            if (hi <= lo) return (int)RL_OK;
-            int rc = rl_set_noise(r, nstd, seed, off + r0);
-            if (rc) return rc;
-            if (single)
-                return rl_check_collision_many(r, poses + 3 * p0, (int)(hi - lo), fov, num_rays, edge, thresh, res,
-                                               ranges ? ranges + r0 : nullptr);
-            return rl_check_collision_groups(r, poses + 3 * p0, (int)(hi - lo), group, fov, num_rays, edge, thresh, res,
-                                             ranges ? ranges + r0 : nullptr);
-        });
-    }
-    const int rc = h->pool->run(jobs);
-    if (rc) return rc;
-    if (single) {
-        *first_crashed = -(group + 1);                            // Car::isCrashed: -(poses + 1) when none crashed
-        for (int i = 0; i < k; ++i)
-            if (his[i] > los[i] && part[i] >= 0) {
-                *first_crashed = (int)los[i] + part[i];
-                break;
-            }
-    }
-    return RL_OK;
-}
-
-extern "C" int rl_calc_range_fan(rl_method *h, const float *poses, int n_poses, float fov,
-                                 int num_rays, float *outs, int32_t *hits, uint16_t *steps)
-{
-    int rc = check_fan_args(h, n_poses, fov, num_rays);
-    if (rc) return rc;
-    if (n_poses > 0 && (!poses || !outs))
-        return fail(RL_ERR_INVALID, "rl_calc_range_fan: null pointer");
-    if (!h->reps.empty()) return n_poses ? multi_fan(h, poses, nullptr, n_poses, fov, num_rays, outs, hits, steps) : RL_OK;
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
-    return fan_host(h, poses, n_poses, fov, num_rays, outs, hits, steps, nullptr, 0.0, nullptr);
-}
-
-extern "C" int rl_calc_range_many_fan(rl_method *h, const float *ins_rows3, float *outs, int n_rows,
-                                      float fov, int num_rays)
-{
-    if (!h) return fail(RL_ERR_INVALID, "null method handle");
-    if (num_rays <= 0) return fail(RL_ERR_INVALID, "num_rays must be > 0");
-    if (n_rows < 0) return fail(RL_ERR_INVALID, "n_rows must be >= 0");
-    // n_poses = ins.shape[0] / num_rays; trailing rows that do
-    // not make a whole fan are left untouched
-    const int n_poses = n_rows / num_rays;
-    int rc = check_fan_args(h, n_poses, fov, num_rays);
-    if (rc) return rc;
-    if (n_poses > 0 && (!ins_rows3 || !outs))
-        return fail(RL_ERR_INVALID, "rl_calc_range_many_fan: null pointer");
-    if (!h->reps.empty()) return n_poses ? multi_fan(h, nullptr, ins_rows3, n_poses, fov, num_rays, outs, nullptr, nullptr) : RL_OK;
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
-    // gather the live row of every pose (row p*num_rays): 12 B per pose cross PCIe,
-    // not the reference's 12 B per ray (scripts/scan_simulator.py:39-40)
-    h->h_poses.resize((size_t)n_poses * 3);
-    for (int p = 0; p < n_poses; ++p) {
-        const float *row = ins_rows3 + (size_t)p * num_rays * 3;
-        h->h_poses[3 * (size_t)p] = row[0];
-        h->h_poses[3 * (size_t)p + 1] = row[1];
-        h->h_poses[3 * (size_t)p + 2] = row[2];
-    }
-    return fan_host(h, h->h_poses.data(), n_poses, fov, num_rays, outs, nullptr, nullptr, nullptr,
-                    0.0, nullptr);
-}
-
-extern "C" int rl_calc_range_many(rl_method *h, const float *ins, float *outs, int n)
-{
-    if (!h) return fail(RL_ERR_INVALID, "null method handle");
-    if (n < 0) return fail(RL_ERR_INVALID, "n must be >= 0");
-    if (n == 0) return RL_OK;
-    if (!ins || !outs) return fail(RL_ERR_INVALID, "rl_calc_range_many: null pointer");
-    if (!h->reps.empty()) return multi_rays(h, ins, outs, n);
     std::lock_guard<std::mutex> lk(h->mu);
     std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
     int rc = set_device(h->map);
@@ -2425,29 +1573,6 @@ extern "C" int rl_calc_range_many(rl_method *h, const float *ins, float *outs, i
                           h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return RL_OK;
-}
-
-extern "C" int rl_check_collision_many(rl_method *h, const float *poses, int n_poses, float fov,
-                                       int num_rays, const double *edge, double crash_thresh,
-                                       int *first_crashed, float *ranges_or_null)
-{
-    int rc = check_fan_args(h, n_poses, fov, num_rays);
-    if (rc) return rc;
-    if (!first_crashed || !edge || (n_poses > 0 && !poses))
-        return fail(RL_ERR_INVALID, "rl_check_collision_many: null pointer");
-    if (n_poses == 0) {
-        *first_crashed = -1;
-        return RL_OK;
-    }
-    if (!h->reps.empty())
-        return multi_crash(h, poses, 1, n_poses, fov, num_rays, edge, crash_thresh, first_crashed, ranges_or_null, true);
-    if (h->kind != RL_RM && h->kind != RL_RM_GPU)      // generic: scan, then one crash pass
-        return rl_check_collision_groups(h, poses, 1, n_poses, fov, num_rays, edge, crash_thresh,
-                                         first_crashed, ranges_or_null);
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
-    return fan_host(h, poses, n_poses, fov, num_rays, ranges_or_null, nullptr, nullptr, edge,
-                    crash_thresh, first_crashed);
 }
 
 extern "C" int rl_method_read_lut(rl_method *h, int row0, int row1, uint16_t *out)
@@ -2491,7 +1616,7 @@ extern "C" int rl_debug_read_stamps(rl_method *h, uint64_t *out, int max_words)
 // d_first[g] <- first crashed pose of group g, or INT_MAX when none (finalize = false), or
 // -(group+1) (finalize = true).  Ray-marching methods fuse the test into the march kernel; the
 // others scan into d_ranges (required then) and run one pass over the ranges.
-static int crash_groups_device(rl_method *h, const float *d_poses, int n_groups, int group, float fov,
+int crash_groups_device(rl_method *h, const float *d_poses, int n_groups, int group, float fov,
                                int num_rays, const double *d_edge, double thresh, int *d_first,
                                float *d_ranges, bool finalize, hipStream_t stream)
 {
@@ -2542,232 +1667,6 @@ extern "C" int rl_check_collision_groups_device(rl_method *h, const float *d_pos
                                d_first_crashed, d_ranges_or_null, true, (hipStream_t)hip_stream);
 }
 
-extern "C" int rl_check_collision_groups(rl_method *h, const float *poses, int n_groups, int group,
-                                         float fov, int num_rays, const double *edge,
-                                         double crash_thresh, int *first_crashed, float *ranges_or_null)
-{
-    if (n_groups < 0 || group <= 0) return fail(RL_ERR_INVALID, "n_groups >= 0 and group > 0 required");
-    const long n_poses_l = (long)n_groups * group;
-    if (n_poses_l > INT_MAX) return fail(RL_ERR_INVALID, "too many poses");
-    const int n_poses = (int)n_poses_l;
-    int rc = check_fan_args(h, n_poses, fov, num_rays);
-    if (rc) return rc;
-    if (n_groups == 0) return RL_OK;
-    if (!poses || !edge || !first_crashed) return fail(RL_ERR_INVALID, "rl_check_collision_groups: null pointer");
-    if (!h->reps.empty())
-        return multi_crash(h, poses, n_groups, group, fov, num_rays, edge, crash_thresh, first_crashed, ranges_or_null, false);
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
-    if ((rc = set_device(h->map))) return rc;
-    const size_t n_rays = (size_t)n_poses * num_rays;
-    if ((rc = h->poses.ensure((size_t)n_poses * 12)) || (rc = h->outs.ensure(n_rays * 4)) ||
-        (rc = upload_edge(h, edge, num_rays)) || (rc = h->flag.ensure((size_t)n_groups * 4)))
-        return rc;
-    HIPCHK(hipMemcpyAsync(h->poses.p, poses, (size_t)n_poses * 12, hipMemcpyHostToDevice, h->stream));
-    rc = crash_groups_device(h, (const float *)h->poses.p, n_groups, group, fov, num_rays,
-                             (const double *)h->edge.p, crash_thresh, (int *)h->flag.p,
-                             (float *)h->outs.p, true, h->stream);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(first_crashed, h->flag.p, (size_t)n_groups * 4, hipMemcpyDeviceToHost, h->stream));
-    if (ranges_or_null)
-        HIPCHK(hipMemcpyAsync(ranges_or_null, h->outs.p, n_rays * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return RL_OK;
-}
-
-struct rl_car {
-    std::vector<rl_car *> reps;          // multi-device (rl_car_create_multi): one ordinary handle per device
-    std::unique_ptr<MultiPool> pool;
-    int device = 0;
-    CarParams P{};
-    hipStream_t stream = nullptr;
-    DevBuf states, actions, poses, states_out, vel, ranges, edge, first;
-    std::mutex mu;
-};
-
-extern "C" int rl_car_create(int device, const double *p, rl_car **out)
-{
-    if (!p || !out) return fail(RL_ERR_INVALID, "rl_car_create: null pointer");
-    int ndev = rl_device_count();
-    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
-    rl_car *c = new (std::nothrow) rl_car();
-    if (!c) return fail(RL_ERR_NOMEM, "out of host memory");
-    c->device = device;
-    c->P = CarParams{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12],
-                     p[13], p[14], p[15], p[16]};
-    if (hipSetDevice(device) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
-        return fail(RL_ERR_HIP, "stream creation failed");
-    }
-    *out = c;
-    return RL_OK;
-}
-
-extern "C" int rl_car_create_multi(const int *devices, int n_devices, const double *p, rl_car **out)
-{
-    if (!p || !out || !devices) return fail(RL_ERR_INVALID, "rl_car_create_multi: null pointer");
-    if (n_devices < 1 || n_devices > 64) return fail(RL_ERR_INVALID, "rl_car_create_multi: 1..64 devices (got %d)", n_devices);
-    rl_car *c = new (std::nothrow) rl_car();
-    if (!c) return fail(RL_ERR_NOMEM, "out of host memory");
-    std::vector<int> devs;
-    for (int i = 0; i < n_devices; ++i) {
-        rl_car *r = nullptr;
-        const int rc = rl_car_create(devices[i], p, &r);
-        if (rc) {
-            const std::string keep = g_err;
-            rl_car_destroy(c);
-            g_err = keep;
-            return rc;
-        }
-        c->reps.push_back(r);
-        devs.push_back(devices[i]);
-    }
-    c->device = devices[0];
-    c->P = c->reps[0]->P;
-    c->pool = std::make_unique<MultiPool>();
-    c->pool->start(devs);
-    *out = c;
-    return RL_OK;
-}
-
-extern "C" void rl_car_destroy(rl_car *c)
-{
-    if (!c) return;
-    if (!c->reps.empty() || c->pool) {
-        c->pool.reset();
-        for (rl_car *r : c->reps) rl_car_destroy(r);
-        delete c;
-        return;
-    }
-    (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->states, &c->actions, &c->poses, &c->states_out, &c->vel, &c->ranges, &c->edge, &c->first})
-        b->release();
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
-}
-
-static int car_rollout_device(rl_car *c, const double *states_in, const double *actions, int R,
-                              int n_steps, int every, double dt, bool want_states, bool want_vel)
-{
-    if (R < 0 || n_steps <= 0 || every <= 0) return fail(RL_ERR_INVALID, "n_rollouts >= 0, n_steps > 0, action_every > 0 required");
-    if ((long)R * n_steps > INT_MAX / 4) return fail(RL_ERR_INVALID, "too many roll-out poses");
-    HIPCHK(hipSetDevice(c->device));
-    if (R == 0) return RL_OK;
-    const int n_act = (n_steps + every - 1) / every;
-    int rc;
-    if ((rc = c->states.ensure((size_t)R * 11 * 8)) || (rc = c->actions.ensure((size_t)R * n_act * 16)) ||
-        (rc = c->poses.ensure((size_t)R * n_steps * 12)) || (rc = c->states_out.ensure((size_t)R * 11 * 8)) ||
-        (rc = c->vel.ensure((size_t)R * n_steps * 8)))
-        return rc;
-    HIPCHK(hipMemcpyAsync(c->states.p, states_in, (size_t)R * 11 * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->actions.p, actions, (size_t)R * n_act * 16, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(rollout_kernel, dim3((R + 63) / 64), dim3(64), 0, c->stream, c->P,
-                       (const double *)c->states.p, (const double *)c->actions.p, R, n_steps, every, dt,
-                       (float *)c->poses.p, want_states ? (double *)c->states_out.p : nullptr,
-                       want_vel ? (double *)c->vel.p : nullptr);
-    HIPCHK(hipGetLastError());
-    return RL_OK;
-}
-
-extern "C" int rl_car_rollout(rl_car *c, const double *states_in, const double *actions, int R,
-                              int n_steps, int every, double dt, float *poses_out, double *states_out,
-                              double *vel_out)
-{
-    if (!c || (R > 0 && (!states_in || !actions || !poses_out))) return fail(RL_ERR_INVALID, "rl_car_rollout: null pointer");
-    if (!c->reps.empty()) {
-        // roll-outs are independent: contiguous blocks of them, one per device
-        if (R < 0 || n_steps <= 0 || every <= 0) return fail(RL_ERR_INVALID, "n_rollouts >= 0, n_steps > 0, action_every > 0 required");
-        std::lock_guard<std::mutex> lk(c->mu);
-        const int k = (int)std::max<long>(1, std::min<long>((long)c->reps.size(), (long)R / 64));
-        const size_t n_act = (size_t)(n_steps + every - 1) / every;
-        std::vector<std::function<int()>> jobs;
-        for (int i = 0; i < k; ++i) {
-            long lo, hi;
-            block_of(R, i, k, lo, hi);
-            rl_car *r = c->reps[i];
-            jobs.push_back([=]() {
-                return rl_car_rollout(r, states_in + 11 * lo, actions + 2 * n_act * lo, (int)(hi - lo), n_steps, every, dt,
-                                      poses_out + (size_t)3 * n_steps * lo, states_out ? states_out + 11 * lo : nullptr,
-                                      vel_out ? vel_out + (size_t)n_steps * lo : nullptr);
-            });
-        }
-        return c->pool->run(jobs);
-    }
-    std::lock_guard<std::mutex> lk(c->mu);
-    int rc = car_rollout_device(c, states_in, actions, R, n_steps, every, dt, states_out != nullptr, vel_out != nullptr);
-    if (rc || R == 0) return rc;
-    HIPCHK(hipMemcpyAsync(poses_out, c->poses.p, (size_t)R * n_steps * 12, hipMemcpyDeviceToHost, c->stream));
-    if (states_out) HIPCHK(hipMemcpyAsync(states_out, c->states_out.p, (size_t)R * 11 * 8, hipMemcpyDeviceToHost, c->stream));
-    if (vel_out) HIPCHK(hipMemcpyAsync(vel_out, c->vel.p, (size_t)R * n_steps * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return RL_OK;
-}
-
-extern "C" int rl_car_rollout_check(rl_car *c, rl_method *h, const double *states_in, const double *actions,
-                                    int R, int n_steps, int every, double dt, float fov, int num_rays,
-                                    const double *edge, double crash_thresh, int *first_crashed,
-                                    double *states_out, double *vel_out)
-{
-    if (!c || !h || (R > 0 && (!states_in || !actions || !edge || !first_crashed)))
-        return fail(RL_ERR_INVALID, "rl_car_rollout_check: null pointer");
-    if (c->reps.empty() != h->reps.empty() || c->reps.size() != h->reps.size())
-        return fail(RL_ERR_INVALID, "car and range method must both be single-device or span the same devices");
-    if (!c->reps.empty()) {
-        // MCTS.rollout + checkCollisionMany for R roll-outs over several devices: contiguous blocks of roll-outs,
-        // each device integrates, scans and tests its own (nothing but the crash indices comes back)
-        if (R < 0 || n_steps <= 0 || every <= 0) return fail(RL_ERR_INVALID, "n_rollouts >= 0, n_steps > 0, action_every > 0 required");
-        for (size_t i = 0; i < c->reps.size(); ++i)
-            if (c->reps[i]->device != h->reps[i]->map->device)
-                return fail(RL_ERR_INVALID, "car and range method replicas live on different devices");
-        std::scoped_lock lk(c->mu, h->mu);
-        std::shared_lock<std::shared_mutex> ml(h->map->multi_mu);
-        if (h->map->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
-        const int k = (int)std::max<long>(1, std::min<long>(multi_parts(h, (long)R * n_steps), std::max(R, 1)));
-        const size_t n_act = (size_t)(n_steps + every - 1) / every;
-        const float nstd = h->noise_std;
-        const uint64_t seed = h->noise_seed, off = h->ray_offset;
-        std::vector<std::function<int()>> jobs;
-        for (int i = 0; i < k; ++i) {
-            long lo, hi;
-            block_of(R, i, k, lo, hi);
-            rl_car *cr = c->reps[i];
-            rl_method *hr = h->reps[i];
-            jobs.push_back([=]() {
-                if (hi <= lo) return (int)RL_OK;
-                int rc = rl_set_noise(hr, nstd, seed, off + (uint64_t)lo * n_steps * num_rays);
-                if (rc) return rc;
-                return rl_car_rollout_check(cr, hr, states_in + 11 * lo, actions + 2 * n_act * lo, (int)(hi - lo), n_steps,
-                                            every, dt, fov, num_rays, edge, crash_thresh, first_crashed + lo,
-                                            states_out ? states_out + 11 * lo : nullptr,
-                                            vel_out ? vel_out + (size_t)n_steps * lo : nullptr);
-            });
-        }
-        return c->pool->run(jobs);
-    }
-    if (c->device != h->map->device) return fail(RL_ERR_INVALID, "car and range method live on different devices");
-    std::scoped_lock lk(c->mu, h->mu);
-    std::shared_lock<std::shared_mutex> ml(h->map->tables_mu);
-    int rc = car_rollout_device(c, states_in, actions, R, n_steps, every, dt, states_out != nullptr, vel_out != nullptr);
-    if (rc || R == 0) return rc;
-    if ((rc = check_fan_args(h, R * n_steps, fov, num_rays))) return rc;
-    const size_t n_rays = (size_t)R * n_steps * num_rays;
-    if ((rc = c->ranges.ensure(n_rays * 4)) || (rc = c->edge.ensure((size_t)num_rays * 8)) ||
-        (rc = c->first.ensure((size_t)R * 4)))
-        return rc;
-    HIPCHK(hipMemcpyAsync(c->edge.p, edge, (size_t)num_rays * 8, hipMemcpyHostToDevice, c->stream));
-    rc = crash_groups_device(h, (const float *)c->poses.p, R, n_steps, fov, num_rays,
-                             (const double *)c->edge.p, crash_thresh, (int *)c->first.p,
-                             (float *)c->ranges.p, true, c->stream);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(first_crashed, c->first.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
-    if (states_out) HIPCHK(hipMemcpyAsync(states_out, c->states_out.p, (size_t)R * 11 * 8, hipMemcpyDeviceToHost, c->stream));
-    if (vel_out) HIPCHK(hipMemcpyAsync(vel_out, c->vel.p, (size_t)R * n_steps * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return RL_OK;
-}
 
 extern "C" int rl_last_kernel_ms(rl_method *h, float *ms_out)
 {
@@ -2782,344 +1681,3 @@ extern "C" int rl_last_kernel_ms(rl_method *h, float *ms_out)
     return RL_OK;
 }
 
-
-// ---------------------------------------------------------------- FollowGap
-struct rl_followgap {
-    int device = 0;
-    FollowGapParams P{};
-    int window_size = 0;           // kept for the caller; FollowGap::eval never reads it
-    int n_cu = 256;                // (queried once: hipGetDeviceProperties costs the host tens of microseconds per call)
-    hipStream_t stream = nullptr;
-    DevBuf scans, angles;
-    std::mutex mu;
-};
-
-extern "C" int rl_followgap_create(int device, int window_size, float max_distance, float max_angle,
-                                   float angle_inc, rl_followgap **out)
-{
-    if (!out) return fail(RL_ERR_INVALID, "rl_followgap_create: null pointer");
-    int ndev = rl_device_count();
-    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
-    rl_followgap *g = new (std::nothrow) rl_followgap();
-    if (!g) return fail(RL_ERR_NOMEM, "out of host memory");
-    g->device = device;
-    g->window_size = window_size;
-    g->P.max_distance = max_distance;
-    g->P.max_angle = max_angle;
-    g->P.angle_inc = angle_inc;
-    if (hipSetDevice(device) != hipSuccess ||
-        hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete g;
-        return fail(RL_ERR_HIP, "stream creation failed");
-    }
-    int n_cu = 0;
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) g->n_cu = n_cu;
-    *out = g;
-    return RL_OK;
-}
-
-extern "C" void rl_followgap_destroy(rl_followgap *g)
-{
-    if (!g) return;
-    (void)hipSetDevice(g->device);
-    if (g->stream) (void)hipStreamSynchronize(g->stream);
-    g->scans.release();
-    g->angles.release();
-    if (g->stream) (void)hipStreamDestroy(g->stream);
-    delete g;
-}
-
-static int followgap_launch(rl_followgap *g, const float *d_scans, int n_scans, int size,
-                            float *d_angles, hipStream_t stream)
-{
-    if (n_scans < 0) return fail(RL_ERR_INVALID, "n_scans must be >= 0");
-    // (the reference's preprocessLidar runs off its vector below 10 beams, followgap.hpp:21)
-    if (size < 10) return fail(RL_ERR_INVALID, "FollowGap needs at least 10 beams per scan (got %d)", size);
-    if (size > 12288) return fail(RL_ERR_UNSUPPORTED, "at most 12288 beams per scan (got %d)", size);
-    if (n_scans == 0) return RL_OK;
-    FollowGapParams p = g->P;
-    p.size = size;
-    const int grid = std::min(n_scans, g->n_cu * 32);
-    hipLaunchKernelGGL(followgap_kernel, dim3(grid), dim3(64), (size_t)size * sizeof(float), stream,
-                       d_scans, n_scans, p, d_angles);
-    HIPCHK(hipGetLastError());
-    return RL_OK;
-}
-
-extern "C" int rl_followgap_eval(rl_followgap *g, const float *scans, int n_scans, int size,
-                                 float *angles)
-{
-    if (!g || !scans || !angles) return fail(RL_ERR_INVALID, "rl_followgap_eval: null pointer");
-    std::lock_guard<std::mutex> lk(g->mu);
-    HIPCHK(hipSetDevice(g->device));
-    if (n_scans < 0 || size < 10)
-        return followgap_launch(g, nullptr, n_scans, size, nullptr, g->stream);   // (argument errors)
-    if (n_scans == 0) return RL_OK;
-    const size_t bytes = (size_t)n_scans * size * sizeof(float);
-    int rc;
-    if ((rc = g->scans.ensure(bytes)) || (rc = g->angles.ensure((size_t)n_scans * sizeof(float)))) return rc;
-    HIPCHK(hipMemcpyAsync(g->scans.p, scans, bytes, hipMemcpyHostToDevice, g->stream));
-    if ((rc = followgap_launch(g, (const float *)g->scans.p, n_scans, size, (float *)g->angles.p, g->stream)))
-        return rc;
-    HIPCHK(hipMemcpyAsync(angles, g->angles.p, (size_t)n_scans * sizeof(float), hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
-    return RL_OK;
-}
-
-extern "C" int rl_followgap_eval_device(rl_followgap *g, const float *d_scans, int n_scans, int size,
-                                        float *d_angles, void *hip_stream)
-{
-    if (!g || (n_scans > 0 && (!d_scans || !d_angles)))
-        return fail(RL_ERR_INVALID, "rl_followgap_eval_device: null pointer");
-    std::lock_guard<std::mutex> lk(g->mu);
-    HIPCHK(hipSetDevice(g->device));
-    return followgap_launch(g, d_scans, n_scans, size, d_angles, (hipStream_t)hip_stream);
-}
-
-// ---------------------------------------------------------------- diagnostics: HBM stream probe
-static int probe_hbm_modes(int device, size_t bytes, double *gbs_out, int mode_lo, int mode_hi);
-
-extern "C" int rl_probe_hbm(int device, size_t bytes, double *gbs_out5)
-{
-    return probe_hbm_modes(device, bytes, gbs_out5, 0, 5);
-}
-
-extern "C" int rl_probe_hbm_nt(int device, size_t bytes, double *gbs_out3)
-{
-    return probe_hbm_modes(device, bytes, gbs_out3, 5, 8);
-}
-
-extern "C" int rl_probe_literal_sincosf(int device, const float *x, size_t n, float *sin_out, float *cos_out)
-{
-    if (!x || !sin_out || !cos_out) return fail(RL_ERR_INVALID, "rl_probe_literal_sincosf: null pointer");
-    int ndev = rl_device_count();
-    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
-    if (n == 0) return RL_OK;
-    HIPCHK(hipSetDevice(device));
-    float *d = nullptr;
-    if (hipMalloc((void **)&d, 3 * n * sizeof(float)) != hipSuccess) return fail(RL_ERR_NOMEM, "rl_probe_literal_sincosf: %zu floats", 3 * n);
-    int rc = RL_OK;
-    if (hipMemcpy(d, x, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RL_ERR_HIP, "upload failed");
-    if (rc == RL_OK) {
-        const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(literal_sincosf_kernel, dim3(grid), dim3(256), 0, nullptr, d, (long)n, d + n, d + 2 * n);
-        if (hipMemcpy(sin_out, d + n, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(cos_out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
-            rc = fail(RL_ERR_HIP, "rl_probe_literal_sincosf: kernel or download failed");
-    }
-    (void)hipFree(d);
-    return rc;
-}
-
-static int probe_hbm_modes(int device, size_t bytes, double *gbs_out5, int mode_lo, int mode_hi)
-{
-    if (!gbs_out5) return fail(RL_ERR_INVALID, "rl_probe_hbm: null pointer");
-    if (bytes < ((size_t)1 << 20)) return fail(RL_ERR_INVALID, "rl_probe_hbm: at least 1 MiB per buffer");
-    int ndev = rl_device_count();
-    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available");
-    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
-    HIPCHK(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    uint4 *a = nullptr, *b = nullptr;
-    uint32_t *sink = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipStream_t st = nullptr;
-    int rc = RL_OK;
-    const size_t n16 = bytes / 16;
-    if (hipMalloc((void **)&a, n16 * 16) != hipSuccess || hipMalloc((void **)&b, n16 * 16) != hipSuccess ||
-        hipMalloc((void **)&sink, 4) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess ||
-        hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipMemsetAsync(a, 1, n16 * 16, st) != hipSuccess ||
-        hipMemsetAsync(b, 2, n16 * 16, st) != hipSuccess) {
-        rc = fail(RL_ERR_NOMEM, "rl_probe_hbm: setup failed (2 x %zu bytes)", n16 * 16);
-    } else {
-        const int grid = prop.multiProcessorCount * 8, reps = 10;
-        for (int mode = mode_lo; mode < mode_hi && rc == RL_OK; ++mode) {
-            hipLaunchKernelGGL(hbm_probe_kernel, dim3(grid), dim3(256), 0, st, a, b, n16, mode, sink);     // warm
-            (void)hipEventRecord(e0, st);
-            for (int r = 0; r < reps; ++r)
-                hipLaunchKernelGGL(hbm_probe_kernel, dim3(grid), dim3(256), 0, st, a, b, n16, mode, sink);
-            (void)hipEventRecord(e1, st);
-            float ms = 0.f;
-            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) {
-                rc = fail(RL_ERR_HIP, "rl_probe_hbm: launch failed");
-                break;
-            }
-            const double moved = (double)n16 * 16.0 * ((mode == 0 || mode == 3 || mode == 6 || mode == 7) ? 2.0 : 1.0);
-            gbs_out5[mode - mode_lo] = moved * reps / ((double)ms * 1e-3) / 1e9;
-        }
-    }
-    if (a) (void)hipFree(a);
-    if (b) (void)hipFree(b);
-    if (sink) (void)hipFree(sink);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (st) (void)hipStreamDestroy(st);
-    return rc;
-}
-
-// ---------------------------------------------------------------- 16-bit ranges for the xGMI exchange (opt-in, lossy)
-static int u16_args(int device, size_t n, float max_range_m, const void *a, const void *b)
-{
-    if (!(max_range_m > 0.0f)) return fail(RL_ERR_INVALID, "max_range_m must be > 0");
-    if (n > 0 && (!a || !b)) return fail(RL_ERR_INVALID, "null device pointer");
-    int ndev = rl_device_count();
-    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
-    return RL_OK;
-}
-
-// leading elements until the u16 pointer is 16-B aligned, and whether the f32 pointer is aligned there too
-static void u16_split(const void *f32, const void *u16, size_t n, size_t &head, int &vec)
-{
-    head = ((16 - ((uintptr_t)u16 & 15)) & 15) / 2;
-    if (head > n) head = n;
-    vec = (((uintptr_t)f32 + 4 * head) & 15) == 0 && ((uintptr_t)u16 & 1) == 0 && ((uintptr_t)f32 & 3) == 0;
-}
-
-extern "C" int rl_ranges_to_u16_device(int device, const float *d_ranges, size_t n, float max_range_m,
-                                       uint16_t *d_out, void *hip_stream)
-{
-    int rc = u16_args(device, n, max_range_m, d_ranges, d_out);
-    if (rc || n == 0) return rc;
-    HIPCHK(hipSetDevice(device));
-    size_t head;
-    int vec;
-    u16_split(d_ranges, d_out, n, head, vec);
-    const int grid = (int)std::min<size_t>((n / 8 + 255) / 256 + 1, 256 * 16);
-    hipLaunchKernelGGL(ranges_to_u16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_ranges, n,
-                       max_range_m, 65535.0f / max_range_m, d_out, head, vec);
-    HIPCHK(hipGetLastError());
-    return RL_OK;
-}
-
-extern "C" int rl_ranges_from_u16_device(int device, const uint16_t *d_in, size_t n, float max_range_m,
-                                         float *d_ranges, void *hip_stream)
-{
-    int rc = u16_args(device, n, max_range_m, d_in, d_ranges);
-    if (rc || n == 0) return rc;
-    HIPCHK(hipSetDevice(device));
-    size_t head;
-    int vec;
-    u16_split(d_ranges, d_in, n, head, vec);
-    const int grid = (int)std::min<size_t>((n / 8 + 255) / 256 + 1, 256 * 16);
-    hipLaunchKernelGGL(ranges_from_u16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, d_in, n,
-                       max_range_m / 65535.0f, d_ranges, head, vec);
-    HIPCHK(hipGetLastError());
-    return RL_OK;
-}
-
-// ---------------------------------------------------------------- diagnostics: gather-rate probe
-extern "C" int rl_probe_gather_rate(int device, int active_lanes, double *lanes_per_clk_per_cu,
-                                    double *clock_hz, int *n_cu_out)
-{
-    if (!lanes_per_clk_per_cu) return fail(RL_ERR_INVALID, "rl_probe_gather_rate: null pointer");
-    if (active_lanes < 1 || active_lanes > 64) return fail(RL_ERR_INVALID, "active_lanes must be in [1,64]");
-    int ndev = rl_device_count();
-    if (ndev <= 0) return fail(RL_ERR_NO_DEVICE, "no HIP device available");
-    if (device < 0 || device >= ndev) return fail(RL_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
-    HIPCHK(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    const int n_cu = prop.multiProcessorCount;
-    const double clk = (double)prop.clockRate * 1e3;
-    float *tab = nullptr, *sink = nullptr;
-    int *d_off = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipStream_t st = nullptr;
-    int rc = RL_OK;
-    auto cleanup = [&]() {
-        if (tab) (void)hipFree(tab);
-        if (sink) (void)hipFree(sink);
-        if (d_off) (void)hipFree(d_off);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-        if (st) (void)hipStreamDestroy(st);
-    };
-    // random cells of a 32x32 window in the 4-row-interleaved layout of the step map, fixed seed
-    int off[64];
-    uint32_t lcg = 12345u;
-    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (lcg >> 8) & 0xffffu; };
-    for (int l = 0; l < 64; ++l) {
-        const int r = (int)(rnd() % 32), c = (int)(rnd() % 32) + 3;
-        off[l] = (r >> 2) * 4 * 64 + 4 * c + (r & 3);
-    }
-    unsigned long long mask = 0;
-    while (__builtin_popcountll(mask) < active_lanes) mask |= 1ull << (rnd() % 64);
-    const int iters = 2000, grid = n_cu * 2;
-    float ms = 0.f;
-    if (hipMalloc((void **)&tab, 4 * 2048 * sizeof(float)) != hipSuccess || hipMalloc((void **)&sink, 4) != hipSuccess ||
-        hipMalloc((void **)&d_off, sizeof off) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
-        hipEventCreate(&e1) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
-        hipMemsetAsync(tab, 0, 4 * 2048 * sizeof(float), st) != hipSuccess ||
-        hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, st) != hipSuccess) {
-        rc = fail(RL_ERR_HIP, "gather probe: setup failed");
-    } else {
-        hipLaunchKernelGGL(gather_probe_kernel, dim3(grid), dim3(1024), 0, st, tab, d_off, mask, 10, sink);
-        (void)hipEventRecord(e0, st);
-        hipLaunchKernelGGL(gather_probe_kernel, dim3(grid), dim3(1024), 0, st, tab, d_off, mask, iters, sink);
-        (void)hipEventRecord(e1, st);
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f))
-            rc = fail(RL_ERR_HIP, "gather probe: launch failed");
-    }
-    cleanup();
-    if (rc) return rc;
-    // 2 workgroups x 16 waves per CU, each iters x 8 wave-loads
-    const double clk_per_wave_load = (double)ms * 1e-3 * clk / (2.0 * 16 * iters * 8);
-    *lanes_per_clk_per_cu = (double)active_lanes / clk_per_wave_load;
-    if (clock_hz) *clock_hz = clk;
-    if (n_cu_out) *n_cu_out = n_cu;
-    return RL_OK;
-}
-
-// ---------------------------------------------------------------- Car outline table and crash test (host)
-// Car::setCarEdgeDistances (racecar/src/racecar.cpp:239-292): for every beam, how far from the lidar
-// the car's own outline lies.  A one-off table per configuration, so it is host C++ (the crash test
-// over scanned batches is fused into the march kernels, see CrashParams).  The reference's quirks are
-// part of the contract (the crash codes scripts/mcts.py acts on depend on them): the beam angle is
-// advanced BEFORE it is used (the table is shifted by one increment, :256), pi is 3.145
-// (racecar.hpp:117), and a beam at exactly 0 rad is nudged to +1e-4 rad while still being treated as a
-// non-positive angle, so its side distance is width/2 / sin(-1e-4): about -1016 m, and that beam
-// reports a crash for any range (:277-283).  The nudge stays in the running angle.
-extern "C" int rl_car_edge_distances(int num_rays, double min_ang, double ang_inc, double scan_dist_to_base,
-                                     double width, double wheelbase, double *edge_out)
-{
-    if (num_rays < 0 || (num_rays > 0 && !edge_out))
-        return fail(RL_ERR_INVALID, "rl_car_edge_distances: bad arguments");
-    const double quarter_turn = 3.145 / 2.0;
-    const double to_side = width / 2.0, to_front = wheelbase - scan_dist_to_base, to_back = scan_dist_to_base;
-    double beam = min_ang;
-    for (int j = 0; j < num_rays; ++j) {
-        beam += ang_inc;
-        const bool left = beam > 0.0;                           // decided before the nudge
-        if (!left && beam == 0.0) beam += 0.0001;
-        const double turned = left ? beam : -beam;              // angle away from straight ahead
-        const bool ahead = turned < quarter_turn;               // hits the front edge, else the rear edge
-        const double off_axis = ahead ? turned : turned - quarter_turn;
-        const double along = (ahead ? to_front : to_back) / cos(off_axis);
-        const double across = to_side / sin(off_axis);
-        edge_out[j] = across < along ? across : along;
-    }
-    return RL_OK;
-}
-
-// Car::isCrashed (racecar/src/racecar.cpp:305-328) over host ranges: index of the first scan with a
-// beam inside the car outline (+ threshold), else -(n_scans + 1).
-extern "C" int rl_car_is_crashed(const float *ranges, int num_rays, int n_scans, const double *edge,
-                                 double crash_thresh, int *first_crashed)
-{
-    if (!first_crashed || num_rays < 0 || n_scans < 0 || ((size_t)num_rays * n_scans > 0 && (!ranges || !edge)))
-        return fail(RL_ERR_INVALID, "rl_car_is_crashed: bad arguments");
-    *first_crashed = -(n_scans + 1);
-    for (int k = 0; k < n_scans; ++k) {
-        const float *scan = ranges + (size_t)k * num_rays;
-        for (int j = 0; j < num_rays; ++j)
-            if (((double)scan[j] - edge[j]) < crash_thresh) {
-                *first_crashed = k;
-                return RL_OK;
-            }
-    }
-    return RL_OK;
-}

@@ -2,6 +2,7 @@
 // the north_star kernel shape (unit steps on an LDS window).  Part of scan_kernels.h.
 #pragma once
 #include "scan_device.h"
+#include "scan_params.h"
 #include "rm_kernels.h"
 
 // ==============================================================================
@@ -259,12 +260,6 @@ __global__ __launch_bounds__(256) void occ_fan_lds_kernel(MapParams m, FanParams
 // Origins so far outside that the padded copies do not cover their walk never reach the map: they
 // run the stepping arithmetic without map reads when they are claimed (their step count is still
 // the statement's).  Bit-identical to the CPU statement (ranges, hit cells, step counts).
-struct BlPad {
-    const uint32_t *bits;       // both padded copies in one buffer
-    uint32_t k_n, k_t;          // byte offset of the word holding cell (0, 0): normal / transposed copy
-    int stride_n, stride_t;     // words per padded row
-    float near;                 // origins with -near < g < dim + near are covered by the padding
-};
 
 // out[(pr) * stride + w]: 32 cells of the padded view; view(rr, cc) = occ[rr][cc] or, transposed, occ[cc][rr]
 __global__ __launch_bounds__(256) void bl_pad_bits_kernel(const uint8_t *__restrict__ occ, int rows, int cols,

@@ -2,6 +2,7 @@
 // kernel, the theta-major kernels for large batches, the per-ray kernels.  Part of scan_kernels.h.
 #pragma once
 #include "scan_device.h"
+#include "scan_params.h"
 #include "rm_kernels.h"
 #include "lut_kernels.h"
 
@@ -19,69 +20,6 @@ namespace scan {
 
 constexpr float CDDT_EPS = 1e-5f;
 
-struct CddtParams {
-    int theta_disc, n_bins;
-    const float *cosv, *sinv, *trans;   // per bin
-    const int *width;                   // per bin: buckets
-    const uint32_t *bucket_off;         // per bin: first bucket (n_bins + 1)
-    uint32_t *offsets;                  // per bucket: [start, end) in xs (n_buckets + 1)   (build intermediate)
-    float *xs;                          // CSR values as projected, unsorted                 (build intermediate)
-    // what the queries read: the blocked table.  A bucket of n values owns a run of 128-B lines starting at
-    // line hdr[b].x: its values in LEAVES of 32 (sorted, the last one padded with +inf), and — more than one
-    // leaf — in front of them the SEPARATORS, the first value of every leaf, 32 per line (padded with +inf).
-    // A query reads the header, one separator line and one leaf line: two table lines instead of the 3.6 a
-    // bisection over the packed CSR run touched, three dependent loads instead of eight.
-    uint2 *hdr;                         // per bucket: {first line, n}
-    float *tab;
-    float bins_per_rad;
-    int debug;                          // diagnostics only: bit0 skip the bucket searches, bit1 skip the range stores
-};
-
-constexpr int EDGE_ROWS_PER_WG = 8;
-
-__global__ __launch_bounds__(256) void cddt_edges_kernel(const uint8_t *__restrict__ occ, int rows,
-                                                         int cols, uint32_t *__restrict__ n_edges,
-                                                         uint32_t *__restrict__ edges /* r<<16|c */)
-{
-    // a workgroup owns 256 columns x EDGE_ROWS_PER_WG rows; ONE global atomic per workgroup reserves
-    // its run of the list (same-word atomics retire ~10 per us: per-cell or per-wave atomics would
-    // dominate a 2049^2 map).  The order of the list is irrelevant: every bucket is sorted afterwards.
-    __shared__ uint32_t s_cnt[4 * EDGE_ROWS_PER_WG + 1];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long bal[EDGE_ROWS_PER_WG];
-    uint32_t edge_bits = 0;
-#pragma unroll
-    for (int k = 0; k < EDGE_ROWS_PER_WG; ++k) {
-        const int r = blockIdx.y * EDGE_ROWS_PER_WG + k;
-        bool edge = false;
-        if (c < cols && r < rows && occ[(size_t)r * cols + c]) {
-            // occupied cell with a free 4-neighbour; border cells count as edges
-            edge = r == 0 || c == 0 || r == rows - 1 || c == cols - 1;
-            if (!edge)
-                edge = !occ[(size_t)(r - 1) * cols + c] || !occ[(size_t)(r + 1) * cols + c] ||
-                       !occ[(size_t)r * cols + c - 1] || !occ[(size_t)r * cols + c + 1];
-        }
-        bal[k] = __ballot(edge);
-        edge_bits |= (edge ? 1u : 0u) << k;
-        if (lane == 0) s_cnt[k * 4 + wave] = (uint32_t)__popcll(bal[k]);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int i = 0; i < 4 * EDGE_ROWS_PER_WG; ++i) { const uint32_t v = s_cnt[i]; s_cnt[i] = tot; tot += v; }
-        s_cnt[4 * EDGE_ROWS_PER_WG] = tot ? atomicAdd(n_edges, tot) : 0u;
-    }
-    __syncthreads();
-    const uint32_t base = s_cnt[4 * EDGE_ROWS_PER_WG];
-#pragma unroll
-    for (int k = 0; k < EDGE_ROWS_PER_WG; ++k)
-        if ((edge_bits >> k) & 1u) {
-            const int r = blockIdx.y * EDGE_ROWS_PER_WG + k;
-            edges[base + s_cnt[k * 4 + wave] + (uint32_t)__popcll(bal[k] & ((1ull << lane) - 1ull))] =
-                ((uint32_t)r << 16) | (uint32_t)c;
-        }
-}
 
 // Projection of the edge cells into the buckets of every theta bin, in two passes around an exclusive
 // scan: COUNT (bucket sizes into counts[]) and FILL (values into xs at the CSR offsets).
@@ -224,7 +162,6 @@ __global__ __launch_bounds__(256) void cddt_scan_add_kernel(CddtParams cp, const
 //  * workgroups < n_big_wg: the queued buckets of more than 64 values (long straight walls parallel to
 //    a bin's direction), one workgroup each: bitonic sort in LDS up to lds_cap values, beyond that a
 //    rank sort straight from global memory (quadratic, but such a bucket needs a wall of > 5000 cells).
-constexpr uint32_t CDDT_LDS_SORT = 16384;
 
 // where rank r of a bucket goes in the blocked table, and the padding the ranks leave free
 struct CddtRun {

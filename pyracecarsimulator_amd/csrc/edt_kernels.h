@@ -116,4 +116,54 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *__restric
     bits[(size_t)r * stride + w] = word;
 }
 
+// ------------------------------------------------------------------------------
+// Edge cells of the map (occupied with a free 4-neighbour): the input of every CDDT table of this map, built with
+// the other map tables (abi_map.hip: map_build_tables).
+// ------------------------------------------------------------------------------
+constexpr int EDGE_ROWS_PER_WG = 8;
+
+__global__ __launch_bounds__(256) void cddt_edges_kernel(const uint8_t *__restrict__ occ, int rows,
+                                                         int cols, uint32_t *__restrict__ n_edges,
+                                                         uint32_t *__restrict__ edges /* r<<16|c */)
+{
+    // a workgroup owns 256 columns x EDGE_ROWS_PER_WG rows; ONE global atomic per workgroup reserves
+    // its run of the list (same-word atomics retire ~10 per us: per-cell or per-wave atomics would
+    // dominate a 2049^2 map).  The order of the list is irrelevant: every bucket is sorted afterwards.
+    __shared__ uint32_t s_cnt[4 * EDGE_ROWS_PER_WG + 1];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long bal[EDGE_ROWS_PER_WG];
+    uint32_t edge_bits = 0;
+#pragma unroll
+    for (int k = 0; k < EDGE_ROWS_PER_WG; ++k) {
+        const int r = blockIdx.y * EDGE_ROWS_PER_WG + k;
+        bool edge = false;
+        if (c < cols && r < rows && occ[(size_t)r * cols + c]) {
+            // occupied cell with a free 4-neighbour; border cells count as edges
+            edge = r == 0 || c == 0 || r == rows - 1 || c == cols - 1;
+            if (!edge)
+                edge = !occ[(size_t)(r - 1) * cols + c] || !occ[(size_t)(r + 1) * cols + c] ||
+                       !occ[(size_t)r * cols + c - 1] || !occ[(size_t)r * cols + c + 1];
+        }
+        bal[k] = __ballot(edge);
+        edge_bits |= (edge ? 1u : 0u) << k;
+        if (lane == 0) s_cnt[k * 4 + wave] = (uint32_t)__popcll(bal[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < 4 * EDGE_ROWS_PER_WG; ++i) { const uint32_t v = s_cnt[i]; s_cnt[i] = tot; tot += v; }
+        s_cnt[4 * EDGE_ROWS_PER_WG] = tot ? atomicAdd(n_edges, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t base = s_cnt[4 * EDGE_ROWS_PER_WG];
+#pragma unroll
+    for (int k = 0; k < EDGE_ROWS_PER_WG; ++k)
+        if ((edge_bits >> k) & 1u) {
+            const int r = blockIdx.y * EDGE_ROWS_PER_WG + k;
+            edges[base + s_cnt[k * 4 + wave] + (uint32_t)__popcll(bal[k] & ((1ull << lane) - 1ull))] =
+                ((uint32_t)r << 16) | (uint32_t)c;
+        }
+}
+
 }  // namespace scan

@@ -3,7 +3,7 @@
 // ONE pure function of (range method, CU count, map shape, options, batch shape): no HIP call, no
 // handle state, so it is tested on a box without a GPU (tests/test_host.py, through rl_plan_fan)
 // for every BASELINE.json configuration and for the reference's own 200-pose roll-out batch
-// (/root/reference/params.yaml:126, scripts/mcts.py:214-237).  launch_fan (scanlib.hip) executes
+// (/root/reference/params.yaml:126, scripts/mcts.py:214-237).  launch_fan (abi_fan.hip) executes
 // exactly the plan this returns; the thresholds in here are measured optima (profiles/r03/
 // plan_sweep*.txt), not derived constants.
 #pragma once
@@ -16,7 +16,7 @@
 
 namespace plan {
 
-// layout constants shared with rm_kernels.h (static_asserts in scanlib.hip tie them together)
+// layout constants shared with rm_kernels.h (static_asserts in abi_fan.hip tie them together)
 constexpr int WG = 256;                  // threads of the unit workgroup grid_mult counts in
 constexpr int STREAM_HDR = 66;           // LDS header words of the stream kernels
 constexpr int STRIPE_BINS = 64;
@@ -41,7 +41,7 @@ inline void default_opts(rl_plan_opts &o)
     o.variant = 1;
     o.grid_mult = 8;          // workgroups (x256 threads) per CU of a persistent launch
     o.wg_threads = 1024;
-    o.low_water = -1;                          // (auto: scanlib.hip)
+    o.low_water = -1;                          // (auto: abi_fan.hip)
     o.sort_poses = 1;
     o.xcd_bands = 8;
     o.slots = 0;              // auto
@@ -123,7 +123,7 @@ inline TiledFit tiled_fit(int rows, int cols, float max_range)
 // device limit a launch's dynamic LDS must stay within (gfx950: 160 KB per workgroup)
 constexpr int DEVICE_LDS_BYTES = 160 * 1024;
 
-// the binning pass a batch of n_poses takes when one is needed (bin_poses in scanlib.hip)
+// the binning pass a batch of n_poses takes when one is needed (bin_poses in abi_fan.hip)
 inline bool keys_only_ok(const rl_plan_opts &o, int n_poses)
 {
     return o.sort_poses && n_poses >= 64 && n_poses < o.bin_multi_min && n_poses <= 8192 && !o.bin_generic;
@@ -137,7 +137,7 @@ inline int binning_for(const rl_plan_opts &o, int n_poses, bool keys_only)
     return RL_BIN_GENERIC;
 }
 
-// Bresenham / occupancy window in LDS (make_bl in scanlib.hip)
+// Bresenham / occupancy window in LDS (make_bl in abi_fan.hip)
 inline void bl_window(float max_range, int num_rays, int &R, int &ww, bool &use_lds, size_t &lds_bytes)
 {
     R = (int)std::ceil(max_range) + 5;

@@ -89,15 +89,4 @@ __global__ __launch_bounds__(256) void rm_literal_kernel(MapParams m, FanParams 
     }
 }
 
-// diagnostics: lit_sinf / lit_cosf of an array (rl_probe_literal_sincosf: the GPU test holds it against the host's libm)
-__global__ __launch_bounds__(256) void literal_sincosf_kernel(const float *__restrict__ x, long n, float *__restrict__ s,
-                                                              float *__restrict__ c)
-{
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        s[i] = lit_sinf(x[i]);
-        c[i] = lit_cosf(x[i]);
-    }
-}
-
 }  // namespace scan

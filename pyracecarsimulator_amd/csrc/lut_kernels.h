@@ -1,6 +1,7 @@
 // lut_kernels.h — K3: GiantLUTCast, table build and the fan kernels.  Part of scan_kernels.h.
 #pragma once
 #include "scan_device.h"
+#include "scan_params.h"
 #include "rm_kernels.h"
 
 // ==============================================================================
@@ -13,14 +14,6 @@
 // ==============================================================================
 namespace scan {
 
-struct LutParams {
-    uint16_t *lut;
-    int theta_disc;
-    float bins_per_rad;      // theta_disc / 2pi (float)
-    float bin_width;         // 2pi / theta_disc
-    float quant, dequant;    // 65535/max_range, max_range/65535
-    int debug;               // diagnostics only: bit0 skip table loads, bit1 skip range stores
-};
 
 __device__ __forceinline__ int lut_bin(float th, const LutParams &lp)
 {

@@ -7,6 +7,7 @@
 // bench.py runs it in its untimed section and reports the march kernel's samples/s against it.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "literal_math.h"
 
 namespace scan {
 
@@ -85,6 +86,17 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const uint4 *__restrict_
         else dst[i] = a;
     }
     if (acc == 0x12345678u) sink[0] = acc;
+}
+
+// diagnostics: lit_sinf / lit_cosf of an array (rl_probe_literal_sincosf: the GPU test holds it against the host's libm)
+__global__ __launch_bounds__(256) void literal_sincosf_kernel(const float *__restrict__ x, long n, float *__restrict__ s,
+                                                              float *__restrict__ c)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        s[i] = lit_sinf(x[i]);
+        c[i] = lit_cosf(x[i]);
+    }
 }
 
 }  // namespace scan

@@ -3,6 +3,7 @@
 // the persistent stream kernel rm_fan_stream_kernel.  Part of scan_kernels.h.
 #pragma once
 #include "scan_device.h"
+#include "scan_params.h"
 #include "literal_math.h"
 
 namespace scan {
@@ -452,8 +453,6 @@ __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const
 // global atomics — clustered roll-out poses would serialise on a few words), written tile-major
 // as hist_all[tile * n_wg + w]; one scan over that array then gives every (tile, workgroup) pair
 // its base slot, and the scatter pass hands out slots from LDS cursors.
-constexpr int POSES_PER_WG = 512;      // (2048 while one workgroup scanned all the counters; with the per-tile
-                                       //  scan 256..1024 are equally good and 4..13 % ahead of that)
 
 __global__ __launch_bounds__(256) void pose_prep_kernel(MapParams m, const float *__restrict__ poses,
                                                         int n, PoseRec *__restrict__ rec,

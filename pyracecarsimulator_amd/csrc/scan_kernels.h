@@ -6,8 +6,8 @@
 // (DESIGN.md section 4).  K1 (rm_fan_kernel: a chunk of 64 consecutive beams per wave, no refill) is variant 0, the
 // round-1 shape kept as an A/B partner and for launches the stream kernel cannot index (>= 2^30 rays without slicing).
 //
-// The kernels live in one header per family:
-//   edt_kernels.h   K0   exact EDT
+// The kernels live in one header per family (this header = what abi_fan.hip launches; edt_kernels.h — K0, the exact EDT, the
+// bit map and the edge-cell list — belongs to abi_map.hip):
 //   rm_kernels.h    K1 / K1b ray marching: chunk-per-wave kernels, pose binning, step map, the hand-scheduled
 //                   march and drain loops, the persistent stream kernel
 //   lut_kernels.h   K3   GiantLUT build + fan kernels
@@ -16,7 +16,6 @@
 //   literal_kernels.h    the audit mode of the ray-marching methods: upstream-literal arithmetic with glibc's sinf / cosf
 #pragma once
 #include "scan_device.h"
-#include "edt_kernels.h"
 #include "rm_kernels.h"
 #include "lut_kernels.h"
 #include "bl_kernels.h"

@@ -8,11 +8,14 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "pyracecarsimulator_amd", "csrc", "scanlib.hip")
-FLAGS = ("-O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math "
+CSRC = os.path.join(ROOT, "pyracecarsimulator_amd", "csrc")
+UNITS = ("abi_map", "abi_fan", "abi_multi", "abi_car")
+FLAGS = ("-O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "
          "-fhip-fp32-correctly-rounded-divide-sqrt -w -mllvm -amdgpu-atomic-optimizer-strategy=None "
-         "-Rpass-analysis=kernel-resource-usage").split()
-out = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-o", "/tmp/_kres.so", SRC], capture_output=True, text=True).stderr
+         "-Rpass-analysis=kernel-resource-usage --cuda-device-only -c").split()
+procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", *FLAGS, "-o", "/tmp/_kres_%s.o" % u, os.path.join(CSRC, u + ".hip")],
+                          stderr=subprocess.PIPE, text=True) for u in UNITS]
+out = "".join(p.communicate()[1] for p in procs)
 pat = sys.argv[1] if len(sys.argv) > 1 else ""
 cur = None
 rows = []
