@@ -305,8 +305,10 @@ typedef struct rl_plan_opts {
     int variant, grid_mult, wg_threads, low_water, sort_poses, xcd_bands, slots, tiled;
     int inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min, bin_generic;
     int run_log2, cddt_bins, cddt_sort, lut_debug, debug_stamps, slice_log2, cddt_theta_min;
-    int cddt_search;     /* theta-major CDDT search kernel: 1 = look-ups prepared once per pose, picked up by the 8-lane groups
-                            (cddt_theta_search2_kernel, round 5: default), 0 = every group prepares its own (round 4)      */
+    int cddt_search;     /* theta-major CDDT: 1 = look-ups prepared once per pose, picked up by the 8-lane groups
+                            (cddt_theta_search2_kernel + cddt_theta_fan_kernel, round 5), 0 = every group prepares its own
+                            (round 4), 2 = search and fan of a 64-pose tile fused in one workgroup, per-bin results in
+                            LDS only (cddt_theta_fused_kernel)                                                            */
     int reserved[1];
 } rl_plan_opts;
 
@@ -321,7 +323,7 @@ typedef enum rl_kernel_id {
     RL_K_LUT_FAN = 7,       /* lut_fan_kernel<CH>                                                         */
     RL_K_CDDT_BINS = 8,     /* cddt_fan_bins_kernel                                                       */
     RL_K_CDDT_RAYS = 9,     /* cddt_fan_kernel                                                            */
-    RL_K_CDDT_THETA = 10,   /* cddt_theta_search[2]_kernel + cddt_theta_fan_kernel (theta-major, large batches) */
+    RL_K_CDDT_THETA = 10,   /* cddt_theta_search[2]_kernel + cddt_theta_fan_kernel | cddt_theta_fused_kernel (large batches) */
     RL_K_RM_LITERAL = 11,   /* rm_literal_kernel<AUX, RAYS>: upstream-literal arithmetic, one lane per ray — variant 3 with
                                diagnostics (hit cells / sample counts), the 2-argument per-ray form, fans below 64 beams */
     RL_K_RM_STREAM_LIT = 12 /* rm_fan_stream_kernel<false, CRASH, 1024, true, true, SLOTS, true>: variant 3 in production —

@@ -206,7 +206,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "xcd_bands")) h->xcd_bands = value < 1 ? 1 : value;
     else if (!strcmp(name, "slots")) h->slots = value >= 3 ? 3 : (value == 2 ? 2 : (value == 1 ? 1 : 0));
     else if (!strcmp(name, "cddt_bins")) h->cddt_bins_kernel = value != 0;
-    else if (!strcmp(name, "cddt_search")) h->cddt_search = value != 0;
+    else if (!strcmp(name, "cddt_search")) h->cddt_search = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(name, "cddt_sort")) h->cddt_sort = value != 0;
     else if (!strcmp(name, "cddt_theta_min")) h->cddt_theta_min = value < 0 ? 0 : value;
     else if (!strcmp(name, "cddt_lds_sort")) {
@@ -940,13 +940,19 @@ static int launch_cddt_theta(const FanLaunch &L)
     FAN_LAUNCH_LOCALS;
     if ((rc = ensure_cddt(h, stream))) return rc;
     // scratch of the launch context: R[raw bin][pose] behind the per-pose records {gx, gy, first bin, bins}
+    const bool fused = !strcmp(pl.name, "scan::cddt_theta_fused_kernel");     // (the planner's decision: cddt_search 2 and the tile fits LDS)
     const size_t prep_bytes = (((size_t)n_poses * 16) + 255) & ~(size_t)255;
-    if ((rc = cx->cddt_r.ensure(prep_bytes + (size_t)h->cdp.theta_disc * (size_t)n_poses * sizeof(float)))) return rc;
+    if ((rc = cx->cddt_r.ensure(prep_bytes + (fused ? 0 : (size_t)h->cdp.theta_disc * (size_t)n_poses * sizeof(float))))) return rc;
     float4 *d_prep = (float4 *)cx->cddt_r.p;
     float *d_r = (float *)((char *)cx->cddt_r.p + prep_bytes);
     if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));
     hipLaunchKernelGGL(cddt_theta_prep_kernel, dim3((unsigned)std::max(1, std::min((n_poses + 255) / 256, m->n_cu * 8))),
                        dim3(256), 0, stream, m->mp, f, h->cdp, d_poses, d_prep);
+    if (fused) {
+        hipLaunchKernelGGL(cddt_theta_fused_kernel, grid, block, lds, stream, m->mp, f, h->cdp, d_poses,
+                           (const float4 *)d_prep, d_out, pl.nl);
+        return RL_OK;
+    }
     if (h->cddt_search)
         hipLaunchKernelGGL(cddt_theta_search2_kernel, grid, block, 0, stream, m->mp, f, h->cdp, d_poses,
                            (const float4 *)d_prep, d_r, pl.bands);

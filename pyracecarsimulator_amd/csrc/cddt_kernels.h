@@ -690,12 +690,120 @@ void cddt_theta_search_kernel(MapParams m, FanParams f, CddtParams cp, const flo
 // 8-lane groups pick their look-up's three words {lx, first line, count | flags} from the preparing lane with
 // ds_bpermute: 64 look-ups per wave iteration in two rounds of 8 groups x CDDT_TK.  Same arithmetic, same table
 // lines, same insertion points: bit-identical.  A unit = (table bin, 256 poses).
+// One table bin t for the 64 poses p0 .. p0 + 63 (lane i prepares pose p0 + i; `pr` = its {gx, gy, first raw bin, count}
+// from cddt_theta_prep_kernel): both raw bins the look-up answers go to sink(raw bin, pose, range in metres).
+template <class Sink>
+__device__ __forceinline__ void cddt_theta_search_bin(const MapParams &m, const FanParams &f, const CddtParams &cp,
+                                                      const float4 pr, int p0, int t, Sink &&sink)
+{
+    const int td = cp.theta_disc, half = td / 2;
+    const float INF = __builtin_inff();
+    const int lane = (int)threadIdx.x & 63;
+    const int c = lane & 7, grp = lane >> 3;
+    const float4 *tab4 = reinterpret_cast<const float4 *>(cp.tab);
+    const bool dbg_off = !(cp.debug & 1);
+    static_assert(CDDT_TK == 4, "the reductions below are written for four look-ups per group");
+    const float cs = cp.cosv[t], sn = cp.sinv[t], tr = cp.trans[t], wdt = (float)cp.width[t];
+    const uint32_t boff = cp.bucket_off[t];
+    const int rb = t + half;
+    const bool has_b = rb >= cp.n_bins && rb < td;
+    // ---- preparation: lane i <-> pose p0 + i
+    const int pose = p0 + lane;
+    const int first = __builtin_bit_cast(int, pr.z), cnt = __builtin_bit_cast(int, pr.w);
+    int df = t - first, db = rb - first;
+    df += df < 0 ? td : 0;
+    db += db < 0 ? td : 0;
+    const bool live = (pose < f.n_poses) & dbg_off;
+    const bool nf = live & (df < cnt), nbk = live & has_b & (db < cnt);
+    const float my_lx = __builtin_fmaf(pr.x, cs, -(pr.y * sn));
+    const float ly = __builtin_fmaf(pr.x, sn, pr.y * cs) + tr;
+    const bool inside = (nf | nbk) & (ly >= 0.0f) & (ly < wdt);
+    uint2 hd = cp.hdr[inside ? boff + (uint32_t)(int)ly : 0u];
+    hd.y = inside ? hd.y : 0u;                             // (nothing stored: both ranges stay max_range)
+    const bool my_slow = ((hd.y + 31u) >> 5) > 32u;        // several separator lines: the general look-up below
+    // the three words a group needs of its look-up: lx, first line, count | need flags (counts stay below 2^29)
+    const int w_lx = __builtin_bit_cast(int, my_lx), w_line = (int)hd.x;
+    const int w_cnt = (int)((my_slow ? 0u : hd.y) | (nf ? 0x80000000u : 0u) | (nbk ? 0x40000000u : 0u) |
+                            (my_slow ? 0x20000000u : 0u));
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        float lx[CDDT_TK];
+        uint32_t line0[CDDT_TK], nval[CDDT_TK], flg[CDDT_TK];
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            const int src = (r * 32 + k * 8 + grp) << 2;   // the lane that prepared this group's look-up k
+            lx[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, w_lx));
+            line0[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, w_line);
+            const uint32_t wc = (uint32_t)__builtin_amdgcn_ds_bpermute(src, w_cnt);
+            nval[k] = wc & 0x1fffffffu;
+            flg[k] = wc >> 29;                             // bit 2 need_f, bit 1 need_b, bit 0 slow
+        }
+        float4 sq[CDDT_TK];
+        uint32_t nleaf[CDDT_TK];
+        bool seps[CDDT_TK];
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            nleaf[k] = (nval[k] + 31u) >> 5;
+            seps[k] = nleaf[k] > 1u;
+            sq[k] = tab4[seps[k] ? (size_t)line0[k] * 8 + c : (size_t)c];
+        }
+        uint32_t cn[CDDT_TK];
+        float fs[CDDT_TK];
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            cn[k] = count_le(sq[k], lx[k]);
+            fs[k] = first_gt(sq[k], lx[k], INF);
+        }
+        red8_add_min_x4(cn[0], fs[0], cn[1], fs[1], cn[2], fs[2], cn[3], fs[3]);
+        float4 lq[CDDT_TK];
+        bool have_leaf[CDDT_TK];
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            fs[k] = seps[k] ? fs[k] : INF;
+            have_leaf[k] = (nval[k] != 0u) & (!seps[k] | (cn[k] > 0u));
+            const uint32_t leaf = seps[k] ? min(cn[k], nleaf[k]) - 1u : 0u;
+            lq[k] = tab4[have_leaf[k] ? ((size_t)line0[k] + (seps[k] ? 1u : 0u) + leaf) * 8 + c : (size_t)c];
+        }
+        float f4[CDDT_TK], b4[CDDT_TK];
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            f4[k] = first_ge(lq[k], lx[k], INF);
+            b4[k] = last_le(lq[k], lx[k], -INF);
+        }
+        red8_min_max_x4(f4[0], b4[0], f4[1], b4[1], f4[2], b4[2], f4[3], b4[3]);
+        float my_f = 0.0f, my_b = 0.0f;
+        uint32_t my_flg = 0;
+#pragma unroll
+        for (int k = 0; k < CDDT_TK; ++k) {
+            const float x_ = lx[k];
+            const float rf = vmin((have_leaf[k] ? vmin(fs[k], f4[k]) : fs[k]) - x_, f.max_range);
+            const float rbk = vmin(x_ - (have_leaf[k] ? b4[k] : -INF), f.max_range);
+            const bool mine = c == k;                      // lane k of the group stores look-up k
+            my_f = mine ? rf : my_f;
+            my_b = mine ? rbk : my_b;
+            my_flg = mine ? flg[k] : my_flg;
+        }
+        // the round's 32 look-ups are the poses p0 + r * 32 + k * 8 + grp: lanes (grp, c = k < 4) write one 128-B line
+        const int pq = p0 + r * 32 + c * 8 + grp;
+        if (c < CDDT_TK && (my_flg & 1u) == 0u) {
+            if (my_flg & 4u) sink(t, pq, my_f * m.res);
+            if (my_flg & 2u) sink(rb, pq, my_b * m.res);
+        }
+    }
+    // buckets beyond 1024 values (several separator lines; a long straight wall along the bin's direction): the
+    // general one-lane look-up, by the lane that prepared the pose
+    if (my_slow && (nf | nbk)) {
+        float rf, rbk;
+        cddt_query_pair(cp, f.max_range, pr.x, pr.y, t, rf, rbk);
+        if (nf) sink(t, pose, rf * m.res);
+        if (nbk) sink(rb, pose, rbk * m.res);
+    }
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(88), amdgpu_waves_per_eu(8, 8)))
 void cddt_theta_search2_kernel(MapParams m, FanParams f, CddtParams cp, const float *__restrict__ poses,
                                const float4 *__restrict__ prep, float *__restrict__ R, int n_xcd)
 {
-    const int td = cp.theta_disc, half = td / 2;
-    const float INF = __builtin_inff();
     constexpr int PB = 256;
     const int n_pb = (f.n_poses + PB - 1) / PB;
     const int x = (int)(blockIdx.x % (unsigned)n_xcd), g = (int)(blockIdx.x / (unsigned)n_xcd);
@@ -703,110 +811,62 @@ void cddt_theta_search2_kernel(MapParams m, FanParams f, CddtParams cp, const fl
     const int t_lo = (int)((long)cp.n_bins * x / n_xcd), t_hi = (int)((long)cp.n_bins * (x + 1) / n_xcd);
     const uint32_t u1 = (uint32_t)(t_hi - t_lo) * (uint32_t)n_pb;
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-    const int c = lane & 7, grp = lane >> 3;
-    const float4 *tab4 = reinterpret_cast<const float4 *>(cp.tab);
-    const bool dbg_off = !(cp.debug & 1);
-    static_assert(CDDT_TK == 4, "the reductions below are written for four look-ups per group");
     for (uint32_t u = (uint32_t)g; u < u1; u += (uint32_t)G) {
         const uint32_t ut = u / (uint32_t)n_pb;
         const int t = t_lo + (int)ut, p0 = (int)(u - ut * (uint32_t)n_pb) * PB + wave * 64;
         if (p0 >= f.n_poses) continue;                         // (wave-uniform: this wave's 64 poses do not exist)
-        const float cs = cp.cosv[t], sn = cp.sinv[t], tr = cp.trans[t], wdt = (float)cp.width[t];
-        const uint32_t boff = cp.bucket_off[t];
-        const int rb = t + half;
-        const bool has_b = rb >= cp.n_bins && rb < td;
-        // ---- preparation: lane i <-> pose p0 + i
-        const int pose = p0 + lane;
-        const float4 pr = prep[min(pose, f.n_poses - 1)];
-        const int first = __builtin_bit_cast(int, pr.z), cnt = __builtin_bit_cast(int, pr.w);
-        int df = t - first, db = rb - first;
-        df += df < 0 ? td : 0;
-        db += db < 0 ? td : 0;
-        const bool live = (pose < f.n_poses) & dbg_off;
-        const bool nf = live & (df < cnt), nbk = live & has_b & (db < cnt);
-        const float my_lx = __builtin_fmaf(pr.x, cs, -(pr.y * sn));
-        const float ly = __builtin_fmaf(pr.x, sn, pr.y * cs) + tr;
-        const bool inside = (nf | nbk) & (ly >= 0.0f) & (ly < wdt);
-        uint2 hd = cp.hdr[inside ? boff + (uint32_t)(int)ly : 0u];
-        hd.y = inside ? hd.y : 0u;                             // (nothing stored: both ranges stay max_range)
-        const bool my_slow = ((hd.y + 31u) >> 5) > 32u;        // several separator lines: the general look-up below
-        // the three words a group needs of its look-up: lx, first line, count | need flags (counts stay below 2^29)
-        const int w_lx = __builtin_bit_cast(int, my_lx), w_line = (int)hd.x;
-        const int w_cnt = (int)((my_slow ? 0u : hd.y) | (nf ? 0x80000000u : 0u) | (nbk ? 0x40000000u : 0u) |
-                                (my_slow ? 0x20000000u : 0u));
-#pragma unroll 1
-        for (int r = 0; r < 2; ++r) {
-            float lx[CDDT_TK];
-            uint32_t line0[CDDT_TK], nval[CDDT_TK], flg[CDDT_TK];
+        const float4 pr = prep[min(p0 + lane, f.n_poses - 1)];
+        cddt_theta_search_bin(m, f, cp, pr, p0, t,
+                              [&](int bin, int pose, float v) { R[(size_t)bin * f.n_poses + pose] = v; });
+    }
+}
+
+// The ranges of the poses p0 .. p0 + np - 1 from their per-bin results in LDS (bin_range[q * stride + raw bin], headings
+// thg_l[q]): every beam looks its bin up.
+__device__ __forceinline__ void cddt_theta_fan_group(const FanParams &f, const CddtParams &cp, const LutParams &lp, float td_f,
+                                                     float inv_td, const float *bin_range, const float *thg_l, int stride,
+                                                     int p0, int np, float *__restrict__ out)
+{
+    // the group's ranges are ONE contiguous run of np x num_rays floats (pose-major output): written 16 B per
+    // lane — 1 KiB per wave instruction — when the run starts on a 16-B boundary (always for the planner's
+    // groups of >= 4 poses on an aligned buffer), else beam by beam.  (Round 4: the dword row stores of the
+    // first form ran at 4.7 TB/s, profiles/r04/write_probe.txt.)
+    const size_t run0 = (size_t)p0 * f.num_rays;
+    const uint32_t B = (uint32_t)f.num_rays, total = (uint32_t)np * B;
+    float *run = out + run0;
+    auto lookup = [&](uint32_t q, uint32_t j, uint32_t e) {
+        float r = bin_range[(size_t)q * stride + lut_bin_fast(-(thg_l[q] + fan_alpha(f, (int)j)), lp, td_f, inv_td)];
+        if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + run0 + e);
+        return r;
+    };
+    if ((reinterpret_cast<uintptr_t>(run) & 15) == 0 && !(cp.debug & 2)) {
+        const float inv_b = 1.0f / (float)B;
+        for (uint32_t c = threadIdx.x; c < (total >> 2); c += 256) {
+            const uint32_t e = c << 2;
+            uint32_t q = (uint32_t)(((float)e + 0.5f) * inv_b);          // e / B (e < 2^24: one correction step)
+            q -= (q * B > e) ? 1u : 0u;
+            q += ((q + 1u) * B <= e) ? 1u : 0u;
+            uint32_t j = e - q * B;
+            float v[4];
 #pragma unroll
-            for (int k = 0; k < CDDT_TK; ++k) {
-                const int src = (r * 32 + k * 8 + grp) << 2;   // the lane that prepared this group's look-up k
-                lx[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, w_lx));
-                line0[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, w_line);
-                const uint32_t wc = (uint32_t)__builtin_amdgcn_ds_bpermute(src, w_cnt);
-                nval[k] = wc & 0x1fffffffu;
-                flg[k] = wc >> 29;                             // bit 2 need_f, bit 1 need_b, bit 0 slow
+            for (int k = 0; k < 4; ++k) {
+                if (j == B) { j = 0; ++q; }
+                v[k] = lookup(q, j, e + (uint32_t)k);
+                ++j;
             }
-            float4 sq[CDDT_TK];
-            uint32_t nleaf[CDDT_TK];
-            bool seps[CDDT_TK];
-#pragma unroll
-            for (int k = 0; k < CDDT_TK; ++k) {
-                nleaf[k] = (nval[k] + 31u) >> 5;
-                seps[k] = nleaf[k] > 1u;
-                sq[k] = tab4[seps[k] ? (size_t)line0[k] * 8 + c : (size_t)c];
-            }
-            uint32_t cn[CDDT_TK];
-            float fs[CDDT_TK];
-#pragma unroll
-            for (int k = 0; k < CDDT_TK; ++k) {
-                cn[k] = count_le(sq[k], lx[k]);
-                fs[k] = first_gt(sq[k], lx[k], INF);
-            }
-            red8_add_min_x4(cn[0], fs[0], cn[1], fs[1], cn[2], fs[2], cn[3], fs[3]);
-            float4 lq[CDDT_TK];
-            bool have_leaf[CDDT_TK];
-#pragma unroll
-            for (int k = 0; k < CDDT_TK; ++k) {
-                fs[k] = seps[k] ? fs[k] : INF;
-                have_leaf[k] = (nval[k] != 0u) & (!seps[k] | (cn[k] > 0u));
-                const uint32_t leaf = seps[k] ? min(cn[k], nleaf[k]) - 1u : 0u;
-                lq[k] = tab4[have_leaf[k] ? ((size_t)line0[k] + (seps[k] ? 1u : 0u) + leaf) * 8 + c : (size_t)c];
-            }
-            float f4[CDDT_TK], b4[CDDT_TK];
-#pragma unroll
-            for (int k = 0; k < CDDT_TK; ++k) {
-                f4[k] = first_ge(lq[k], lx[k], INF);
-                b4[k] = last_le(lq[k], lx[k], -INF);
-            }
-            red8_min_max_x4(f4[0], b4[0], f4[1], b4[1], f4[2], b4[2], f4[3], b4[3]);
-            float my_f = 0.0f, my_b = 0.0f;
-            uint32_t my_flg = 0;
-#pragma unroll
-            for (int k = 0; k < CDDT_TK; ++k) {
-                const float x_ = lx[k];
-                const float rf = vmin((have_leaf[k] ? vmin(fs[k], f4[k]) : fs[k]) - x_, f.max_range);
-                const float rbk = vmin(x_ - (have_leaf[k] ? b4[k] : -INF), f.max_range);
-                const bool mine = c == k;                      // lane k of the group stores look-up k
-                my_f = mine ? rf : my_f;
-                my_b = mine ? rbk : my_b;
-                my_flg = mine ? flg[k] : my_flg;
-            }
-            // the round's 32 look-ups are the poses p0 + r * 32 + k * 8 + grp: lanes (grp, c = k < 4) write one 128-B line
-            const int pq = p0 + r * 32 + c * 8 + grp;
-            if (c < CDDT_TK && (my_flg & 1u) == 0u) {
-                if (my_flg & 4u) R[(size_t)t * f.n_poses + pq] = my_f * m.res;
-                if (my_flg & 2u) R[(size_t)rb * f.n_poses + pq] = my_b * m.res;
-            }
+            *reinterpret_cast<float4 *>(run + e) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        // buckets beyond 1024 values (several separator lines; a long straight wall along the bin's direction): the
-        // general one-lane look-up, by the lane that prepared the pose
-        if (my_slow && (nf | nbk)) {
-            float rf, rbk;
-            cddt_query_pair(cp, f.max_range, pr.x, pr.y, t, rf, rbk);
-            if (nf) R[(size_t)t * f.n_poses + pose] = rf * m.res;
-            if (nbk) R[(size_t)rb * f.n_poses + pose] = rbk * m.res;
+        const uint32_t e = (total & ~3u) + threadIdx.x;                     // the run's last 0..3 floats
+        if (threadIdx.x < (total & 3u)) {
+            const uint32_t q = e / B;
+            run[e] = lookup(q, e - q * B, e);
         }
+    } else {
+        for (uint32_t q = 0; q < (uint32_t)np; ++q)
+            for (uint32_t j = threadIdx.x; j < B; j += 256) {
+                const float r = lookup(q, j, q * B + j);
+                if (!(cp.debug & 2) || r == 123.456f) run[q * B + j] = r;
+            }
     }
 }
 
@@ -832,47 +892,39 @@ __global__ __launch_bounds__(256) void cddt_theta_fan_kernel(MapParams m, FanPar
         }
         if ((int)threadIdx.x < np) thg_l[threadIdx.x] = poses[3 * (size_t)(p0 + (int)threadIdx.x) + 2] + m.wa;
         __syncthreads();
-        // the group's ranges are ONE contiguous run of np x num_rays floats (pose-major output): written 16 B per
-        // lane — 1 KiB per wave instruction — when the run starts on a 16-B boundary (always for the planner's
-        // groups of >= 4 poses on an aligned buffer), else beam by beam.  (Round 4: the dword row stores of the
-        // first form ran at 4.7 TB/s, profiles/r04/write_probe.txt.)
-        const size_t run0 = (size_t)p0 * f.num_rays;
-        const uint32_t B = (uint32_t)f.num_rays, total = (uint32_t)np * B;
-        float *run = out + run0;
-        auto lookup = [&](uint32_t q, uint32_t j, uint32_t e) {
-            float r = bin_range[(size_t)q * stride + lut_bin_fast(-(thg_l[q] + fan_alpha(f, (int)j)), lp, td_f, inv_td)];
-            if (f.noise_std > 0.0f) r += f.noise_std * gauss_noise(f.noise_seed, f.ray_offset + run0 + e);
-            return r;
-        };
-        if ((reinterpret_cast<uintptr_t>(run) & 15) == 0 && !(cp.debug & 2)) {
-            const float inv_b = 1.0f / (float)B;
-            for (uint32_t c = threadIdx.x; c < (total >> 2); c += 256) {
-                const uint32_t e = c << 2;
-                uint32_t q = (uint32_t)(((float)e + 0.5f) * inv_b);          // e / B (e < 2^24: one correction step)
-                q -= (q * B > e) ? 1u : 0u;
-                q += ((q + 1u) * B <= e) ? 1u : 0u;
-                uint32_t j = e - q * B;
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (j == B) { j = 0; ++q; }
-                    v[k] = lookup(q, j, e + (uint32_t)k);
-                    ++j;
-                }
-                *reinterpret_cast<float4 *>(run + e) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-            const uint32_t e = (total & ~3u) + threadIdx.x;                     // the run's last 0..3 floats
-            if (threadIdx.x < (total & 3u)) {
-                const uint32_t q = e / B;
-                run[e] = lookup(q, e - q * B, e);
-            }
-        } else {
-            for (uint32_t q = 0; q < (uint32_t)np; ++q)
-                for (uint32_t j = threadIdx.x; j < B; j += 256) {
-                    const float r = lookup(q, j, q * B + j);
-                    if (!(cp.debug & 2) || r == 123.456f) run[q * B + j] = r;
-                }
-        }
+        cddt_theta_fan_group(f, cp, lp, td_f, inv_td, bin_range, thg_l, stride, p0, np, out);
+        __syncthreads();
+    }
+}
+
+
+// Search and fan of a tile of 64 poses in ONE workgroup (round 5): the four waves share the tile's table bins (wave w:
+// bins w, w + 4, ...), every look-up's two raw-bin results go straight into the LDS array the fan stage reads — R[bin][pose]
+// never exists in memory (29 MB written and read back per cfg3 step by the two-kernel form) and the fan's stores of one
+// tile overlap the searches of the tiles next to it on the same CU (29 KB of LDS per tile: five tiles per CU).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
+void cddt_theta_fused_kernel(MapParams m, FanParams f, CddtParams cp, const float *__restrict__ poses,
+                             const float4 *__restrict__ prep, float *__restrict__ out, int stride)
+{
+    extern __shared__ float bin_range[];                 // 64 x stride floats (stride: theta_disc made odd), then 64 headings
+    constexpr int TP = 64;
+    float *thg_l = bin_range + (size_t)stride * TP;
+    const int td = cp.theta_disc;
+    LutParams lp{};
+    lp.theta_disc = td;
+    lp.bins_per_rad = cp.bins_per_rad;
+    const float td_f = (float)td, inv_td = 1.0f / (float)td;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int n_tiles = (f.n_poses + TP - 1) / TP;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int p0 = tile * TP, np = min(TP, f.n_poses - p0);
+        const float4 pr = prep[min(p0 + lane, f.n_poses - 1)];
+        if (wave == 0 && lane < np) thg_l[lane] = poses[3 * (size_t)(p0 + lane) + 2] + m.wa;
+        for (int t = wave; t < cp.n_bins; t += 4)
+            cddt_theta_search_bin(m, f, cp, pr, p0, t,
+                                  [&](int bin, int pose, float v) { bin_range[(pose - p0) * stride + bin] = v; });
+        __syncthreads();
+        cddt_theta_fan_group(f, cp, lp, td_f, inv_td, bin_range, thg_l, stride, p0, np, out);
         __syncthreads();
     }
 }

@@ -90,7 +90,7 @@ inline rl_plan_opts sanitized(rl_plan_opts o)
     o.cddt_bins = o.cddt_bins != 0;
     o.cddt_sort = o.cddt_sort != 0;
     o.cddt_theta_min = clampi(o.cddt_theta_min, 0, 1 << 30);
-    o.cddt_search = o.cddt_search != 0;
+    o.cddt_search = clampi(o.cddt_search, 0, 2);
     o.slice_log2 = clampi(o.slice_log2, 8, 30);
     return o;
 }
@@ -199,6 +199,18 @@ inline int plan_one(const In &in, rl_launch_plan *p)
             //  generations level the end: cfg3 341 -> 364 Grays/s serial, ~350 -> 382-405 with four launches in
             //  flight; 4 and 16 generations are 2-4 % behind: profiles/r04/cddt_grid_sweep.txt)
             // (a unit of work = one table bin x 128 poses; 256 poses with the round-5 search kernel, whose waves take 64 each)
+            if (o.cddt_search == 2 && (((in.theta_disc | 1) + 1) * 64 * (int)sizeof(float)) <= 65536) {
+                // search + fan fused: a workgroup owns a tile of 64 poses, its per-bin results live in LDS only
+                // ((theta_disc | 1) + 1) x 64 floats: 29 KB at theta_disc 112 -> five tiles per CU)
+                p->ch = 6;
+                p->nl = in.theta_disc | 1;
+                p->lds_bytes = (p->nl + 1) * 64 * (int)sizeof(float);
+                const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(p->lds_bytes, 1)));
+                p->grid = (int)std::max(1L, std::min((long)(n_poses + 63) / 64, (long)n_cu * per_cu));
+                p->bands = 1;
+                std::snprintf(p->name, sizeof p->name, "scan::cddt_theta_fused_kernel");
+                return RL_OK;
+            }
             const int unit_poses = o.cddt_search ? 256 : 128;
             p->grid = (int)std::max(1L, std::min((long)((in.theta_disc + 1) / 2) * ((n_poses + unit_poses - 1) / unit_poses), (long)n_cu * 64));
             p->bands = (p->grid >= o.xcd_bands && (in.theta_disc + 1) / 2 >= o.xcd_bands) ? std::max(o.xcd_bands, 1) : 1;

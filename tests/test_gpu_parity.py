@@ -937,12 +937,16 @@ def test_cddt_fan_searches_only_the_bins_the_fan_touches(oracle_mod):
             assert np.array_equal(out, want), (td, fov, B)
             if td <= B:                                   # the theta-major pair of kernels on the same fans
                 m.set_option("cddt_theta_min", 1)
-                for search in (1, 0):                     # round 5's search kernel (look-ups prepared once per pose) and round 4's
+                # round 5's search kernel (look-ups prepared once per pose), round 4's, and search + fan fused per 64-pose tile
+                for search in (1, 0, 2):
                     m.set_option("cddt_search", search)
                     out[:] = -1.0
                     m.calc_range_fan(poses, out, fov, B)
                     assert m.last_plan()["kernel"] == "cddt_theta"
-                    assert m.last_plan()["name"] == ("scan::cddt_theta_search2_kernel" if search else "scan::cddt_theta_search_kernel")
+                    # (the fused form needs its tile's (theta_disc | 1) + 1 rows of 64 floats in 64 KiB of LDS)
+                    fits = ((td | 1) + 1) * 256 <= 65536
+                    assert m.last_plan()["name"] == ("scan::cddt_theta_search_kernel", "scan::cddt_theta_search2_kernel",
+                                                     "scan::cddt_theta_fused_kernel" if fits else "scan::cddt_theta_search2_kernel")[search]
                     assert np.array_equal(out, want), ("theta-major", search, td, fov, B)
                 m.set_option("cddt_search", 1)
                 m.set_option("cddt_theta_min", 32768)
@@ -975,7 +979,7 @@ def test_cddt_long_walls_fill_large_buckets(oracle_mod, lds_sort):
             assert np.array_equal(out, want), (td, bins)
         m.set_option("cddt_bins", 1)
         m.set_option("cddt_theta_min", 1)                 # theta-major (buckets beyond 1024 values: several separator lines)
-        for search in (1, 0):
+        for search in (1, 0, 2):
             m.set_option("cddt_search", search)
             out = np.empty(len(poses) * 1081, np.float32)
             m.calc_range_fan(poses, out, 4.71, 1081)
@@ -1734,6 +1738,10 @@ def test_cfg3_cddt_full_size(oracle_mod):
     old = np.empty_like(out)
     m.calc_range_fan(poses, old, w.fov, B)
     assert m.last_plan()["name"] == "scan::cddt_theta_search_kernel" and np.array_equal(old, out)
+    m.set_option("cddt_search", 2)                                    # search + fan fused per tile of 64 poses
+    old[:] = -1.0
+    m.calc_range_fan(poses, old, w.fov, B)
+    assert m.last_plan()["name"] == "scan::cddt_theta_fused_kernel" and np.array_equal(old, out)
     del old
     m.set_option("cddt_search", 1)
     m.set_option("cddt_theta_min", 0)                                 # the pose-major kernel on the same batch

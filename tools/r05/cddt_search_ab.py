@@ -19,7 +19,7 @@ for td in (112, 108):
     m.set_option("cddt_search", 0)
     m.calc_range_fan_device(d_p.data_ptr(), n, w.fov, B, d_ref.data_ptr()); torch.cuda.synchronize()
     m.set_option("timing", 1)
-    for search in (0, 1, 0, 1):
+    for search in (0, 1, 2, 1, 2):
         m.set_option("cddt_search", search)
         d_o.fill_(-1.0)
         ks = []
