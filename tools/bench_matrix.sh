@@ -3,7 +3,7 @@
 TAG=${1:-bench_matrix}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-run() { name=$1; shift; python bench.py --no-cpu-baseline "$@" > $OUT/$name.json 2> $OUT/$name.err || echo "FAILED $name"; tail -c 400 $OUT/$name.err | grep -i -E "error|Traceback" ; }
+run() { name=$1; shift; python bench.py --no-cpu-baseline --no-other-configs "$@" > $OUT/$name.json 2> $OUT/$name.err || echo "FAILED $name"; tail -c 400 $OUT/$name.err | grep -i -E "error|Traceback" ; }
 run cfg2_default
 run cfg2_steps20 --steps 20 --warmup 5
 run cfg2_serial --pipeline 1
