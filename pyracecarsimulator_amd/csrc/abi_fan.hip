@@ -209,7 +209,6 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "cddt_search")) h->cddt_search = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (!strcmp(name, "cddt_sort")) h->cddt_sort = value != 0;
     else if (!strcmp(name, "cddt_theta_min")) h->cddt_theta_min = value < 0 ? 0 : value;
-    else if (!strcmp(name, "pool")) h->band_pool = value < 0 ? 0 : value > 90 ? 90 : value;
     else if (!strcmp(name, "cddt_lds_sort")) {
         int v = 128;                                   // a power of two in [128, CDDT_LDS_SORT]: the bitonic network pads to one
         while (v * 2 <= value && v * 2 <= (int)CDDT_LDS_SORT) v *= 2;
@@ -270,7 +269,6 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "cddt_search")) *value_out = h->cddt_search;
     else if (!strcmp(name, "cddt_sort")) *value_out = h->cddt_sort;
     else if (!strcmp(name, "cddt_theta_min")) *value_out = h->cddt_theta_min;
-    else if (!strcmp(name, "pool")) *value_out = h->band_pool;
     else if (!strcmp(name, "cddt_lds_sort")) *value_out = h->cddt_lds_sort;
     else if (!strcmp(name, "map_epoch")) *value_out = (int64_t)h->map->epoch;
     else return fail(RL_ERR_INVALID, "unknown info '%s'", name);
@@ -1121,14 +1119,6 @@ static int launch_rm_stream_family(const FanLaunch &L)
         sp.left_cnt = (uint32_t *)cx->left_cnt.p;
         sp.left_cap_log2 = cap_log2;
         sp.drain_cap = std::min(sp.drain_cap, 1 << cap_log2);
-    }
-    // band pool (two rays per lane, records derived in LDS): the band counters start at zero
-    if (h->band_pool > 0 && pl.record_source != 0 && pl.slots == 2 && pl.tiled && !aux && !h->debug_stamps && pl.bands <= 64) {
-        const size_t ctr_bytes = (size_t)pl.bands * 32 * sizeof(uint32_t);
-        if ((rc = cx->pool_ctr.ensure(ctr_bytes))) return rc;
-        HIPCHK(hipMemsetAsync(cx->pool_ctr.p, 0, ctr_bytes, stream));
-        sp.pool_ctr = (uint32_t *)cx->pool_ctr.p;
-        sp.pool_pct = h->band_pool;
     }
     if (h->timing == 2) HIPCHK(hipEventRecord(h->ev0, stream));   // march kernel(s) alone
     if ((rc = dispatch_rm_stream(pl, stream, pm, f, sp, d_out, d_hits, d_steps, cp))) return rc;

@@ -132,11 +132,10 @@ struct LaunchCtx {
     uint64_t last_use = 0;
     DevBuf rec, rec_sorted, order, keys, hist, pose_first, dbg, d0, cddt_r;   // cddt_r: theta-major CDDT, R[raw bin][pose]
     DevBuf left_rec, left_cnt;     // hand-off march: the leftover list (rm_leftover_kernel), one region per wave of the main grid
-    DevBuf pool_ctr;               // band pool: one claim counter per XCD band, 128 B apart (zeroed in front of every pooled launch)
     int crash_epoch = 0;           // mark value of the last per-pose crash launch (pose_marks)
     void release()
     {
-        for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg, &d0, &cddt_r, &left_rec, &left_cnt, &pool_ctr}) b->release();
+        for (DevBuf *b : {&rec, &rec_sorted, &order, &keys, &hist, &pose_first, &dbg, &d0, &cddt_r, &left_rec, &left_cnt}) b->release();
     }
 };
 constexpr int N_LAUNCH_CTX = 8;      // (HIP's default 4 hardware queues carry 4 concurrent streams; GPU_MAX_HW_QUEUES=8 carries 8)
@@ -280,8 +279,6 @@ struct rl_method {
     int drain_cap = 64;          // several rays per lane: compact a wave's last rays into one slot from <= this many (<= 64)
     int drain_stretch = 8;       //   ... plain samples between two speculation attempts of the compacted rays
     int group_drain = 0;         //   ... and from 2 N / N live rays down 2 / 4 lanes per ray, 8 / 16 samples per round trip (N <= 16; 0: off)
-    int band_pool = 0;           // two rays per lane, LDS records: this share (percent) of a band's blocks is not split among the band's
-                                 // workgroups but claimed by whichever wave runs dry first (0: static split only)
     int handoff = 0;             // several rays per lane, 1: a dry wave hands its last <= handoff_cap rays to rm_leftover_kernel (the
                                  // next launch on the stream) instead of draining them in place (0: drain in place)
     int handoff_cap = 16;        //   ... rays per wave handed over (8, 16, 32 or 64)

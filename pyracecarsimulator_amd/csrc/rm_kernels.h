@@ -1317,16 +1317,7 @@ struct StreamParams {
     LeftoverRec *left_rec;
     uint32_t *left_cnt;
     int left_cap_log2;
-    // INLINE, two rays per lane, BAND POOL (round 5): the workgroups of a band split only the first (100 - pool_pct) % of
-    // the band's runs statically; the rest is claimed, POOL_UNIT blocks at a time, by whichever WAVE has run out of work
-    // (one device-scope atomic on the band's counter per claim, the claiming wave derives the unit's block records into
-    // its own LDS scratch): a lone launch no longer ends with its unluckiest workgroup (static split: max / mean 1.2).
-    // pool_ctr: one counter per band, 32 words apart, zero at launch; nullptr: static split only.
-    uint32_t *pool_ctr;
-    int pool_pct;
 };
-
-constexpr uint32_t POOL_UNIT_LOG2 = 2;         // blocks per pool claim: 4 (256 rays; a returning atomic per claim: 292 ns idle, 88 per us and line)
 
 
 // ------------------------------------------------------------------------------
@@ -1517,43 +1508,12 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     const uint32_t seg_chunks = INLINE ? (seg_hi - seg_lo) * sp.cpp : (seg_rays + 63u) >> 6;
     const uint32_t rl = (uint32_t)sp.run_log2, rmask = (1u << rl) - 1u;
     const uint32_t seg_runs = (seg_chunks + rmask) >> rl;
-    // band pool: every workgroup takes the same number of whole rounds statically, the blocks from pool_b0 on are claimed
-    // by waves that ran dry (only bands with at least four full rounds)
-    constexpr bool POOL = INLINE && SLOTS == 2 && TILED && !AUX;
-    uint32_t pool_b0 = 0xffffffffu;                  // first block of the band's pool (none)
-    uint32_t K = (g < seg_runs ? (seg_runs - g + G - 1) / G : 0) << rl;
-    if (POOL && sp.pool_ctr && seg_runs / G >= 4u) {
-        const uint32_t rounds = max(1u, (seg_runs / G) * (uint32_t)(100 - sp.pool_pct) / 100u);
-        K = rounds << rl;
-        pool_b0 = (rounds * G) << rl;
-    }
+    const uint32_t K = (g < seg_runs ? (seg_runs - g + G - 1) / G : 0) << rl;
     const uint32_t total = K << 6;
     // i-th block of this workgroup's stream -> its index in the band / first ray of the block
     auto blkidx_of = [&](uint32_t i) { return ((g + (i >> rl) * G) << rl) + (i & rmask); };
     auto blk_of = [&](uint32_t i) { return blkidx_of(i) << 6; };
     const unsigned lane = threadIdx.x & 63;
-    // INLINE: the record of block b of the band (prologue: the workgroup's own blocks; band pool: a claimed unit's)
-    auto make_rec = [&](uint32_t b) {
-        BlockRec br{0.0f, 0.0f, 1.0f, 0.0f, PDT_NO_RAY, 0u, 0u, 0u};
-        if (INLINE && b < seg_chunks) {
-            const MapParams mp = *sp.map;
-            const uint32_t *list = reinterpret_cast<const uint32_t *>(lrec + sp.k_max);     // (stripe mode, below)
-            const uint32_t p0 = fast_div(b, sp.div_cpp);
-            const uint32_t j0 = (b - p0 * sp.cpp) << 6;
-            const uint32_t nvalid = min(64u, (uint32_t)f.num_rays - j0);
-            const uint32_t pid = sp.stripe == 1 ? list[p0]
-                               : sp.stripe == 2 ? (sp.order[seg_lo + p0] & ~POSE_INVALID) : seg_lo + p0;
-            PoseRec r;
-            const uint32_t kf = LIT ? pose_record_lit(mp, sp.lit, sp.raw_poses, (int)pid, r)
-                                    : pose_record(mp, sp.raw_poses, (int)pid, 0, 1, 1, r);
-            br.gx = r.gx; br.gy = r.gy; br.ct = r.ct; br.st = r.st;
-            br.d0 = pose_first_step(mp, r.gx, r.gy, kf, f.step_coeff);
-            br.obase = (pid * (uint32_t)f.num_rays + j0) << 2;
-            br.j0nv = j0 | (nvalid << 16);
-            br.pose = pid;
-        }
-        return br;
-    };
     if (INLINE) {
         // no binning launch (or a keys-only one) in front of the march — each workgroup turns the poses
         // of its own blocks into records (a few hundred, one per lane) and keeps them in LDS
@@ -1564,7 +1524,23 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
             stripe_band_list<NT>(mp, sp.raw_poses, f.n_poses, seg_lo, seg_hi, list,
                                  reinterpret_cast<int *>(list + (seg_hi - seg_lo) + 1));
         for (uint32_t i = threadIdx.x; i < K; i += NT) {
-            const BlockRec br = make_rec(blkidx_of(i));
+            const uint32_t b = blkidx_of(i);
+            BlockRec br{0.0f, 0.0f, 1.0f, 0.0f, PDT_NO_RAY, 0u, 0u, 0u};
+            if (b < seg_chunks) {
+                const uint32_t p0 = fast_div(b, sp.div_cpp);
+                const uint32_t j0 = (b - p0 * sp.cpp) << 6;
+                const uint32_t nvalid = min(64u, (uint32_t)f.num_rays - j0);
+                const uint32_t pid = sp.stripe == 1 ? list[p0]
+                                   : sp.stripe == 2 ? (sp.order[seg_lo + p0] & ~POSE_INVALID) : seg_lo + p0;
+                PoseRec r;
+                const uint32_t kf = LIT ? pose_record_lit(mp, sp.lit, sp.raw_poses, (int)pid, r)
+                                        : pose_record(mp, sp.raw_poses, (int)pid, 0, 1, 1, r);
+                br.gx = r.gx; br.gy = r.gy; br.ct = r.ct; br.st = r.st;
+                br.d0 = pose_first_step(mp, r.gx, r.gy, kf, f.step_coeff);
+                br.obase = (pid * (uint32_t)f.num_rays + j0) << 2;
+                br.j0nv = j0 | (nvalid << 16);
+                br.pose = pid;
+            }
             lrec[i] = br;
         }
     }
@@ -1586,12 +1562,12 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     };
     // ray slot q of this workgroup's stream -> the lane's slot state; false: a padding slot (no ray).
     // s.oidx is the BYTE offset of the ray's range in `out` (the store needs no shift).
-    auto claim = [&](Slot &s, uint32_t q, const BlockRec *recs) -> bool {
+    auto claim = [&](Slot &s, uint32_t q) -> bool {
         if (INLINE) {
             // everything is read before validity is known (one LDS round trip, not two): a padding slot of
             // a pose's last block becomes a slot without a ray — t past max_range, oidx NO_RAY — whose other
             // fields are never looked at (its beam index may point past the fan table: LDS reads are harmless)
-            const uint4 *rp = reinterpret_cast<const uint4 *>(recs + (q >> 6));
+            const uint4 *rp = reinterpret_cast<const uint4 *>(lrec + (q >> 6));
             const uint4 ra = rp[0], rb = rp[1];
             const uint32_t l = q & 63u;
             const bool valid = l < (rb.z >> 16);
@@ -1660,11 +1636,6 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         Slot sa{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, NO_RAY, 0u, 0}, sb = sa, sc = sa;
         bool exhausted = total == 0;
         uint32_t left_n = 0;              // rays this wave hands to rm_leftover_kernel
-        // band pool: this wave's current unit (block records in the wave's own drain scratch, which nothing else uses before
-        // the pool is empty) — wq of its wtotal ray slots handed out
-        bool pool_live = POOL && pool_b0 != 0xffffffffu;
-        uint32_t wq = 0, wtotal = 0;
-        BlockRec *wrec = reinterpret_cast<BlockRec *>(drain_scr);
         auto finish = [&](Slot &s) {
             float r = f.max_range;
             if (s.d_last == PDT_HIT) {
@@ -1704,48 +1675,22 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)idle_a, 0u));
                     const uint32_t qbb = qb + cnt_a + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_b >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)idle_b, 0u));
-                    if (mine_a && qa < total) claim(sa, qa, lrec);
-                    if (mine_b && qbb < total) claim(sb, qbb, lrec);
+                    if (mine_a && qa < total) claim(sa, qa);
+                    if (mine_b && qbb < total) claim(sb, qbb);
                     if (SLOTS == 3) {
                         const uint32_t qc = qb + cnt_a + cnt_b + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_c >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)idle_c, 0u));
-                        if (mine_c && qc < total) claim(sc, qc, lrec);
-                    }
-                } else if (POOL && pool_live) {       // wave-uniform: the workgroup's stream is dry, the band's pool is not
-                    if (wq >= wtotal) {
-                        uint32_t u = 0;
-                        if (lane == 0) u = atomicAdd(sp.pool_ctr + (band << 5), 1u);
-                        u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
-                        const uint32_t b0 = pool_b0 + (u << POOL_UNIT_LOG2);
-                        if (b0 >= seg_chunks) {
-                            pool_live = false;
-                        } else {
-                            if (lane < (1u << POOL_UNIT_LOG2)) wrec[lane] = make_rec(b0 + lane);
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: LDS operations complete in order)
-                            wq = 0;
-                            wtotal = 64u << POOL_UNIT_LOG2;
-                        }
-                    }
-                    if (pool_live) {
-                        const uint32_t cnt_a = (uint32_t)__popcll(idle_a), cnt_b = (uint32_t)__popcll(idle_b);
-                        const uint32_t qa = wq + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_a >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)idle_a, 0u));
-                        const uint32_t qbb = wq + cnt_a + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_b >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)idle_b, 0u));
-                        if (mine_a && qa < wtotal) claim(sa, qa, wrec);
-                        if (mine_b && qbb < wtotal) claim(sb, qbb, wrec);
-                        wq += cnt_a + cnt_b;
+                        if (mine_c && qc < total) claim(sc, qc);
                     }
                 }
             }
-            const bool dry = exhausted && !(POOL && pool_live);      // nothing left to claim anywhere: drain, then leave
-            if (dry && !__ballot(sa.t < f.max_range) && !__ballot(sb.t < f.max_range) &&
+            if (exhausted && !__ballot(sa.t < f.max_range) && !__ballot(sb.t < f.max_range) &&
                 !__ballot(sa.oidx != NO_RAY) && !__ballot(sb.oidx != NO_RAY) &&
                 (SLOTS < 3 || (!__ballot(sc.t < f.max_range) && !__ballot(sc.oidx != NO_RAY))))
                 break;
-            if (sp.dbg && dry && !t_drain) t_drain = wall_clock64();
+            if (sp.dbg && exhausted && !t_drain) t_drain = wall_clock64();
             if constexpr (TILED) {
-                if (dry && sp.spec_drain > 0) {
+                if (exhausted && sp.spec_drain > 0) {
                     // drain phase.  (Every idle slot has been finished by the service above: what is live below is
                     // all this wave still owes.)
                     const unsigned long long la = __ballot(sa.t < f.max_range), lb = __ballot(sb.t < f.max_range);
@@ -1894,11 +1839,11 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 march_loop3<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
                             sb.t, sb.pc, sb.pr, sb.d_last, sc.dx, sc.dy, sc.gx, sc.gy, sc.t, sc.pc, sc.pr, sc.d_last,
                             pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
-                            dry ? 0u : 3u * (uint32_t)sp.low_water);
+                            exhausted ? 0u : 3u * (uint32_t)sp.low_water);
             else
                 march_loop2<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
                             sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
-                            dry ? 0u : 2u * (uint32_t)sp.low_water);
+                            exhausted ? 0u : 2u * (uint32_t)sp.low_water);
         }
         // (every wave of the grid writes its count, 0 included: the list needs no clearing between launches)
         if (sp.left_cnt && lane == 0) sp.left_cnt[(size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)] = left_n;
@@ -1965,7 +1910,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 exhausted = qb + cnt >= total;
                 const uint32_t q = qb + rank;
                 if (mine && q < total) {
-                    const bool got = claim(s1, q, lrec);
+                    const bool got = claim(s1, q);
                     // (branch-free: a branch on `got` would split the claim's LDS reads into dependent trips)
                     if (AUX) nstep = got ? ((s1.t > 0.0f && s1.t < PDT_NO_RAY) ? 1u : 0u) : nstep;
                 }

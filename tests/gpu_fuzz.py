@@ -78,7 +78,7 @@ def one_case(seed):
                                  "slots": int(r.choice([1, 2, 3])), "spec_drain": int(r.choice([0, 8, 64])),
                                  "spec_stretch": int(r.choice([1, 4, 16])), "drain_cap": int(r.choice([1, 24, 64])),
                                  "drain_stretch": int(r.choice([1, 8])), "handoff": int(r.integers(0, 2)), "group_drain": int(r.choice([0, 2, 16])),
-                                 "handoff_cap": int(r.choice([8, 16, 32, 64])), "handoff_wg": int(r.choice([64, 128, 256])), "pool": int(r.choice([0, 0, 15, 50, 90]))}
+                                 "handoff_cap": int(r.choice([8, 16, 32, 64])), "handoff_wg": int(r.choice([64, 128, 256]))}
                         if os.environ.get("FUZZ_NO_GROUP"):
                             sched["group_drain"] = 0
                         if os.environ.get("FUZZ_NO_HANDOFF"):

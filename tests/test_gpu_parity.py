@@ -84,11 +84,6 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "slots": 2, "handoff": 1, "handoff_cap": 8, "handoff_wg": 64, "inline_map_kb": 0, "stripe_max": 0},
     {"variant": 1, "slots": 2, "handoff": 1, "handoff_cap": 64, "inline_prep": 0, "grid_mult": 2},
     {"variant": 1, "slots": 3, "handoff": 1, "handoff_cap": 32, "handoff_wg": 128},
-    {"variant": 1, "slots": 2, "pool": 15},                     # band pool: 15 % of a band's blocks claimed by whichever wave runs dry
-    {"variant": 1, "slots": 2, "pool": 50, "grid_mult": 2},
-    {"variant": 1, "slots": 2, "pool": 90, "run_log2": 0, "xcd_bands": 3},
-    {"variant": 1, "slots": 2, "pool": 25, "inline_map_kb": 0, "stripe_max": 0},   # ... behind the keys-only binning launch
-    {"variant": 1, "slots": 2, "pool": 25, "group_drain": 8, "low_water": 40},
 ])
 def test_every_kernel_schedule_is_bit_identical(oracle_mod, opts):
     g = maps.make_maze(400, cell=40, wall=3, p=0.45, seed=21, origin=(-7.0, 3.0, -0.4))
@@ -345,8 +340,7 @@ def test_upstream_literal_mode_in_production_shape(oracle_mod):
         m = cls(omap, mrx)
         m.set_option("variant", 3)
         for n, opts in ((200, {}), (600, {"slots": 2}), (600, {"slots": 2, "group_drain": 8}), (1000, {"slots": 1}),
-                        (1000, {"slots": 2, "inline_map_kb": 0, "stripe_max": 0}), (1000, {"slots": 2, "grid_mult": 3}),
-                        (1000, {"slots": 2, "pool": 40, "grid_mult": 2})):
+                        (1000, {"slots": 2, "inline_map_kb": 0, "stripe_max": 0}), (1000, {"slots": 2, "grid_mult": 3})):
             for k, v in opts.items():
                 m.set_option(k, v)
             poses = np.ascontiguousarray(all_poses[:n])
