@@ -105,6 +105,8 @@ def lib():
         L.orc_rm_rays_libm.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, _f32p, _i32p, _u16p]
         L.orc_rm_fan_libm.argtypes = [mp, _f32p, C.c_float, C.c_float, _f32p, C.c_int, C.c_float, C.c_int,
                                       _f32p, _i32p, _u16p]
+        L.orc_bl_rays_libm.argtypes = [mp, C.c_float, _f32p, C.c_int, _f32p, _i32p, _u16p]
+        L.orc_bl_fan_libm.argtypes = [mp, C.c_float, _f32p, C.c_int, C.c_float, C.c_int, _f32p, _i32p, _u16p]
         L.orc_libm_sincosf.argtypes = [_f32p, C.c_long, _f32p, _f32p]
         L.orc_lit_sincosf.argtypes = [_f32p, C.c_long, _f32p, _f32p]
         L.orc_libm_restatement_check.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_long), C.c_int]
@@ -250,6 +252,28 @@ class OracleMap:
         return ranges, hits, steps
 
     # -- BresenhamsLine ----------------------------------------------------
+    def bl_rays_libm(self, ins):
+        """Upstream-literal BresenhamsLine (libm trig, un-fused end point and hit distance) -> ranges, hit cells (col, row), steps."""
+        ins = np.ascontiguousarray(ins, dtype=np.float32).reshape(-1, 3)
+        n = ins.shape[0]
+        ranges = np.empty(n, dtype=np.float32)
+        hits = np.empty((n, 2), dtype=np.int32)
+        steps = np.empty(n, dtype=np.uint16)
+        lib().orc_bl_rays_libm(C.byref(self._m), self.max_range_px, _p(ins, _f32p), n, _p(ranges, _f32p), _p(hits, _i32p),
+                               _p(steps, _u16p))
+        return ranges, hits, steps
+
+    def bl_fan_libm(self, poses, fov, num_rays):
+        """The 4-argument fan of the upstream-literal BresenhamsLine: one cast per beam at theta + (-fov/2 + j*fov/B)."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        n = poses.shape[0] * num_rays
+        ranges = np.empty(n, dtype=np.float32)
+        hits = np.empty((n, 2), dtype=np.int32)
+        steps = np.empty(n, dtype=np.uint16)
+        lib().orc_bl_fan_libm(C.byref(self._m), self.max_range_px, _p(poses, _f32p), poses.shape[0], fov, num_rays,
+                              _p(ranges, _f32p), _p(hits, _i32p), _p(steps, _u16p))
+        return ranges, hits, steps
+
     def bl_fan(self, poses, fov, num_rays, nthreads=1, native=False):
         poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
         n = poses.shape[0] * num_rays

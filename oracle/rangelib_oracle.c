@@ -583,6 +583,107 @@ void orc_bl_rays(const orc_map *m, float max_range_px,
     }
 }
 
+/* Upstream-literal form of BresenhamsLine (RangeMethod::numpy_calc_range + BresenhamsLine::calc_range, row a12 /
+ * Appendix A), with the conventions of rm_cast_libm above: theta' = -theta_w + (-world_angle - 3pi/2),
+ * calc_range(y, x, theta') — the first coordinate indexes rows —, end point x0 + max_range * cosf(theta'),
+ * y0 + max_range * sinf(theta') with libm trig, every product and sum its own float32 rounding, hit distance
+ * sqrtf(xd * xd + yd * yd).  PARITY UNPINNED (range_libc is absent): the closest available statement of upstream's
+ * arithmetic; the canonical orc_bl_* forms are gated against it (tests/golden/table_libm_forms.npz,
+ * tests/test_gpu_parity.py::test_device_tables_vs_upstream_literal_libm_forms).  hit = (col, row) or (-1, -1).      */
+static float bl_cast_libm(const orc_map *m, float max_range, float rotation_const, float wsin, float wcos,
+                          float xw, float yw, float thw, int32_t *hit, uint16_t *steps)
+{
+    float theta = -thw + rotation_const;
+    float x = (xw - m->ox) * m->inv_res;
+    float y = (yw - m->oy) * m->inv_res;
+    float temp = x;
+    x = wcos * x - wsin * y;
+    y = wsin * temp + wcos * y;
+    /* calc_range(y, x, theta): first coordinate indexes rows */
+    const float r0 = y, c0 = x;
+    const float frows = (float)m->rows, fcols = (float)m->cols;
+    int hc = -1, hr = -1;
+    unsigned n = 0;
+    float out = max_range;
+    const int sane = fabsf(r0) < 1e9f && fabsf(c0) < 1e9f && (theta - theta) == 0.0f;
+    if (!sane) {
+        /* miss, no steps (upstream's (int) conversions are undefined there) */
+    } else if (r0 > -1.0f && r0 < frows && c0 > -1.0f && c0 < fcols && m->occ[(size_t)(int)r0 * m->cols + (int)c0]) {
+        out = 0.0f;
+        hc = (int)c0;
+        hr = (int)r0;
+    } else {
+        volatile float mx = max_range * cosf(theta), my = max_range * sinf(theta);   /* (volatile: product and sum apart) */
+        float x0 = r0, y0 = c0;                  /* upstream's names: x walks rows, y walks columns */
+        float x1 = x0 + mx, y1 = y0 + my;
+        const int steep = fabsf(y1 - y0) > fabsf(x1 - x0);
+        if (steep) {
+            float tmp = x0; x0 = y0; y0 = tmp;
+            tmp = x1; x1 = y1; y1 = tmp;
+        }
+        const float lim_major = steep ? fcols : frows;
+        const float lim_minor = steep ? frows : fcols;
+        const float deltax = fabsf(x1 - x0), deltay = fabsf(y1 - y0);
+        float error = 0.0f;
+        float _x = x0, _y = y0;
+        const float xstep = x0 < x1 ? 1.0f : -1.0f;
+        const float ystep = y0 < y1 ? 1.0f : -1.0f;
+        const int end = (int)(x1 + xstep);
+        int cap = (int)max_range + 3;
+        while ((int)_x != end && cap-- > 0) {
+            _x += xstep;
+            error += deltay;
+            if (error * 2.0f >= deltax) {
+                _y += ystep;
+                error -= deltax;
+            }
+            ++n;
+            if (_x >= 0.0f && _x < lim_major && _y >= 0.0f && _y < lim_minor) {
+                const int row = steep ? (int)_y : (int)_x;
+                const int col = steep ? (int)_x : (int)_y;
+                if (m->occ[(size_t)row * m->cols + col]) {
+                    volatile float xx = (_x - x0) * (_x - x0), yy = (_y - y0) * (_y - y0);
+                    out = sqrtf(xx + yy);
+                    hc = col;
+                    hr = row;
+                    break;
+                }
+            }
+        }
+    }
+    if (hit) { hit[0] = hc; hit[1] = hr; }
+    if (steps) *steps = (uint16_t)n;
+    return out * m->res;
+}
+
+void orc_bl_rays_libm(const orc_map *m, float max_range_px, const float *ins, int n, float *ranges, int32_t *hits,
+                      uint16_t *steps)
+{
+    float rotation_const = (float)(-1.0 * (double)m->wa - 3.0 * M_PI / 2.0);
+    float wsin = (float)sin((double)m->wa), wcos = (float)cos((double)m->wa);
+    for (int i = 0; i < n; ++i)
+        ranges[i] = bl_cast_libm(m, max_range_px, rotation_const, wsin, wcos, ins[3 * i], ins[3 * i + 1], ins[3 * i + 2],
+                                 hits ? hits + 2 * (size_t)i : NULL, steps ? steps + i : NULL);
+}
+
+/* the 4-argument fan form, beam j of pose p at theta_p + (-fov/2 + j * (fov / num_rays)) rounded to float32 (as
+ * orc_rm_fan_libm) */
+void orc_bl_fan_libm(const orc_map *m, float max_range_px, const float *poses, int n_poses, float fov, int num_rays,
+                     float *ranges, int32_t *hits, uint16_t *steps)
+{
+    float rotation_const = (float)(-1.0 * (double)m->wa - 3.0 * M_PI / 2.0);
+    float wsin = (float)sin((double)m->wa), wcos = (float)cos((double)m->wa);
+    const float amin = -0.5f * fov, inc = fov / (float)num_rays;
+    for (int p = 0; p < n_poses; ++p)
+        for (int j = 0; j < num_rays; ++j) {
+            const size_t i = (size_t)p * num_rays + j;
+            volatile float aj = (float)j * inc;
+            const float th = poses[3 * p + 2] + (amin + aj);
+            ranges[i] = bl_cast_libm(m, max_range_px, rotation_const, wsin, wcos, poses[3 * p], poses[3 * p + 1], th,
+                                     hits ? hits + 2 * i : NULL, steps ? steps + i : NULL);
+        }
+}
+
 /* ------------------------------------------------------------------------ */
 /* GiantLUTCast (row a14)                                                     */
 /* ------------------------------------------------------------------------ */

@@ -78,6 +78,11 @@ void orc_rm_fan_libm(const orc_map *m, const float *dt, float max_range_px, floa
 
 /* the host libm's sinf / cosf in bulk; the statement of glibc's algorithm the product's audit mode runs on the
  * device (csrc/literal_kernels.h); and how many float inputs the two differ on (0 on glibc >= 2.28, x86-64 + FMA) */
+/* BresenhamsLine in the upstream-literal form (libm trig, un-fused end point and hit distance; parity unpinned) */
+void orc_bl_rays_libm(const orc_map *m, float max_range_px, const float *ins, int n, float *ranges, int32_t *hits,
+                      uint16_t *steps);
+void orc_bl_fan_libm(const orc_map *m, float max_range_px, const float *poses, int n_poses, float fov, int num_rays,
+                     float *ranges, int32_t *hits, uint16_t *steps);
 void orc_libm_sincosf(const float *x, long n, float *s_out, float *c_out);
 void orc_lit_sincosf(const float *x, long n, float *s_out, float *c_out);
 long orc_libm_restatement_check(uint32_t first, uint32_t step, long *bad_cos, int nthreads);

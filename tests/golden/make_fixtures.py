@@ -339,6 +339,31 @@ def table_libm_forms(n_poses=8):
     print("table_libm_forms", os.path.getsize(os.path.join(GOLD, "table_libm_forms.npz")) // 1024, "KiB")
 
 
+def bl_libm_forms(n_poses=8):
+    """BresenhamsLine in the upstream-literal form (orc_bl_rays_libm / orc_bl_fan_libm: libm cosf / sinf of
+    theta' = -theta + rotation constant, calc_range(y, x, theta'), un-fused end point and hit distance) for the first
+    ``n_poses`` poses of every rm_*.npz: the 2-argument per-ray form on host-built float32 thetas and the 4-argument
+    fan form; ranges, hit cells, step counts.  The GPU test gates the device's canonical walk against them
+    (tests/test_gpu_parity.py::test_device_bresenham_vs_upstream_literal_libm_form).  Generated with this container's
+    glibc; the arrays are committed data."""
+    out = {}
+    for name in ("rm_colombia", "rm_maze256", "rm_maze192_yaw"):
+        z = dict(np.load(os.path.join(GOLD, name + ".npz")))
+        rows, cols = (int(v) for v in z["shape"])
+        occ = np.ascontiguousarray(np.unpackbits(z["occ_packed"], axis=1)[:, :cols].astype(np.uint8))
+        g = maps.GridMap(occ, float(z["resolution"]), tuple(float(v) for v in z["origin"]), name)
+        om = O.OracleMap.from_gridmap(g, int(z["max_range_px"]))
+        poses = np.ascontiguousarray(z["poses"][:n_poses])
+        fov, B = float(z["fov"]), int(z["num_rays"])
+        r, h, s = om.bl_rays_libm(table_ray_rows(poses, fov, B))
+        out[name + "_rays_ranges"], out[name + "_rays_hits"], out[name + "_rays_steps"] = r, h.astype(np.int16), s
+        r, h, s = om.bl_fan_libm(poses, fov, B)
+        out[name + "_fan_ranges"], out[name + "_fan_hits"], out[name + "_fan_steps"] = r, h.astype(np.int16), s
+        out[name + "_n_poses"] = np.int32(len(poses))
+    np.savez_compressed(os.path.join(GOLD, "bl_libm_forms.npz"), **out)
+    print("bl_libm_forms", os.path.getsize(os.path.join(GOLD, "bl_libm_forms.npz")) // 1024, "KiB")
+
+
 def table_ray_rows(poses, fov, B):
     """(x, y, theta) rows of the 2-argument form for the fans of ``poses``: theta = heading + the float32 np.arange
     angle row scripts/two_player/scan.py:57-62 builds on the host."""
@@ -363,6 +388,7 @@ def main():
     rm_golden("rm_maze192_yaw", g, 16, 103, mrx=120, fov=6.0, num_rays=360)
     libm_forms()
     table_libm_forms()
+    bl_libm_forms()
     followgap_ref()
 
 

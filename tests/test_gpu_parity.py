@@ -215,6 +215,46 @@ def test_device_tables_vs_upstream_literal_libm_forms():
     print("device tables vs upstream-literal libm table forms — (map, method, share of rays bit-equal, max |d| in cells):", seen)
 
 
+def test_device_bresenham_vs_upstream_literal_libm_form():
+    """BresenhamsLine against upstream's literal arithmetic (range_libc absent: PARITY UNPINNED; the closest available
+    statement is oracle/rangelib_oracle.c's orc_bl_*_libm — libm cosf / sinf of theta' = -theta + rotation constant,
+    un-fused end point and hit distance): the device walks the CANONICAL statement bit for bit (test_bresenham_*); this
+    gate pins its distance to the literal form on the committed vectors (tests/golden/bl_libm_forms.npz,
+    make_fixtures.py::bl_libm_forms), both kernels (stream and LDS window): in the fan form the same hit cell and step
+    count on every ray and every range within 1e-3 cell; in the per-ray form at most 1e-4 of the rays (one ray of a
+    small set) off by more than 1e-3 cell, none by more than 1.5 cells."""
+    L = np.load(os.path.join(GOLD, "bl_libm_forms.npz"))
+    seen = []
+    for name in ("rm_colombia", "rm_maze256", "rm_maze192_yaw"):
+        g, z = load_golden(name)
+        omap = range_libc.PyOMap(g)
+        fov, B, mrx = float(z["fov"]), int(z["num_rays"]), int(z["max_range_px"])
+        n = int(L[name + "_n_poses"])
+        poses = np.ascontiguousarray(z["poses"][:n])
+        for variant in (1, 0):
+            m = range_libc.PyBresenhamsLine(omap, mrx)
+            m.set_option("variant", variant)
+            r, h, s = _fan(m, poses, fov, B)
+            e = np.abs(r - L[name + "_fan_ranges"]) / g.resolution
+            assert np.array_equal(h, L[name + "_fan_hits"].astype(np.int32)), (name, variant, "hit cells")
+            assert np.array_equal(s, L[name + "_fan_steps"]), (name, variant, "step counts")
+            assert e.max() <= 1e-3, (name, variant, float(e.max()))
+            seen.append((name, "fan v%d" % variant, float((e == 0).mean()), float(e.max())))
+            m.close()
+        m = range_libc.PyBresenhamsLine(omap, mrx)
+        got = np.empty(n * B, np.float32)
+        m.calc_range_many(_ray_rows(poses, fov, B), got)
+        # (per-ray form: the canonical direction is det_sincosf(theta), the literal one libm cosf / sinf of
+        #  -theta + rotation constant — a walk that grazes a corner can take the neighbouring cell: 0-2 of 69 184 rays on
+        #  the CPU statements; the same gate as the ray-marching methods' _libm_gate)
+        e = np.abs(got - L[name + "_rays_ranges"]) / g.resolution
+        off = e > 1e-3
+        assert int(off.sum()) <= max(1, int(1e-4 * e.size)) and e.max() <= 1.5, (name, "2-argument form", int(off.sum()), float(e.max()))
+        seen.append((name, "rays", float((e == 0).mean()), float(e.max())))
+        m.close()
+    print("device Bresenham vs the upstream-literal libm form — (map, form, share of rays bit-equal, max |d| in cells):", seen)
+
+
 def _exact_rm_gate(err_cells, theta_disc, mean_range_cells, origin_cells, what):
     """K2 / K3 ranges "<= 1 cell vs oracle RM".  One cell is what the METHODS' conventions allow
     on most rays, not on all of them, so the gate is the distribution (recorded on bench.py's line as vs_exact_rm):

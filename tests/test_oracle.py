@@ -486,3 +486,33 @@ def test_audit_mode_trig_statement_equals_this_hosts_libm():
     assert O.libm_restatement_mismatches(first=0x3f000000, step=1 << 30) == (0, 0)      # (tiny call: argument handling)
     x = np.array([0.3, -2.0, 11.0, 119.9, 120.0, 1e7, -3e38, 0.0, 1e-40], np.float32)
     assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(O.libm_sincosf(x), O.lit_sincosf(x)))
+
+
+def test_committed_bresenham_literal_vectors_match_this_hosts_libm(oracle_mod):
+    """tests/golden/bl_libm_forms.npz — BresenhamsLine in the upstream-literal statement (libm cosf / sinf of
+    theta' = -theta + rotation constant, calc_range(y, x, theta'), un-fused end point and hit distance), 2-argument and
+    4-argument forms — recomputed on this host: equal to the committed arrays, and the CANONICAL statement (what the
+    device walks bit for bit) stays inside the gate the GPU test applies to the device: the same hit cell and step count
+    on every ray, ranges within 1e-3 cell."""
+    import os
+    from conftest import GOLD
+    L = np.load(os.path.join(GOLD, "bl_libm_forms.npz"))
+    for name in ("rm_colombia", "rm_maze256", "rm_maze192_yaw"):
+        g, z = load_golden(name)
+        om = oracle_mod.OracleMap.from_gridmap(g, int(z["max_range_px"]))
+        n = int(L[name + "_n_poses"])
+        poses, fov, B = np.ascontiguousarray(z["poses"][:n]), float(z["fov"]), int(z["num_rays"])
+        r, h, s = om.bl_fan_libm(poses, fov, B)
+        assert np.abs(r - L[name + "_fan_ranges"]).max() <= 1e-3 * g.resolution, name
+        assert np.array_equal(h, L[name + "_fan_hits"].astype(np.int32)) and np.array_equal(s, L[name + "_fan_steps"]), name
+        rc, hc, sc = om.bl_fan(poses, fov, B)
+        assert np.array_equal(hc, h) and np.array_equal(sc, s), (name, "canonical walk differs from the literal one")
+        assert np.abs(rc - r).max() <= 1e-3 * g.resolution, (name, float(np.abs(rc - r).max()))
+        ang = (np.float32(-0.5) * np.float32(fov) + np.arange(B, dtype=np.float32) * (np.float32(fov) / np.float32(B))).astype(np.float32)
+        ins = np.zeros((n * B, 3), np.float32)
+        for q in range(n):
+            ins[q * B:(q + 1) * B, :2] = poses[q, :2]
+            ins[q * B:(q + 1) * B, 2] = poses[q, 2] + ang
+        r2, h2, s2 = om.bl_rays_libm(ins)
+        assert np.abs(r2 - L[name + "_rays_ranges"]).max() <= 1e-3 * g.resolution, name
+        assert np.array_equal(h2, L[name + "_rays_hits"].astype(np.int32)) and np.array_equal(s2, L[name + "_rays_steps"]), name

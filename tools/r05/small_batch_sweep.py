@@ -18,7 +18,7 @@ for n in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,1
     m.set_option("slots", 1); m.set_option("group_drain", 0); m.set_option("timing", 0)
     m.calc_range_fan_device(d_p.data_ptr(), n, w.fov, B, d_ref.data_ptr()); torch.cuda.synchronize()
     m.set_option("timing", 2)
-    for slots, gd in ((1, 0), (2, 0), (2, 4), (2, 8), (1, 0), (2, 4)):
+    for slots, gd in ((1, 0), (2, 0), (2, 4), (2, 8), (2, 16), (2, 0), (2, 8)):
         m.set_option("slots", slots); m.set_option("group_drain", gd)
         ks = []
         for _ in range(80):
