@@ -97,6 +97,9 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed output verification (tuning sweeps)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the same-batch figure, the end-to-end host latencies and the gather-rate probe")
+    ap.add_argument("--theta-disc", type=int, default=0,
+                    help="CDDT / GiantLUT: theta_disc of the table (default: the workload's; CDDT 108 — the reference's "
+                         "two-player CDDT uses 112, which the driver line's other_configs leg times)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short verified side legs (cfg3 GiantLUT / CDDT, cfg2 crash / steer, a cfg5 shard) that "
                          "the default 1-GPU cfg2 run appends to its line as `other_configs`")
@@ -144,7 +147,12 @@ def make_method(range_libc, omap, w, method):
     raise SystemExit("unknown method %r" % method)
 
 
+_THETA_OVERRIDE = 0          # --theta-disc N (CDDT / GiantLUT): the table's angular resolution instead of the workload's
+
+
 def theta_disc_of(w, method):
+    if _THETA_OVERRIDE and method in ("CDDT", "GLT"):
+        return _THETA_OVERRIDE
     # CDDT: 108 ~ the two-player game's 112 (scripts/two_player/rcs_two_player.py:121) on an even bin count
     # per quadrant; GiantLUT: bin spacing = beam spacing
     if method == "CDDT":
@@ -288,6 +296,8 @@ def pmc_entry(workload, method, n, plan):
 
 def main():
     a = parse_args()
+    global _THETA_OVERRIDE
+    _THETA_OVERRIDE = max(0, a.theta_disc)
     for kv in list(a.opt):                       # (`--opt variant=3` is `--variant 3`: the checker's statement follows it)
         if kv.startswith("variant="):
             a.variant = int(kv.split("=")[1])

@@ -35,11 +35,11 @@ def error_stats_cells(got_m, want_m, resolution):
 LEGS = (
     # name, workload, method, theta_disc, poses, pipeline, reduce, steps, bursts
     ("cfg3_glt", "cfg3", "GLT", 1442, 65536, 1, None, 8, 5),
-    ("cfg3_cddt", "cfg3", "CDDT", 112, 65536, 4, None, 24, 5),
-    ("cfg3_cddt_theta108", "cfg3", "CDDT", 108, 65536, 4, None, 24, 5),
+    ("cfg3_cddt", "cfg3", "CDDT", 112, 65536, 4, None, 64, 5),
+    ("cfg3_cddt_theta108", "cfg3", "CDDT", 108, 65536, 4, None, 64, 5),
     ("cfg2_crash", "cfg2", "RMGPU", 0, 4096, 4, "crash", 80, 7),
     ("cfg2_steer", "cfg2", "RMGPU", 0, 4096, 4, "steer", 80, 7),
-    ("cfg5_shard", "cfg5", "RMGPU", 0, 32768, 4, None, 24, 5),
+    ("cfg5_shard", "cfg5", "RMGPU", 0, 32768, 4, None, 40, 5),
 )
 
 
