@@ -12,8 +12,12 @@ def run(seconds, seed):
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
     n_cases = 0
+    t0 = t_mark = time.time()
     while time.time() < t_end:
         n_cases += one_case(int(rng.integers(0, 2**31)))
+        if time.time() - t_mark >= 300.0:          # a progress line every five minutes (a run cut short still says how far it got)
+            t_mark = time.time()
+            print("... %d cases after %.0f s, all bit-identical so far" % (n_cases, t_mark - t0), flush=True)
     return n_cases
 
 
