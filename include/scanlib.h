@@ -309,7 +309,10 @@ typedef struct rl_plan_opts {
                             (cddt_theta_search2_kernel + cddt_theta_fan_kernel, round 5), 0 = every group prepares its own
                             (round 4), 2 = search and fan of a 64-pose tile fused in one workgroup, per-bin results in
                             LDS only (cddt_theta_fused_kernel)                                                            */
-    int reserved[1];
+    int code_map;        /* ray marching: 2 = the step map as 16-bit palette codes, the palette (exact float32 steps) in LDS
+                            (rm_fan_stream_kernel<..., CODE = 2>: the same sample sequence, half the bytes per cell);
+                            0 = float32 steps.  Takes effect on handles whose map's palette fits (rl_method_plan_fan;
+                            the device-less rl_plan_fan does not know a palette and plans the float32 map)             */
 } rl_plan_opts;
 
 typedef enum rl_kernel_id {
@@ -354,6 +357,8 @@ typedef struct rl_launch_plan {
                             kernel: lanes per pose, poses per workgroup pass                              */
     int slices;          /* > 1: the batch goes through in this many pose slices of slice_poses poses,    */
     int slice_poses;     /*      each its own launch sequence planned like this one (for its own size)    */
+    int code;            /* RL_K_RM_STREAM[_LIT]: 2 = marches on the 16-bit code map, 0 = float32 step map  */
+    int code_entries;    /*      ... palette entries the workgroups copy to LDS                           */
     char name[192];
 } rl_launch_plan;
 

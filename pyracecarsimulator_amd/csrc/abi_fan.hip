@@ -105,6 +105,8 @@ extern "C" void rl_method_destroy(rl_method *h)
         ft.tab.release();
     }
     h->pdt.release();
+    for (DevBuf *b : {&h->cmap, &h->cval, &h->cidx, &h->ctab, &h->cnum}) b->release();
+    if (h->pin_cnum) (void)hipHostFree(h->pin_cnum);
     h->blpad.release();
     h->lut.release();
     for (DevBuf *b : {&h->cd_cos, &h->cd_sin, &h->cd_trans, &h->cd_width, &h->cd_boff, &h->cd_offsets,
@@ -192,6 +194,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
     else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
     else if (!strcmp(name, "tiled")) h->tiled = value != 0;
+    else if (!strcmp(name, "code_map")) h->code_map = value == 2 ? 2 : 0;
     else if (!strcmp(name, "pinned_max_rays")) h->pinned_max_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "direct_max_rays")) h->direct_max_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "overlap_min_rays")) h->overlap_min_rays = value < 0 ? 0 : value;
@@ -252,6 +255,8 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "inline_prep")) *value_out = h->inline_prep;
     else if (!strcmp(name, "bin_generic")) *value_out = h->bin_generic;
     else if (!strcmp(name, "tiled")) *value_out = h->tiled;
+    else if (!strcmp(name, "code_map")) *value_out = h->code_map;
+    else if (!strcmp(name, "code_entries")) *value_out = h->code_n;
     else if (!strcmp(name, "pinned_max_rays")) *value_out = h->pinned_max_rays;
     else if (!strcmp(name, "direct_max_rays")) *value_out = h->direct_max_rays;
     else if (!strcmp(name, "overlap_min_rays")) *value_out = h->overlap_min_rays;
@@ -725,6 +730,7 @@ static rl_plan_opts opts_of(const rl_method *h)
     o.lut_debug = h->lut_debug;
     o.debug_stamps = h->debug_stamps;
     o.slice_log2 = h->slice_log2;
+    o.code_map = h->code_map;
     return o;
 }
 
@@ -742,6 +748,7 @@ static int plan_for(const rl_method *h, int n_poses, int num_rays, bool aux, boo
     in.num_rays = num_rays;
     in.aux = aux;
     in.crash = crash;
+    in.code_n = (h->code_map && h->code_built == h->code_map && h->pdt_epoch == h->map->epoch) ? h->code_n : 0;
     return plan::plan_fan(in, out);
 }
 
@@ -755,7 +762,8 @@ static int ensure_step_map(rl_method *h, hipStream_t stream)
     //  plan::tiled_fit — elongated maps whose pitch would need K > 24, tables beyond 4 GiB)
     const plan::TiledFit fit = plan::tiled_fit(m->rows, m->cols, h->max_range);
     const int want_tiled = (h->tiled && fit.ok) ? 1 : 0;
-    if (h->pdt_epoch == m->epoch && h->pdt.p && h->pdt_tiled == want_tiled) return table_wait(h->pdt_dep, stream);
+    if (h->pdt_epoch == m->epoch && h->pdt.p && h->pdt_tiled == want_tiled && h->code_built == h->code_map)
+        return table_wait(h->pdt_dep, stream);
     if (h->pdt.p) HIPCHK(hipDeviceSynchronize());   // launches of other streams may still read the old copy
     h->pad = (int)std::ceil(h->max_range) + 2;
     if (want_tiled) {
@@ -789,13 +797,52 @@ static int ensure_step_map(rl_method *h, hipStream_t stream)
         h->pdt_mask = 0;
         h->pdt_base_off = 0;
     }
+    // the CODE map next to it: palette of the map's distinct steps (mark -> scan), then the tiled map of their codes.
+    // The palette size decides the launches' LDS, so the host reads it back here (a map build, not a scan).
+    h->code_n = 0;
+    const plan::CodeFit cf = plan::code_fit(m->rows, m->cols, h->max_range, 1);
+    if (h->code_map == 2 && want_tiled && cf.ok) {
+        const uint32_t cap = (uint32_t)plan::CODE_MAX_ENTRIES;
+        if ((rc = h->cval.ensure((size_t)cf.nb * sizeof(float)))) return rc;
+        if ((rc = h->cidx.ensure((size_t)cf.nb * sizeof(uint32_t)))) return rc;
+        if ((rc = h->ctab.ensure((size_t)cap * sizeof(float)))) return rc;
+        if ((rc = h->cnum.ensure(2 * sizeof(uint32_t)))) return rc;
+        if (!h->pin_cnum) HIPCHK(hipHostMalloc((void **)&h->pin_cnum, 2 * sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(h->cval.p, 0, (size_t)cf.nb * sizeof(float), stream));
+        const size_t n_cells = (size_t)m->rows * m->cols;
+        hipLaunchKernelGGL(code_mark_kernel, dim3((unsigned)std::min<size_t>((n_cells + 255) / 256, (size_t)m->n_cu * 8)), dim3(256),
+                           0, stream, m->d_dt, n_cells, (float *)h->cval.p, cf.nb, h->step_coeff, h->max_range);
+        hipLaunchKernelGGL(code_scan_kernel, dim3(1), dim3(1024), 0, stream, (const float *)h->cval.p, cf.nb, h->step_coeff,
+                           (uint32_t *)h->cidx.p, (float *)h->ctab.p, cap, (uint32_t *)h->cnum.p);
+        HIPCHK(hipMemcpyAsync(h->pin_cnum, h->cnum.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (h->pin_cnum[1] == 0u && h->pin_cnum[0] <= cap) {
+            TiledGeom tg{};
+            tg.pad = cf.pad;
+            tg.padr = cf.padr;
+            tg.pcols = cf.pcols;
+            tg.prows = cf.prows;
+            tg.K = cf.K;
+            if ((rc = h->cmap.ensure(cf.bytes))) return rc;
+            hipLaunchKernelGGL((pad_code_tiled_kernel<1>), dim3((tg.pcols + 255) / 256, tg.prows), dim3(256), 0, stream,
+                               m->d_dt, m->rows, m->cols, h->cmap.p, tg, h->step_coeff, h->max_range,
+                               (const uint32_t *)h->cidx.p, cf.nb, (const uint32_t *)h->cnum.p);
+            const uint32_t M = (1u << cf.es) + (1u << (cf.K - 3));
+            h->cstride = (int)M;
+            h->cmask = (7u << cf.es) | (~0u << cf.K);
+            h->ck4 = (uint32_t)cf.padr * M;
+            h->cbase_off = (size_t)cf.pad << (3 + cf.es);
+            h->code_n = (int)h->pin_cnum[0];
+        }
+    }
+    h->code_built = h->code_map;
     h->pdt_epoch = m->epoch;
     h->pdt_tiled = want_tiled;
     return table_built(h->pdt_dep, stream);
 }
 
 // the stream-kernel instantiation a plan names
-template <bool A, bool C, int N, bool I, bool T, int S, bool L = false>
+template <bool A, bool C, int N, bool I, bool T, int S, bool L = false, int CD = 0>
 static void launch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, const PadMap &pm, const FanParams &f,
                              const StreamParams &sp, float *d_out, int32_t *d_hits, uint16_t *d_steps,
                              const CrashParams &cp)
@@ -803,9 +850,9 @@ static void launch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, const
     // (more dynamic LDS than HIP's default cap — fans of several thousand beams, with the crash table —: opt in,
     //  as the BL / occ / CDDT kernels do; the attribute is sticky per function and device, the call is cheap)
     if (pl.lds_bytes > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rm_fan_stream_kernel<A, C, N, I, T, S, L>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rm_fan_stream_kernel<A, C, N, I, T, S, L, CD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_bytes);
-    hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, N, I, T, S, L>), dim3(pl.grid), dim3(N), (size_t)pl.lds_bytes, stream,
+    hipLaunchKernelGGL((rm_fan_stream_kernel<A, C, N, I, T, S, L, CD>), dim3(pl.grid), dim3(N), (size_t)pl.lds_bytes, stream,
                        pm, f, sp, d_out, d_hits, d_steps, cp);
 }
 
@@ -817,10 +864,17 @@ static int dispatch_rm_stream(const rl_launch_plan &pl, hipStream_t stream, cons
     const int nt = pl.block;
 #define RM_ARGS pl, stream, pm, f, sp, d_out, d_hits, d_steps, cp
     if (pl.kernel == RL_K_RM_STREAM_LIT) {     // upstream-literal arithmetic (variant 3): INLINE records, tiled step map
-        if (pl.slots >= 2) { if (crash) launch_rm_stream<false, true, 1024, true, true, 2, true>(RM_ARGS);
+        if (pl.slots >= 2 && pl.code == 2) { if (crash) launch_rm_stream<false, true, 1024, true, true, 2, true, 2>(RM_ARGS);
+                                             else launch_rm_stream<false, false, 1024, true, true, 2, true, 2>(RM_ARGS); }
+        else if (pl.slots >= 2) { if (crash) launch_rm_stream<false, true, 1024, true, true, 2, true>(RM_ARGS);
                              else launch_rm_stream<false, false, 1024, true, true, 2, true>(RM_ARGS); }
         else               { if (crash) launch_rm_stream<false, true, 1024, true, true, 1, true>(RM_ARGS);
                              else launch_rm_stream<false, false, 1024, true, true, 1, true>(RM_ARGS); }
+    } else if (pl.code == 2 && pl.slots == 2 && tiled && !aux && nt == 1024) {     // two rays per lane on the u16 code map
+        if (inl) { if (crash) launch_rm_stream<false, true, 1024, true, true, 2, false, 2>(RM_ARGS);
+                   else launch_rm_stream<false, false, 1024, true, true, 2, false, 2>(RM_ARGS); }
+        else     { if (crash) launch_rm_stream<false, true, 1024, false, true, 2, false, 2>(RM_ARGS);
+                   else launch_rm_stream<false, false, 1024, false, true, 2, false, 2>(RM_ARGS); }
     } else if (pl.slots == 3) {                // three rays per lane: plain ranges, 1024 lanes
         if (!inl) launch_rm_stream<false, false, 1024, false, true, 3>(RM_ARGS);
         else if (tiled) launch_rm_stream<false, false, 1024, true, true, 3>(RM_ARGS);
@@ -1073,7 +1127,17 @@ static int launch_rm_stream_family(const FanLaunch &L)
     pm.k4 = h->pdt_k4;
     pm.div_stride = make_fastdiv((uint32_t)h->pstride);
     pm.res = m->res;
+    if (pl.code) {                               // the march reads the map of palette codes: its base and address constants
+        if (h->code_n <= 0 || pl.code_entries != h->code_n)
+            return fail(RL_ERR_INVALID, "internal: code-map plan (%d entries) without a matching palette (%d)", pl.code_entries, h->code_n);
+        pm.pdt = (const float *)((const char *)h->cmap.p + h->cbase_off);
+        pm.stride = h->cstride;
+        pm.nstride = (int)h->cmask;
+        pm.k4 = h->ck4;
+    }
     StreamParams sp{};
+    sp.code_tab = (const float *)h->ctab.p;
+    sp.code_n = pl.code ? h->code_n : 0;
     sp.rec = (const PoseRec *)cx->rec_sorted.p;
     sp.order = (const uint32_t *)cx->order.p;
     sp.d0 = (const float *)cx->d0.p;
@@ -1108,7 +1172,7 @@ static int launch_rm_stream_family(const FanLaunch &L)
     // context's leftover list — one region of handoff_cap records per wave of the main grid —, the second launch
     // finishes them
     const bool handoff = h->handoff && pl.slots >= 2 && pl.tiled && h->spec_drain > 0 && !h->debug_stamps &&
-                         pl.kernel == RL_K_RM_STREAM;      // (the leftover kernel marches the canonical arithmetic)
+                         pl.kernel == RL_K_RM_STREAM && !pl.code;   // (the leftover kernel marches the canonical arithmetic on the float32 map)
     int cap_log2 = 4;
     const int n_src = pl.grid * waves_per_wg;
     if (handoff) {
@@ -1188,7 +1252,10 @@ static int launch_fan(rl_method *h, const float *d_poses, int n_poses, float fov
             return fail(RL_ERR_UNSUPPORTED, "hit cells / step counts exist only for RM and Bresenham");
     }
     rl_launch_plan pl;
-    int rc = plan_for(h, n_poses, num_rays, aux, crash != nullptr, &pl);
+    int rc = RL_OK;
+    // (a code-map handle plans with its palette size: the step map and the palette are built before the plan)
+    if (h->code_map && (h->kind == RL_RM || h->kind == RL_RM_GPU) && h->variant >= 1 && (rc = ensure_step_map(h, stream))) return rc;
+    rc = plan_for(h, n_poses, num_rays, aux, crash != nullptr, &pl);
     if (rc == RL_ERR_UNSUPPORTED)
         return fail(rc, (h->variant >= 2 && crash) ? "the fused crash test needs variant 0 or 1 (not the occupancy-window or the audit kernel)"
                         : h->variant == 2 ? "occupancy window of max_range %g does not fit LDS (num_rays %d)"
@@ -1332,7 +1399,13 @@ extern "C" int rl_method_plan_fan(rl_method *h, int n_poses, int num_rays, int w
         return rl_method_plan_fan(h->reps[0], (int)(hi - lo), num_rays, want_aux, want_crash, out);
     }
     std::lock_guard<std::mutex> lk(h->mu);
-    const int rc = plan_for(h, n_poses, num_rays, want_aux != 0, want_crash != 0, out);
+    int rc = RL_OK;
+    if (h->code_map && (h->kind == RL_RM || h->kind == RL_RM_GPU) && h->variant >= 1) {
+        if ((rc = set_device(h->map))) return rc;
+        std::shared_lock<std::shared_mutex> tl(h->map->tables_mu);
+        if ((rc = ensure_step_map(h, h->stream))) return rc;
+    }
+    rc = plan_for(h, n_poses, num_rays, want_aux != 0, want_crash != 0, out);
     if (rc) return fail(rc, "no kernel of this variant serves the request");
     return RL_OK;
 }

@@ -360,6 +360,17 @@ struct rl_method {
     int pdt_tiled = -1;          // layout the padded copy was built with
     uint32_t pdt_k4 = 0, pdt_mask = 0;
     size_t pdt_base_off = 0;     // tiled: the column bias (pad << 4 bytes) folded into the base address
+    // the CODE map (option code_map = 2): the step map as u16 palette codes + the palette (rm_kernels.h), built next to
+    // the float32 step map by ensure_step_map; code_n = palette entries with the two stop codes, 0 = none (option off,
+    // geometry does not fit, or more distinct steps than plan::CODE_MAX_ENTRIES)
+    int code_map = 0;
+    DevBuf cmap, cval, cidx, ctab, cnum;
+    uint32_t *pin_cnum = nullptr;
+    int code_n = 0;
+    int code_built = -1;         // code_map value the tables were built for
+    int cstride = 0;             // M of the code map's address
+    uint32_t ck4 = 0, cmask = 0;
+    size_t cbase_off = 0;
     int slice_log2 = 30;         // launches are cut into pose slices below 2^slice_log2 rays
     int bin_generic = 0;         // diagnostics: force the generic single-workgroup binning kernel
     int inline_prep = 1;         // tiny batches: no binning launch, workgroups derive their own records

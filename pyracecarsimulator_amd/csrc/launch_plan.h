@@ -24,6 +24,7 @@ constexpr int STRIPE_MAX_PER_LANE = 8;
 constexpr int INLINE_LDS_BUDGET = 72 * 1024;   // LDS an INLINE workgroup may use (two 1024-lane workgroups per CU)
 constexpr int INLINE_REC_BYTES = 32;     // one BlockRec per owned 64-ray block (rm_kernels.h)
 constexpr int LIT_SLICE_POSES = 4096;    // upstream-literal stream form: poses per slice of a batch too large for one INLINE launch
+constexpr int CODE_MAX_ENTRIES = 4096;   // palette entries (16 KB of LDS) a code-map launch may carry; u16 codes hold 4 * index
 constexpr int DRAIN_CAP = 64, DRAIN_FIELDS = 7;   // several rays per lane: per-wave compaction scratch of the drain phase
                                                   // (7 dwords per ray, 9 with the fused crash test)
 
@@ -33,6 +34,8 @@ struct In {
     rl_plan_opts o{};
     int n_poses = 0, num_rays = 0;
     bool aux = false, crash = false;
+    int code_n = 0;          // entries of the map's step palette with the two stop codes (0: not known / does not fit):
+                             // what a handle learns when it builds its code map; the code-map kernels need it for their LDS
 };
 
 inline void default_opts(rl_plan_opts &o)
@@ -62,6 +65,7 @@ inline void default_opts(rl_plan_opts &o)
     o.lut_debug = 0;
     o.debug_stamps = 0;
     o.slice_log2 = 30;
+    o.code_map = 0;           // (set by the round-6 A/B: see DESIGN.md section 4)
 }
 
 // Options as the planner may use them: every field a division, a shift or a template choice depends on is
@@ -92,6 +96,7 @@ inline rl_plan_opts sanitized(rl_plan_opts o)
     o.cddt_theta_min = clampi(o.cddt_theta_min, 0, 1 << 30);
     o.cddt_search = clampi(o.cddt_search, 0, 2);
     o.slice_log2 = clampi(o.slice_log2, 8, 30);
+    o.code_map = o.code_map == 2 ? 2 : 0;          // (u16 codes; 1 = u8 codes is not instantiated)
     return o;
 }
 
@@ -117,6 +122,34 @@ inline TiledFit tiled_fit(int rows, int cols, float max_range)
     t.K = lg + 4;
     t.bytes = ((size_t)(t.prows >> 2)) << t.K;
     t.ok = t.K <= 24 && t.bytes <= ((size_t)1 << 32) && max_range < 1.0e6f;
+    return t;
+}
+
+// The tiled CODE map (pad_code_tiled_kernel: groups of 8 rows, 2^es bytes per cell — es 1: u16, 0: u8): the same
+// checks for its address arithmetic — M = 2^es + 2^(K-3) a signed 24-bit operand, r' * M below 2^31, the table
+// below 4 GiB.  nb: slots of the palette's d^2 histogram — every step below max_range comes from an EDT value
+// below max_range / coeff, coeff >= 0.999.
+struct CodeFit {
+    bool ok;
+    int pad, padr, pcols, prows, K, es;
+    size_t bytes;
+    unsigned nb;
+};
+inline CodeFit code_fit(int rows, int cols, float max_range, int es)
+{
+    CodeFit t{};
+    t.es = es;
+    t.pad = (((int)std::ceil(max_range) + 2) + 15) & ~15;
+    t.padr = t.pad + 8;
+    t.pcols = cols + 2 * t.pad;
+    t.prows = (rows + 2 * t.pad + 8 + 7) & ~7;
+    int lg = 3;
+    while ((1L << lg) < (long)std::max(t.pcols, t.prows) && lg < 30) ++lg;
+    t.K = lg + 3 + es;
+    t.bytes = ((size_t)(t.prows >> 3)) << t.K;
+    const double lim = ((double)max_range / 0.999) * ((double)max_range / 0.999) * 1.001 + 4.0;
+    t.nb = lim < 2097152.0 ? (unsigned)lim : 0u;
+    t.ok = t.K <= 25 && 2 * lg + es + 1 < 31 && t.bytes <= ((size_t)1 << 32) && t.nb != 0u;
     return t;
 }
 
@@ -289,8 +322,8 @@ inline int plan_one(const In &in, rl_launch_plan *p)
                 q.block == 1024 && q.slots <= 2) {
                 *p = q;
                 p->kernel = RL_K_RM_STREAM_LIT;
-                std::snprintf(p->name, sizeof p->name, "scan::rm_fan_stream_kernel<false, %s, 1024, true, true, %d, true>",
-                              tf(in.crash), q.slots);
+                std::snprintf(p->name, sizeof p->name, "scan::rm_fan_stream_kernel<false, %s, 1024, true, true, %d, true, %d>",
+                              tf(in.crash), q.slots, q.code);
                 return RL_OK;
             }
         }
@@ -347,7 +380,10 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     const long n_blocks_inl = (long)n_poses * cpp;
     // several rays per lane (decided from the ray count before the record source, which needs the LDS size):
     // every wave of a workgroup gets DRAIN_FIELDS x DRAIN_CAP dwords of compaction scratch behind the tables
-    const size_t tables_b = (((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays + 7) & ~(size_t)7) * sizeof(float);
+    auto tables_bytes = [&](size_t tabw) {
+        return (((size_t)STREAM_HDR + tabw + (in.crash ? 4 : 2) * (size_t)num_rays + 7) & ~(size_t)7) * sizeof(float);
+    };
+    size_t tables_b = tables_bytes(0);
     const size_t drain_wave = (size_t)(DRAIN_FIELDS + (in.crash ? 2 : 0)) * DRAIN_CAP * 4;
     // auto: two rays per lane from 2^23 rays up, and from 2^20 on maps beyond the small-map bound (long rays:
     // +6 % on a lone 2049^2 launch of 1024 ... 16 384 poses since dry waves compact their last rays; colombia's
@@ -357,6 +393,13 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     //  20.5 -> 18.8 us, 1024 poses 26.4 -> 24.2 us on 2049^2; 200 poses 21.9 -> 19.4 us, 4096 poses 54 -> 48.6 us on
     //  4096^2 —, and still lose 3..8 % on colombia below 4096 poses)
     int slots_req = o.slots ? o.slots : ((rays >= (1L << 23) || !small_map) ? 2 : 1);
+    // the code map (u16 palette codes + the palette in LDS): the two-rays-per-lane kernels of 1024 lanes on the tiled
+    // layout, when the handle knows the palette fits (code_n)
+    int code = (o.code_map == 2 && in.code_n > 0 && in.code_n <= CODE_MAX_ENTRIES && !in.aux && tiled_opt && slots_req == 2 &&
+                o.wg_threads == 1024) ? 2 : 0;
+    const size_t tabw = ((size_t)in.code_n + 1) & ~(size_t)1;
+    if (code && tables_bytes(tabw) + 16 * drain_wave > (size_t)INLINE_LDS_BUDGET) code = 0;
+    if (code) tables_b = tables_bytes(tabw);
     // (a fan whose tables leave no room for the scratch of 16 waves marches one ray per lane)
     if (slots_req >= 2 && (in.aux || !tiled_opt || tables_b + 16 * drain_wave > (size_t)INLINE_LDS_BUDGET)) slots_req = 1;
     const bool multi = slots_req >= 2;                                // <=> the launch takes 2 or 3 rays per lane
@@ -418,6 +461,8 @@ inline int plan_one(const In &in, rl_launch_plan *p)
         s = 2;
     }
     p->kernel = RL_K_RM_STREAM;
+    p->code = (s == 2 && t) ? code : 0;
+    p->code_entries = p->code ? in.code_n : 0;
     p->slots = s;
     p->tiled = t;
     p->block = inl ? (s == 2 ? inl_nt : 1024) : nt;
@@ -425,8 +470,9 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     p->lds_bytes = (int)(inl ? inl_tables + (size_t)k_max * INLINE_REC_BYTES + lds_extra
                              : (s >= 2 ? tables_b + drain_bytes(p->block)
                                        : ((size_t)STREAM_HDR + (in.crash ? 4 : 2) * (size_t)num_rays) * sizeof(float)));
-    std::snprintf(p->name, sizeof p->name, "scan::rm_fan_stream_kernel<%s, %s, %d, %s, %s, %d>", tf(a), tf(c),
-                  p->block, tf(inl), tf(t), s);
+    // (the label is the real symbol: all eight template arguments, as rocprofv3's kernel trace prints them)
+    std::snprintf(p->name, sizeof p->name, "scan::rm_fan_stream_kernel<%s, %s, %d, %s, %s, %d, false, %d>", tf(a), tf(c),
+                  p->block, tf(inl), tf(t), s, p->code);
     // (a fan of ~20 000 beams: the beam tables alone exceed a workgroup's LDS — say so instead of failing the launch)
     if (p->lds_bytes > DEVICE_LDS_BYTES) return RL_ERR_UNSUPPORTED;
     return RL_OK;

@@ -222,6 +222,107 @@ __global__ __launch_bounds__(256) void pad_dt_kernel(const float *__restrict__ d
     }
 }
 
+// ---- the CODE map: palette of the map's distinct steps + the tiled map of their indices (see RM_LOAD / RM_DECODE) ----
+// Layout: groups of 8 rows interleaved element-wise, power-of-two group pitch, like the float32 map with
+//   byte(r, c) = ((r' >> 3) << K) | (c' << cs) | ((r' & 7) << es)        es = 1 (u16), 0 (u8);  cs = 3 + es
+// so a 128-B line is 8 rows x 8 (u16) / 16 (u8) columns, and the march's three address instructions stay:
+//   a = r * M + padM,  M = 2^es + 2^(K-3);   a &= MASK,  MASK = (7 << es) | (~0 << K);   a = (c << cs) + a.
+__device__ __host__ __forceinline__ size_t code_tiled_byte(int rp, int cp, int K, int es)
+{
+    return ((size_t)(rp >> 3) << K) | ((size_t)cp << (3 + es)) | ((size_t)(rp & 7) << es);
+}
+
+// (1) every free cell whose step stays below max_range leaves its EDT value in slot d^2 of `val` (the EDT is
+//     sqrtf of an integer: cells of one slot hold the same float, the store is idempotent; d * d rounds to d^2
+//     exactly far beyond the 2^21 slots a palette may have)
+__global__ __launch_bounds__(256) void code_mark_kernel(const float *__restrict__ dt, size_t n_cells,
+                                                        float *__restrict__ val, uint32_t nb, float coeff,
+                                                        float max_range)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += stride) {
+        const float d = dt[i];
+        if (d > 0.0f && __builtin_fmaxf(d * coeff, 1.0f) < max_range) {
+            const uint32_t d2 = (uint32_t)__builtin_fmaf(d, d, 0.5f);
+            if (d2 < nb) val[d2] = d;
+        }
+    }
+}
+
+// (2) one workgroup: exclusive scan over the occupied slots -> idx[d^2] = palette index, tab[index] = the march's
+//     step of that EDT value (the two roundings of pad_dt_tiled_kernel), then the two stop codes; n_out[0] = palette
+//     size with the stop codes, n_out[1] = 1 when it does not fit `cap`.
+__global__ __launch_bounds__(1024) void code_scan_kernel(const float *__restrict__ val, uint32_t nb, float coeff,
+                                                         uint32_t *__restrict__ idx, float *__restrict__ tab,
+                                                         uint32_t cap, uint32_t *__restrict__ n_out)
+{
+    __shared__ uint32_t part[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t lo = tid * per, hi = min(nb, lo + per);
+    uint32_t local = 0;
+    for (uint32_t i = lo; i < hi; ++i) local += val[i] > 0.0f ? 1u : 0u;
+    uint32_t incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= (uint32_t)off) incl += o;
+    }
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < wave) before += part[w];
+        total += part[w];
+    }
+    uint32_t k = before + incl - local;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const float d = val[i];
+        if (d > 0.0f) {
+            idx[i] = k;
+            if (k < cap) tab[k] = __builtin_fmaxf(d * coeff, 1.0f);
+            ++k;
+        }
+    }
+    if (tid == 0) {
+        if (total + 2u <= cap) {
+            tab[total] = PDT_HIT;
+            tab[total + 1] = PDT_OUTSIDE;
+        }
+        n_out[0] = total + 2u;
+        n_out[1] = total + 2u <= cap ? 0u : 1u;
+    }
+}
+
+// (3) the padded, tiled map of codes.  u16: 4 * index (the LDS byte offset of the step); u8: the index.
+//     hit = n_free, outside / a step of max_range or more = n_free + 1.
+template <int ES>
+__global__ __launch_bounds__(256) void pad_code_tiled_kernel(const float *__restrict__ dt, int rows, int cols,
+                                                             void *__restrict__ cmap, TiledGeom tg, float coeff,
+                                                             float max_range, const uint32_t *__restrict__ idx,
+                                                             uint32_t nb, const uint32_t *__restrict__ n_pal)
+{
+    const uint32_t n_free = n_pal[0] - 2u;
+    const int pr = blockIdx.y;
+    const int r = pr - tg.padr;
+    for (int pc = blockIdx.x * blockDim.x + threadIdx.x; pc < tg.pcols; pc += gridDim.x * blockDim.x) {
+        const int c = pc - tg.pad;
+        uint32_t code = n_free + 1u;
+        if (r >= 0 && r < rows && c >= 0 && c < cols) {
+            const float d = dt[(size_t)r * cols + c];
+            if (d <= 0.0f) {
+                code = n_free;
+            } else if (__builtin_fmaxf(d * coeff, 1.0f) < max_range) {
+                const uint32_t d2 = (uint32_t)__builtin_fmaf(d, d, 0.5f);
+                code = d2 < nb ? idx[d2] : n_free + 1u;
+            }
+        }
+        char *at = reinterpret_cast<char *>(cmap) + code_tiled_byte(pr, pc, tg.K, ES);
+        if (ES == 1) *reinterpret_cast<uint16_t *>(at) = (uint16_t)(code << 2);
+        else *reinterpret_cast<uint8_t *>(at) = (uint8_t)code;
+    }
+}
+
 // The FIRST sample of a ray is taken at t = 0, i.e. at the pose's own cell, whatever the beam: it is
 // read once per pose (with the record) instead of once per ray, and the ray starts at t = first step.
 //   free origin cell   -> its step max(d*coeff, 1): the ray starts there with one sample counted
@@ -607,6 +708,40 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f)
     "v_pk_fma_f32 " D ", " DIR ", " T ", " ORG " op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"                        \
     ".endif\n\t"
 
+// LDS header of the stream kernels in floats: [0] slot counter, [1] spare, [2..66) crash_seen.  CODE launches keep
+// the code -> step table right behind it, at a byte offset the march loops name as an immediate (RM_DECODE).
+constexpr int STREAM_HDR = 66;
+
+// ------------------------------------------------------------------------------
+// The CODE map (round 6): the step map in 16-bit codes (CODE = 2) or 8-bit codes (CODE = 1) instead of float32 steps.
+// A map holds few DISTINCT steps — the EDT is sqrtf of an integer, a maze of 40-cell corridors has 624 of them, a
+// 4096^2 one 1591 —, so a cell stores the index of its step in the map's palette and the workgroup keeps the palette
+// (exact float32 steps, +inf for "hit", 3e38 for "left the map or a step past max_range") in LDS: the sample sequence
+// and every bit of the result are those of the float32 step map, a 128-B line holds 8 x 8 (u16) or 8 x 16 (u8) cells
+// instead of 4 x 8, and a band of the map is half / a quarter of the bytes in the XCD's L2.
+//   u16: the cell holds 4 * index — the LDS byte offset: sample = global_load_ushort + ds_read_b32, no VALU more;
+//   u8:  the cell holds the index: one shift more per sample.
+// RM_LOAD fetches a sample's cell, RM_DECODE (behind the s_waitcnt that returned it) turns it into the step in place.
+// ------------------------------------------------------------------------------
+#define RM_LOAD(D, A)                                                                                      \
+    ".if %[code] == 2\n\t"                                                                                 \
+    "global_load_ushort " D ", " A ", %[base]\n\t"                                                          \
+    ".elseif %[code] == 1\n\t"                                                                             \
+    "global_load_ubyte " D ", " A ", %[base]\n\t"                                                           \
+    ".else\n\t"                                                                                            \
+    "global_load_dword " D ", " A ", %[base]\n\t"                                                           \
+    ".endif\n\t"
+#define RM_DECODE(D)                                                                                       \
+    ".if %[code] == 1\n\t"                                                                                 \
+    "v_lshlrev_b32_e32 " D ", 2, " D "\n\t"                                                                 \
+    ".endif\n\t"                                                                                           \
+    ".if %[code]\n\t"                                                                                      \
+    "ds_read_b32 " D ", " D " offset:%[taboff]\n\t"                                                         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                             \
+    ".endif\n\t"
+// (the column shift of the tiled address: bytes a column takes inside a row group — 4 rows x 4 B, 8 rows x 2 B: 16; 8 rows x 1 B: 8)
+#define RM_CODE_OPERANDS [code] "n"(CODE), [cs] "n"(CODE == 1 ? 3 : 4), [taboff] "n"(STREAM_HDR * 4)
+
 // ------------------------------------------------------------------------------
 // The march loop of K1b, hand-scheduled for gfx950.  EXEC holds the live lanes
 // (v_cmpx drops a lane the moment its t reaches max_range, hits, or leaves the map),
@@ -618,7 +753,7 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f)
 //   d  = step map at (r, c)              = max(dt*coeff, 1) | +inf (occupied) | 3e38 (border)
 //   t += d                               => a hit / leaving the map pushes t past max_range
 // ------------------------------------------------------------------------------
-template <bool AUX, bool TILED, bool LIT = false>
+template <bool AUX, bool TILED, bool LIT = false, int CODE = 0>
 __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float gy, float &t, int &c,
                                            int &r, float &d, uint32_t &nstep, const float *pdt,
                                            int stride, int nstride, uint32_t k4, float max_range,
@@ -644,16 +779,17 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
         ".if %[tiled]\n\t"
         "v_mad_i32_i24 v26, %[r], %[stride], %[k4]\n\t"
         "v_and_b32_e32 v26, %[nstride], v26\n\t"
-        "v_lshl_add_u32 v26, %[c], 4, v26\n\t"
+        "v_lshl_add_u32 v26, %[c], %[cs], v26\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v26, %[r], %[stride], %[c]\n\t"
         "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
         ".endif\n\t"
-        "global_load_dword %[d], v26, %[base]\n\t"
+        RM_LOAD("%[d]", "v26")
         ".if %[aux]\n\t"
         "v_add_u32_e32 %[ns], 1, %[ns]\n\t"
         ".endif\n\t"
         "s_waitcnt vmcnt(0)\n\t"
+        RM_DECODE("%[d]")
         "v_add_f32_e32 v20, v20, %[d]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
         "s_bcnt1_i32_b64 %[n], exec\n\t"
@@ -664,14 +800,14 @@ __device__ __forceinline__ void march_loop(float dx, float dy, float gx, float g
           [save] "=&s"(save), [n] "=&s"(n)
         : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy),
           [mx] "s"(max_range), [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4),
-          [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), [low] "s"(low), [aux] "n"(AUX ? 1 : 0), [tiled] "n"(TILED ? 1 : 0)
+          [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), RM_CODE_OPERANDS, [low] "s"(low), [aux] "n"(AUX ? 1 : 0), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "vcc", "scc", "memory");
 }
 
 
 // march_loop with an iteration cap (drain phase: a bounded stretch of the plain loop between two attempts of
 // the speculating loop).  Leaves when no lane is live or after `iters` samples per lane.
-template <bool TILED, bool LIT = false>
+template <bool TILED, bool LIT = false, int CODE = 0>
 __device__ __forceinline__ void march_loop_capped(float dx, float dy, float gx, float gy, float &t, int &c, int &r,
                                                   float &d, const float *pdt, int stride, int nstride, uint32_t k4,
                                                   float max_range, uint32_t iters)
@@ -689,14 +825,15 @@ __device__ __forceinline__ void march_loop_capped(float dx, float dy, float gx, 
         ".if %[tiled]\n\t"
         "v_mad_i32_i24 v26, %[r], %[stride], %[k4]\n\t"
         "v_and_b32_e32 v26, %[nstride], v26\n\t"
-        "v_lshl_add_u32 v26, %[c], 4, v26\n\t"
+        "v_lshl_add_u32 v26, %[c], %[cs], v26\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v26, %[r], %[stride], %[c]\n\t"
         "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
         ".endif\n\t"
-        "global_load_dword %[d], v26, %[base]\n\t"
+        RM_LOAD("%[d]", "v26")
         "s_sub_u32 %[n], %[n], 1\n\t"
         "s_waitcnt vmcnt(0)\n\t"
+        RM_DECODE("%[d]")
         "v_add_f32_e32 v20, v20, %[d]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
         "s_cbranch_execz L_cap_done_%=\n\t"
@@ -706,7 +843,7 @@ __device__ __forceinline__ void march_loop_capped(float dx, float dy, float gx, 
         "s_mov_b64 exec, %[save]\n\t"
         : [t] "+{v20}"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [save] "=&s"(save), [n] "+s"(n)
         : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy), [mx] "s"(max_range),
-          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), [tiled] "n"(TILED ? 1 : 0)
+          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), RM_CODE_OPERANDS, [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "vcc", "scc", "memory");
 }
 
@@ -727,7 +864,7 @@ __device__ __forceinline__ void march_loop_capped(float dx, float dy, float gx, 
 // samples 0 and 3 in v42 / v43 — exactly the fixed registers of slots B and C of the several-rays-per-lane
 // kernels, which are dead when this loop runs there (no register beyond theirs).
 // ------------------------------------------------------------------------------
-template <bool TILED, bool LIT = false>
+template <bool TILED, bool LIT = false, int CODE = 0>
 __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float gy, float &t, int &c, int &r,
                                              float &d, const float *pdt, int stride, int nstride, uint32_t k4,
                                              float max_range)
@@ -754,8 +891,8 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "v_cvt_i32_f32_e32 v27, v27\n\t"
         "v_mad_i32_i24 v27, v27, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v27, %[nstride], v27\n\t"
-        "v_lshl_add_u32 v26, v26, 4, v27\n\t"
-        "global_load_dword v42, v26, %[base]\n\t"
+        "v_lshl_add_u32 v26, v26, %[cs], v27\n\t"
+        RM_LOAD("v42", "v26")
         // sample 1 where t1 is still inside the range window
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         RM_POS("v[34:35]", "v[22:23]", "v[28:29]", "v[24:25]")
@@ -763,8 +900,8 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "v_cvt_i32_f32_e32 v35, v35\n\t"
         "v_mad_i32_i24 v35, v35, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v35, %[nstride], v35\n\t"
-        "v_lshl_add_u32 v34, v34, 4, v35\n\t"
-        "global_load_dword v31, v34, %[base]\n\t"
+        "v_lshl_add_u32 v34, v34, %[cs], v35\n\t"
+        RM_LOAD("v31", "v34")
         // sample 2
         "v_cmpx_gt_f32_e32 %[mx], v30\n\t"
         RM_POS("v[36:37]", "v[22:23]", "v[30:31]", "v[24:25]")
@@ -772,8 +909,8 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "v_cvt_i32_f32_e32 v37, v37\n\t"
         "v_mad_i32_i24 v37, v37, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v37, %[nstride], v37\n\t"
-        "v_lshl_add_u32 v36, v36, 4, v37\n\t"
-        "global_load_dword v33, v36, %[base]\n\t"
+        "v_lshl_add_u32 v36, v36, %[cs], v37\n\t"
+        RM_LOAD("v33", "v36")
         // sample 3
         "v_cmpx_gt_f32_e32 %[mx], v32\n\t"
         RM_POS("v[38:39]", "v[22:23]", "v[32:33]", "v[24:25]")
@@ -781,11 +918,12 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "v_cvt_i32_f32_e32 v39, v39\n\t"
         "v_mad_i32_i24 v39, v39, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v39, %[nstride], v39\n\t"
-        "v_lshl_add_u32 v38, v38, 4, v39\n\t"
-        "global_load_dword v43, v38, %[base]\n\t"
+        "v_lshl_add_u32 v38, v38, %[cs], v39\n\t"
+        RM_LOAD("v43", "v38")
         // stage 0: the sample at t is always real
         "s_mov_b64 exec, %[live]\n\t"
         "s_waitcnt vmcnt(3)\n\t"
+        RM_DECODE("v42")
         "v_mov_b32_e32 v40, v20\n\t"
         "v_mov_b32_e32 %[d], v42\n\t"
         "v_add_f32_e32 v20, v20, v42\n\t"
@@ -794,6 +932,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "s_mov_b64 %[hit], exec\n\t"
         // stage 1: the march arrived at t1 exactly
         "s_waitcnt vmcnt(2)\n\t"
+        RM_DECODE("v31")
         "v_mov_b32_e32 v40, v20\n\t"
         "v_mov_b32_e32 %[d], v31\n\t"
         "v_add_f32_e32 v20, v20, v31\n\t"
@@ -801,6 +940,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "v_cmpx_eq_f32_e32 v31, v29\n\t"
         // stage 2
         "s_waitcnt vmcnt(1)\n\t"
+        RM_DECODE("v33")
         "v_mov_b32_e32 v40, v20\n\t"
         "v_mov_b32_e32 %[d], v33\n\t"
         "v_add_f32_e32 v20, v20, v33\n\t"
@@ -808,6 +948,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         "v_cmpx_eq_f32_e32 v33, v29\n\t"
         // stage 3
         "s_waitcnt vmcnt(0)\n\t"
+        RM_DECODE("v43")
         "v_mov_b32_e32 v40, v20\n\t"
         "v_mov_b32_e32 %[d], v43\n\t"
         "v_add_f32_e32 v20, v20, v43\n\t"
@@ -829,7 +970,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
         : [t] "+{v20}"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [save] "=&s"(save), [ent] "=&s"(ent),
           [live] "=&s"(live), [hit] "=&s"(hit)
         : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy), [mx] "s"(max_range),
-          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0)
+          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), RM_CODE_OPERANDS
         : "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40",
           "v41", "v42", "v43", "vcc", "scc", "memory");
 }
@@ -853,7 +994,7 @@ __device__ __forceinline__ void march_drain4(float dx, float dy, float gx, float
 // that are dead at that point: a single VGPR more in this block's footprint made the compiler spill ray state around the
 // hot loops of the kernel, which sits at its 64-VGPR occupancy limit).
 // ------------------------------------------------------------------------------
-template <bool TILED, bool LIT = false>
+template <bool TILED, bool LIT = false, int CODE = 0>
 __device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, float gy, float &t, int &c, int &r,
                                                   float &d, const float *pdt, int stride, int nstride, uint32_t k4,
                                                   float max_range, uint32_t lm1, uint32_t low_lanes)
@@ -901,8 +1042,8 @@ __device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, 
         "v_cvt_i32_f32_e32 v27, v27\n\t"
         "v_mad_i32_i24 v27, v27, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v27, %[nstride], v27\n\t"
-        "v_lshl_add_u32 v26, v26, 4, v27\n\t"
-        "global_load_dword v42, v26, %[base]\n\t"
+        "v_lshl_add_u32 v26, v26, %[cs], v27\n\t"
+        RM_LOAD("v42", "v26")
         // sample 1 where t1 is still inside the range window
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         RM_POS("v[34:35]", "v[22:23]", "v[28:29]", "v[24:25]")
@@ -910,8 +1051,8 @@ __device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, 
         "v_cvt_i32_f32_e32 v35, v35\n\t"
         "v_mad_i32_i24 v35, v35, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v35, %[nstride], v35\n\t"
-        "v_lshl_add_u32 v34, v34, 4, v35\n\t"
-        "global_load_dword v31, v34, %[base]\n\t"
+        "v_lshl_add_u32 v34, v34, %[cs], v35\n\t"
+        RM_LOAD("v31", "v34")
         // sample 2
         "v_cmpx_gt_f32_e32 %[mx], v30\n\t"
         RM_POS("v[36:37]", "v[22:23]", "v[30:31]", "v[24:25]")
@@ -919,8 +1060,8 @@ __device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, 
         "v_cvt_i32_f32_e32 v37, v37\n\t"
         "v_mad_i32_i24 v37, v37, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v37, %[nstride], v37\n\t"
-        "v_lshl_add_u32 v36, v36, 4, v37\n\t"
-        "global_load_dword v33, v36, %[base]\n\t"
+        "v_lshl_add_u32 v36, v36, %[cs], v37\n\t"
+        RM_LOAD("v33", "v36")
         // sample 3
         "v_cmpx_gt_f32_e32 %[mx], v32\n\t"
         RM_POS("v[38:39]", "v[22:23]", "v[32:33]", "v[24:25]")
@@ -928,11 +1069,12 @@ __device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, 
         "v_cvt_i32_f32_e32 v39, v39\n\t"
         "v_mad_i32_i24 v39, v39, %[stride], %[k4]\n\t"
         "v_and_b32_e32 v39, %[nstride], v39\n\t"
-        "v_lshl_add_u32 v38, v38, 4, v39\n\t"
-        "global_load_dword v43, v38, %[base]\n\t"
+        "v_lshl_add_u32 v38, v38, %[cs], v39\n\t"
+        RM_LOAD("v43", "v38")
         // stage 0: the sample at the lane's start (real for lane 0; for lane j > 0 if the lanes in front all repeated)
         "s_mov_b64 exec, %[ent]\n\t"
         "s_waitcnt vmcnt(3)\n\t"
+        RM_DECODE("v42")
         "v_mov_b32_e32 v40, v20\n\t"
         "v_mov_b32_e32 %[d], v42\n\t"
         "v_add_f32_e32 v20, v20, v42\n\t"
@@ -940,6 +1082,7 @@ __device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, 
         "v_cmpx_eq_f32_e32 v42, v29\n\t"
         // stage 1
         "s_waitcnt vmcnt(2)\n\t"
+        RM_DECODE("v31")
         "v_mov_b32_e32 v40, v20\n\t"
         "v_mov_b32_e32 %[d], v31\n\t"
         "v_add_f32_e32 v20, v20, v31\n\t"
@@ -947,6 +1090,7 @@ __device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, 
         "v_cmpx_eq_f32_e32 v31, v29\n\t"
         // stage 2
         "s_waitcnt vmcnt(1)\n\t"
+        RM_DECODE("v33")
         "v_mov_b32_e32 v40, v20\n\t"
         "v_mov_b32_e32 %[d], v33\n\t"
         "v_add_f32_e32 v20, v20, v33\n\t"
@@ -954,6 +1098,7 @@ __device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, 
         "v_cmpx_eq_f32_e32 v33, v29\n\t"
         // stage 3
         "s_waitcnt vmcnt(0)\n\t"
+        RM_DECODE("v43")
         "v_mov_b32_e32 v40, v20\n\t"
         "v_mov_b32_e32 %[d], v43\n\t"
         "v_add_f32_e32 v20, v20, v43\n\t"
@@ -992,7 +1137,7 @@ __device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, 
         : [t] "+{v20}"(t), [c] "+v"(c), [r] "+v"(r), [d] "+v"(d), [save] "=&s"(save), [ent0] "=&s"(ent0),
           [live] "=&s"(live), [ent] "=&s"(ent), [am] "=&s"(am), [n] "=&s"(n)
         : [dy] "{v22}"(dy), [dx] "{v23}"(dx), [gx] "{v24}"(gx), [gy] "{v25}"(gy), [mx] "s"(max_range),
-          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), [lm1] "s"(lm1),
+          [stride] "s"(stride), [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), RM_CODE_OPERANDS, [lm1] "s"(lm1),
           [low] "s"(low_lanes)
         : "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40",
           "v41", "v42", "v43", "vcc", "scc", "memory");
@@ -1005,7 +1150,7 @@ __device__ __forceinline__ void march_drain_group(float dx, float dy, float gx, 
 // siblings on its SIMD.  (Round 1 tried two slots with per-slot predication on the row-major layout:
 // the extra VALU per sample made it 6 % slower.)  Registers are fixed as in march_loop: slot A
 // t v20 / dir v[22:23] / origin v[24:25] / scratch v[26:27], slot B t v28 / v[30:31] / v[32:33] / v[34:35].
-template <bool TILED, bool LIT = false>
+template <bool TILED, bool LIT = false, int CODE = 0>
 __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, float gyA, float &tA, int &cA, int &rA,
                                             float &dA, float dxB, float dyB, float gxB, float gyB, float &tB,
                                             int &cB, int &rB, float &dB, const float *pdt, int stride, int nstride,
@@ -1029,12 +1174,12 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         ".if %[tiled]\n\t"
         "v_mad_i32_i24 v26, %[rA], %[stride], %[k4]\n\t"
         "v_and_b32_e32 v26, %[nstride], v26\n\t"
-        "v_lshl_add_u32 v26, %[cA], 4, v26\n\t"
+        "v_lshl_add_u32 v26, %[cA], %[cs], v26\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v26, %[rA], %[stride], %[cA]\n\t"
         "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
         ".endif\n\t"
-        "global_load_dword %[dA], v26, %[base]\n\t"
+        RM_LOAD("%[dA]", "v26")
         "s_mov_b64 exec, %[mB]\n\t"
         RM_POS("v[34:35]", "v[30:31]", "v[28:29]", "v[32:33]")
         "v_cvt_i32_f32_e32 %[cB], v34\n\t"
@@ -1042,15 +1187,16 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         ".if %[tiled]\n\t"
         "v_mad_i32_i24 v34, %[rB], %[stride], %[k4]\n\t"
         "v_and_b32_e32 v34, %[nstride], v34\n\t"
-        "v_lshl_add_u32 v34, %[cB], 4, v34\n\t"
+        "v_lshl_add_u32 v34, %[cB], %[cs], v34\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v34, %[rB], %[stride], %[cB]\n\t"
         "v_lshl_add_u32 v34, v34, 2, %[k4]\n\t"
         ".endif\n\t"
-        "global_load_dword %[dB], v34, %[base]\n\t"
+        RM_LOAD("%[dB]", "v34")
         "L_march2_%=:\n\t"
         "s_mov_b64 exec, %[mA]\n\t"
         "s_waitcnt vmcnt(1)\n\t"
+        RM_DECODE("%[dA]")
         "v_add_f32_e32 v20, v20, %[dA]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
         "s_mov_b64 %[mA], exec\n\t"
@@ -1060,14 +1206,15 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         ".if %[tiled]\n\t"
         "v_mad_i32_i24 v26, %[rA], %[stride], %[k4]\n\t"
         "v_and_b32_e32 v26, %[nstride], v26\n\t"
-        "v_lshl_add_u32 v26, %[cA], 4, v26\n\t"
+        "v_lshl_add_u32 v26, %[cA], %[cs], v26\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v26, %[rA], %[stride], %[cA]\n\t"
         "v_lshl_add_u32 v26, v26, 2, %[k4]\n\t"
         ".endif\n\t"
-        "global_load_dword %[dA], v26, %[base]\n\t"
+        RM_LOAD("%[dA]", "v26")
         "s_mov_b64 exec, %[mB]\n\t"
         "s_waitcnt vmcnt(1)\n\t"
+        RM_DECODE("%[dB]")
         "v_add_f32_e32 v28, v28, %[dB]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         "s_mov_b64 %[mB], exec\n\t"
@@ -1077,12 +1224,12 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         ".if %[tiled]\n\t"
         "v_mad_i32_i24 v34, %[rB], %[stride], %[k4]\n\t"
         "v_and_b32_e32 v34, %[nstride], v34\n\t"
-        "v_lshl_add_u32 v34, %[cB], 4, v34\n\t"
+        "v_lshl_add_u32 v34, %[cB], %[cs], v34\n\t"
         ".else\n\t"
         "v_mad_i32_i24 v34, %[rB], %[stride], %[cB]\n\t"
         "v_lshl_add_u32 v34, v34, 2, %[k4]\n\t"
         ".endif\n\t"
-        "global_load_dword %[dB], v34, %[base]\n\t"
+        RM_LOAD("%[dB]", "v34")
         "s_bcnt1_i32_b64 %[n], %[mA]\n\t"
         "s_bcnt1_i32_b64 %[n2], %[mB]\n\t"
         "s_add_u32 %[n], %[n], %[n2]\n\t"
@@ -1091,11 +1238,13 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         // the two samples in flight belong to live rays: consume them
         "s_mov_b64 exec, %[mA]\n\t"
         "s_waitcnt vmcnt(1)\n\t"
+        RM_DECODE("%[dA]")
         "v_add_f32_e32 v20, v20, %[dA]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
         "s_mov_b64 %[mA], exec\n\t"
         "s_mov_b64 exec, %[mB]\n\t"
         "s_waitcnt vmcnt(0)\n\t"
+        RM_DECODE("%[dB]")
         "v_add_f32_e32 v28, v28, %[dB]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         "s_mov_b64 %[mB], exec\n\t"
@@ -1105,7 +1254,7 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
           [n2] "=&s"(n2)
         : [dyA] "{v22}"(dyA), [dxA] "{v23}"(dxA), [gxA] "{v24}"(gxA), [gyA] "{v25}"(gyA), [dyB] "{v30}"(dyB),
           [dxB] "{v31}"(dxB), [gxB] "{v32}"(gxB), [gyB] "{v33}"(gyB), [mx] "s"(max_range), [stride] "s"(stride),
-          [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
+          [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), RM_CODE_OPERANDS, [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "v34", "v35", "vcc", "scc", "memory");
 }
 
@@ -1317,6 +1466,10 @@ struct StreamParams {
     LeftoverRec *left_rec;
     uint32_t *left_cnt;
     int left_cap_log2;
+    // CODE launches: the map's palette (code_scan_kernel: exact float32 steps + the two stop codes), copied to LDS
+    // behind the header by every workgroup
+    const float *code_tab;
+    int code_n;
 };
 
 
@@ -1431,9 +1584,6 @@ __device__ __forceinline__ uint32_t stripe_band_list(const MapParams &m, const f
     return npos;
 }
 
-// LDS header of the stream kernels in floats: [0] slot counter, [1] spare, [2..66) crash_seen
-constexpr int STREAM_HDR = 66;
-
 // INLINE: everything a ray slot of a 64-ray block needs, in ONE 32-byte LDS record per owned block (two
 // ds_read_b128).  Blocks of an INLINE launch never straddle a pose — a pose's beams are padded to a
 // multiple of 64 (1081 beams: 7 idle slots in 1088, 0.65 %) — so block -> pose is one record, not the
@@ -1455,11 +1605,14 @@ constexpr uint32_t NO_RAY = 0xffffffffu;       // output index of a slot that ho
 constexpr int DRAIN_CAP = 64;                  // capacity; the threshold is StreamParams::drain_cap <= DRAIN_CAP
 constexpr int DRAIN_FIELDS = 7;                // gx, gy, dx, dy, t, last step, output offset (+ 2 with the crash test)
 
-template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED, int SLOTS = 1, bool LIT = false>
+template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED, int SLOTS = 1, bool LIT = false, int CODE = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
 void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__restrict__ out,
                           int32_t *__restrict__ hits, uint16_t *__restrict__ steps, CrashParams cp)
 {
+    // CODE: pm describes the map of palette codes (pad_code_tiled_kernel), the palette sits in LDS behind the header;
+    // every march loop of the two-rays-per-lane form decodes its samples through it (RM_DECODE)
+    static_assert(CODE == 0 || (TILED && SLOTS == 2 && !AUX), "code map: tiled layout, two rays per lane, no diagnostics");
     // LIT: the upstream-literal arithmetic (variant 3) on this kernel's schedule — per-ray libm directions at claim time,
     // un-fused position (packed multiply + packed add in the march loops), un-fused hit range, records in (row, col)
     // naming: bit-identical to the checker's orc_rm_fan_libm.  Records come from the INLINE prologue only.
@@ -1471,12 +1624,13 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     // (direct-mapped): a pose scraping a wall crashes on hundreds of beams, all marched by this
     // workgroup, and only the first of them needs to touch the group's word in global memory
     uint32_t *crash_seen = reinterpret_cast<uint32_t *>(lds_f + 2);
-    float2 *fan_cs = reinterpret_cast<float2 *>(lds_f + STREAM_HDR);     // num_rays float2
+    const size_t tabw = CODE ? ((size_t)sp.code_n + 1) & ~(size_t)1 : 0;     // palette words (kept even: float2 / double tables follow)
+    float2 *fan_cs = reinterpret_cast<float2 *>(lds_f + STREAM_HDR + tabw);     // num_rays float2
     // CRASH: the car-outline table next to the fan table (read when a ray finishes: from LDS it does
     // not sit behind the range store in vmcnt — a global read there made every refill wait for the
     // store's acknowledgement and the kernel 2.5x slower)
-    double *edge_l = reinterpret_cast<double *>(lds_f + STREAM_HDR + 2 * (size_t)f.num_rays);
-    const size_t tables = STREAM_HDR + (CRASH ? 4 : 2) * (size_t)f.num_rays;
+    double *edge_l = reinterpret_cast<double *>(lds_f + STREAM_HDR + tabw + 2 * (size_t)f.num_rays);
+    const size_t tables = STREAM_HDR + tabw + (CRASH ? 4 : 2) * (size_t)f.num_rays;
     // several rays per lane: per-wave compaction scratch of the drain phase (DRAIN_FIELDS x DRAIN_CAP dwords)
     constexpr int DRAIN_F = DRAIN_FIELDS + (CRASH ? 2 : 0);
     constexpr size_t DRAIN_WORDS = (SLOTS >= 2 && TILED) ? (size_t)(NT / 64) * DRAIN_F * DRAIN_CAP : 0;
@@ -1492,6 +1646,12 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     for (int j = threadIdx.x; j < f.num_rays; j += NT) {
         fan_cs[j] = sp.fan_tab[j];
         if (CRASH) edge_l[j] = cp.edge[j];
+    }
+    if (CODE) {
+        // (RM_DECODE names the table's LDS address as an immediate: the dynamic LDS block starts at 0 — this kernel has
+        //  no static LDS —, anything else would be a build that silently reads the wrong table)
+        if ((uint32_t)(uintptr_t)lds_f != 0u) __builtin_trap();
+        for (int j = threadIdx.x; j < sp.code_n; j += NT) lds_f[STREAM_HDR + j] = sp.code_tab[j];
     }
 
     // ---- which band of the sorted pose list, and which workgroups share it
@@ -1706,7 +1866,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                                         sb.gy, sb.t, sb.pc, sb.pr, sb.d_last, sc.dx, sc.dy, sc.gx, sc.gy, sc.t, sc.pc, sc.pr,
                                         sc.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range, cap);
                         else
-                            march_loop2<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx,
+                            march_loop2<TILED, LIT, CODE>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx,
                                         sb.gy, sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4,
                                         f.max_range, cap);
                         continue;
@@ -1819,13 +1979,13 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                                 continue;
                             }
                             if (L == 1u) {
-                                march_loop_capped<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt,
+                                march_loop_capped<TILED, LIT, CODE>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt,
                                                          pm.stride, pm.nstride, pm.k4, f.max_range, (uint32_t)sp.drain_stretch);
-                                march_drain4<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt, pm.stride,
+                                march_drain4<TILED, LIT, CODE>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt, pm.stride,
                                                     pm.nstride, pm.k4, f.max_range);
                             } else {
                                 // (2 lanes per ray: until 16 rays are left — 32 lanes —, then 4 lanes per ray to the end)
-                                march_drain_group<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt,
+                                march_drain_group<TILED, LIT, CODE>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, pm.pdt,
                                                          pm.stride, pm.nstride, pm.k4, f.max_range, L - 1u,
                                                          L == 2u ? 2u * gdn : 0u);
                             }
@@ -1841,7 +2001,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                             pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
                             exhausted ? 0u : 3u * (uint32_t)sp.low_water);
             else
-                march_loop2<TILED, LIT>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
+                march_loop2<TILED, LIT, CODE>(sa.dx, sa.dy, sa.gx, sa.gy, sa.t, sa.pc, sa.pr, sa.d_last, sb.dx, sb.dy, sb.gx, sb.gy,
                             sb.t, sb.pc, sb.pr, sb.d_last, pm.pdt, pm.stride, pm.nstride, pm.k4, f.max_range,
                             exhausted ? 0u : 2u * (uint32_t)sp.low_water);
         }

@@ -43,7 +43,7 @@ def test_cfg2_bench_shape_four_batches_in_flight_bit_equal_to_oracle(oracle_mod)
     m.set_option("grid_mult", 3)
     m.set_option("slots", 2)
     plan = m.plan_fan(n, B)
-    assert plan["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2>"
+    assert plan["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, false, 0>"
     assert (plan["grid"], plan["block"], plan["binning"], plan["record_source"]) == (192, 1024, "small_keys", 3)
     torch.cuda.synchronize()
     for rep in range(10):                          # 40 launches, up to four in flight, round robin like bench.py
@@ -67,7 +67,7 @@ def test_cfg2_bench_shape_four_batches_in_flight_bit_equal_to_oracle(oracle_mod)
     for k in range(P):
         m.calc_range_fan_device(d_poses[k].data_ptr(), n, fov, B, ref.data_ptr())
         torch.cuda.synchronize()
-        assert m.last_plan()["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 1>"
+        assert m.last_plan()["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 1, false, 0>"
         assert torch.equal(ref, d_out[k]), "batch %d: pipelined three-rays-per-lane launch != serial launch" % k
 
 
@@ -144,7 +144,7 @@ def test_bench_default_line_is_verified_and_complete():
     assert d["bursts"] >= 25 and d["value_min"] <= d["value"] <= d["value_max"]
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["scaling"] == "weak" and d["dtype"] == "f32"
     rf = d["roofline"]
-    assert rf["kernel"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2>" and rf["grid"] == 192
+    assert rf["kernel"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, false, 0>" and rf["grid"] == 192
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["launches_in_flight"] == 4
     assert "measured_hbm_gbs" in rf and rf["serial"]["kernel"].endswith(", 2>") and rf["serial"]["grid"] == 512
     cb = d["cpu_baseline"]

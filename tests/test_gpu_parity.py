@@ -84,6 +84,12 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "slots": 2, "handoff": 1, "handoff_cap": 8, "handoff_wg": 64, "inline_map_kb": 0, "stripe_max": 0},
     {"variant": 1, "slots": 2, "handoff": 1, "handoff_cap": 64, "inline_prep": 0, "grid_mult": 2},
     {"variant": 1, "slots": 3, "handoff": 1, "handoff_cap": 32, "handoff_wg": 128},
+    {"variant": 1, "slots": 2, "code_map": 2},                  # the step map as u16 palette codes, the palette in LDS (round 6)
+    {"variant": 1, "slots": 2, "code_map": 2, "inline_map_kb": 0, "stripe_max": 0},
+    {"variant": 1, "slots": 2, "code_map": 2, "inline_prep": 0, "low_water": 0},
+    {"variant": 1, "slots": 2, "code_map": 2, "inline_prep": 0, "bin_multi_min": 64, "xcd_bands": 3, "grid_mult": 2},
+    {"variant": 1, "slots": 2, "code_map": 2, "group_drain": 16, "drain_cap": 8, "drain_stretch": 1},
+    {"variant": 1, "slots": 2, "code_map": 2, "drain_cap": 3, "spec_stretch": 1},
 ])
 def test_every_kernel_schedule_is_bit_identical(oracle_mod, opts):
     g = maps.make_maze(400, cell=40, wall=3, p=0.45, seed=21, origin=(-7.0, 3.0, -0.4))
@@ -360,6 +366,73 @@ def test_audit_mode_reproduces_the_upstream_literal_form_bit_for_bit(oracle_mod)
     edge = oracle_mod.edge_distances(B, -w.fov / 2, w.fov / B, 0.275, 0.2032, 0.3302)
     assert m.check_collision_many(poses, w.fov, B, edge, 0.001) == oracle_mod.is_crashed(rb, B, len(poses), edge, 0.001)
     assert m.last_plan()["kernel"] == "rm_stream_literal" and m.last_plan()["crash"] == 1
+
+
+def test_code_map_is_engaged_and_bit_identical(oracle_mod):
+    """Round 6: the step map as 16-bit palette codes + the palette of exact float32 steps in LDS (rm_fan_stream_kernel<...,
+    CODE = 2>).  Same sample sequence as the float32 step map by construction — so the ranges, the fused crash index and the
+    upstream-literal form are bit-identical to the oracle —, and the launches really take it (plan: code 2, the palette size
+    the handle reports), on a maze (hundreds of distinct steps), colombia and an empty map (a palette of stop codes and steps
+    past max_range only); a map whose palette does not fit falls back to the float32 map."""
+    from pyracecarsimulator_amd import racecar as RC
+    B, fov = 1081, 4.71
+    edge = RC.edge_distances(B, -fov / 2.0, fov / B, 0.275, RC.DEFAULT_CAR["width"], RC.DEFAULT_CAR["wb"])
+    cases = [("maze400", maps.make_maze(400, cell=40, wall=3, p=0.45, seed=21, origin=(-7.0, 3.0, -0.4)), 300),
+             ("colombia", maps.load_colombia(), 300),
+             ("maze700_r120", maps.make_maze(700, cell=64, wall=2, p=0.5, seed=4), 120)]
+    for name, g, mrx in cases:
+        om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+        omap = range_libc.PyOMap(g)
+        poses = maps.sample_free_poses(g, 300, 9, dt=om.dt)
+        poses[11] = [np.nan, 0, 0]
+        poses[12] = [1e6, 1e6, 1.0]
+        for cls, sc in ((range_libc.PyRayMarchingGPU, 1.0), (range_libc.PyRayMarching, 0.999)):
+            m = cls(omap, mrx)
+            m.set_option("slots", 2)
+            m.set_option("code_map", 2)
+            want = om.rm_fan(poses, fov, B, step_coeff=sc, nthreads=4, want_hits=False, want_steps=False)[0]
+            for opts in ({}, {"inline_prep": 0}, {"inline_map_kb": 0, "stripe_max": 0, "inline_prep": 1}):
+                for k, v in opts.items():
+                    m.set_option(k, v)
+                got = np.full(len(poses) * B, -1.0, np.float32)
+                m.calc_range_fan(poses, got, fov, B)
+                pl = m.last_plan()
+                assert pl["code"] == 2 and pl["code_entries"] == m.get_info("code_entries") > 2, (name, opts, pl)
+                assert pl["name"].endswith(", 2, false, 2>"), pl["name"]
+                assert np.array_equal(got, want), (name, cls.__name__, opts, int((got != want).sum()))
+                # fused crash test on the code map
+                grp = 100
+                first = m.check_collision_groups(poses, grp, fov, B, edge, 0.001)
+                assert m.last_plan()["code"] == 2 and m.last_plan()["crash"] == 1
+                ref = [oracle_mod.is_crashed(want[q * grp * B:(q + 1) * grp * B], B, grp, edge, 0.001) for q in range(len(poses) // grp)]
+                assert first.tolist() == ref, (name, cls.__name__, opts)
+            # upstream-literal arithmetic on the code map
+            m.set_option("variant", 3)
+            got = np.full(len(poses) * B, -1.0, np.float32)
+            m.calc_range_fan(poses, got, fov, B)
+            assert m.last_plan()["kernel"] == "rm_stream_literal" and m.last_plan()["code"] == 2, m.last_plan()
+            assert np.array_equal(got, om.rm_fan_libm(poses, fov, B, step_coeff=sc)[0]), (name, cls.__name__, "literal")
+            # diagnostics (hit cells / sample counts) stay on the float32 map
+            m.set_option("variant", 1)
+            r, h, s_ = _fan(m, poses[:40], fov, B)
+            r0, h0, s0 = om.rm_fan(poses[:40], fov, B, step_coeff=sc)
+            assert m.last_plan()["code"] == 0 and np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s_, s0)
+            m.close()
+        # a map update rebuilds the palette and the code map
+        occ2 = np.array(g.occ, copy=True)
+        occ2[g.rows // 3:g.rows // 3 + 9, g.cols // 4:g.cols // 4 + 30] = 1
+        m = range_libc.PyRayMarchingGPU(omap, mrx)
+        m.set_option("slots", 2)
+        m.set_option("code_map", 2)
+        got = np.empty(len(poses) * B, np.float32)
+        m.calc_range_fan(poses, got, fov, B)
+        omap.update(occ2)
+        om2 = oracle_mod.OracleMap(occ2, g.resolution, g.origin, mrx)
+        m.calc_range_fan(poses, got, fov, B)
+        assert m.last_plan()["code"] == 2
+        assert np.array_equal(got, om2.rm_fan(poses, fov, B, step_coeff=1.0, nthreads=4, want_hits=False, want_steps=False)[0]), name
+        m.close()
+        omap.close()
 
 
 def test_upstream_literal_mode_in_production_shape(oracle_mod):

@@ -230,17 +230,17 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
     assert (p["kernel"], p["binning"], p["record_source"], p["grid"], p["bands"]) == ("rm_stream", "none", 1, 2, 1)
     # cfg2 through the library's defaults (a lone launch): keys-only binning + INLINE march, whole machine
     p = _plan(RMGPU, 2049, 2049, 4096, 1081)
-    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2>"
+    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, false, 0>"
     assert (p["binning"], p["record_source"], p["grid"], p["block"], p["bands"]) == ("small_keys", 3, 512, 1024, 8)
     # cfg2 the way bench.py pipelines it: three rays per lane, 0.75 workgroups per CU
     p = _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, grid_mult=3)
-    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 3>"
+    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 3, false, 0>"
     assert (p["grid"], p["slots"], p["binning"]) == (192, 3, "small_keys")
     assert p["lds_bytes"] <= 72 * 1024
     # diagnostics and the fused crash test keep one or two rays per lane
     assert _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, aux=True)["slots"] == 1
     assert _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, crash=True)["name"] == \
-        "scan::rm_fan_stream_kernel<false, true, 1024, true, true, 2>"
+        "scan::rm_fan_stream_kernel<false, true, 1024, true, true, 2, false, 0>"
     # cfg3: GiantLUT rows of 1442 bins = 3 x 16-B loads per lane, 17 chunks of 64 beams; and the CDDT variant
     p = _plan(GLT, 2000, 2000, 65536, 1081, theta_disc=1442)
     assert (p["name"], p["grid"], p["block"], p["lds_bytes"]) == ("scan::lut_fan_lds_kernel<3, 17>", 4096, 256, 12288)
@@ -268,7 +268,7 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
     assert p["slices"] == 2 and p["slice_poses"] * 1081 < 1 << 30
     p = _plan(RMGPU, 350, 435, 131072, 1081)
     assert (p["slices"], p["binning"], p["record_source"], p["slots"], p["grid"]) == (1, "grid_sort", 0, 2, 512)
-    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, false, true, 2>"
+    assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, false, true, 2, false, 0>"
     # ... while a 4096-pose batch on it needs no binning at all
     assert _plan(RMGPU, 350, 435, 4096, 1081)["binning"] == "none"
     # cfg5: 720 beams, 4096^2
@@ -341,9 +341,9 @@ def test_launch_plan_survives_zeroed_and_out_of_range_options():
     #  be derived in LDS and no diagnostics are asked for; the one-lane-per-ray kernel otherwise)
     pl = _plan(_lib.RL_RM, 2049, 2049, 4096, 1081, variant=3)
     assert (pl["kernel"], pl["block"], pl["binning"], pl["slots"], pl["name"]) == (
-        "rm_stream_literal", 1024, "small_keys", 2, "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, true>")
+        "rm_stream_literal", 1024, "small_keys", 2, "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, true, 0>")
     pl = _plan(_lib.RL_RM_GPU, 2049, 2049, 200, 1081, variant=3, crash=True)              # the reference's roll-out batch
-    assert (pl["kernel"], pl["crash"], pl["name"]) == ("rm_stream_literal", 1, "scan::rm_fan_stream_kernel<false, true, 1024, true, true, 2, true>")
+    assert (pl["kernel"], pl["crash"], pl["name"]) == ("rm_stream_literal", 1, "scan::rm_fan_stream_kernel<false, true, 1024, true, true, 2, true, 0>")
     pl = _plan(_lib.RL_RM_GPU, 2049, 2049, 65536, 1081, variant=3)                        # beyond one INLINE launch: pose slices
     assert (pl["kernel"], pl["slices"], pl["slice_poses"]) == ("rm_stream_literal", 16, 4096)
     assert _plan(_lib.RL_RM_GPU, 435, 350, 100000, 1081, variant=3)["kernel"] == "rm_stream_literal"   # small map
@@ -370,7 +370,7 @@ def test_launch_plan_falls_back_when_the_tiled_step_map_or_the_lds_does_not_fit(
     whose beam tables exceed a workgroup's 160 KB of LDS is refused with RL_ERR_UNSUPPORTED, not launched."""
     RMGPU = _lib.RL_RM_GPU
     p = _plan(RMGPU, 300, 1100000, 4096, 1081, slots=2)
-    assert p["tiled"] == 0 and p["slots"] == 1 and ", false, 1>" in p["name"]
+    assert p["tiled"] == 0 and p["slots"] == 1 and ", false, 1, false, 0>" in p["name"]
     assert _plan(RMGPU, 2049, 2049, 4096, 1081)["tiled"] == 1
     assert _plan(RMGPU, 16384, 16384, 4096, 1081)["tiled"] == 1          # K = 19: fits
     with pytest.raises(_lib.ScanLibError) as e:
