@@ -369,6 +369,8 @@ def main():
     meth = make_method(range_libc, omap, w, method)
     if a.variant >= 0:
         meth.set_option("variant", a.variant)
+    # the arithmetic in effect: "RM" (range_libc's CPU RayMarching) defaults to the upstream-literal form, variant 3
+    variant_eff = meth.get_info("variant") if method in ("RM", "RMGPU") else a.variant
     if w.noise_std > 0:
         meth.set_noise(w.noise_std, w.noise_seed, lo * B)    # keyed by the GLOBAL ray id: shard-invariant
     max_range_m = w.max_range_px * gmap.resolution
@@ -649,7 +651,7 @@ def main():
             for pipelined in (True, False):
                 apply_schedule(pipelined)
                 meth.calc_range_fan(poses, got, w.fov, B)
-                if method in ("RM", "RMGPU") and a.variant == 3:
+                if method in ("RM", "RMGPU") and variant_eff == 3:
                     # --variant 3: the upstream-literal arithmetic is what is timed — its statement is the checker's libm form
                     want = om.rm_fan_libm(poses, w.fov, B, step_coeff=1.0 if method == "RMGPU" else 0.999)[0]
                 elif method in ("RM", "RMGPU"):
@@ -694,7 +696,7 @@ def main():
             extra["vs_exact_rm"] = dict(bench_legs.error_stats_cells(got, exact, gmap.resolution),
                                         what="|range - exact ray marching (oracle rm_fan, coefficient 1.0)| in cells, "
                                              "%d poses x %d beams of batch 0" % (len(sub), B))
-        if method in ("RM", "RMGPU") and not a.selftest_corrupt and a.variant != 3:
+        if method in ("RM", "RMGPU") and not a.selftest_corrupt and variant_eff != 3:
             # parity on the record (range_libc is absent: the oracle is UNPINNED): the same subsample
             # through the AUDIT mode (variant 3: upstream-literal arithmetic, glibc sinf / cosf on the device) must equal
             # the oracle's libm form bit for bit, and the line states how far the canonical default is from it
@@ -708,7 +710,7 @@ def main():
                 meth.set_option("variant", 3)
                 meth.calc_range_fan(poses, lit_r, w.fov, B, hit_cells=lit_h)
             finally:
-                meth.set_option("variant", a.variant if a.variant >= 0 else 1)
+                meth.set_option("variant", variant_eff)
                 if w.noise_std > 0:
                     meth.set_noise(w.noise_std, w.noise_seed, lo * B)
             ref_r, ref_h, _ = om.rm_fan_libm(poses, w.fov, B, step_coeff=sc)
@@ -965,7 +967,7 @@ def main():
             out["same_batch"] = {"value": round(sb["value"], 2), "ms_per_step": round(sb["ms_per_step"], 4),
                                  "bursts": sb["bursts"],
                                  "what": "all %d steps in flight scan batch 0 (not the reported configuration)" % P}
-        if not a.no_extras and is_rm and a.variant < 0 and not scan.reduced and not a.selftest_corrupt:
+        if not a.no_extras and is_rm and a.variant < 0 and variant_eff != 3 and not scan.reduced and not a.selftest_corrupt:
             # strict parity as a production mode: the SAME schedule — steps in flight, streams, pose
             # batches — with the upstream-literal arithmetic (option variant 3 -> rm_fan_stream_kernel<.., LIT>)
             meth.set_option("variant", 3)

@@ -34,6 +34,7 @@ extern "C" int rl_method_create(rl_map *m, int kind, float max_range_px, int the
     h->max_range = max_range_px;
     h->theta_disc = theta_disc;
     h->step_coeff = kind == RL_RM_GPU ? 1.0f : 0.999f;   // kernels.cu STEP_COEFF vs RayMarching (also seeds the LUT)
+    h->variant = plan::default_variant(kind);             // RL_RM: the upstream-literal arithmetic; the others canonical
     if (!m->reps.empty()) {
         // multi-device: one ordinary method per device replica of the map + one worker thread per extra device
         std::vector<int> devs;
@@ -173,7 +174,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
         return RL_OK;
     }
     std::lock_guard<std::mutex> lk(h->mu);
-    if (!strcmp(name, "variant")) h->variant = value;
+    if (!strcmp(name, "variant")) h->variant = value < 0 ? plan::default_variant(h->kind) : value;
     else if (!strcmp(name, "grid_mult")) h->grid_mult = value < 1 ? 1 : value;
     else if (!strcmp(name, "low_water")) h->low_water = value < 0 ? -1 : (value > 63 ? 63 : value);
     else if (!strcmp(name, "sort_poses")) h->sort_poses = value != 0;
@@ -731,6 +732,7 @@ static rl_plan_opts opts_of(const rl_method *h)
     o.debug_stamps = h->debug_stamps;
     o.slice_log2 = h->slice_log2;
     o.code_map = h->code_map;
+    o.code_entries = (h->code_map && h->code_built == h->code_map && h->pdt_epoch == h->map->epoch) ? h->code_n : 0;
     return o;
 }
 
@@ -748,7 +750,6 @@ static int plan_for(const rl_method *h, int n_poses, int num_rays, bool aux, boo
     in.num_rays = num_rays;
     in.aux = aux;
     in.crash = crash;
-    in.code_n = (h->code_map && h->code_built == h->code_map && h->pdt_epoch == h->map->epoch) ? h->code_n : 0;
     return plan::plan_fan(in, out);
 }
 

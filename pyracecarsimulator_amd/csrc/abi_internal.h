@@ -363,7 +363,7 @@ struct rl_method {
     // the CODE map (option code_map = 2): the step map as u16 palette codes + the palette (rm_kernels.h), built next to
     // the float32 step map by ensure_step_map; code_n = palette entries with the two stop codes, 0 = none (option off,
     // geometry does not fit, or more distinct steps than plan::CODE_MAX_ENTRIES)
-    int code_map = 0;
+    int code_map = 2;
     DevBuf cmap, cval, cidx, ctab, cnum;
     uint32_t *pin_cnum = nullptr;
     int code_n = 0;

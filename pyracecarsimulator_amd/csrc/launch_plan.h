@@ -34,14 +34,19 @@ struct In {
     rl_plan_opts o{};
     int n_poses = 0, num_rays = 0;
     bool aux = false, crash = false;
-    int code_n = 0;          // entries of the map's step palette with the two stop codes (0: not known / does not fit):
-                             // what a handle learns when it builds its code map; the code-map kernels need it for their LDS
 };
+
+// The arithmetic a range method runs by default.  RL_RM is range_libc's CPU RayMarching (scripts/scan_simulator.py:72-73,
+// simple_params.yaml:114): it computes what numpy_calc_range + RayMarching::calc_range compute — per-ray float32 angle,
+// glibc sinf / cosf, un-fused march — i.e. variant 3, the upstream-literal statement (the checker's rm_fan_libm).  RL_RM_GPU
+// stands for kernels.cu, whose device trig cannot be known here: the canonical arithmetic (variant 1).  Everything
+// else has one form.  Option "variant" overrides either way.
+inline int default_variant(int kind) { return kind == RL_RM ? 3 : 1; }
 
 inline void default_opts(rl_plan_opts &o)
 {
     std::memset(&o, 0, sizeof o);
-    o.variant = 1;
+    o.variant = -1;           // the default of the kind (default_variant): resolved by plan_fan
     o.grid_mult = 8;          // workgroups (x256 threads) per CU of a persistent launch
     o.wg_threads = 1024;
     o.low_water = -1;                          // (auto: abi_fan.hip)
@@ -65,7 +70,8 @@ inline void default_opts(rl_plan_opts &o)
     o.lut_debug = 0;
     o.debug_stamps = 0;
     o.slice_log2 = 30;
-    o.code_map = 0;           // (set by the round-6 A/B: see DESIGN.md section 4)
+    o.code_map = 2;           // u16 palette codes wherever the palette fits (profiles/r06/ab_code_map.txt)
+    o.code_entries = 0;       // (a handle fills in its map's palette size)
 }
 
 // Options as the planner may use them: every field a division, a shift or a template choice depends on is
@@ -75,7 +81,7 @@ inline void default_opts(rl_plan_opts &o)
 inline rl_plan_opts sanitized(rl_plan_opts o)
 {
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    o.variant = clampi(o.variant, 0, 3);
+    o.variant = o.variant < 0 ? -1 : clampi(o.variant, 0, 3);
     o.grid_mult = clampi(o.grid_mult, 1, 64);
     o.wg_threads = o.wg_threads >= 1024 ? 1024 : (o.wg_threads >= 512 ? 512 : 256);
     o.low_water = o.low_water < 0 ? -1 : clampi(o.low_water, 0, 63);
@@ -97,6 +103,7 @@ inline rl_plan_opts sanitized(rl_plan_opts o)
     o.cddt_search = clampi(o.cddt_search, 0, 2);
     o.slice_log2 = clampi(o.slice_log2, 8, 30);
     o.code_map = o.code_map == 2 ? 2 : 0;          // (u16 codes; 1 = u8 codes is not instantiated)
+    o.code_entries = clampi(o.code_entries, 0, 1 << 30);
     return o;
 }
 
@@ -395,9 +402,10 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     int slots_req = o.slots ? o.slots : ((rays >= (1L << 23) || !small_map) ? 2 : 1);
     // the code map (u16 palette codes + the palette in LDS): the two-rays-per-lane kernels of 1024 lanes on the tiled
     // layout, when the handle knows the palette fits (code_n)
-    int code = (o.code_map == 2 && in.code_n > 0 && in.code_n <= CODE_MAX_ENTRIES && !in.aux && tiled_opt && slots_req == 2 &&
+    const int code_n = o.code_entries;
+    int code = (o.code_map == 2 && code_n >= 2 && code_n <= CODE_MAX_ENTRIES && !in.aux && tiled_opt && slots_req == 2 &&
                 o.wg_threads == 1024) ? 2 : 0;
-    const size_t tabw = ((size_t)in.code_n + 1) & ~(size_t)1;
+    const size_t tabw = ((size_t)code_n + 1) & ~(size_t)1;
     if (code && tables_bytes(tabw) + 16 * drain_wave > (size_t)INLINE_LDS_BUDGET) code = 0;
     if (code) tables_b = tables_bytes(tabw);
     // (a fan whose tables leave no room for the scratch of 16 waves marches one ray per lane)
@@ -462,7 +470,7 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     }
     p->kernel = RL_K_RM_STREAM;
     p->code = (s == 2 && t) ? code : 0;
-    p->code_entries = p->code ? in.code_n : 0;
+    p->code_entries = p->code ? code_n : 0;
     p->slots = s;
     p->tiled = t;
     p->block = inl ? (s == 2 ? inl_nt : 1024) : nt;
@@ -482,6 +490,7 @@ inline int plan_fan(const In &in_raw, rl_launch_plan *p)
 {
     In in = in_raw;
     in.o = sanitized(in_raw.o);
+    if (in.o.variant < 0) in.o.variant = default_variant(in.kind);
     std::memset(p, 0, sizeof *p);
     if (in.n_poses <= 0 || in.num_rays <= 0) {
         std::snprintf(p->name, sizeof p->name, "(nothing to launch)");

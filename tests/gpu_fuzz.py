@@ -159,9 +159,9 @@ def one_case(seed):
             occ2 = occ.copy(); occ2[rows // 3: rows // 3 + 3, cols // 3: cols // 3 + 3] ^= 1
             omap.update(occ2)
             om2 = O.OracleMap(occ2, res, origin, mrx)
-            m = range_libc.PyRayMarching(omap, mrx)
+            m = range_libc.PyRayMarching(omap, mrx)          # (default arithmetic of "RM": upstream-literal)
             out = np.empty(n, np.float32); m.calc_range_fan(poses, out, fov, B)
-            assert np.array_equal(out, om2.rm_fan(poses, fov, B, 0.999)[0]), "after map update"
+            assert np.array_equal(out, om2.rm_fan_libm(poses, fov, B, step_coeff=0.999)[0]), "after map update"
             m.close(); omap.update(occ)
             if r.random() < 0.25:
                 # one handle over several devices (the box has one GPU: device 0 two or three times): the batch cut into
@@ -176,6 +176,8 @@ def one_case(seed):
             ins = poses[r.integers(0, P, 500)].copy(); ins[:, 2] = r.uniform(-9, 9, 500).astype(np.float32)
             outs = np.empty(500, np.float32)
             m = range_libc.PyRayMarching(omap, mrx); m.calc_range_many(ins, outs)
+            assert np.array_equal(outs, om.rm_rays_libm(ins, step_coeff=0.999)), "RM rays (literal)"
+            m.set_option("variant", 1); m.calc_range_many(ins, outs)
             assert np.array_equal(outs, om.rm_rays(ins)[0]), "RM rays"
             m.close(); omap.close()
         except AssertionError as e:

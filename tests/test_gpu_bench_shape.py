@@ -43,7 +43,7 @@ def test_cfg2_bench_shape_four_batches_in_flight_bit_equal_to_oracle(oracle_mod)
     m.set_option("grid_mult", 3)
     m.set_option("slots", 2)
     plan = m.plan_fan(n, B)
-    assert plan["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, false, 0>"
+    assert plan["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, false, 2>"      # (u16 code map: the default)
     assert (plan["grid"], plan["block"], plan["binning"], plan["record_source"]) == (192, 1024, "small_keys", 3)
     torch.cuda.synchronize()
     for rep in range(10):                          # 40 launches, up to four in flight, round robin like bench.py
@@ -84,8 +84,9 @@ def test_launch_plan_is_what_runs():
         before = m.plan_fan(700, 360)
         m.calc_range_fan(poses, out, 4.0, 360)
         assert m.last_plan() == before
+        # (the map's palette size is the one thing the device-less planner cannot know: the handle reports it)
         pure = _lib.plan_fan(kind, g.rows, g.cols, 700, 360, max_range_px=120.0, theta_disc=td,
-                             n_cu=m.get_info("n_cu"))
+                             n_cu=m.get_info("n_cu"), code_entries=m.get_info("code_entries"))
         assert pure == before, (cls.__name__, pure, before)
         m.close()
 
@@ -144,7 +145,7 @@ def test_bench_default_line_is_verified_and_complete():
     assert d["bursts"] >= 25 and d["value_min"] <= d["value"] <= d["value_max"]
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["scaling"] == "weak" and d["dtype"] == "f32"
     rf = d["roofline"]
-    assert rf["kernel"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, false, 0>" and rf["grid"] == 192
+    assert rf["kernel"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, false, 2>" and rf["grid"] == 192
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and rf["launches_in_flight"] == 4
     assert "measured_hbm_gbs" in rf and rf["serial"]["kernel"].endswith(", 2>") and rf["serial"]["grid"] == 512
     cb = d["cpu_baseline"]

@@ -123,8 +123,24 @@ def test_rm_fan_reproduces_golden_vectors(name):
     g, z = load_golden(name)
     omap = range_libc.PyOMap(g)
     fov, B, mrx = float(z["fov"]), int(z["num_rays"]), int(z["max_range_px"])
+    L = np.load(os.path.join(GOLD, "rm_libm_forms.npz"))
+    npz = int(L[name + "_n_poses"])
     for tag, cls in (("cpu", range_libc.PyRayMarching), ("gpu", range_libc.PyRayMarchingGPU)):
-        r, h, s = _fan(cls(omap, mrx), z["poses"], fov, B)
+        m = cls(omap, mrx)
+        if tag == "cpu":
+            # "RM" names range_libc's CPU RayMarching (scripts/scan_simulator.py:72-73): by default it computes the
+            # upstream-literal statement — the committed libm-form vectors, bit for bit: ranges, hit cells, sample counts
+            assert m.get_info("variant") == 3
+            r, h, s = _fan(m, z["poses"][:npz], fov, B)
+            assert np.array_equal(r, L["%s_ranges_cpu" % name]) and np.array_equal(h, L["%s_hits_cpu" % name].astype(np.int32))
+            assert np.array_equal(s, L["%s_steps_cpu" % name])
+            rr = np.empty(npz * B, np.float32)
+            m.calc_range_fan(z["poses"][:npz], rr, fov, B)             # ranges only: the stream form
+            assert m.last_plan()["kernel"] == "rm_stream_literal" and np.array_equal(rr, L["%s_ranges_cpu" % name])
+            m.set_option("variant", 1)                                 # the canonical arithmetic stays selectable
+        else:
+            assert m.get_info("variant") == 1
+        r, h, s = _fan(m, z["poses"], fov, B)
         assert np.array_equal(r, z["ranges_" + tag]), tag
         assert np.array_equal(h, z["hits_" + tag].astype(np.int32)), tag
         assert np.array_equal(s, z["steps_" + tag]), tag
@@ -158,7 +174,9 @@ def test_device_fan_vs_upstream_literal_libm_form(oracle_mod):
         fov, B, mrx = float(z["fov"]), int(z["num_rays"]), int(z["max_range_px"])
         npz = int(L[name + "_n_poses"])
         for tag, cls in (("cpu", range_libc.PyRayMarching), ("gpu", range_libc.PyRayMarchingGPU)):
-            r, h, s_ = _fan(cls(omap, mrx), z["poses"][:npz], fov, B)
+            mc = cls(omap, mrx)
+            mc.set_option("variant", 1)                 # the CANONICAL form of both classes against the literal vectors
+            r, h, s_ = _fan(mc, z["poses"][:npz], fov, B)
             seen.append((name, tag) + _libm_gate(r, h, L["%s_ranges_%s" % (name, tag)], L["%s_hits_%s" % (name, tag)],
                                                  g.resolution, name + "/" + tag))
             assert (s_ != L["%s_steps_%s" % (name, tag)]).mean() < 2e-3
@@ -397,7 +415,7 @@ def test_code_map_is_engaged_and_bit_identical(oracle_mod):
                 got = np.full(len(poses) * B, -1.0, np.float32)
                 m.calc_range_fan(poses, got, fov, B)
                 pl = m.last_plan()
-                assert pl["code"] == 2 and pl["code_entries"] == m.get_info("code_entries") > 2, (name, opts, pl)
+                assert pl["code"] == 2 and pl["code_entries"] == m.get_info("code_entries") >= 2, (name, opts, pl)
                 assert pl["name"].endswith(", 2, false, 2>"), pl["name"]
                 assert np.array_equal(got, want), (name, cls.__name__, opts, int((got != want).sum()))
                 # fused crash test on the code map
@@ -520,7 +538,7 @@ def test_pyomap_from_occupancy_grid_message_scans_like_the_oracle(oracle_mod):
     g = maps.make_maze(200, cell=25, wall=2, p=0.5, seed=12, resolution=0.05, origin=(-3.0, 1.5, 0.7))
     om = oracle_mod.OracleMap.from_gridmap(g, 300)
     poses = maps.sample_free_poses(g, 40, 3, dt=om.dt)
-    want = om.rm_fan(poses, 4.71, 1081, step_coeff=0.999, nthreads=4)[0]
+    want = om.rm_fan_libm(poses, 4.71, 1081, step_coeff=0.999)[0]      # "RM": the upstream-literal arithmetic
     for binarise in (True, False):
         omap = range_libc.PyOMap(occupancy_grid_msg(g, binarise))
         assert (omap.height, omap.width) == (g.rows, g.cols)
@@ -571,6 +589,7 @@ def test_edge_cases(oracle_mod):
     om = oracle_mod.OracleMap.from_gridmap(g, 300)
     omap = range_libc.PyOMap(g)
     m = range_libc.PyRayMarching(omap, 300)
+    m.set_option("variant", 1)                  # (the canonical kernels; the literal form's edge cases: test_upstream_literal_*)
     poses = np.array([
         [3.0, 3.0, 0.0], [3.0, 3.0, 1e-30], [3.0, 3.0, -1e-38], [3.0, 3.0, 1e-42],   # tiny / denormal
         [0.01, 0.01, 0.7],                      # inside the wall
@@ -610,15 +629,22 @@ def test_two_arg_rays_api_and_four_arg_sparse_api(oracle_mod):
     ins[:, 2] = rng.uniform(-7, 7, len(ins)).astype(np.float32)
     outs = np.zeros(len(ins), np.float32)
     assert m.calc_range_many(ins, outs) is None
-    r0, _, _ = om.rm_rays(ins)
+    r0 = om.rm_rays_libm(ins, step_coeff=0.999)                   # PyRayMarching: the upstream-literal arithmetic
     assert np.array_equal(outs, r0)
     assert m.calc_range(*ins[7]) == float(r0[7])
+    m.set_option("variant", 1)
+    m.calc_range_many(ins, outs)
+    assert np.array_equal(outs, om.rm_rays(ins)[0])               # ... the canonical one on request
+    m.set_option("variant", 3)
     # the fork's 4-arg form exactly as ScanSimulator2D calls it: sparse ins, pose p at row p*B
     P = 5
     sparse = np.zeros((P * B, 3), np.float32)
     sparse[::B] = z["poses"][:P]
     outs = np.full(P * B, -1, np.float32)
     assert m.calc_range_many(sparse, outs, fov, B) is None
+    assert np.array_equal(outs, om.rm_fan_libm(z["poses"][:P], fov, B, step_coeff=0.999)[0])
+    m.set_option("variant", 1)
+    m.calc_range_many(sparse, outs, fov, B)
     assert np.array_equal(outs, z["ranges_cpu"][:P * B])
     with pytest.raises(ValueError):
         m.calc_range_many(sparse.astype(np.float64), outs, fov, B)
@@ -636,7 +662,7 @@ def test_scan_simulator_end_to_end(oracle_mod):
         sim = ScanSimulator2D(1081, 4.71, 0.01, batch_size=8)
         sim.setMap(omap, mrx, g.resolution, g.origin)
         sim.setRaytracingMethod(method)
-        want, _, _ = om.rm_fan(poses[:8], 4.71, 1081, step_coeff=sc)
+        want = (om.rm_fan_libm if method == "RM" else om.rm_fan)(poses[:8], 4.71, 1081, step_coeff=sc)[0]
         many = sim.scanMany(poses)                  # 10 given, batch_size 8 scanned
         assert many is sim.output_vector_many and np.array_equal(many, want)
         one = sim.scan(float(poses[2, 0]), float(poses[2, 1]), float(poses[2, 2]))
@@ -718,6 +744,7 @@ def test_map_update_rebuilds_tables(oracle_mod):
     g = maps.make_maze(200, cell=25, wall=2, seed=5)
     omap = range_libc.PyOMap(g)
     m = range_libc.PyRayMarching(omap, 120)
+    m.set_option("variant", 1)
     poses = maps.sample_free_poses(g, 6, 1)
     occ2 = g.occ.copy()
     occ2[90:110, 90:110] = 1                         # stamp an obstacle (two-player car outline)
@@ -771,8 +798,15 @@ def test_cfg1_one_pose_through_scan_simulator(oracle_mod):
     for p in poses:
         got = sim.scan(float(p[0]), float(p[1]), float(p[2]))
         assert got is sim.output_vector
-        want = om.rm_fan(p[None, :], w.fov, w.num_rays, step_coeff=0.999)[0]
+        # "RM" = range_libc's CPU RayMarching = the upstream-literal statement (per-ray float32 angle, glibc sinf / cosf,
+        # un-fused march: the checker's rm_fan_libm), bit for bit
+        want = om.rm_fan_libm(p[None, :], w.fov, w.num_rays, step_coeff=0.999)[0]
         assert np.array_equal(got, want)
+    assert sim.scan_method.get_info("variant") == 3 and sim.scan_method.last_plan()["kernel"] == "rm_stream_literal"
+    sim.scan_method.set_option("variant", 1)                      # the canonical arithmetic on request
+    for p in poses[:3]:
+        assert np.array_equal(sim.scan(float(p[0]), float(p[1]), float(p[2])),
+                              om.rm_fan(p[None, :], w.fov, w.num_rays, step_coeff=0.999)[0])
 
 
 def test_cfg2_full_size_properties(oracle_mod):
@@ -1786,6 +1820,7 @@ def test_speculating_drain_loop_on_long_chains_bit_equal_to_oracle(oracle_mod, c
     assert steps.max() >= 120 and (steps >= 60).sum() > 500          # the chains this test is about exist
     cls = range_libc.PyRayMarchingGPU if coeff_cls == "RMGPU" else range_libc.PyRayMarching
     m = cls(omap, mrx)
+    m.set_option("variant", 1)             # (the drain loops of the canonical kernels, either step coefficient)
     m.set_option("slots", 1)
     out = np.empty(P * B, np.float32)
     for big_map_policy in (0, 1):

@@ -226,12 +226,25 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
     """Which kernel every BASELINE.json configuration launches, decided without a device."""
     RM, RMGPU, CDDT, GLT, BL = _lib.RL_RM, _lib.RL_RM_GPU, _lib.RL_CDDT, _lib.RL_GIANT_LUT, _lib.RL_BRESENHAM
     # cfg1: one pose — no binning pass, the two workgroups derive their records in LDS
+    # ("RM" is range_libc's CPU RayMarching: the upstream-literal arithmetic by default — variant 3 —, canonical on request)
     p = _plan(RM, 2049, 2049, 1, 1081)
+    assert (p["kernel"], p["binning"], p["record_source"], p["grid"], p["bands"]) == ("rm_stream_literal", "none", 1, 2, 1)
+    p = _plan(RM, 2049, 2049, 1, 1081, variant=1)
     assert (p["kernel"], p["binning"], p["record_source"], p["grid"], p["bands"]) == ("rm_stream", "none", 1, 2, 1)
     # cfg2 through the library's defaults (a lone launch): keys-only binning + INLINE march, whole machine
     p = _plan(RMGPU, 2049, 2049, 4096, 1081)
     assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, false, 0>"
     assert (p["binning"], p["record_source"], p["grid"], p["block"], p["bands"]) == ("small_keys", 3, 512, 1024, 8)
+    # ... on the u16 code map once the handle knows the map's palette (626 entries on this maze): the palette rides in LDS
+    pc = _plan(RMGPU, 2049, 2049, 4096, 1081, code_entries=626)
+    assert pc["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, false, 2>"
+    assert (pc["code"], pc["code_entries"], pc["grid"], pc["binning"]) == (2, 626, 512, "small_keys")
+    assert pc["lds_bytes"] >= p["lds_bytes"] + 626 * 4 - 32 * 4 and pc["lds_bytes"] <= 72 * 1024
+    assert _plan(RMGPU, 2049, 2049, 4096, 1081, code_entries=626, code_map=0)["code"] == 0
+    assert _plan(RMGPU, 2049, 2049, 4096, 1081, code_entries=5000)["code"] == 0          # palette beyond the LDS table
+    assert _plan(RMGPU, 2049, 2049, 4096, 1081, code_entries=626, aux=True)["code"] == 0  # diagnostics: float32 map
+    assert _plan(RM, 2049, 2049, 4096, 1081, code_entries=626)["name"] == \
+        "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 2, true, 2>"
     # cfg2 the way bench.py pipelines it: three rays per lane, 0.75 workgroups per CU
     p = _plan(RMGPU, 2049, 2049, 4096, 1081, slots=3, grid_mult=3)
     assert p["name"] == "scan::rm_fan_stream_kernel<false, false, 1024, true, true, 3, false, 0>"
