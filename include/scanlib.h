@@ -312,6 +312,8 @@ typedef struct rl_plan_opts {
     int code_map;        /* ray marching: 2 = the step map as 16-bit palette codes, the palette (exact float32 steps) in LDS
                             (rm_fan_stream_kernel<..., CODE = 2>: the same sample sequence, half the bytes per cell);
                             0 = float32 steps.  Takes effect where the map's palette fits (code_entries)                */
+    int code_min_rays;   /* ... from this many rays per launch: below it the look-up's latency in every dependent sample costs a
+                            lone launch more than the smaller footprint buys (profiles/r06/ab_code_map.txt)              */
     int code_entries;    /* entries of the map's step palette with its two stop codes — a handle knows it once its step map
                             is built (rl_method_get_info "code_entries", filled in by rl_method_plan_fan); 0 = unknown or
                             too many: the device-less rl_plan_fan then plans the float32 map                          */

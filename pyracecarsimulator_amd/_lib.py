@@ -32,7 +32,7 @@ class PlanOpts(C.Structure):
         "variant", "grid_mult", "wg_threads", "low_water", "sort_poses", "xcd_bands", "slots", "tiled",
         "inline_prep", "inline_max", "inline_map_kb", "stripe_max", "order_inline", "bin_multi_min",
         "bin_generic", "run_log2", "cddt_bins", "cddt_sort", "lut_debug", "debug_stamps", "slice_log2",
-        "cddt_theta_min", "cddt_search", "code_map", "code_entries")]
+        "cddt_theta_min", "cddt_search", "code_map", "code_min_rays", "code_entries")]
 
 
 class LaunchPlan(C.Structure):

@@ -196,6 +196,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
     else if (!strcmp(name, "tiled")) h->tiled = value != 0;
     else if (!strcmp(name, "code_map")) h->code_map = value == 2 ? 2 : 0;
+    else if (!strcmp(name, "code_min_rays")) h->code_min_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "pinned_max_rays")) h->pinned_max_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "direct_max_rays")) h->direct_max_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "overlap_min_rays")) h->overlap_min_rays = value < 0 ? 0 : value;
@@ -257,6 +258,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "bin_generic")) *value_out = h->bin_generic;
     else if (!strcmp(name, "tiled")) *value_out = h->tiled;
     else if (!strcmp(name, "code_map")) *value_out = h->code_map;
+    else if (!strcmp(name, "code_min_rays")) *value_out = h->code_min_rays;
     else if (!strcmp(name, "code_entries")) *value_out = h->code_n;
     else if (!strcmp(name, "pinned_max_rays")) *value_out = h->pinned_max_rays;
     else if (!strcmp(name, "direct_max_rays")) *value_out = h->direct_max_rays;
@@ -732,6 +734,7 @@ static rl_plan_opts opts_of(const rl_method *h)
     o.debug_stamps = h->debug_stamps;
     o.slice_log2 = h->slice_log2;
     o.code_map = h->code_map;
+    o.code_min_rays = h->code_min_rays;
     o.code_entries = (h->code_map && h->code_built == h->code_map && h->pdt_epoch == h->map->epoch) ? h->code_n : 0;
     return o;
 }

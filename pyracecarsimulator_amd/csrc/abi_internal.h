@@ -364,6 +364,7 @@ struct rl_method {
     // the float32 step map by ensure_step_map; code_n = palette entries with the two stop codes, 0 = none (option off,
     // geometry does not fit, or more distinct steps than plan::CODE_MAX_ENTRIES)
     int code_map = 2;
+    int code_min_rays = 1 << 22;
     DevBuf cmap, cval, cidx, ctab, cnum;
     uint32_t *pin_cnum = nullptr;
     int code_n = 0;

@@ -71,6 +71,7 @@ inline void default_opts(rl_plan_opts &o)
     o.debug_stamps = 0;
     o.slice_log2 = 30;
     o.code_map = 2;           // u16 palette codes wherever the palette fits (profiles/r06/ab_code_map.txt)
+    o.code_min_rays = 1 << 22;   // (cfg2's 4096 x 1081 and up)
     o.code_entries = 0;       // (a handle fills in its map's palette size)
 }
 
@@ -104,6 +105,7 @@ inline rl_plan_opts sanitized(rl_plan_opts o)
     o.slice_log2 = clampi(o.slice_log2, 8, 30);
     o.code_map = o.code_map == 2 ? 2 : 0;          // (u16 codes; 1 = u8 codes is not instantiated)
     o.code_entries = clampi(o.code_entries, 0, 1 << 30);
+    o.code_min_rays = clampi(o.code_min_rays, 0, 1 << 30);
     return o;
 }
 
@@ -403,7 +405,7 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     // the code map (u16 palette codes + the palette in LDS): the two-rays-per-lane kernels of 1024 lanes on the tiled
     // layout, when the handle knows the palette fits (code_n)
     const int code_n = o.code_entries;
-    int code = (o.code_map == 2 && code_n >= 2 && code_n <= CODE_MAX_ENTRIES && !in.aux && tiled_opt && slots_req == 2 &&
+    int code = (o.code_map == 2 && code_n >= 2 && code_n <= CODE_MAX_ENTRIES && rays >= (long)o.code_min_rays && !in.aux && tiled_opt && slots_req == 2 &&
                 o.wg_threads == 1024) ? 2 : 0;
     const size_t tabw = ((size_t)code_n + 1) & ~(size_t)1;
     if (code && tables_bytes(tabw) + 16 * drain_wave > (size_t)INLINE_LDS_BUDGET) code = 0;

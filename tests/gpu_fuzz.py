@@ -83,7 +83,7 @@ def one_case(seed):
                                  "spec_stretch": int(r.choice([1, 4, 16])), "drain_cap": int(r.choice([1, 24, 64])),
                                  "drain_stretch": int(r.choice([1, 8])), "handoff": int(r.integers(0, 2)), "group_drain": int(r.choice([0, 2, 16])),
                                  "handoff_cap": int(r.choice([8, 16, 32, 64])), "handoff_wg": int(r.choice([64, 128, 256])),
-                                 "code_map": int(r.choice([0, 2]))}
+                                 "code_map": int(r.choice([0, 2])), "code_min_rays": 0}
                         if os.environ.get("FUZZ_NO_GROUP"):
                             sched["group_drain"] = 0
                         if os.environ.get("FUZZ_NO_HANDOFF"):
@@ -113,7 +113,7 @@ def one_case(seed):
             if n <= 400000 or r.random() < 0.2:
                 for cls, sc in ((range_libc.PyRayMarching, 0.999), (range_libc.PyRayMarchingGPU, 1.0)):
                     m = cls(omap, mrx); m.set_option("variant", 3)
-                    m.set_option("code_map", int(r.choice([0, 2]))); m.set_option("slots", int(r.choice([0, 2])))
+                    m.set_option("code_map", int(r.choice([0, 2]))); m.set_option("code_min_rays", 0); m.set_option("slots", int(r.choice([0, 2])))
                     o3 = np.empty(n, np.float32); m.calc_range_fan(poses, o3, fov, B)      # ranges only: the stream form (code map or float32)
                     assert np.array_equal(o3, om.rm_fan_libm(poses, fov, B, step_coeff=sc)[0]), "literal stream form %g %s" % (sc, m.last_plan()["name"])
                     out = np.empty(n, np.float32); hits = np.empty((n, 2), np.int32); st = np.empty(n, np.uint16)
@@ -146,7 +146,7 @@ def one_case(seed):
             edge = r.uniform(0.05, 0.6, B)
             thr = 0.001
             rr = om.rm_fan(poses, fov, B, 1.0)[0]
-            m = range_libc.PyRayMarchingGPU(omap, mrx); m.set_option("slots", int(r.choice([1, 2]))); m.set_option("code_map", int(r.choice([0, 2])))
+            m = range_libc.PyRayMarchingGPU(omap, mrx); m.set_option("slots", int(r.choice([1, 2]))); m.set_option("code_map", int(r.choice([0, 2]))); m.set_option("code_min_rays", 0)
             m.set_option("handoff", 0 if os.environ.get("FUZZ_NO_HANDOFF") else int(r.integers(0, 2))); m.set_option("handoff_cap", int(r.choice([8, 64])))
             if os.environ.get("FUZZ_NO_GROUP"):
                 m.set_option("group_drain", 0)

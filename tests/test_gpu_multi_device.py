@@ -84,9 +84,10 @@ def test_fan_blocks_equal_the_single_device_scan_and_the_oracle(world, oracle_mo
         assert np.array_equal(a, b), (cls.__name__, n)
         if cls is range_libc.PyBresenhamsLine:
             want = om.bl_fan(poses, FOV, B, nthreads=oracle_mod.max_threads())[0]
+        elif cls is range_libc.PyRayMarching:            # range_libc's CPU RayMarching: the upstream-literal arithmetic
+            want = om.rm_fan_libm(poses, FOV, B, step_coeff=0.999)[0]
         else:
-            want = om.rm_fan(poses, FOV, B, step_coeff=1.0 if cls is range_libc.PyRayMarchingGPU else 0.999,
-                             nthreads=oracle_mod.max_threads())[0]
+            want = om.rm_fan(poses, FOV, B, step_coeff=1.0, nthreads=oracle_mod.max_threads())[0]
         assert np.array_equal(b, want)
     # diagnostics travel per block too
     poses = maps.sample_free_poses(g, 333, 9)

@@ -84,12 +84,12 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "slots": 2, "handoff": 1, "handoff_cap": 8, "handoff_wg": 64, "inline_map_kb": 0, "stripe_max": 0},
     {"variant": 1, "slots": 2, "handoff": 1, "handoff_cap": 64, "inline_prep": 0, "grid_mult": 2},
     {"variant": 1, "slots": 3, "handoff": 1, "handoff_cap": 32, "handoff_wg": 128},
-    {"variant": 1, "slots": 2, "code_map": 2},                  # the step map as u16 palette codes, the palette in LDS (round 6)
-    {"variant": 1, "slots": 2, "code_map": 2, "inline_map_kb": 0, "stripe_max": 0},
-    {"variant": 1, "slots": 2, "code_map": 2, "inline_prep": 0, "low_water": 0},
-    {"variant": 1, "slots": 2, "code_map": 2, "inline_prep": 0, "bin_multi_min": 64, "xcd_bands": 3, "grid_mult": 2},
-    {"variant": 1, "slots": 2, "code_map": 2, "group_drain": 16, "drain_cap": 8, "drain_stretch": 1},
-    {"variant": 1, "slots": 2, "code_map": 2, "drain_cap": 3, "spec_stretch": 1},
+    {"variant": 1, "slots": 2, "code_map": 2, "code_min_rays": 0},                  # the step map as u16 palette codes, the palette in LDS (round 6)
+    {"variant": 1, "slots": 2, "code_map": 2, "code_min_rays": 0, "inline_map_kb": 0, "stripe_max": 0},
+    {"variant": 1, "slots": 2, "code_map": 2, "code_min_rays": 0, "inline_prep": 0, "low_water": 0},
+    {"variant": 1, "slots": 2, "code_map": 2, "code_min_rays": 0, "inline_prep": 0, "bin_multi_min": 64, "xcd_bands": 3, "grid_mult": 2},
+    {"variant": 1, "slots": 2, "code_map": 2, "code_min_rays": 0, "group_drain": 16, "drain_cap": 8, "drain_stretch": 1},
+    {"variant": 1, "slots": 2, "code_map": 2, "code_min_rays": 0, "drain_cap": 3, "spec_stretch": 1},
 ])
 def test_every_kernel_schedule_is_bit_identical(oracle_mod, opts):
     g = maps.make_maze(400, cell=40, wall=3, p=0.45, seed=21, origin=(-7.0, 3.0, -0.4))
@@ -406,8 +406,10 @@ def test_code_map_is_engaged_and_bit_identical(oracle_mod):
         poses[12] = [1e6, 1e6, 1.0]
         for cls, sc in ((range_libc.PyRayMarchingGPU, 1.0), (range_libc.PyRayMarching, 0.999)):
             m = cls(omap, mrx)
+            m.set_option("variant", 1)
             m.set_option("slots", 2)
-            m.set_option("code_map", 2)
+            assert m.get_info("code_map") == 2 and m.get_info("code_min_rays") == 1 << 22         # (the defaults)
+            m.set_option("code_min_rays", 0)
             want = om.rm_fan(poses, fov, B, step_coeff=sc, nthreads=4, want_hits=False, want_steps=False)[0]
             for opts in ({}, {"inline_prep": 0}, {"inline_map_kb": 0, "stripe_max": 0, "inline_prep": 1}):
                 for k, v in opts.items():
@@ -441,7 +443,7 @@ def test_code_map_is_engaged_and_bit_identical(oracle_mod):
         occ2[g.rows // 3:g.rows // 3 + 9, g.cols // 4:g.cols // 4 + 30] = 1
         m = range_libc.PyRayMarchingGPU(omap, mrx)
         m.set_option("slots", 2)
-        m.set_option("code_map", 2)
+        m.set_option("code_min_rays", 0)
         got = np.empty(len(poses) * B, np.float32)
         m.calc_range_fan(poses, got, fov, B)
         omap.update(occ2)

@@ -241,6 +241,10 @@ def test_launch_plan_of_every_baseline_config_and_of_the_reference_rollout_batch
     assert (pc["code"], pc["code_entries"], pc["grid"], pc["binning"]) == (2, 626, 512, "small_keys")
     assert pc["lds_bytes"] >= p["lds_bytes"] + 626 * 4 - 32 * 4 and pc["lds_bytes"] <= 72 * 1024
     assert _plan(RMGPU, 2049, 2049, 4096, 1081, code_entries=626, code_map=0)["code"] == 0
+    # (small launches are latency-bound: the palette look-up in every dependent sample costs them more than the smaller
+    #  footprint buys — the reference's 200-pose roll-out stays on the float32 map)
+    assert _plan(RMGPU, 2049, 2049, 200, 1080, code_entries=626)["code"] == 0
+    assert _plan(RMGPU, 2049, 2049, 200, 1080, code_entries=626, code_min_rays=0)["code"] == 2
     assert _plan(RMGPU, 2049, 2049, 4096, 1081, code_entries=5000)["code"] == 0          # palette beyond the LDS table
     assert _plan(RMGPU, 2049, 2049, 4096, 1081, code_entries=626, aux=True)["code"] == 0  # diagnostics: float32 map
     assert _plan(RM, 2049, 2049, 4096, 1081, code_entries=626)["name"] == \
