@@ -99,12 +99,35 @@ int rl_map_create(const uint8_t *occ, int rows, int cols, float res, float ox, f
 int rl_map_create_multi(const uint8_t *occ, int rows, int cols, float res, float ox, float oy, float oyaw,
                         const int *devices, int n_devices, rl_map **out);
 int rl_map_n_devices(const rl_map *m);                 /* 1 for a map of rl_map_create                    */
+/* ... and with the results in DEVICE memory of one of the handle's devices (round 6): the reference's consumer of a
+ * roll-out batch is one process (scripts/mcts.py:237 -> scripts/racecar_simulator_v2.py:146-167 -> Car::isCrashed); when
+ * what comes next is itself a kernel on ONE GPU (a policy network, the tree update), the ranges — or the fused crash
+ * indices — of every device should land in that GPU's HBM, not in host memory.  h: a method of a multi-device map;
+ * poses (and edge): HOST pointers; `consumer`: index of the replica (0 .. rl_method_n_devices - 1) whose device owns
+ * d_outs_on_consumer (n_poses * num_rays floats) / d_first_on_consumer (n_groups ints).  Every device marches its
+ * contiguous pose block into its own HBM in `chunks` pieces (0 = 4) and sends each piece to the consumer with
+ * hipMemcpyPeerAsync on a second stream — device to device over xGMI where peer access exists — while the next piece
+ * marches; the consumer's own block is marched in place.  Synchronous: the data is in the consumer's memory on return.
+ * Bit-identical to the single-device scan (noise keyed by the global ray id, crash indices global).  Tested with
+ * repeated device indices on one GPU (the peer copy degenerates to a device-to-device copy) and with distinct devices
+ * wherever more than one is visible; rates over xGMI are MODELLED, not measured.                 */
+int rl_calc_range_fan_multi_device(rl_method *h, const float *poses, int n_poses, float fov, int num_rays, int consumer,
+                                   float *d_outs_on_consumer, int chunks);
+int rl_check_collision_groups_multi_device(rl_method *h, const float *poses, int n_groups, int group, float fov,
+                                           int num_rays, const double *edge, double crash_thresh, int consumer,
+                                           int *d_first_on_consumer);
 rl_map *rl_map_replica(rl_map *m, int i);              /* NULL when i is out of range                     */
 /* replace the occupancy (same shape) and rebuild the distance transform: the
  * per-scan rebuild of scripts/two_player/rcs_two_player.py:110-121 and the
  * updateMap stub of scripts/scan_simulator.py:81-86.  Methods created from the
  * map see the new data (CDDT / GiantLUT tables are rebuilt lazily).            */
 int rl_map_update(rl_map *m, const uint8_t *occ);
+/* ... the two-player tick without the grid crossing PCIe (round 6): the occupancy becomes the BASE map — as created or
+ * last rl_map_update'd — with the n cells flat_idx[i] = row * cols + col set to `value` (nonzero = occupied; the
+ * reference writes 255), and every table is rebuilt on the device.  Indices outside the grid are skipped, as the
+ * reference's own guard skips them (rcs_two_player.py:113).  A stamp replaces the previous one (`ego_map[:] = org_map`,
+ * rcs_two_player.py:110).  n = 0 restores the base map.                                                                */
+int rl_map_stamp_cells(rl_map *m, const int32_t *flat_idx, int n, uint8_t value);
 void rl_map_destroy(rl_map *m);
 int rl_map_rows(const rl_map *m);
 int rl_map_cols(const rl_map *m);

@@ -65,6 +65,7 @@ SYMBOLS = {
     "rl_map_n_devices": (C.c_int, [C.c_void_p]),
     "rl_map_replica": (C.c_void_p, [C.c_void_p, C.c_int]),
     "rl_map_update": (C.c_int, [C.c_void_p, u8p]),
+    "rl_map_stamp_cells": (C.c_int, [C.c_void_p, i32p, C.c_int, C.c_uint8]),
     "rl_map_destroy": (None, [C.c_void_p]),
     "rl_map_rows": (C.c_int, [C.c_void_p]),
     "rl_map_cols": (C.c_int, [C.c_void_p]),
@@ -93,6 +94,9 @@ SYMBOLS = {
     "rl_check_collision_groups_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                                    C.c_int, C.c_void_p, C.c_double, C.c_void_p,
                                                    C.c_void_p, C.c_void_p]),
+    "rl_calc_range_fan_multi_device": (C.c_int, [C.c_void_p, f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "rl_check_collision_groups_multi_device": (C.c_int, [C.c_void_p, f32p, C.c_int, C.c_int, C.c_float, C.c_int, f64p,
+                                                         C.c_double, C.c_int, C.c_void_p]),
     "rl_followgap_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                       C.POINTER(C.c_void_p)]),
     "rl_followgap_destroy": (None, [C.c_void_p]),

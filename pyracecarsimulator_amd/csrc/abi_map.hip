@@ -307,6 +307,60 @@ extern "C" int rl_map_update(rl_map *m, const uint8_t *occ)
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyAsync(m->d_occ, occ, (size_t)m->rows * m->cols, hipMemcpyHostToDevice,
                           m->stream));
+    if (m->d_occ_base)                                // (a new base for later stamps)
+        HIPCHK(hipMemcpyAsync(m->d_occ_base, m->d_occ, (size_t)m->rows * m->cols, hipMemcpyDeviceToDevice, m->stream));
+    rc = map_build_tables(m);
+    if (rc) return rc;
+    m->epoch++;
+    return RL_OK;
+}
+
+// The two-player tick (scripts/two_player/rcs_two_player.py:105-124): the map as it was created (or last rl_map_update'd)
+// with the other car's outline laid over it, tables rebuilt — without the grid crossing PCIe again: the caller sends
+// the n outline cells (4 B each) instead of rows x cols bytes.  Every stamp starts from the BASE occupancy: the previous
+// outline is gone, like the reference's `ego_map[:] = org_map`.
+extern "C" int rl_map_stamp_cells(rl_map *m, const int32_t *flat_idx, int n, uint8_t value)
+{
+    if (!m || (n > 0 && !flat_idx)) return fail(RL_ERR_INVALID, "rl_map_stamp_cells: null pointer");
+    if (n < 0) return fail(RL_ERR_INVALID, "rl_map_stamp_cells: n must be >= 0");
+    if (!m->reps.empty()) {
+        std::lock_guard<std::mutex> lk(m->mu);
+        std::unique_lock<std::shared_mutex> wl(m->multi_mu);
+        if (m->broken.load()) return fail(RL_ERR_INVALID, "multi-device map is inconsistent after a failed update: destroy it");
+        for (size_t i = 0; i < m->reps.size(); ++i) {
+            const int rc = rl_map_stamp_cells(m->reps[i], flat_idx, n, value);
+            if (rc) {
+                if (i > 0) m->broken.store(true);
+                return rc;
+            }
+        }
+        m->epoch++;
+        return RL_OK;
+    }
+    std::lock_guard<std::mutex> lk(m->mu);
+    std::unique_lock<std::shared_mutex> wl(m->tables_mu);
+    int rc = set_device(m);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());                  // launches the *_device entry points left in flight still read the tables
+    const size_t cells = (size_t)m->rows * m->cols;
+    if (!m->d_occ_base) {
+        HIPCHK(hipMalloc((void **)&m->d_occ_base, cells));
+        HIPCHK(hipMemcpyAsync(m->d_occ_base, m->d_occ, cells, hipMemcpyDeviceToDevice, m->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(m->d_occ, m->d_occ_base, cells, hipMemcpyDeviceToDevice, m->stream));
+    }
+    if (n > 0) {
+        if (n > m->stamp_cap) {
+            if (m->d_stamp) (void)hipFree(m->d_stamp);
+            m->d_stamp = nullptr;
+            m->stamp_cap = 0;
+            HIPCHK(hipMalloc((void **)&m->d_stamp, (size_t)(n + 256) * sizeof(int32_t)));
+            m->stamp_cap = n + 256;
+        }
+        HIPCHK(hipMemcpyAsync(m->d_stamp, flat_idx, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+        hipLaunchKernelGGL(stamp_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, m->d_occ, cells,
+                           (const int32_t *)m->d_stamp, n, value);
+    }
     rc = map_build_tables(m);
     if (rc) return rc;
     m->epoch++;
@@ -323,6 +377,8 @@ extern "C" void rl_map_destroy(rl_map *m)
     }
     (void)hipSetDevice(m->device);
     if (m->d_occ) (void)hipFree(m->d_occ);
+    if (m->d_occ_base) (void)hipFree(m->d_occ_base);
+    if (m->d_stamp) (void)hipFree(m->d_stamp);
     if (m->d_g) (void)hipFree(m->d_g);
     if (m->d_dt) (void)hipFree(m->d_dt);
     if (m->d_bits) (void)hipFree(m->d_bits);

@@ -166,4 +166,16 @@ __global__ __launch_bounds__(256) void cddt_edges_kernel(const uint8_t *__restri
         }
 }
 
+// rl_map_stamp_cells: occupied cells laid over the map (the other car's outline of the two-player tick,
+// scripts/two_player/rcs_two_player.py:110-116): indices outside the grid are skipped, as the reference's guard skips them
+__global__ __launch_bounds__(256) void stamp_cells_kernel(uint8_t *__restrict__ occ, size_t n_cells,
+                                                          const int32_t *__restrict__ idx, int n, uint8_t value)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int32_t c = idx[i];
+        if (c >= 0 && (size_t)c < n_cells) occ[c] = value;
+    }
+}
+
 }  // namespace scan

@@ -739,16 +739,6 @@ constexpr int STREAM_HDR = 66;
     "ds_read_b32 " D ", " D " offset:%[taboff]\n\t"                                                         \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                             \
     ".endif\n\t"
-#define RM_DECODE_ISSUE(D)                                                                                 \
-    ".if %[code] == 1\n\t"                                                                                 \
-    "v_lshlrev_b32_e32 " D ", 2, " D "\n\t"                                                                 \
-    ".endif\n\t"                                                                                           \
-    ".if %[code]\n\t"                                                                                      \
-    "ds_read_b32 " D ", " D " offset:%[taboff]\n\t"                                                         \
-    ".endif\n\t"
-#ifndef RL_CODE_PIPE
-#define RL_CODE_PIPE 1       // march_loop2 on a code map: palette look-ups overlapped with the other slot's arithmetic (0: in line)
-#endif
 // one slot of march_loop2 advances by the sample in d: t += d, drop the lane when t left the range window, next cell's address, its load
 #define RM2_ADVANCE_A                                                                                      \
     "v_add_f32_e32 v20, v20, %[dA]\n\t"                                                                    \
@@ -1209,7 +1199,10 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         "s_mov_b64 %[mB], exec\n"
         // (decoupled slots: a slot's next load is issued as soon as ITS previous one has returned — not after both
-        //  have — so the two dependent chains only share the instruction stream, not each other's latency)
+        //  have — so the two dependent chains only share the instruction stream, not each other's latency.
+        //  CODE map: a form that issues a slot's palette look-up and runs the OTHER slot's arithmetic under it was
+        //  built and is no faster — 186 vs 190 Grays/s at cfg2 / 300 steps, equal elsewhere: profiles/r06/ab_code_map.txt,
+        //  tools/r06/rejected/code_pipe.patch — the other seven waves of the SIMD already cover the ~100 clocks)
         "s_mov_b64 exec, %[mA]\n\t"
         RM_POS("v[26:27]", "v[22:23]", "v[20:21]", "v[24:25]")
         "v_cvt_i32_f32_e32 %[cA], v26\n\t"
@@ -1236,45 +1229,6 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "v_lshl_add_u32 v34, v34, 2, %[k4]\n\t"
         ".endif\n\t"
         RM_LOAD("%[dB]", "v34")
-        ".if %[pipe]\n\t"
-        // CODE map, decode pipelined (RL_CODE_PIPE): a slot's palette look-up (ds_read, ~100 clocks) runs under the OTHER
-        // slot's arithmetic instead of stalling the wave —
-        //   (1) B's cell back -> B's look-up out     (2) A's look-up back -> A advances, A's next cell out
-        //   (3) B's look-up back -> B advances, B's next cell out     (4) A's cell back -> A's look-up out
-        // loads and look-ups each return in order: vmcnt / lgkmcnt name exactly the one that is needed.
-        "s_mov_b64 exec, %[mA]\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        RM_DECODE_ISSUE("%[dA]")
-        "L_march2_%=:\n\t"
-        "s_mov_b64 exec, %[mB]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        RM_DECODE_ISSUE("%[dB]")
-        "s_mov_b64 exec, %[mA]\n\t"
-        "s_waitcnt lgkmcnt(1)\n\t"
-        RM2_ADVANCE_A
-        "s_mov_b64 exec, %[mB]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        RM2_ADVANCE_B
-        "s_mov_b64 exec, %[mA]\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        RM_DECODE_ISSUE("%[dA]")
-        "s_bcnt1_i32_b64 %[n], %[mA]\n\t"
-        "s_bcnt1_i32_b64 %[n2], %[mB]\n\t"
-        "s_add_u32 %[n], %[n], %[n2]\n\t"
-        "s_cmp_gt_u32 %[n], %[low]\n\t"
-        "s_cbranch_scc1 L_march2_%=\n\t"
-        // in flight: A's look-up, B's cell — both belong to live rays: consume them
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_add_f32_e32 v20, v20, %[dA]\n\t"
-        "v_cmpx_gt_f32_e32 %[mx], v20\n\t"
-        "s_mov_b64 %[mA], exec\n\t"
-        "s_mov_b64 exec, %[mB]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        RM_DECODE("%[dB]")
-        "v_add_f32_e32 v28, v28, %[dB]\n\t"
-        "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
-        "s_mov_b64 %[mB], exec\n\t"
-        ".else\n\t"
         "L_march2_%=:\n\t"
         "s_mov_b64 exec, %[mA]\n\t"
         "s_waitcnt vmcnt(1)\n\t"
@@ -1302,15 +1256,13 @@ __device__ __forceinline__ void march_loop2(float dxA, float dyA, float gxA, flo
         "v_add_f32_e32 v28, v28, %[dB]\n\t"
         "v_cmpx_gt_f32_e32 %[mx], v28\n\t"
         "s_mov_b64 %[mB], exec\n\t"
-        ".endif\n\t"
         "s_mov_b64 exec, %[save]\n\t"
         : [tA] "+{v20}"(tA), [cA] "+v"(cA), [rA] "+v"(rA), [dA] "+v"(dA), [tB] "+{v28}"(tB), [cB] "+v"(cB),
           [rB] "+v"(rB), [dB] "+v"(dB), [save] "=&s"(save), [mA] "=&s"(mA), [mB] "=&s"(mB), [n] "=&s"(n),
           [n2] "=&s"(n2)
         : [dyA] "{v22}"(dyA), [dxA] "{v23}"(dxA), [gxA] "{v24}"(gxA), [gyA] "{v25}"(gyA), [dyB] "{v30}"(dyB),
           [dxB] "{v31}"(dxB), [gxB] "{v32}"(gxB), [gyB] "{v33}"(gyB), [mx] "s"(max_range), [stride] "s"(stride),
-          [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), RM_CODE_OPERANDS, [low] "s"(low), [tiled] "n"(TILED ? 1 : 0),
-          [pipe] "n"((CODE && RL_CODE_PIPE) ? 1 : 0)
+          [nstride] "s"(nstride), [k4] "v"(k4), [base] "s"(pdt), [lit] "n"(LIT ? 1 : 0), RM_CODE_OPERANDS, [low] "s"(low), [tiled] "n"(TILED ? 1 : 0)
         : "v26", "v27", "v34", "v35", "vcc", "scc", "memory");
 }
 

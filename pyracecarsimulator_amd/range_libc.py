@@ -113,7 +113,22 @@ class PyOMap:
         if occ.shape != self.occ.shape:
             raise ValueError("PyOMap.update: shape mismatch")
         self.occ = occ
+        self._base_occ = None
         _lib.check(_lib.lib().rl_map_update(self._h, occ.ctypes.data_as(u8p)))
+
+    def stamp_cells(self, flat_idx, value=255):
+        """The two-player tick without re-uploading the grid (rl_map_stamp_cells): the occupancy becomes the BASE map
+        (as constructed / last ``update``d) with the cells ``flat_idx`` (row * width + col; out-of-range ones are
+        skipped like the reference's guard, scripts/two_player/rcs_two_player.py:113) occupied, tables rebuilt on the
+        device.  Each stamp replaces the previous one; an empty list restores the base map."""
+        idx = np.ascontiguousarray(flat_idx, dtype=np.int32).ravel()
+        if getattr(self, "_base_occ", None) is None:
+            self._base_occ = self.occ.copy()
+        _lib.check(_lib.lib().rl_map_stamp_cells(self._h, idx.ctypes.data_as(_lib.i32p), int(idx.size), int(value) & 0xff))
+        occ = self._base_occ.copy()
+        ok = idx[(idx >= 0) & (idx < occ.size)]
+        occ.reshape(-1)[ok] = 1 if (int(value) & 0xff) else 0
+        self.occ = occ
 
     def distance_transform(self):
         """float32 (H, W) exact EDT in cells as built on the device (test hook)."""
@@ -282,6 +297,30 @@ class _RangeMethod:
             self._h, C.c_void_p(d_poses_ptr), int(n_groups), int(group), float(fov), int(num_rays),
             C.c_void_p(d_edge_ptr), float(crash_thresh), C.c_void_p(d_first_ptr),
             C.c_void_p(d_ranges_ptr or None), C.c_void_p(stream or None)))
+
+    def calc_range_fan_multi_device(self, poses, d_outs_ptr, fov, num_rays, consumer=0, chunks=0):
+        """Multi-device handle, results in DEVICE memory of replica ``consumer``'s GPU (rl_calc_range_fan_multi_device):
+        every device marches its pose block into its own HBM and sends it to the consumer chunk by chunk
+        (hipMemcpyPeerAsync: xGMI between peers) under the next chunk's march.  ``poses``: host array (n, 3);
+        ``d_outs_ptr``: device address (int) of n * num_rays float32 on the consumer's device.  Synchronous."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        _lib.check(_lib.lib().rl_calc_range_fan_multi_device(
+            self._h, poses.ctypes.data_as(f32p), poses.shape[0], float(fov), int(num_rays), int(consumer),
+            C.c_void_p(d_outs_ptr), int(chunks)))
+
+    def check_collision_groups_multi_device(self, poses, group, fov, num_rays, edge_distances, crash_thresh, d_first_ptr,
+                                            consumer=0):
+        """... the fused crash indices (int32 per roll-out of ``group`` poses) of every device's block, gathered in the
+        consumer device's memory at ``d_first_ptr`` (rl_check_collision_groups_multi_device)."""
+        poses = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 3)
+        if poses.shape[0] % group:
+            raise ValueError("number of poses is not a multiple of the group size")
+        edge = np.ascontiguousarray(edge_distances, dtype=np.float64)
+        if edge.size < num_rays:
+            raise ValueError("edge_distances needs num_rays entries")
+        _lib.check(_lib.lib().rl_check_collision_groups_multi_device(
+            self._h, poses.ctypes.data_as(f32p), poses.shape[0] // int(group), int(group), float(fov), int(num_rays),
+            edge.ctypes.data_as(f64p), float(crash_thresh), int(consumer), C.c_void_p(d_first_ptr)))
 
     @property
     def n_devices(self):

@@ -41,11 +41,29 @@ class ScanSimulator2D:
         occ, res, org = range_libc.PyOMap._ingest(map_msg, None, None, None)
         key = (occ.shape, float(res), tuple(float(v) for v in org), float(mrx), int(theta_disc))
         if self.omap is not None and key == self._built_for:
-            self.omap.update(occ)                     # same grid geometry: rebuild tables in place
+            # same grid geometry.  The reference's caller lays the other car's outline over the SAME original map before
+            # every scan (rcs_two_player.py:110-118): when the new grid is the base grid plus a few occupied cells, only
+            # those cell indices cross PCIe (rl_map_stamp_cells) — otherwise the whole grid (rl_map_update)
+            new = np.ascontiguousarray(occ, dtype=np.uint8) != 0
+            diff = np.flatnonzero(new.reshape(-1) != self._base.reshape(-1))
+            if diff.size <= self.STAMP_MAX and bool(new.reshape(-1)[diff].all()):
+                self.omap.stamp_cells(diff)
+            else:
+                self.omap.update(occ)
+                self._base = new.copy()
             return
         self.omap = range_libc.PyOMap(map_msg)
         self.scan_method = range_libc.PyCDDTCast(self.omap, mrx, theta_disc)
+        self._base = np.ascontiguousarray(occ, dtype=np.uint8) != 0
         self._built_for = key
+
+    #: build(): grids that differ from the base map by at most this many newly occupied cells are sent as cell indices
+    STAMP_MAX = 4096
+
+    def build_with_outline(self, bound_cells):
+        """The same tick when the caller has the outline CELLS at hand (flat indices x * map_width + y as
+        rcs_two_player.py:112-114 computes them): nothing but the indices is touched on the host."""
+        self.omap.stamp_cells(bound_cells)
 
     def scan(self, x, y, theta):
         """One fan of ``num_rays`` beams from (x, y, theta) (scan.py:49-72)."""

@@ -310,3 +310,52 @@ def test_multi_device_handle_from_several_threads(world):
     assert not errs, errs
     mm.close()
     m1.close()
+
+
+@pytest.mark.parametrize("cls", [range_libc.PyRayMarchingGPU, range_libc.PyRayMarching, range_libc.PyCDDTCast])
+def test_device_resident_exchange_lands_in_the_consumer_gpu(world, oracle_mod, cls):
+    """rl_calc_range_fan_multi_device / rl_check_collision_groups_multi_device (round 6): every device marches its pose
+    block into its own HBM and sends it — chunk by chunk under the next chunk's march, hipMemcpyPeerAsync — to ONE
+    consumer device; the caller (one process: scripts/mcts.py:237) finds every range / every roll-out's crash index in
+    that GPU's memory.  Bit-identical to the single-device scan, with noise (global ray ids), for every consumer index,
+    chunk count and batch size (fewer blocks than devices included).  One visible GPU: device 0 several times (the peer
+    copy degenerates to a device-to-device copy); several: distinct devices."""
+    torch = pytest.importorskip("torch")
+    g, one, multi = world
+    args = (112,) if cls is range_libc.PyCDDTCast else ()
+    m1, mm = cls(one, MRX, *args), _split(cls(multi, MRX, *args))
+    nd = mm.n_devices
+    devs = _devs(3)
+    for n, chunks, consumer in ((1000, 0, 0), (1000, 3, nd - 1), (200, 1, 1 % nd), (37, 7, nd - 1), (1, 4, 0)):
+        poses = maps.sample_free_poses(g, n, 500 + n)
+        poses[n // 2] = [np.nan, 0.0, 0.0]
+        for noise in (0.0, 0.01):
+            for m in (m1, mm):
+                m.set_noise(noise, seed=11, ray_offset=12345)
+            want = np.empty(n * B, np.float32)
+            m1.calc_range_fan(poses, want, FOV, B)
+            with torch.cuda.device(devs[consumer]):
+                d_out = torch.full((n * B,), -7.0, dtype=torch.float32, device="cuda:%d" % devs[consumer])
+                torch.cuda.synchronize()
+                mm.calc_range_fan_multi_device(poses, d_out.data_ptr(), FOV, B, consumer=consumer, chunks=chunks)
+                got = d_out.cpu().numpy()
+            assert np.array_equal(got, want, equal_nan=True), (cls.__name__, n, chunks, consumer, noise, int((got != want).sum()))
+    for m in (m1, mm):
+        m.set_noise(0.0)
+    with pytest.raises(_lib.ScanLibError):
+        mm.calc_range_fan_multi_device(poses, 8, FOV, B, consumer=nd)         # not a replica of this handle
+    with pytest.raises(_lib.ScanLibError):
+        m1.calc_range_fan_multi_device(poses, 8, FOV, B, consumer=0)          # not a multi-device handle
+    if cls is not range_libc.PyCDDTCast:
+        # the fused crash test: one int32 per roll-out lands in the consumer's memory
+        edge = _edge()
+        for n_groups, grp, consumer in ((20, 50, 0), (7, 100, nd - 1), (1, 64, 1 % nd)):
+            poses = maps.sample_free_poses(g, n_groups * grp, 900 + grp)
+            want = m1.check_collision_groups(poses, grp, FOV, B, edge, 0.001)
+            with torch.cuda.device(devs[consumer]):
+                d_first = torch.full((n_groups,), 12345, dtype=torch.int32, device="cuda:%d" % devs[consumer])
+                torch.cuda.synchronize()
+                mm.check_collision_groups_multi_device(poses, grp, FOV, B, edge, 0.001, d_first.data_ptr(), consumer=consumer)
+                assert d_first.cpu().numpy().tolist() == want.tolist(), (cls.__name__, n_groups, grp, consumer)
+    mm.close()
+    m1.close()

@@ -1746,6 +1746,48 @@ def test_two_player_front_end_rebuilds_in_place(oracle_mod):
         om = oracle_mod.OracleMap(occ, g.resolution, g.origin, 300)
         want = om.cddt_rays(td, sim.input_vector)
         assert np.array_equal(out, want), tick
+        # (from the second tick on the outline travels as cell indices — rl_map_stamp_cells —, not as a grid: the device's
+        #  occupancy and EDT are those of the host-stamped grid, bit for bit)
+        assert np.array_equal(sim.omap.occ != 0, occ != 0) and np.array_equal(sim.omap.distance_transform(), om.dt), tick
+    # the caller has the outline cells at hand (rcs_two_player.py:110-116: x * map_width + y, indices past the grid skipped)
+    cells = np.array([50 * g.cols + 100, 51 * g.cols + 100, 52 * g.cols + 101, g.rows * g.cols + 5, -3, 2**31 - 1], np.int64)
+    sim.build_with_outline(cells)
+    occ = g.occ.copy()
+    occ.reshape(-1)[cells[:3]] = 1
+    om = oracle_mod.OracleMap(occ, g.resolution, g.origin, 300)
+    assert np.array_equal(sim.omap.distance_transform(), om.dt)
+    out = sim.scan(float(pose[0]), float(pose[1]), float(pose[2]))
+    assert np.array_equal(out, om.cddt_rays(td, sim.input_vector))
+    sim.build_with_outline([])                                            # no outline: the original map again
+    assert np.array_equal(sim.omap.distance_transform(), om0.dt) and np.array_equal(sim.omap.occ != 0, g.occ != 0)
+    # a grid that also FREES cells of the base map is not an outline: the whole grid is sent (rl_map_update), and it is
+    # the new base of later stamps
+    occ = g.occ.copy()
+    occ[100:104, 100:140] = 0
+    occ[60:64, 210:214] = 1
+    sim.build(maps.GridMap(occ, g.resolution, g.origin, name="edited"), 300, td)
+    assert sim.scan_method is first_method
+    om = oracle_mod.OracleMap(occ, g.resolution, g.origin, 300)
+    assert np.array_equal(sim.omap.distance_transform(), om.dt)
+    occ2 = occ.copy()
+    occ2[70:73, 220:226] = 1
+    sim.build(maps.GridMap(occ2, g.resolution, g.origin, name="edited+outline"), 300, td)
+    om2 = oracle_mod.OracleMap(occ2, g.resolution, g.origin, 300)
+    assert np.array_equal(sim.omap.distance_transform(), om2.dt)
+    out = sim.scan(float(pose[0]), float(pose[1]), float(pose[2]))
+    assert np.array_equal(out, om2.cddt_rays(td, sim.input_vector))
+    # ray marching on a stamped map (step map + code map follow the map's epoch), and a multi-device map
+    m = range_libc.PyRayMarchingGPU(sim.omap, 300)
+    got = np.empty(B, np.float32)
+    m.calc_range_fan(pose[None, :], got, fov, B)
+    assert np.array_equal(got, om2.rm_fan(pose[None, :], fov, B, step_coeff=1.0)[0])
+    m.close()
+    multi = range_libc.PyOMap(g, device=[0, 0])
+    multi.stamp_cells(cells)
+    occ = g.occ.copy()
+    occ.reshape(-1)[cells[:3]] = 1
+    assert np.array_equal(multi.distance_transform(), oracle_mod.OracleMap(occ, g.resolution, g.origin, 300).dt)
+    multi.close()
 
 
 @pytest.mark.gpu
