@@ -40,6 +40,11 @@ LEGS = (
     ("cfg2_crash", "cfg2", "RMGPU", 0, 4096, 4, "crash", 80, 7),
     ("cfg2_steer", "cfg2", "RMGPU", 0, 4096, 4, "steer", 80, 7),
     ("cfg5_shard", "cfg5", "RMGPU", 0, 32768, 4, None, 40, 5),
+    # cfg4: colombia (the one map the reference ships), one rank's shard of the 2^20 roll-out poses, serial
+    ("cfg4_shard", "cfg4", "RMGPU", 0, 131072, 1, None, 4, 3),
+    # cfg4 as the reference's caller produces it (scripts/mcts.py:202-245): 4096 roll-outs x 200 control steps ->
+    # 819 200 poses -> scan -> first crashed pose per roll-out, ONE host call (rl_car_rollout_check); run_rollout_leg
+    ("cfg4_rollout_check", "cfg4", "RMGPU", 0, 4096, 1, "rollout", 5, 3),
 )
 
 
@@ -223,8 +228,12 @@ def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=
     bpr = _alg_bytes(method, mean_steps, B, nbar)
     frac = bpr * rays / (ms * 1e-3) / HBM_PEAK
     pe = pmc_lookup(wl, method, n, plan) if pmc_lookup else None
-    out.update({"mrays_s": round(rays / (ms * 1e-3) / 1e6, 1), "ms_per_step": round(ms, 4), "frac": round(frac, 5),
-                "frac_hbm": round(pe["bytes"] / (ms * 1e-3) / HBM_PEAK, 5) if pe else None,
+    frac_hbm = round(pe["bytes"] / (ms * 1e-3) / HBM_PEAK, 5) if pe else None
+    out.update({"mrays_s": round(rays / (ms * 1e-3) / 1e6, 1), "ms_per_step": round(ms, 4),
+                # CDDT: the yardstick is the bytes the kernels of a step MOVE (committed PMC pass) / time / peak — SURVEY
+                # section 8(d)'s per-ray bisection bytes are not what a kernel that answers ~10 beams per look-up moves
+                "frac": frac_hbm if method == "CDDT" else round(frac, 5),
+                "frac_hbm": frac_hbm,
                 "verified": bool(ok), "verification": ver,
                 "config": {"workload": "%s: %s %dx%d, %d poses x %d beams" % (wl, w.gmap.name, w.gmap.rows, w.gmap.cols, n, B),
                            "method": method + (" theta_disc %d" % theta if theta else "") +
@@ -237,15 +246,95 @@ def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=
                 "traffic_source": pe["profile"] if pe else None,
                 "leg_seconds": None})
     if method == "CDDT":
-        # (SURVEY section 8(d) prices a per-RAY bisection; the theta-major kernels answer one look-up per (pose, table bin)
-        #  and ~B / theta_disc beams share it, so frac exceeds 1 by construction: frac_hbm is the figure to read)
-        out["frac_is"] = "algorithmic bytes of a per-ray bisection / time / HBM peak: > 1 because ~%d beams share one look-up; read frac_hbm" % max(1, B // max(1, theta or 108))
+        out["frac_bisection"] = round(frac, 5)
+        out["frac_is"] = ("HBM bytes the step's kernels move (committed rocprofv3 PMC pass of this launch shape) / ms_per_step / 8 TB/s; "
+                          "frac_bisection = SURVEY 8(d)'s per-RAY bisection bytes / time / peak, > 1 because ~%d beams share one look-up"
+                          % max(1, B // max(1, theta or 108)))
     if is_rm:
         out["mean_samples_per_ray"] = round(mean_steps, 3)
     sc.unbind()
     del sc
     if fg is not None:
         del fg
+    meth.close()
+    omap.close()
+    out["leg_seconds"] = round(time.perf_counter() - t_leg, 2)
+    return out
+
+
+def run_rollout_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None):
+    """The MCTS roll-out chain in one call (rl_car_rollout_check: Car::control + updatePosition x 200 per roll-out ->
+    poses -> scan -> Car::isCrashed per roll-out; scripts/mcts.py:202-245, racecar_simulator_v2.py:146-167), host
+    pointers in, crash indices out: states / actions (host) -> int32 per roll-out (host).  The rate counts the rays the
+    chain marches.  Verified: indices == the staged form (rl_car_rollout's poses through rl_check_collision_groups), a
+    subsample of roll-outs == Car::isCrashed over the CPU oracle's scan of those poses."""
+    from pyracecarsimulator_amd import range_libc, workloads, maps, racecar as RC
+    name, wl, method, _theta, R, _P, _reduce, steps, bursts = spec
+    t_leg = time.perf_counter()
+    w = workloads.CONFIGS[wl]()
+    B, n_steps = w.num_rays, 200
+    omap = range_libc.PyOMap(w.gmap, device=device_index)
+    meth = range_libc.PyRayMarchingGPU(omap, w.max_range_px)
+    cars = RC.CarBatch(device=device_index)
+    dt = omap.distance_transform()
+    rng = np.random.default_rng(w.pose_seed + 17)
+    start = maps.sample_free_poses(w.gmap, R, w.pose_seed + 3, 4.0, dt)
+    states = np.zeros((R, 11))
+    states[:, :3] = start
+    states[:, 3] = 1.0
+    actions = np.stack([rng.uniform(0, 7, (R, 20)), rng.uniform(-0.4189, 0.4189, (R, 20))], -1)
+    edge = RC.edge_distances(B, -w.fov / 2.0, w.fov / B, 0.275, RC.DEFAULT_CAR["width"], RC.DEFAULT_CAR["wb"])
+    THRESH = 0.001
+    for _ in range(2):
+        first, _, _ = cars.rollout_check(meth, states, actions, w.fov, B, edge, THRESH, n_steps=n_steps)
+    plan = meth.last_plan()
+    walls = []
+    for _ in range(bursts):
+        t0 = time.perf_counter()
+        for _i in range(steps):
+            first, final, vel = cars.rollout_check(meth, states, actions, w.fov, B, edge, THRESH, n_steps=n_steps)
+        walls.append((time.perf_counter() - t0) / steps)
+    ms = float(np.median(walls)) * 1e3
+    rays = R * n_steps * B
+    # ---- verification
+    ver, ok = {}, True
+    poses, final2, vel2 = cars.rollout(states, actions, n_steps=n_steps)
+    staged = meth.check_collision_groups(poses.reshape(-1, 3), n_steps, w.fov, B, edge, THRESH)
+    same = bool(np.array_equal(first, staged) and np.array_equal(final, final2) and np.array_equal(vel, vel2))
+    ver["chain_equals_staged_calls"] = same
+    ok &= same
+    sub = np.unique(np.linspace(0, R - 1, 6).astype(np.int64))
+    sub_poses = np.ascontiguousarray(poses[sub].reshape(-1, 3))
+    st = np.empty(len(sub_poses) * B, np.uint16)
+    rr = np.empty(len(sub_poses) * B, np.float32)
+    meth.calc_range_fan(sub_poses, rr, w.fov, B, steps=st)
+    mean_steps = float(st.astype(np.float64).mean())
+    if O is not None:
+        om = O.OracleMap.from_gridmap(w.gmap, w.max_range_px)
+        want_r = om.rm_fan(sub_poses, w.fov, B, step_coeff=1.0, nthreads=O.max_threads(), want_hits=False, want_steps=False)[0]
+        want = [O.is_crashed(want_r[i * n_steps * B:(i + 1) * n_steps * B], B, n_steps, edge, THRESH) for i in range(len(sub))]
+        same = bool(np.array_equal(rr, want_r)) and first[sub].tolist() == want
+        ver["oracle_subsample"] = same
+        ver["oracle_sample"] = "%d roll-outs x %d poses x %d beams: ranges and Car::isCrashed index against the oracle" % (len(sub), n_steps, B)
+        ok &= same
+    else:
+        ver["oracle_subsample"] = "not run (the oracle is loaded by the cpu_baseline leg only)"
+    bpr = _alg_bytes("RMGPU", mean_steps, B, 0.0) + 24.0 / B      # (+ the pose the roll-out kernel writes and the march reads)
+    pe = pmc_lookup(wl, "RMGPU+rollout", R * n_steps, plan) if pmc_lookup else None
+    out = {"mrays_s": round(rays / (ms * 1e-3) / 1e6, 1), "ms_per_step": round(ms, 4),
+           "us_per_rollout": round(ms * 1e3 / R, 3),
+           "frac": round(bpr * rays / (ms * 1e-3) / HBM_PEAK, 5),
+           "frac_hbm": round(pe["bytes"] / (ms * 1e-3) / HBM_PEAK, 5) if pe else None,
+           "verified": bool(ok), "verification": ver,
+           "config": {"workload": "%s: %s %dx%d, %d roll-outs x %d control steps x %d beams (scripts/mcts.py:202-245)"
+                                  % (wl, w.gmap.name, w.gmap.rows, w.gmap.cols, R, n_steps, B),
+                      "method": "RMGPU", "schedule": "one synchronous host call per step (rl_car_rollout_check): states / actions in, "
+                                                     "int32 crash index per roll-out out",
+                      "reduce": "fused Car::isCrashed per %d-pose roll-out" % n_steps,
+                      "kernel": plan["name"], "grid": plan["grid"], "crashed_rollouts": int((first >= 0).sum())},
+           "steps": steps, "bursts": bursts, "algorithmic_bytes_per_ray": round(bpr, 3), "mean_samples_per_ray": round(mean_steps, 3),
+           "traffic_source": pe["profile"] if pe else None, "leg_seconds": None}
+    cars.close()
     meth.close()
     omap.close()
     out["leg_seconds"] = round(time.perf_counter() - t_leg, 2)
@@ -265,7 +354,10 @@ def other_configs(torch, dev, device_index, O=None, pmc_lookup=None, only=None, 
             res[spec[0]] = {"skipped": "time budget of %.0f s for the side legs used up" % budget_s}
             continue
         try:
-            res[spec[0]] = run_leg(spec, torch, dev, device_index, O=O, pmc_lookup=pmc_lookup, cache=cache, streams=streams)
+            if spec[6] == "rollout":
+                res[spec[0]] = run_rollout_leg(spec, torch, dev, device_index, O=O, pmc_lookup=pmc_lookup)
+            else:
+                res[spec[0]] = run_leg(spec, torch, dev, device_index, O=O, pmc_lookup=pmc_lookup, cache=cache, streams=streams)
         except Exception as e:                      # noqa: BLE001 — a side leg must not take the headline down
             res[spec[0]] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()

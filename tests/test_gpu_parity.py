@@ -563,7 +563,18 @@ def test_rm_fan_vs_oracle_beam_counts(oracle_mod, B, fov):
     omap = range_libc.PyOMap(g)
     poses = maps.sample_free_poses(g, 37, B + 1, dt=om.dt)
     for sc, cls in ((0.999, range_libc.PyRayMarching), (1.0, range_libc.PyRayMarchingGPU)):
-        r, h, s = _fan(cls(omap, mrx), poses, fov, B)
+        m = cls(omap, mrx)
+        if cls is range_libc.PyRayMarching:
+            # range_libc's CPU RayMarching: the upstream-literal arithmetic by default — ranges, hit cells, sample counts
+            # (diagnostics: one lane per ray) and the ranges-only launch (stream form from 64 beams up), bit for bit
+            rl, hl, sl = _fan(m, poses, fov, B)
+            r0, h0, s0 = om.rm_fan_libm(poses, fov, B, step_coeff=sc)
+            assert np.array_equal(rl, r0) and np.array_equal(hl, h0) and np.array_equal(sl, s0)
+            rr = np.empty(len(poses) * B, np.float32)
+            m.calc_range_fan(poses, rr, fov, B)
+            assert np.array_equal(rr, r0) and m.last_plan()["kernel"] == ("rm_stream_literal" if B >= 64 else "rm_literal")
+            m.set_option("variant", 1)
+        r, h, s = _fan(m, poses, fov, B)
         r0, h0, s0 = oracle_mod.OracleMap.rm_fan(om, poses, fov, B, step_coeff=sc)
         assert np.array_equal(r, r0) and np.array_equal(h, h0) and np.array_equal(s, s0)
 

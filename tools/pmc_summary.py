@@ -8,7 +8,8 @@ for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), re
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            if not any(t in k for t in ("rm_fan", "pose_bin", "rm_rays", "bl_", "lut_", "cddt_", "occ_fan")):
+            if not any(t in k for t in ("rm_fan", "pose_bin", "pose_prep", "pose_scatter", "tile_scan", "rm_rays", "bl_", "lut_", "cddt_",
+                                        "occ_fan", "rollout_kernel", "crash_", "followgap")):
                 continue
             short = k.split("(")[0].replace("void ", "").replace("scan::", "")
             try:
