@@ -337,6 +337,9 @@ typedef struct rl_plan_opts {
                             0 = float32 steps.  Takes effect where the map's palette fits (code_entries)                */
     int code_min_rays;   /* ... from this many rays per launch: below it the look-up's latency in every dependent sample costs a
                             lone launch more than the smaller footprint buys (profiles/r06/ab_code_map.txt)              */
+    int tail_pct;        /* ray marching, launches that fill the machine: this share (%) of every band's work goes to a SECOND
+                            generation of tail_wg_pct % as many workgroups, dispatched as resident ones finish (0 = off)    */
+    int tail_wg_pct;
     int code_entries;    /* entries of the map's step palette with its two stop codes — a handle knows it once its step map
                             is built (rl_method_get_info "code_entries", filled in by rl_method_plan_fan); 0 = unknown or
                             too many: the device-less rl_plan_fan then plans the float32 map                          */
@@ -386,6 +389,7 @@ typedef struct rl_launch_plan {
     int slice_poses;     /*      each its own launch sequence planned like this one (for its own size)    */
     int code;            /* RL_K_RM_STREAM[_LIT]: 2 = marches on the 16-bit code map, 0 = float32 step map  */
     int code_entries;    /*      ... palette entries the workgroups copy to LDS                           */
+    int gen1;            /* > 0: the first gen1 workgroups are the resident generation, grid - gen1 follow (tail_pct) */
     char name[192];
 } rl_launch_plan;
 

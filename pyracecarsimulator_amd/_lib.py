@@ -32,14 +32,14 @@ class PlanOpts(C.Structure):
         "variant", "grid_mult", "wg_threads", "low_water", "sort_poses", "xcd_bands", "slots", "tiled",
         "inline_prep", "inline_max", "inline_map_kb", "stripe_max", "order_inline", "bin_multi_min",
         "bin_generic", "run_log2", "cddt_bins", "cddt_sort", "lut_debug", "debug_stamps", "slice_log2",
-        "cddt_theta_min", "cddt_search", "code_map", "code_min_rays", "code_entries")]
+        "cddt_theta_min", "cddt_search", "code_map", "code_min_rays", "tail_pct", "tail_wg_pct", "code_entries")]
 
 
 class LaunchPlan(C.Structure):
     """rl_launch_plan (include/scanlib.h)."""
     _fields_ = [(n, C.c_int) for n in (
         "kernel", "grid", "block", "lds_bytes", "binning", "record_source", "slots", "bands", "run_log2",
-        "k_max", "tiled", "aux", "crash", "nl", "ch", "slices", "slice_poses", "code", "code_entries")] + [("name", C.c_char * 192)]
+        "k_max", "tiled", "aux", "crash", "nl", "ch", "slices", "slice_poses", "code", "code_entries", "gen1")] + [("name", C.c_char * 192)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "name"}

@@ -197,6 +197,8 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "tiled")) h->tiled = value != 0;
     else if (!strcmp(name, "code_map")) h->code_map = value == 2 ? 2 : 0;
     else if (!strcmp(name, "code_min_rays")) h->code_min_rays = value < 0 ? 0 : value;
+    else if (!strcmp(name, "tail_pct")) h->tail_pct = value < 0 ? 0 : (value > 75 ? 75 : value);
+    else if (!strcmp(name, "tail_wg_pct")) h->tail_wg_pct = value < 10 ? 10 : (value > 400 ? 400 : value);
     else if (!strcmp(name, "pinned_max_rays")) h->pinned_max_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "direct_max_rays")) h->direct_max_rays = value < 0 ? 0 : value;
     else if (!strcmp(name, "overlap_min_rays")) h->overlap_min_rays = value < 0 ? 0 : value;
@@ -259,6 +261,8 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "tiled")) *value_out = h->tiled;
     else if (!strcmp(name, "code_map")) *value_out = h->code_map;
     else if (!strcmp(name, "code_min_rays")) *value_out = h->code_min_rays;
+    else if (!strcmp(name, "tail_pct")) *value_out = h->tail_pct;
+    else if (!strcmp(name, "tail_wg_pct")) *value_out = h->tail_wg_pct;
     else if (!strcmp(name, "code_entries")) *value_out = h->code_n;
     else if (!strcmp(name, "pinned_max_rays")) *value_out = h->pinned_max_rays;
     else if (!strcmp(name, "direct_max_rays")) *value_out = h->direct_max_rays;
@@ -735,6 +739,8 @@ static rl_plan_opts opts_of(const rl_method *h)
     o.slice_log2 = h->slice_log2;
     o.code_map = h->code_map;
     o.code_min_rays = h->code_min_rays;
+    o.tail_pct = h->tail_pct;
+    o.tail_wg_pct = h->tail_wg_pct;
     o.code_entries = (h->code_map && h->code_built == h->code_map && h->pdt_epoch == h->map->epoch) ? h->code_n : 0;
     return o;
 }
@@ -1142,6 +1148,8 @@ static int launch_rm_stream_family(const FanLaunch &L)
     StreamParams sp{};
     sp.code_tab = (const float *)h->ctab.p;
     sp.code_n = pl.code ? h->code_n : 0;
+    sp.tail_g1 = pl.gen1 > 0 ? pl.gen1 / std::max(pl.bands, 1) : 0;
+    sp.tail_pct = std::min(h->tail_pct, h->tail_wg_pct);
     sp.rec = (const PoseRec *)cx->rec_sorted.p;
     sp.order = (const uint32_t *)cx->order.p;
     sp.d0 = (const float *)cx->d0.p;

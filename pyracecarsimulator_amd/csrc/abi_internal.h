@@ -368,6 +368,7 @@ struct rl_method {
     // geometry does not fit, or more distinct steps than plan::CODE_MAX_ENTRIES)
     int code_map = 2;
     int code_min_rays = 1 << 22;
+    int tail_pct = 0, tail_wg_pct = 50;
     DevBuf cmap, cval, cidx, ctab, cnum;
     uint32_t *pin_cnum = nullptr;
     int code_n = 0;

@@ -416,6 +416,16 @@ __device__ __forceinline__ float vmin(float a, float b)
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// ... the same two written on the ONE set of compares (q_i <= x) that count_le / last_le use (round 6: the search kernel
+// issued 64 v_cmp per round of 32 look-ups, half of them the mirror image of the other half): the values are finite or
+// +inf and x is finite, so "not <=" is ">"
+__device__ __forceinline__ float first_gt_le(const float4 &q, float x, float none)
+{
+    float r = !(q.w <= x) ? q.w : none;
+    r = !(q.z <= x) ? q.z : r;
+    r = !(q.y <= x) ? q.y : r;
+    return !(q.x <= x) ? q.x : r;
+}
 // how many of a lane's four ascending values are <= x
 __device__ __forceinline__ uint32_t count_le(const float4 &q, float x)
 {
@@ -752,7 +762,7 @@ __device__ __forceinline__ void cddt_theta_search_bin(const MapParams &m, const 
 #pragma unroll
         for (int k = 0; k < CDDT_TK; ++k) {
             cn[k] = count_le(sq[k], lx[k]);
-            fs[k] = first_gt(sq[k], lx[k], INF);
+            fs[k] = first_gt_le(sq[k], lx[k], INF);
         }
         red8_add_min_x4(cn[0], fs[0], cn[1], fs[1], cn[2], fs[2], cn[3], fs[3]);
         float4 lq[CDDT_TK];
@@ -767,22 +777,29 @@ __device__ __forceinline__ void cddt_theta_search_bin(const MapParams &m, const 
         float f4[CDDT_TK], b4[CDDT_TK];
 #pragma unroll
         for (int k = 0; k < CDDT_TK; ++k) {
-            f4[k] = first_ge(lq[k], lx[k], INF);
+            // (first value > x and last value <= x on the same four compares; the first value >= x follows behind the
+            //  reduction: it is x itself exactly when the last value <= x is x)
+            f4[k] = first_gt_le(lq[k], lx[k], INF);
             b4[k] = last_le(lq[k], lx[k], -INF);
         }
         red8_min_max_x4(f4[0], b4[0], f4[1], b4[1], f4[2], b4[2], f4[3], b4[3]);
-        float my_f = 0.0f, my_b = 0.0f;
+        // lane k of the group stores look-up k: its five words are picked first, the ranges computed once
+        float m_fs = INF, m_f4 = INF, m_b4 = -INF, m_x = 0.0f;
         uint32_t my_flg = 0;
+        bool m_leaf = false;
 #pragma unroll
         for (int k = 0; k < CDDT_TK; ++k) {
-            const float x_ = lx[k];
-            const float rf = vmin((have_leaf[k] ? vmin(fs[k], f4[k]) : fs[k]) - x_, f.max_range);
-            const float rbk = vmin(x_ - (have_leaf[k] ? b4[k] : -INF), f.max_range);
-            const bool mine = c == k;                      // lane k of the group stores look-up k
-            my_f = mine ? rf : my_f;
-            my_b = mine ? rbk : my_b;
+            const bool mine = c == k;
+            m_fs = mine ? fs[k] : m_fs;
+            m_f4 = mine ? f4[k] : m_f4;
+            m_b4 = mine ? b4[k] : m_b4;
+            m_x = mine ? lx[k] : m_x;
+            m_leaf = mine ? have_leaf[k] : m_leaf;
             my_flg = mine ? flg[k] : my_flg;
         }
+        m_f4 = m_b4 == m_x ? m_x : m_f4;                   // first value >= x of the leaf
+        const float my_f = vmin((m_leaf ? vmin(m_fs, m_f4) : m_fs) - m_x, f.max_range);
+        const float my_b = vmin(m_x - (m_leaf ? m_b4 : -INF), f.max_range);
         // the round's 32 look-ups are the poses p0 + r * 32 + k * 8 + grp: lanes (grp, c = k < 4) write one 128-B line
         const int pq = p0 + r * 32 + c * 8 + grp;
         if (c < CDDT_TK && (my_flg & 1u) == 0u) {

@@ -73,6 +73,8 @@ inline void default_opts(rl_plan_opts &o)
     o.code_map = 2;           // u16 palette codes wherever the palette fits (profiles/r06/ab_code_map.txt)
     o.code_min_rays = 1 << 22;   // (cfg2's 4096 x 1081 and up)
     o.code_entries = 0;       // (a handle fills in its map's palette size)
+    o.tail_pct = 0;
+    o.tail_wg_pct = 50;
 }
 
 // Options as the planner may use them: every field a division, a shift or a template choice depends on is
@@ -106,6 +108,8 @@ inline rl_plan_opts sanitized(rl_plan_opts o)
     o.code_map = o.code_map == 2 ? 2 : 0;          // (u16 codes; 1 = u8 codes is not instantiated)
     o.code_entries = clampi(o.code_entries, 0, 1 << 30);
     o.code_min_rays = clampi(o.code_min_rays, 0, 1 << 30);
+    o.tail_wg_pct = clampi(o.tail_wg_pct, 10, 400);
+    o.tail_pct = clampi(o.tail_pct, 0, std::min(o.tail_wg_pct, 75));   // (a second-generation workgroup never owns more than a first-generation one)
     return o;
 }
 
@@ -452,6 +456,14 @@ inline int plan_one(const In &in, rl_launch_plan *p)
     const long want_q = (n_blocks + waves_per_wg - 1) / waves_per_wg;
     const long cap_q = (long)n_cu * o.grid_mult * WG / nt;
     p->grid = (int)std::max((long)bands, std::min(want_q, std::max(cap_q, 1L)));
+    // two generations: only launches that fill the machine (every resident slot taken, whole bands of workgroups) and have
+    // work to split (>= 32 blocks per workgroup)
+    if (o.tail_pct > 0 && bands > 1 && want_q >= cap_q && (long)p->grid == cap_q && p->grid % bands == 0 &&
+        n_blocks / p->grid >= 32) {
+        const int g1 = p->grid / bands, g2 = std::max(1, g1 * o.tail_wg_pct / 100);
+        p->gen1 = p->grid;
+        p->grid += g2 * bands;
+    }
     p->block = nt;
     int rl2 = o.run_log2;
     if (rl2 < 0) {

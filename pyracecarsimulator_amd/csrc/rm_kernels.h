@@ -1478,6 +1478,11 @@ struct StreamParams {
     // behind the header by every workgroup
     const float *code_tab;
     int code_n;
+    // TWO GENERATIONS of workgroups (round 6, lone whole-machine launches): the first tail_g1 workgroups of every band
+    // — the resident generation — split the band's first (100 - tail_pct) % of runs as before; the workgroups behind
+    // them split the rest and are dispatched as resident ones finish: the hardware's dispatcher is the work pool (a
+    // claim costs nothing), the launch no longer ends with its most loaded resident workgroup.  0: one generation.
+    int tail_g1, tail_pct;
 };
 
 
@@ -1676,10 +1681,22 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     const uint32_t seg_chunks = INLINE ? (seg_hi - seg_lo) * sp.cpp : (seg_rays + 63u) >> 6;
     const uint32_t rl = (uint32_t)sp.run_log2, rmask = (1u << rl) - 1u;
     const uint32_t seg_runs = (seg_chunks + rmask) >> rl;
-    const uint32_t K = (g < seg_runs ? (seg_runs - g + G - 1) / G : 0) << rl;
+    // (runs own_first, own_first + own_stride, ... below own_limit are this workgroup's)
+    uint32_t own_first = g, own_stride = G, own_limit = seg_runs;
+    if (sp.tail_g1 > 0 && G > (uint32_t)sp.tail_g1) {
+        const uint32_t G1 = (uint32_t)sp.tail_g1, R1 = seg_runs - (seg_runs * (uint32_t)sp.tail_pct) / 100u;
+        if (g < G1) {
+            own_stride = G1;
+            own_limit = R1;
+        } else {
+            own_first = R1 + (g - G1);
+            own_stride = G - G1;
+        }
+    }
+    const uint32_t K = (own_first < own_limit ? (own_limit - own_first + own_stride - 1) / own_stride : 0) << rl;
     const uint32_t total = K << 6;
     // i-th block of this workgroup's stream -> its index in the band / first ray of the block
-    auto blkidx_of = [&](uint32_t i) { return ((g + (i >> rl) * G) << rl) + (i & rmask); };
+    auto blkidx_of = [&](uint32_t i) { return ((own_first + (i >> rl) * own_stride) << rl) + (i & rmask); };
     auto blk_of = [&](uint32_t i) { return blkidx_of(i) << 6; };
     const unsigned lane = threadIdx.x & 63;
     if (INLINE) {
