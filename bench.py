@@ -279,9 +279,10 @@ def cpu_baseline(w, gmap, poses_all, method, seconds, check=None):
     return out
 
 
-def pmc_entry(workload, method, n, plan):
+def pmc_entry(workload, method, n, plan, mode=None):
     """The committed rocprofv3 PMC pass of EXACTLY this launch shape (profiles/pmc_traffic.json), or None:
-    workload, method, poses per launch, kernel (template arguments included) and grid must all match."""
+    workload, method, poses per launch, kernel (all template arguments, as the trace prints the symbol), grid and the
+    exchange mode that changes the kernel's stores ("steer": plain range stores for FollowGap) must all match."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             entries = json.load(f).get("entries", [])
@@ -289,7 +290,7 @@ def pmc_entry(workload, method, n, plan):
         return None
     for e in entries:
         if (e.get("workload") == workload and e.get("method") == method and e.get("poses") == n and
-                e.get("kernel") == plan["name"] and e.get("grid") == plan["grid"]):
+                e.get("kernel") == plan["name"] and e.get("grid") == plan["grid"] and e.get("mode") == mode):
             return e
     return None
 
@@ -911,7 +912,7 @@ def main():
         apply_schedule(True)
         k_ms = float(np.median(ks))
         serial_ach = bpr * n * B / (k_ms * 1e-3) / 1e9
-        pe = pmc_entry(a.workload, method, n, plan)
+        pe = pmc_entry(a.workload, method, n, plan, "steer" if mode == "steer" else None)
         traffic = pe["bytes"] if pe else None
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -227,7 +227,7 @@ def run_leg(spec, torch, dev, device_index, O=None, pmc_lookup=None, seed_shift=
         nbar = meth.get_info("cddt_values") / max(meth.get_info("cddt_nonempty_buckets"), 1)
     bpr = _alg_bytes(method, mean_steps, B, nbar)
     frac = bpr * rays / (ms * 1e-3) / HBM_PEAK
-    pe = pmc_lookup(wl, method, n, plan) if pmc_lookup else None
+    pe = pmc_lookup(wl, method, n, plan, "steer" if reduce_ == "steer" else None) if pmc_lookup else None
     frac_hbm = round(pe["bytes"] / (ms * 1e-3) / HBM_PEAK, 5) if pe else None
     out.update({"mrays_s": round(rays / (ms * 1e-3) / 1e6, 1), "ms_per_step": round(ms, 4),
                 # CDDT: the yardstick is the bytes the kernels of a step MOVE (committed PMC pass) / time / peak — SURVEY

@@ -5,7 +5,16 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 run() { name=$1; shift; python bench.py --no-cpu-baseline --no-other-configs "$@" > $OUT/$name.json 2> $OUT/$name.err || echo "FAILED $name"; tail -c 400 $OUT/$name.err | grep -i -E "error|Traceback" ; }
 run cfg2_default
+run cfg2_300steps --steps 300 --warmup 15
+run driver_cmd --gpus 1 --steps 20 --warmup 5
 run cfg2_steps20 --steps 20 --warmup 5
+run cfg2_variant3_literal --variant 3
+run cfg2_variant3_literal_serial --variant 3 --pipeline 1
+run cfg2_RM_canonical --method RM --variant 1
+run cfg2_crash --gather crash
+run cfg2_steer --gather steer
+run cfg2_f32map --opt code_map=0
+run cfg3_CDDT112 --workload cfg3 --method CDDT --theta-disc 112 --steps 40
 run cfg2_serial --pipeline 1
 run cfg2_RM --method RM
 run cfg2_BL --method BL --steps 60

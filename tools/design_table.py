@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Regenerate DESIGN.md section 5's table from the committed bench lines (profiles/r05/bench/*.json): the rows between
+"""Regenerate DESIGN.md section 5's table from the committed bench lines (profiles/r06/bench/*.json): the rows between
 the two `<!-- bench table -->` markers (or the R05_TABLE placeholder)."""
 import json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DIR = "profiles/r05/bench"
+DIR = "profiles/r06/bench"
 def L(n):
     p = os.path.join(ROOT, DIR, n + ".json")
     return json.loads(open(p).read().strip().splitlines()[-1]) if os.path.exists(p) else None
@@ -15,7 +15,9 @@ rows = [
  ("cfg2", "RMGPU, serial", "cfg2_serial"),
  ("cfg2, **upstream-literal arithmetic** (`--variant 3`), 300 steps", "RMGPU, 4 in flight", "cfg2_variant3_literal"),
  ("cfg2, upstream-literal", "RMGPU, serial", "cfg2_variant3_literal_serial"),
- ("cfg2", "RM (0.999), 4 in flight", "cfg2_RM"),
+ ("cfg2, `--method RM` (0.999; upstream-literal arithmetic by default)", "RM, 4 in flight", "cfg2_RM"),
+ ("cfg2, `--method RM --variant 1` (canonical)", "RM, 4 in flight", "cfg2_RM_canonical"),
+ ("cfg2 on the float32 step map (`--opt code_map=0`: round 5's kernel)", "RMGPU, 4 in flight", "cfg2_f32map"),
  ("cfg2, `--gather crash` (fused `Car::isCrashed`)", "RMGPU, 4 in flight", "cfg2_crash"),
  ("cfg2, `--gather steer` (scan + FollowGap)", "RMGPU, 4 in flight", "cfg2_steer"),
  ("cfg2", "Bresenham (K2b), 4 in flight", "cfg2_BL"),
@@ -24,7 +26,8 @@ rows = [
  ("cfg2, 200 poses (the reference's roll-out)", "RMGPU, serial", "cfg2_200"),
  ("cfg2, 32 768 poses", "RMGPU, 4 in flight / serial", ("cfg2_32k", "cfg2_32k_serial")),
  ("cfg3: 2000² maze, 65 536 × 1081", "GiantLUT θ 1442 (K3), serial", "cfg3_GLT_serial"),
- ("cfg3", "CDDT θ 108 (K3b, θ-major; θ 112: the driver line's `other_configs`), 4 in flight / serial", ("cfg3_CDDT", "cfg3_CDDT_serial")),
+ ("cfg3", "CDDT θ 108 (K3b, θ-major), 4 in flight / serial", ("cfg3_CDDT", "cfg3_CDDT_serial")),
+ ("cfg3", "CDDT θ 112 (the reference's bin count), 4 in flight", "cfg3_CDDT112"),
  ("cfg3", "RMGPU, serial", "cfg3_RMGPU"),
  ("cfg4: colombia, 1 048 576 roll-out poses × 1081", "RMGPU, serial", "cfg4_1M"),
  ("cfg4, one rank's shard of 8 (131 072 poses)", "RMGPU, serial", "cfg4_shard131072"),

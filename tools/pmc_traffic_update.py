@@ -9,6 +9,7 @@ import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof, workload, method, poses = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 note = sys.argv[5] if len(sys.argv) > 5 else None
+mode = sys.argv[6] if len(sys.argv) > 6 else None      # "steer": the same kernel with plain range stores + FollowGap behind it
 commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 summ = json.load(open(os.path.join(ROOT, prof, "pmc_summary.json")))
 path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -50,7 +51,8 @@ for key, v in summ.items():
     e["profile"] = prof
     if note:
         e["note"] = note
-    same = lambda o: all(o.get(k) == e[k] for k in ("workload", "method", "poses", "kernel", "grid"))
+    e["mode"] = mode
+    same = lambda o: all(o.get(k) == e[k] for k in ("workload", "method", "poses", "kernel", "grid", "mode"))
     doc["entries"] = [o for o in doc["entries"] if not same(o)] + [e]
     print("entry:", json.dumps(e))
 json.dump(doc, open(path, "w"), indent=1)
