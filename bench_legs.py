@@ -41,7 +41,7 @@ LEGS = (
     ("cfg2_steer", "cfg2", "RMGPU", 0, 4096, 4, "steer", 80, 7),
     ("cfg5_shard", "cfg5", "RMGPU", 0, 32768, 4, None, 40, 5),
     # cfg4: colombia (the one map the reference ships), one rank's shard of the 2^20 roll-out poses, serial
-    ("cfg4_shard", "cfg4", "RMGPU", 0, 131072, 1, None, 4, 3),
+    ("cfg4_shard", "cfg4", "RMGPU", 0, 131072, 1, None, 8, 5),
     # cfg4 as the reference's caller produces it (scripts/mcts.py:202-245): 4096 roll-outs x 200 control steps ->
     # 819 200 poses -> scan -> first crashed pose per roll-out, ONE host call (rl_car_rollout_check); run_rollout_leg
     ("cfg4_rollout_check", "cfg4", "RMGPU", 0, 4096, 1, "rollout", 5, 3),

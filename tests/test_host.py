@@ -434,3 +434,35 @@ def test_housekeeping_gates():
     for i in starts:
         j = next(k for k in range(i, len(src)) if src[k] == "}")
         assert j - i + 1 <= 100, (src[i], j - i + 1)
+
+
+def test_kernel_register_budgets_are_a_build_gate(tmp_path):
+    """the march loops pin physical VGPRs in inline assembly and the stream kernels are held at 64 VGPRs /
+    80 SGPRs for their eighth wave per SIMD — a compiler bump that spends one register more must fail the BUILD, not
+    silently cost 25 % (profiles/r05/sgpr_cap_ab.txt).  csrc/check_resources.py reads hipcc's kernel-resource-usage remarks
+    (the Makefile keeps them next to the objects and runs the check before it links): the current build passes, every
+    budgeted family is present, and a remark that is one register over fails."""
+    import subprocess, sys
+    csrc = os.path.join(ROOT, "pyracecarsimulator_amd", "csrc")
+    obj = os.path.join(csrc, ".obj")
+    if not (os.path.isdir(obj) and any(f.endswith(".remarks") for f in os.listdir(obj))):
+        _lib.build(force=True)                     # (a tree whose objects predate the remarks: rebuild once)
+    chk = os.path.join(csrc, "check_resources.py")
+    r = subprocess.run([sys.executable, chk, obj, "--print"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [ln for ln in r.stdout.splitlines() if "rm_fan_stream_kernel<" in ln]
+    assert len(rows) >= 40 and all(" occupancy 8" in ln for ln in rows), rows[:3]
+    assert any("true, true, 2, false, 2>" in ln for ln in rows)          # the code-map kernel is among them
+    # the gate itself: the same remarks with one kernel pushed to 65 VGPRs / 7 waves
+    text = open(os.path.join(obj, "abi_fan.remarks"), errors="replace").read()
+    i = text.index("rm_fan_stream_kernel")
+    j = text.index("VGPRs:", i)
+    k = text.index("Occupancy [waves/SIMD]:", i)
+    bad = text[:j] + "VGPRs: 65" + text[text.index("\n", j):k] + "Occupancy [waves/SIMD]: 7" + text[text.index("\n", k):]
+    d = tmp_path / "obj"
+    d.mkdir()
+    (d / "abi_fan.remarks").write_text(bad)
+    for f in ("abi_map.remarks", "abi_multi.remarks", "abi_car.remarks"):
+        (d / f).write_text(open(os.path.join(obj, f), errors="replace").read())
+    r = subprocess.run([sys.executable, chk, str(d)], capture_output=True, text=True)
+    assert r.returncode == 1 and "vgpr = 65" in r.stderr and "occupancy = 7" in r.stderr, r.stderr[-1500:]
