@@ -26,7 +26,7 @@ constexpr int INLINE_REC_BYTES = 32;     // one BlockRec per owned 64-ray block 
 constexpr int LIT_SLICE_POSES = 4096;    // upstream-literal stream form: poses per slice of a batch too large for one INLINE launch
 constexpr int CODE_MAX_ENTRIES = 4096;   // palette entries (16 KB of LDS) a code-map launch may carry; u16 codes hold 4 * index
 constexpr int DRAIN_CAP = 64, DRAIN_FIELDS = 7;   // several rays per lane: per-wave compaction scratch of the drain phase
-                                                  // (7 dwords per ray, 8 with the fused crash test)
+                                                  // (7 dwords per ray, 9 with the fused crash test)
 
 struct In {
     int kind = RL_RM_GPU, n_cu = 256, rows = 0, cols = 0, theta_disc = 0;
@@ -397,7 +397,7 @@ inline int plan_one(const In &in, rl_launch_plan *p)
         return (((size_t)STREAM_HDR + tabw + (in.crash ? 4 : 2) * (size_t)num_rays + 7) & ~(size_t)7) * sizeof(float);
     };
     size_t tables_b = tables_bytes(0);
-    const size_t drain_wave = (size_t)(DRAIN_FIELDS + (in.crash ? 1 : 0)) * DRAIN_CAP * 4;
+    const size_t drain_wave = (size_t)(DRAIN_FIELDS + (in.crash ? 2 : 0)) * DRAIN_CAP * 4;
     // auto: two rays per lane from 2^23 rays up, and from 2^20 on maps beyond the small-map bound (long rays:
     // +6 % on a lone 2049^2 launch of 1024 ... 16 384 poses since dry waves compact their last rays; colombia's
     // short rays lose 3 % — profiles/r03/sweep_serial_slots.txt)

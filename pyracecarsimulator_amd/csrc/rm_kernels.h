@@ -1616,7 +1616,7 @@ constexpr uint32_t NO_RAY = 0xffffffffu;       // output index of a slot that ho
 // A (through DRAIN_FIELDS x DRAIN_CAP dwords of LDS per wave) and finished by the one-ray-per-lane drain loops
 // (march_loop_capped / march_drain4).
 constexpr int DRAIN_CAP = 64;                  // capacity; the threshold is StreamParams::drain_cap <= DRAIN_CAP
-constexpr int DRAIN_FIELDS = 7;                // gx, gy, dx, dy, t, last step, output offset (+ 1 with the crash test: pose | beam)
+constexpr int DRAIN_FIELDS = 7;                // gx, gy, dx, dy, t, last step, output offset (+ 2 with the crash test)
 
 template <bool AUX, bool CRASH, int NT, bool INLINE, bool TILED, int SLOTS = 1, bool LIT = false, int CODE = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
@@ -1645,7 +1645,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     double *edge_l = reinterpret_cast<double *>(lds_f + STREAM_HDR + tabw + 2 * (size_t)f.num_rays);
     const size_t tables = STREAM_HDR + tabw + (CRASH ? 4 : 2) * (size_t)f.num_rays;
     // several rays per lane: per-wave compaction scratch of the drain phase (DRAIN_FIELDS x DRAIN_CAP dwords)
-    constexpr int DRAIN_F = DRAIN_FIELDS + (CRASH ? 1 : 0);
+    constexpr int DRAIN_F = DRAIN_FIELDS + (CRASH ? 2 : 0);
     constexpr size_t DRAIN_WORDS = (SLOTS >= 2 && TILED) ? (size_t)(NT / 64) * DRAIN_F * DRAIN_CAP : 0;
     uint32_t *drain_scr = reinterpret_cast<uint32_t *>(lds_f + ((tables + 7) & ~(size_t)7)) +
                           (size_t)(threadIdx.x >> 6) * DRAIN_F * DRAIN_CAP;
@@ -1742,10 +1742,9 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         float gx, gy, dx, dy, t, d_last;
         int pc, pr;
         uint32_t oidx;
-        uint32_t pj;           // CRASH only: pose << jb_bits | beam — ONE register (round 6: pose and beam in two cost the fused crash
-                               //   kernels 20..72 B of scratch per lane; pose * num_rays < 2^30, so pose fits 32 - jb_bits bits)
+        uint32_t pose;         // CRASH only
+        int jbeam;             // CRASH only
     };
-    const uint32_t jb_bits = 32u - (uint32_t)__builtin_clz(((uint32_t)f.num_rays - 1u) | 1u);
     // ray slot q of this workgroup's stream -> the lane's slot state; false: a padding slot (no ray).
     // s.oidx is the BYTE offset of the ray's range in `out` (the store needs no shift).
     auto claim = [&](Slot &s, uint32_t q) -> bool {
@@ -1776,7 +1775,10 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                 s.dy = __builtin_fmaf(st, cs.x, ct * cs.y);
             }
             s.oidx = valid ? rb.y + (l << 2) : NO_RAY;
-            if (CRASH) s.pj = (rb.w << jb_bits) | j;
+            if (CRASH) {
+                s.pose = rb.w;
+                s.jbeam = (int)j;
+            }
             // the sample at t = 0 was taken with the pose record (pose_first_step)
             s.d_last = __builtin_bit_cast(float, rb.x);
             s.t = valid ? s.d_last : __builtin_inff();
@@ -1796,17 +1798,19 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
         s.dx = __builtin_fmaf(pr_.ct, cs.x, -(pr_.st * cs.y));
         s.dy = __builtin_fmaf(pr_.st, cs.x, pr_.ct * cs.y);
         s.oidx = ((po & ~POSE_INVALID) * (uint32_t)f.num_rays + (uint32_t)j) << 2;
-        if (CRASH) s.pj = ((po & ~POSE_INVALID) << jb_bits) | (uint32_t)j;
+        if (CRASH) {
+            s.pose = po & ~POSE_INVALID;
+            s.jbeam = j;
+        }
         s.t = s.d_last = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sp.d0) + (si << 2));
         return true;
     };
     auto crash_test = [&](const Slot &s, float r) {
-        if (((double)r - edge_l[s.pj & ((1u << jb_bits) - 1u)]) < cp.thresh) {
-            const uint32_t pose = s.pj >> jb_bits;
-            uint32_t *seen = &crash_seen[pose & (STREAM_HDR - 3)];
-            if (*seen != pose) {              // (a race only costs a redundant atomic)
-                *seen = pose;
-                crash_note(cp, pose);
+        if (((double)r - edge_l[s.jbeam]) < cp.thresh) {
+            uint32_t *seen = &crash_seen[s.pose & (STREAM_HDR - 3)];
+            if (*seen != s.pose) {            // (a race only costs a redundant atomic)
+                *seen = s.pose;
+                crash_note(cp, s.pose);
             }
         }
     };
@@ -1814,7 +1818,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     if constexpr (SLOTS >= 2) {
         // ---------------- two (three) rays per lane (ranges, optionally the fused crash test; no diagnostics; tiled step map)
         static_assert(!(SLOTS >= 2) || !AUX, "multi-slot form: ranges (+ crash test), no diagnostics");
-        Slot sa{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, NO_RAY, 0u}, sb = sa, sc = sa;
+        Slot sa{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, NO_RAY, 0u, 0}, sb = sa, sc = sa;
         bool exhausted = total == 0;
         uint32_t left_n = 0;              // rays this wave hands to rm_leftover_kernel
         auto finish = [&](Slot &s) {
@@ -1908,7 +1912,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                                 q[0] = make_uint4(__builtin_bit_cast(uint32_t, s.gx), __builtin_bit_cast(uint32_t, s.gy),
                                                   __builtin_bit_cast(uint32_t, s.dx), __builtin_bit_cast(uint32_t, s.dy));
                                 q[1] = make_uint4(__builtin_bit_cast(uint32_t, s.t), __builtin_bit_cast(uint32_t, s.d_last),
-                                                  s.oidx, CRASH ? (s.pj >> jb_bits) : 0u);
+                                                  s.oidx, CRASH ? s.pose : 0u);
                             };
                             if (sa.t < f.max_range)
                                 hand(sa, __builtin_amdgcn_mbcnt_hi((uint32_t)(la >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)la, 0u)));
@@ -1928,7 +1932,10 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                             drain_scr[4 * DRAIN_CAP + r] = __builtin_bit_cast(uint32_t, s.t);
                             drain_scr[5 * DRAIN_CAP + r] = __builtin_bit_cast(uint32_t, s.d_last);
                             drain_scr[6 * DRAIN_CAP + r] = s.oidx;
-                            if (CRASH) drain_scr[7 * DRAIN_CAP + r] = s.pj;
+                            if (CRASH) {
+                                drain_scr[7 * DRAIN_CAP + r] = s.pose;
+                                drain_scr[8 * DRAIN_CAP + r] = (uint32_t)s.jbeam;
+                            }
                         };
                         if (sa.t < f.max_range)
                             put(sa, __builtin_amdgcn_mbcnt_hi((uint32_t)(la >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)la, 0u)));
@@ -1948,7 +1955,10 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                             sa.t = __builtin_bit_cast(float, drain_scr[4 * DRAIN_CAP + lane]);
                             sa.d_last = __builtin_bit_cast(float, drain_scr[5 * DRAIN_CAP + lane]);
                             sa.oidx = drain_scr[6 * DRAIN_CAP + lane];
-                            if (CRASH) sa.pj = drain_scr[7 * DRAIN_CAP + lane];
+                            if (CRASH) {
+                                sa.pose = drain_scr[7 * DRAIN_CAP + lane];
+                                sa.jbeam = (int)drain_scr[8 * DRAIN_CAP + lane];
+                            }
                         }
                         // ... and finish them with the one-ray-per-lane drain loops (value speculation on the step).
                         // Nothing of slots B / C is needed any more: the wave leaves from here (the drain loops use
@@ -1985,7 +1995,10 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
                                     sa.t = __builtin_bit_cast(float, drain_scr[4 * DRAIN_CAP + ri]);
                                     sa.d_last = __builtin_bit_cast(float, drain_scr[5 * DRAIN_CAP + ri]);
                                     if ((lane & (L - 1u)) == 0u) sa.oidx = drain_scr[6 * DRAIN_CAP + ri];
-                                    if (CRASH) sa.pj = drain_scr[7 * DRAIN_CAP + ri];
+                                    if (CRASH) {
+                                        sa.pose = drain_scr[7 * DRAIN_CAP + ri];
+                                        sa.jbeam = (int)drain_scr[8 * DRAIN_CAP + ri];
+                                    }
                                 }
                                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (reads done before the next re-ranking writes)
                                 continue;
@@ -2032,7 +2045,7 @@ void rm_fan_stream_kernel(PadMap pm, FanParams f, StreamParams sp, float *__rest
     }
 
     bool exhausted = total == 0;
-    Slot s1{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, NO_RAY, 0u};
+    Slot s1{0.f, 0.f, 0.f, 0.f, INF, 1.0f, 0, 0, NO_RAY, 0u, 0};
     // (s1.t < max_range  <=>  the lane is marching; d_last: PDT_HIT, PDT_OUTSIDE, or the free cell's step)
     uint32_t nstep = 0;
 
