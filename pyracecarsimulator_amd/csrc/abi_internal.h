@@ -65,8 +65,9 @@ struct rl_map {
     float res = 0, ox = 0, oy = 0, oyaw = 0;
     uint8_t *d_occ = nullptr;
     uint8_t *d_occ_base = nullptr;   // rl_map_stamp_cells: the occupancy as created / last rl_map_update'd (made at the first stamp)
-    int32_t *d_stamp = nullptr;      // ... the cell indices of a stamp
-    int stamp_cap = 0;
+    int32_t *d_stamp = nullptr;      // ... the cell indices of the stamp in place (restored by the next one)
+    int32_t *pin_stamp = nullptr;    // ... pinned, device-mapped landing buffer of a call's indices (no staging copy)
+    int stamp_cap = 0, n_stamped = 0;
     int *d_g = nullptr;          // EDT pass-1 scratch
     float *d_dt = nullptr;
     uint32_t *d_bits = nullptr;

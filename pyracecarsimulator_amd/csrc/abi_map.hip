@@ -307,8 +307,10 @@ extern "C" int rl_map_update(rl_map *m, const uint8_t *occ)
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyAsync(m->d_occ, occ, (size_t)m->rows * m->cols, hipMemcpyHostToDevice,
                           m->stream));
-    if (m->d_occ_base)                                // (a new base for later stamps)
+    if (m->d_occ_base) {                              // (a new base for later stamps; no outline is in place any more)
         HIPCHK(hipMemcpyAsync(m->d_occ_base, m->d_occ, (size_t)m->rows * m->cols, hipMemcpyDeviceToDevice, m->stream));
+        m->n_stamped = 0;
+    }
     rc = map_build_tables(m);
     if (rc) return rc;
     m->epoch++;
@@ -343,24 +345,31 @@ extern "C" int rl_map_stamp_cells(rl_map *m, const int32_t *flat_idx, int n, uin
     if (rc) return rc;
     HIPCHK(hipDeviceSynchronize());                  // launches the *_device entry points left in flight still read the tables
     const size_t cells = (size_t)m->rows * m->cols;
-    if (!m->d_occ_base) {
+    if (!m->d_occ_base) {                            // (first stamp: the map as it stands is the base)
         HIPCHK(hipMalloc((void **)&m->d_occ_base, cells));
         HIPCHK(hipMemcpyAsync(m->d_occ_base, m->d_occ, cells, hipMemcpyDeviceToDevice, m->stream));
-    } else {
+        m->n_stamped = 0;
+    }
+    if (n > m->stamp_cap) {
+        // (the list in place is lost with its buffer: restore the whole grid once)
         HIPCHK(hipMemcpyAsync(m->d_occ, m->d_occ_base, cells, hipMemcpyDeviceToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if (m->d_stamp) (void)hipFree(m->d_stamp);
+        if (m->pin_stamp) (void)hipHostFree(m->pin_stamp);
+        m->d_stamp = m->pin_stamp = nullptr;
+        m->stamp_cap = m->n_stamped = 0;
+        const int cap = std::max(n + 256, 1024);
+        HIPCHK(hipMalloc((void **)&m->d_stamp, (size_t)cap * sizeof(int32_t)));
+        HIPCHK(hipHostMalloc((void **)&m->pin_stamp, (size_t)cap * sizeof(int32_t), hipHostMallocDefault));
+        m->stamp_cap = cap;
     }
-    if (n > 0) {
-        if (n > m->stamp_cap) {
-            if (m->d_stamp) (void)hipFree(m->d_stamp);
-            m->d_stamp = nullptr;
-            m->stamp_cap = 0;
-            HIPCHK(hipMalloc((void **)&m->d_stamp, (size_t)(n + 256) * sizeof(int32_t)));
-            m->stamp_cap = n + 256;
-        }
-        HIPCHK(hipMemcpyAsync(m->d_stamp, flat_idx, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
-        hipLaunchKernelGGL(stamp_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, m->d_occ, cells,
-                           (const int32_t *)m->d_stamp, n, value);
-    }
+    // the indices land in pinned memory the kernel reads directly; ONE launch puts the previous outline's cells back
+    // and sets the new ones (the stream was synchronised above: the pinned buffer is not in use)
+    if (n > 0) memcpy(m->pin_stamp, flat_idx, (size_t)n * sizeof(int32_t));
+    if (n > 0 || m->n_stamped > 0)
+        hipLaunchKernelGGL(stamp_swap_kernel, dim3(1), dim3(1024), 0, m->stream, m->d_occ, (const uint8_t *)m->d_occ_base, cells,
+                           m->d_stamp, m->n_stamped, (const int32_t *)m->pin_stamp, n, value);
+    m->n_stamped = n;
     rc = map_build_tables(m);
     if (rc) return rc;
     m->epoch++;
@@ -379,6 +388,7 @@ extern "C" void rl_map_destroy(rl_map *m)
     if (m->d_occ) (void)hipFree(m->d_occ);
     if (m->d_occ_base) (void)hipFree(m->d_occ_base);
     if (m->d_stamp) (void)hipFree(m->d_stamp);
+    if (m->pin_stamp) (void)hipHostFree(m->pin_stamp);
     if (m->d_g) (void)hipFree(m->d_g);
     if (m->d_dt) (void)hipFree(m->d_dt);
     if (m->d_bits) (void)hipFree(m->d_bits);

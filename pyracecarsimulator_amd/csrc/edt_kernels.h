@@ -168,12 +168,20 @@ __global__ __launch_bounds__(256) void cddt_edges_kernel(const uint8_t *__restri
 
 // rl_map_stamp_cells: occupied cells laid over the map (the other car's outline of the two-player tick,
 // scripts/two_player/rcs_two_player.py:110-116): indices outside the grid are skipped, as the reference's guard skips them
-__global__ __launch_bounds__(256) void stamp_cells_kernel(uint8_t *__restrict__ occ, size_t n_cells,
+// ONE workgroup: the previous stamp's cells go back to the base map's values, then the new cells are set, and the new
+// list is kept (device side) as the next call's "previous" — a tick costs one launch, not a copy of the grid
+__global__ __launch_bounds__(1024) void stamp_swap_kernel(uint8_t *__restrict__ occ, const uint8_t *__restrict__ base,
+                                                          size_t n_cells, int32_t *__restrict__ prev, int n_prev,
                                                           const int32_t *__restrict__ idx, int n, uint8_t value)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
+    for (int i = threadIdx.x; i < n_prev; i += 1024) {
+        const int32_t c = prev[i];
+        if (c >= 0 && (size_t)c < n_cells) occ[c] = base[c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
         const int32_t c = idx[i];
+        prev[i] = c;
         if (c >= 0 && (size_t)c < n_cells) occ[c] = value;
     }
 }

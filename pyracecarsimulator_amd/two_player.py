@@ -41,28 +41,21 @@ class ScanSimulator2D:
         occ, res, org = range_libc.PyOMap._ingest(map_msg, None, None, None)
         key = (occ.shape, float(res), tuple(float(v) for v in org), float(mrx), int(theta_disc))
         if self.omap is not None and key == self._built_for:
-            # same grid geometry.  The reference's caller lays the other car's outline over the SAME original map before
-            # every scan (rcs_two_player.py:110-118): when the new grid is the base grid plus a few occupied cells, only
-            # those cell indices cross PCIe (rl_map_stamp_cells) — otherwise the whole grid (rl_map_update)
-            new = np.ascontiguousarray(occ, dtype=np.uint8) != 0
-            diff = np.flatnonzero(new.reshape(-1) != self._base.reshape(-1))
-            if diff.size <= self.STAMP_MAX and bool(new.reshape(-1)[diff].all()):
-                self.omap.stamp_cells(diff)
-            else:
-                self.omap.update(occ)
-                self._base = new.copy()
+            # same grid geometry: the device objects stay, the grid is re-uploaded and every table rebuilt in place.
+            # (Finding the outline by comparing the new grid with the previous one on the host costs more than the upload
+            #  it would save — 183 vs 171 us per tick on colombia, profiles/r06/cddt_latency.txt —: a caller that HAS the
+            #  outline cells uses build_with_outline.)
+            self.omap.update(occ)
             return
         self.omap = range_libc.PyOMap(map_msg)
         self.scan_method = range_libc.PyCDDTCast(self.omap, mrx, theta_disc)
-        self._base = np.ascontiguousarray(occ, dtype=np.uint8) != 0
         self._built_for = key
 
-    #: build(): grids that differ from the base map by at most this many newly occupied cells are sent as cell indices
-    STAMP_MAX = 4096
-
     def build_with_outline(self, bound_cells):
-        """The same tick when the caller has the outline CELLS at hand (flat indices x * map_width + y as
-        rcs_two_player.py:112-114 computes them): nothing but the indices is touched on the host."""
+        """The tick of rcs_two_player.py:105-121 without the grid crossing PCIe: ``bound_cells`` are the flat indices
+        ``x * map_width + y`` that :112-114 computes from ``Car::getBound``'s points; they are laid over the map ``build``
+        last uploaded (rl_map_stamp_cells: a stamp replaces the previous one, like ``ego_map[:] = org_map``) and every
+        table is rebuilt on the device."""
         self.omap.stamp_cells(bound_cells)
 
     def scan(self, x, y, theta):

@@ -1760,9 +1760,8 @@ def test_two_player_front_end_rebuilds_in_place(oracle_mod):
         om = oracle_mod.OracleMap(occ, g.resolution, g.origin, 300)
         want = om.cddt_rays(td, sim.input_vector)
         assert np.array_equal(out, want), tick
-        # (from the second tick on the outline travels as cell indices — rl_map_stamp_cells —, not as a grid: the device's
-        #  occupancy and EDT are those of the host-stamped grid, bit for bit)
         assert np.array_equal(sim.omap.occ != 0, occ != 0) and np.array_equal(sim.omap.distance_transform(), om.dt), tick
+    sim.build(maps.GridMap(g.occ, g.resolution, g.origin, name="base"), 300, td)          # the original map: the stamps' base
     # the caller has the outline cells at hand (rcs_two_player.py:110-116: x * map_width + y, indices past the grid skipped)
     cells = np.array([50 * g.cols + 100, 51 * g.cols + 100, 52 * g.cols + 101, g.rows * g.cols + 5, -3, 2**31 - 1], np.int64)
     sim.build_with_outline(cells)
@@ -1774,8 +1773,7 @@ def test_two_player_front_end_rebuilds_in_place(oracle_mod):
     assert np.array_equal(out, om.cddt_rays(td, sim.input_vector))
     sim.build_with_outline([])                                            # no outline: the original map again
     assert np.array_equal(sim.omap.distance_transform(), om0.dt) and np.array_equal(sim.omap.occ != 0, g.occ != 0)
-    # a grid that also FREES cells of the base map is not an outline: the whole grid is sent (rl_map_update), and it is
-    # the new base of later stamps
+    # a new grid through build() (rl_map_update) is the new base of later stamps
     occ = g.occ.copy()
     occ[100:104, 100:140] = 0
     occ[60:64, 210:214] = 1
@@ -1785,7 +1783,7 @@ def test_two_player_front_end_rebuilds_in_place(oracle_mod):
     assert np.array_equal(sim.omap.distance_transform(), om.dt)
     occ2 = occ.copy()
     occ2[70:73, 220:226] = 1
-    sim.build(maps.GridMap(occ2, g.resolution, g.origin, name="edited+outline"), 300, td)
+    sim.build_with_outline(np.flatnonzero((occ2 != 0).reshape(-1) & (occ == 0).reshape(-1)))
     om2 = oracle_mod.OracleMap(occ2, g.resolution, g.origin, 300)
     assert np.array_equal(sim.omap.distance_transform(), om2.dt)
     out = sim.scan(float(pose[0]), float(pose[1]), float(pose[2]))

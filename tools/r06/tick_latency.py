@@ -19,10 +19,13 @@ ins = np.zeros((B, 3), np.float32)
 ins[:, :2] = pose[0, :2]
 ins[:, 2] = pose[0, 2] + np.linspace(-4.71 / 2, 4.71 / 2, B, dtype=np.float32)
 outs = np.zeros(B, np.float32)
+# the other car's outline: a 6 x 8-cell block somewhere free (two places, alternating ticks)
+rr, cc = np.nonzero(dt >= 9.0)
 occ = [g.occ.copy(), g.occ.copy()]
-occ[0][190:196, 140:148] = 1
-occ[1][200:206, 150:158] = 1
+for o, k in zip(occ, (len(rr) // 3, 2 * len(rr) // 3)):
+    o[rr[k] - 3:rr[k] + 3, cc[k] - 4:cc[k] + 4] = 1
 cells = [np.flatnonzero((o != 0).reshape(-1) & (g.occ == 0).reshape(-1)).astype(np.int32) for o in occ]
+assert all(len(c) == 48 for c in cells), [len(c) for c in cells]
 med = lambda v: float(np.median(v)) * 1e6
 N = 300
 res = {}
@@ -48,12 +51,40 @@ for k in range(N):
     sim.build(maps_[k & 1], 300, 112)
     sim.scan(*[float(v) for v in pose[0]])
     ts.append(time.perf_counter() - t0)
-print("through two_player.ScanSimulator2D.build(map_msg) + scan(pose) (the facade diffs the grid against its base and sends the "
-      "%d new cells): %.1f us per tick (median of %d)" % (len(cells[0]), med(ts), N), flush=True)
+print("through two_player.ScanSimulator2D.build(map_msg) + scan(pose) (the grid re-uploaded): %.1f us per tick (median of %d)"
+      % (med(ts), N), flush=True)
+sim.build(maps.GridMap(g.occ, g.resolution, g.origin, name="base"), 300, 112)
 ts = []
 for k in range(N):
     t0 = time.perf_counter()
     sim.build_with_outline(cells[k & 1])
     sim.scan(*[float(v) for v in pose[0]])
     ts.append(time.perf_counter() - t0)
-print("through build_with_outline(cells) + scan(pose): %.1f us per tick" % med(ts), flush=True)
+print("through build_with_outline(%d cells) + scan(pose): %.1f us per tick" % (len(cells[0]), med(ts)), flush=True)
+
+# the same two ticks on a 2049^2 map (4.2 MB of grid per re-upload)
+from pyracecarsimulator_amd import workloads
+w = workloads.cfg2()
+g2 = w.gmap
+omap2 = range_libc.PyOMap(g2)
+m2 = range_libc.PyCDDTCast(omap2, 300, 112)
+dt2 = omap2.distance_transform()
+pose2 = maps.sample_free_poses(g2, 1, 3, 2.0, dt2)
+ins[:, :2] = pose2[0, :2]
+ins[:, 2] = pose2[0, 2] + np.linspace(-4.71 / 2, 4.71 / 2, B, dtype=np.float32)
+rr, cc = np.nonzero(dt2 >= 9.0)
+occ2 = [g2.occ.copy(), g2.occ.copy()]
+for o, k in zip(occ2, (len(rr) // 3, 2 * len(rr) // 3)):
+    o[rr[k] - 3:rr[k] + 3, cc[k] - 4:cc[k] + 4] = 1
+cells2 = [np.flatnonzero((o != 0).reshape(-1) & (g2.occ == 0).reshape(-1)).astype(np.int32) for o in occ2]
+for name, tick in (("grid re-uploaded (rl_map_update, %d B)" % g2.occ.size, lambda k: omap2.update(occ2[k & 1])),
+                   ("outline as cell indices (rl_map_stamp_cells, %d B)" % (4 * len(cells2[0])), lambda k: omap2.stamp_cells(cells2[k & 1]))):
+    for k in range(5):
+        tick(k); m2.calc_range_many(ins, outs)
+    t_up, t_scan = [], []
+    for k in range(60):
+        t0 = time.perf_counter(); tick(k); t1 = time.perf_counter()
+        m2.calc_range_many(ins, outs); t2 = time.perf_counter()
+        t_up.append(t1 - t0); t_scan.append(t2 - t1)
+    print("maze 2049^2, CDDT theta_disc 112, %s: map tables %.1f us | CDDT rebuild + %d-beam scan %.1f us | tick %.1f us (median of 60)"
+          % (name, med(t_up), B, med(t_scan), med(np.add(t_up, t_scan))), flush=True)
