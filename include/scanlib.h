@@ -277,9 +277,14 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *   schedule   variant (1 stream kernel | 0 chunk-per-wave | 2 occ_fan_lds: unit steps on an LDS occupancy
  *              window, approximate | 3 the UPSTREAM-LITERAL arithmetic of RL_RM / RL_RM_GPU — range_libc's CPU
  *              statement: per-ray glibc sinf / cosf, un-fused products and sums —, the ONE option that changes result
- *              bits: onto the checker's libm form.  A production mode since round 5: same entry points, same stream
- *              kernel schedule, fused crash test and noise included, ~0.93x the default's rate), grid_mult, wg_threads, low_water (-1 auto), run_log2 (-1 auto), xcd_bands,
+ *              bits: onto the checker's libm form.  A production mode since round 5 — same entry points, same stream
+ *              kernel schedule, fused crash test and noise included, ~0.87x the canonical rate — and since round 6 the
+ *              DEFAULT of RL_RM (the class that names range_libc's CPU RayMarching); RL_RM_GPU defaults to 1; a negative
+ *              value restores the kind's default), grid_mult, wg_threads, low_water (-1 auto), run_log2 (-1 auto), xcd_bands,
  *              sort_poses, tiled (step-map layout), slots (rays per lane: 1 | 2 | 3 | 0 auto),
+ *              code_map (2: launches of >= code_min_rays rays read the step map as 16-bit palette codes, palette in LDS —
+ *              the same sample sequence on half the bytes; 0: float32 steps), code_min_rays (default 2^22),
+ *              tail_pct / tail_wg_pct (a second generation of workgroups for whole-machine launches: measured, off),
  *              cddt_bins (one look-up per pose and table bin), cddt_theta_min (poses from which the look-ups
  *              run theta-major: all poses against one table bin at a time), cddt_lds_sort
  *   binning    inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min,
@@ -299,7 +304,8 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *              non-temporal GiantLUT row loads — the A/B partner of the default)
  *   multi-device handles: every option goes to every device's replica; multi_min_poses (poses per device
  *              from which another device is brought in, default 512) belongs to the handle itself.
- * rl_method_get_info additionally answers n_devices, n_cu, clock_khz, last_grid, map_epoch and, for RL_CDDT
+ * rl_method_get_info additionally answers n_devices, n_cu, clock_khz, last_grid, map_epoch, code_entries (palette entries of
+ * the handle's map incl. the two stop codes; 0 = no code map: option off, geometry or palette does not fit) and, for RL_CDDT
  * (builds the table if needed, synchronises): cddt_values, cddt_buckets, cddt_nonempty_buckets.          */
 int rl_method_set_option(rl_method *h, const char *name, int value);
 int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
@@ -307,7 +313,8 @@ int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
  * Which kernel, grid, LDS size and pose-binning pass a fan call of (n_poses x num_rays) takes is
  * decided by ONE pure function of the map shape, the device's CU count and the options above —
  * no device, no handle state: rl_plan_fan can be called (and is tested) on a box without a GPU.
- * rl_method_plan_fan applies it with a handle's current options; every launch goes through the
+ * rl_method_plan_fan applies it with a handle's current options (a ray-marching handle with the code map on builds its
+ * step map first — the one thing a plan needs from the device is the map's palette size); every launch goes through the
  * same function and rl_method_last_plan returns the plan the last launch of the handle used
  * (`name` is the kernel as a rocprofv3 kernel trace prints it, template arguments included).     */
 /* Which fields still carry weight (round 4; every default is a measured optimum, profiles/r03/plan_sweep.txt):
@@ -317,7 +324,8 @@ int rl_method_get_info(rl_method *h, const char *name, int64_t *value_out);
  *                                  low_water (-1 = automatic) — change them only with a sweep in hand
  *   arithmetic                     variant 3: range_libc's CPU arithmetic stated literally — glibc sinf / cosf per ray,
  *                                  un-fused products and sums — bit-identical to the checker's libm form; the stream
- *                                  kernel's schedule (rm_fan_stream_kernel<.., LIT>), 0.93x the default's rate
+ *                                  kernel's schedule (rm_fan_stream_kernel<.., LIT>), 0.87x the canonical rate; -1 (the
+ *                                  struct's default) = the kind's default: 3 for RL_RM, 1 otherwise
  *   kernel selection for A/B       variant (0 chunk kernel, 2 occ_fan_lds), group_drain, handoff (round 5's measured and
  *                                  rejected drain forms), cddt_search (0 = round 4's search kernel), tiled (0 = row-major step map; the
  *                                  planner clears it by itself when the tiled geometry does not fit), cddt_bins
@@ -348,7 +356,7 @@ typedef struct rl_plan_opts {
 typedef enum rl_kernel_id {
     RL_K_NONE = 0,
     RL_K_RM_CHUNK = 1,      /* rm_fan_kernel<AUX, CRASH>: one 64-beam chunk per wave (variant 0)          */
-    RL_K_RM_STREAM = 2,     /* rm_fan_stream_kernel<AUX, CRASH, NT, INLINE, TILED, SLOTS> (default)       */
+    RL_K_RM_STREAM = 2,     /* rm_fan_stream_kernel<AUX, CRASH, NT, INLINE, TILED, SLOTS, LIT, CODE> (default) */
     RL_K_OCC_LDS = 3,       /* occ_fan_lds_kernel<AUX> (variant 2)                                        */
     RL_K_BL_STREAM = 4,     /* bl_fan_stream_kernel<AUX, 1024>                                            */
     RL_K_BL_LDS = 5,        /* bl_fan_kernel<AUX> (variant 0)                                             */
@@ -359,7 +367,7 @@ typedef enum rl_kernel_id {
     RL_K_CDDT_THETA = 10,   /* cddt_theta_search[2]_kernel + cddt_theta_fan_kernel | cddt_theta_fused_kernel (large batches) */
     RL_K_RM_LITERAL = 11,   /* rm_literal_kernel<AUX, RAYS>: upstream-literal arithmetic, one lane per ray — variant 3 with
                                diagnostics (hit cells / sample counts), the 2-argument per-ray form, fans below 64 beams */
-    RL_K_RM_STREAM_LIT = 12 /* rm_fan_stream_kernel<false, CRASH, 1024, true, true, SLOTS, true>: variant 3 in production —
+    RL_K_RM_STREAM_LIT = 12 /* rm_fan_stream_kernel<false, CRASH, 1024, true, true, SLOTS, true, CODE>: variant 3 in production —
                                the upstream-literal arithmetic on the stream kernel's schedule (ranges, fused crash test,
                                noise; two rays per lane; batches above 8192 poses in pose slices)                 */
 } rl_kernel_id;

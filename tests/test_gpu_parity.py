@@ -458,6 +458,33 @@ def test_code_map_is_engaged_and_bit_identical(oracle_mod):
         omap.close()
 
 
+def test_code_map_falls_back_when_the_palette_does_not_fit(oracle_mod):
+    """A map with more distinct steps than the LDS palette holds (an open 900^2 room with a few obstacles and a 700-cell range:
+    every d^2 = a^2 + b^2 up to 700^2 occurs — tens of thousands of them against plan::CODE_MAX_ENTRIES = 4096): the handle
+    reports no code map, the plan stays on the float32 step map, the results are the oracle's.  And a range so long that
+    the palette's d^2 histogram itself would not fit (max_range 2000 cells) does the same without trying."""
+    occ = np.zeros((900, 900), np.uint8)
+    occ[0, :] = occ[-1, :] = occ[:, 0] = occ[:, -1] = 1
+    occ[450, 450] = occ[100, 700] = occ[777, 123] = 1
+    g = maps.GridMap(occ, 0.05, (-3.0, -2.0, 0.3), "open900")
+    B, fov = 720, 6.0
+    for mrx in (700, 2000):
+        om = oracle_mod.OracleMap.from_gridmap(g, mrx)
+        omap = range_libc.PyOMap(g)
+        poses = maps.sample_free_poses(g, 96, 5, dt=om.dt)
+        m = range_libc.PyRayMarchingGPU(omap, mrx)
+        m.set_option("slots", 2)
+        m.set_option("code_min_rays", 0)
+        got = np.empty(len(poses) * B, np.float32)
+        m.calc_range_fan(poses, got, fov, B)
+        assert m.get_info("code_map") == 2 and m.get_info("code_entries") == 0, (mrx, m.get_info("code_entries"))
+        pl = m.last_plan()
+        assert pl["code"] == 0 and pl["name"].endswith(", 2, false, 0>"), pl
+        assert np.array_equal(got, om.rm_fan(poses, fov, B, step_coeff=1.0, nthreads=4, want_hits=False, want_steps=False)[0]), mrx
+        m.close()
+        omap.close()
+
+
 def test_upstream_literal_mode_in_production_shape(oracle_mod):
     """variant 3 as a PRODUCTION mode: the upstream-literal arithmetic — per-ray theta_p +
     (-fov/2 + j * inc) in float32, glibc sinf / cosf at claim time, un-fused position and hit range, calc_range(y, x,
