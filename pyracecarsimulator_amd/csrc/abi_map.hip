@@ -26,7 +26,7 @@ const std::string &last_error() { return g_err; }
 void set_last_error(const std::string &msg) { g_err = msg; }
 
 extern "C" const char *rl_last_error(void) { return g_err.c_str(); }
-extern "C" const char *rl_version(void) { return "scanlib-amd 0.5 (gfx950)"; }
+extern "C" const char *rl_version(void) { return "scanlib-amd 0.6 (gfx950)"; }
 
 extern "C" int rl_device_count(void)
 {
