@@ -2,6 +2,8 @@
 // section 8f): the MCTS roll-out generator, FollowGap, 16-bit ranges for the xGMI exchange, diagnostics probes, the
 // car-outline table and Car::isCrashed on the host.
 #include "abi_internal.h"
+#include <array>
+#include <utility>
 #include "car_kernels.h"
 #include "consumer_kernels.h"
 #include "probe_kernels.h"
@@ -207,6 +209,7 @@ struct rl_followgap {
     FollowGapParams P{};
     int window_size = 0;           // kept for the caller; FollowGap::eval never reads it
     int n_cu = 256;                // (queried once: hipGetDeviceProperties costs the host tens of microseconds per call)
+    bool walk_kernel = false;      // diagnostics (environment RL_FOLLOWGAP_WALK=1 at create): followgap_kernel at every size
     hipStream_t stream = nullptr;
     DevBuf scans, angles;
     std::mutex mu;
@@ -226,6 +229,8 @@ extern "C" int rl_followgap_create(int device, int window_size, float max_distan
     g->P.max_distance = max_distance;
     g->P.max_angle = max_angle;
     g->P.angle_inc = angle_inc;
+    const char *walk = getenv("RL_FOLLOWGAP_WALK");
+    g->walk_kernel = walk && walk[0] == '1';
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) {
         delete g;
@@ -248,6 +253,15 @@ extern "C" void rl_followgap_destroy(rl_followgap *g)
     delete g;
 }
 
+// followgap_bits_kernel<ROWS>, ROWS = 1 ... FG_ROWS
+typedef void (*fg_bits_fn)(const float *, int, FollowGapParams, float *);
+template <int... R>
+static constexpr std::array<fg_bits_fn, sizeof...(R)> fg_bits_make(std::integer_sequence<int, R...>)
+{
+    return {{followgap_bits_kernel<R + 1>...}};
+}
+static const std::array<fg_bits_fn, FG_ROWS> fg_bits_table = fg_bits_make(std::make_integer_sequence<int, FG_ROWS>());
+
 static int followgap_launch(rl_followgap *g, const float *d_scans, int n_scans, int size,
                             float *d_angles, hipStream_t stream)
 {
@@ -259,8 +273,11 @@ static int followgap_launch(rl_followgap *g, const float *d_scans, int n_scans, 
     FollowGapParams p = g->P;
     p.size = size;
     const int grid = std::min(n_scans, g->n_cu * 32);
-    hipLaunchKernelGGL(followgap_kernel, dim3(grid), dim3(64), (size_t)size * sizeof(float), stream,
-                       d_scans, n_scans, p, d_angles);
+    if (size <= 64 * FG_ROWS && !g->walk_kernel)
+        fg_bits_table[(size + 63) / 64 - 1]<<<dim3(grid), dim3(64), 0, stream>>>(d_scans, n_scans, p, d_angles);
+    else
+        hipLaunchKernelGGL(followgap_kernel, dim3(grid), dim3(64), (size_t)size * sizeof(float), stream,
+                           d_scans, n_scans, p, d_angles);
     HIPCHK(hipGetLastError());
     return RL_OK;
 }

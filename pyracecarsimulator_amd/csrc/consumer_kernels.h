@@ -155,6 +155,154 @@ __global__ __launch_bounds__(64) void followgap_kernel(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------
+// followgap_bits_kernel: the same four passes for scans of up to 64 * FG_ROWS beams, the beams of a scan held in
+// registers (beam 64 u + lane in row u of every lane: coalesced loads, all issued before the first is looked at) and
+// the gap search done on ONE BIT PER BEAM.  followgap_kernel above spends ~1700 wave instructions per 1081-beam scan
+// (two unrolled per-beam walks under lane-divergent branches, LDS round trips, 30 ds_bpermute shuffles), which made
+// `--gather steer` 0.70 of the plain scan: with several scans in flight the consumer competes with the march for
+// issue slots.  Here:
+//   preprocessLidar + min_point — per row: clamp (select), running strict minimum (rows ascend, so within a lane the
+//                                 index order is the beam order); one (value, index) butterfly over the wave;
+//   findMaxGap                  — `v > 1.75` per row is a v_cmp whose 64-bit result IS 64 consecutive bits of the
+//                                 scan's bit string; the rows go through LDS (17 words) and every lane takes a chunk
+//                                 of ceil(size / 64) consecutive bits plus the bit in front of it;
+//   safetyBubble                — the zeroed beams (best-5 ... best+4) are one contiguous range: cleared in the lane's bits;
+//                                 the next zero behind a chunk: a ballot of the lanes that hold one, a 64-bit shift
+//                                 and one shuffle; the runs that START in a chunk are walked with ctz (a scan has
+//                                 few, the loop runs to the wave's maximum);
+//                                 (length desc, start asc) as one packed key, a max-butterfly;
+//   getSteerAng                 — the raw beam read back from the registers (v_readlane), lane 0.
+// ------------------------------------------------------------------------------
+constexpr int FG_ROWS = 20;                                // scans of up to 1280 beams
+
+// v_writelane_b32 (clang has no builtin for it; as the intrinsic, not as inline asm: the compiler must see it to keep the
+// two wait states gfx950 needs between a VALU write of an SGPR and a VALU read of it)
+extern "C" __device__ int fg_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ int fg_dpp_quad1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); }
+__device__ __forceinline__ int fg_dpp_quad2(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false); }
+__device__ __forceinline__ int fg_dpp_half_mirror(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false); }
+__device__ __forceinline__ int fg_dpp_mirror(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false); }
+
+// ROWS = ceil(size / 64): the rows below ROWS - 2 hold 64 beams that all exist and are all clamped (size - 10 > 64 (ROWS - 2))
+template <int ROWS>
+__global__ __launch_bounds__(64) void followgap_bits_kernel(const float *__restrict__ scans, int n_scans,
+                                                            FollowGapParams p, float *__restrict__ angles)
+{
+    static_assert(ROWS >= 1 && ROWS <= FG_ROWS, "one instantiation per row count");
+    __shared__ uint32_t bits[2 * ROWS + 4];                // dword 0 = 0 (the bit in front of beam 0), beam i = bit 32 + i
+    const int lane = threadIdx.x;
+    const int size = p.size;                               // 64 (ROWS - 1) < size <= 64 ROWS (the host picks ROWS)
+    constexpr int cl = ROWS;                               // bits per lane: 64 * cl >= size
+    for (int s = blockIdx.x; s < n_scans; s += gridDim.x) {
+        const float *lidar = scans + (size_t)s * size;
+        float raw[ROWS];
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            if (u < ROWS - 1) raw[u] = lidar[64 * u + lane];
+            else raw[u] = 64 * u + lane < size ? lidar[64 * u + lane] : 0.0f;
+        }
+        const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, raw[0])));
+        float best_v = x0 > p.max_distance && size > 10 ? p.max_distance : x0;
+        int best_u = -1;                                   // row of the lane's minimum (-1: the seed, beam 0)
+        uint32_t wlo = 0, whi = 0;                         // lane u: bits of row u
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            float x = raw[u];
+            if (u < ROWS - 2) x = x > p.max_distance ? p.max_distance : x;
+            else x = (64 * u + lane < size - 10 && x > p.max_distance) ? p.max_distance : x;
+            // running rule `v[i] != 0 && v[i] < v[min_point]` (NaN never passes; beams past the end are 0)
+            const bool take = x != 0.0f && x < best_v;
+            best_v = take ? x : best_v;
+            best_u = take ? u : best_u;
+            const unsigned long long w = __ballot(x > 1.75f);
+            wlo = (uint32_t)fg_writelane((int)(uint32_t)w, u, (int)wlo);
+            whi = (uint32_t)fg_writelane((int)(uint32_t)(w >> 32), u, (int)whi);
+        }
+        int best_i = best_u < 0 ? 0 : 64 * best_u + lane;
+        if (lane < ROWS) { bits[1 + 2 * lane] = wlo; bits[2 + 2 * lane] = whi; }
+        if (lane == 0) { bits[0] = 0u; bits[1 + 2 * ROWS] = 0u; bits[2 + 2 * ROWS] = 0u; }
+        // ---- (value, index) minimum over the wave; a NaN seed is the same in every lane and index 0 survives
+        {
+            auto step = [&](float ov, int oi) {
+                const bool take = ov < best_v || (ov == best_v && oi < best_i);
+                best_v = take ? ov : best_v;
+                best_i = take ? oi : best_i;
+            };
+            step(__builtin_bit_cast(float, fg_dpp_quad1(__builtin_bit_cast(int, best_v))), fg_dpp_quad1(best_i));
+            step(__builtin_bit_cast(float, fg_dpp_quad2(__builtin_bit_cast(int, best_v))), fg_dpp_quad2(best_i));
+            step(__builtin_bit_cast(float, fg_dpp_half_mirror(__builtin_bit_cast(int, best_v))), fg_dpp_half_mirror(best_i));
+            step(__builtin_bit_cast(float, fg_dpp_mirror(__builtin_bit_cast(int, best_v))), fg_dpp_mirror(best_i));
+            step(__shfl_xor(best_v, 16), __shfl_xor(best_i, 16));
+            step(__shfl_xor(best_v, 32), __shfl_xor(best_i, 32));
+        }
+        __syncthreads();
+        // ---- the lane's chunk: beams [a, a + cl), and the beam in front of it as bit 0 of `e`
+        const int a = cl * lane;
+        const int pos = 31 + a;
+        const uint32_t d0 = bits[pos >> 5], d1 = bits[(pos >> 5) + 1];
+        uint32_t e = (uint32_t)((((unsigned long long)d1 << 32) | d0) >> (pos & 31)) & ((2u << cl) - 1u);
+        // safety bubble (:67-79, `for i = -5; i < 5`): beams best-5 ... best+4 inside (0, size - 1) and the centre itself —
+        // one contiguous range [lo_b, hi_b]
+        {
+            const int lo_b = min(best_i, max(best_i - 5, 1));
+            const int hi_b = max(best_i, min(best_i + 4, size - 2));
+            const int b0 = max(lo_b - (a - 1), 0), b1 = min(hi_b - (a - 1), cl);
+            if (b0 <= b1) e &= ~(((2u << (b1 - b0)) - 1u) << b0);
+        }
+        const uint32_t full = (1u << cl) - 1u;
+        const uint32_t m = (e >> 1) & full;
+        // the next beam <= 1.75 behind the chunk: the first lane after this one that holds a zero, its first zero
+        const int fz_abs = a + __builtin_ctz(~m);          // (== a + cl when the chunk is all ones; not used then)
+        const unsigned long long zl = __ballot(m != full);
+        const unsigned long long zs = (zl >> lane) >> 1;
+        const int nl = lane + 1 + (zs ? __builtin_ctzll(zs) : 0);
+        int next_zero = __shfl(fz_abs, nl & 63);
+        next_zero = zs ? min(next_zero, size) : size;
+        // ---- the runs that start in this chunk
+        uint32_t starts = m & ~(e & full);                 // bit u: beam a+u > 1.75 and the beam in front of it is not
+        uint32_t key = 0;
+        while (__ballot(starts != 0)) {
+            if (starts) {
+                const int st = __builtin_ctz(starts);
+                starts &= starts - 1;
+                const int z = __builtin_ctz(~(m >> st));   // bits >= cl of m are 0: z <= cl - st
+                const int len = st + z < cl ? z : next_zero - (a + st);
+                const uint32_t k = ((uint32_t)len << 11) | (uint32_t)(2047 - (a + st));
+                key = k > key ? k : key;
+            }
+        }
+        {
+            auto mx = [&](int o) { key = (uint32_t)o > key ? (uint32_t)o : key; };
+            mx(fg_dpp_quad1((int)key));
+            mx(fg_dpp_quad2((int)key));
+            mx(fg_dpp_half_mirror((int)key));
+            mx(fg_dpp_mirror((int)key));
+            mx(__shfl_xor((int)key, 16));
+            mx(__shfl_xor((int)key, 32));
+        }
+        key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);         // every lane holds the maximum: scalar from here
+        const int run_len = (int)(key >> 11);
+        const int run_start = run_len ? 2047 - (int)(key & 2047u) : 0;
+        const int best = (run_start + run_start + run_len + 1) / 2;        // findBestPoint(start, start+len+1), uniform
+        const int bi = best < size ? best : size - 1;
+        float d = 0.0f;
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u)
+            if (u == (bi >> 6)) d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, raw[u]), bi & 63));
+        if (lane == 0) {
+            float angle;
+            if (best > size / 2) angle = (float)(-p.angle_inc * ((size / 2.0) - best));
+            else angle = (float)(p.angle_inc * (best - (size / 2.0)));
+            angle = 2 * (angle / d);
+            const float lo_a = -p.max_angle;
+            const float a1 = (angle < lo_a) ? lo_a : angle;
+            angles[s] = (p.max_angle < a1) ? p.max_angle : a1;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------
 // Ranges as 16-bit fixed point for the multi-GPU exchange (opt-in, LOSSY, labelled wherever it is used):
 // q = rint(clamp(r, 0, max) * 65535 / max), r' = q * max / 65535 — half the bytes of the all-gather of
 // ranges over xGMI (BASELINE.json north_star) at max/65535/2 = 0.11 mm of error for the reference's 15 m

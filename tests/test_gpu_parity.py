@@ -1570,7 +1570,7 @@ def test_followgap_kernel_reproduces_reference_build_vectors():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [10, 64, 65, 720, 1081, 1217, 1280, 1281, 4097])
+@pytest.mark.parametrize("size", [10, 11, 63, 64, 65, 128, 129, 720, 1081, 1088, 1089, 1217, 1280, 1281, 4097])
 def test_followgap_batches_equal_the_oracle(oracle_mod, size):
     from pyracecarsimulator_amd.followgap import PyFollowGap
     rng = np.random.default_rng(size)
@@ -1592,6 +1592,37 @@ def test_followgap_batches_equal_the_oracle(oracle_mod, size):
     assert same.all(), np.where(~same)[0][:10]
     flat = fg.eval_many(scans.reshape(-1), size)
     assert np.array_equal(flat.view(np.uint32), got.view(np.uint32))
+    # structured scans for the one-bit-per-beam search (followgap_bits_kernel, size <= 1280): runs of every length (many per
+    # lane chunk, runs over many chunks, runs that end at the last beam), ties between equal runs, the minimum — and with it
+    # the safety bubble — at the ends of the scan, next to and inside the longest run, values on either side of 1.75 by one ulp
+    n2 = 400
+    s2 = np.empty((n2, size), np.float32)
+    for k in range(n2):
+        mean = [1.2, 2.0, 4.0, 9.0, 40.0, 300.0][k % 6]
+        v, pos, hi = np.empty(size, np.float32), 0, bool(k & 1)
+        while pos < size:
+            ln = int(rng.geometric(1.0 / mean))
+            v[pos:pos + ln] = rng.choice([1.7500001, 2.0, 9.0, 14.0]) if hi else rng.choice([1.75, 1.7499999, 1.0, 0.0])
+            pos, hi = pos + ln, not hi
+        if k % 5 == 1:                                           # two equal longest runs: the first wins
+            ln = max(2, size // 5)
+            v[:] = 1.0
+            v[1:1 + ln] = 3.0
+            v[size - 1 - ln:size - 1] = 3.0
+        where = [0, 1, 4, 5, 6, size - 1, size - 2, size - 6, size // 2, int(rng.integers(size))][k % 10]
+        if k % 3:
+            v[where] = 0.25                                      # the unique minimum: the bubble covers where-5 ... where+4
+        s2[k] = v
+    # (a steering limit nothing reaches: every `best` beam gives its own angle)
+    for blk in (s2, scans):
+        got2 = PyFollowGap(10, 15.0, 1.0e6, 0.004).eval_many(blk)
+        want2 = np.array([oracle_mod.followgap_eval(blk[i], 15.0, 1.0e6, 0.004) for i in range(len(blk))], np.float32)
+        same2 = (got2.view(np.uint32) == want2.view(np.uint32)) | (np.isnan(got2) & np.isnan(want2))
+        assert same2.all(), np.where(~same2)[0][:10]
+    got2 = fg.eval_many(s2)
+    want2 = np.array([oracle_mod.followgap_eval(s2[i], 15.0, 0.4189, 0.004) for i in range(n2)], np.float32)
+    same2 = (got2.view(np.uint32) == want2.view(np.uint32)) | (np.isnan(got2) & np.isnan(want2))
+    assert same2.all(), np.where(~same2)[0][:10]
 
 
 @pytest.mark.gpu
