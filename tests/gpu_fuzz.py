@@ -21,11 +21,50 @@ def run(seconds, seed):
     return n_cases
 
 
+def followgap_case(r):
+    """FollowGap::eval for a batch of random scans (consumer_kernels.h: followgap_bits_kernel up to 1280 beams, followgap_kernel
+    beyond) against the CPU restatement, bit for bit: runs of random lengths around the 1.75 threshold, zeros, NaNs, the minimum
+    anywhere, random clamp / steering limits."""
+    from pyracecarsimulator_amd.followgap import PyFollowGap
+    size = int(r.choice([10, 11, 37, 64, 65, 127, 128, 360, 720, 1081, 1280, 1281, int(r.integers(10, 1400)), int(r.integers(10, 3000))]))
+    md = float(r.choice([15.0, 1.0, 1.75, 3.0, 100.0]))
+    ma = float(r.choice([0.4189, 1.0e6, 0.01]))
+    inc = float(r.choice([0.004, 0.0058, 0.1]))
+    n = int(r.choice([1, 3, 40, 130]))
+    scans = np.empty((n, size), np.float32)
+    for k in range(n):
+        mean = float(r.choice([1.1, 2.0, 5.0, 20.0, 100.0, 1000.0]))
+        pos, hi = 0, bool(r.integers(0, 2))
+        while pos < size:
+            ln = int(r.geometric(1.0 / mean))
+            val = r.choice([1.7500001, 2.0, 9.0, 14.0, 40.0]) if hi else r.choice([1.75, 1.7499999, 1.0, 0.0, 0.5])
+            scans[k, pos:pos + ln] = val * (1.0 if r.random() < 0.5 else r.uniform(1.0, 1.0001))
+            pos, hi = pos + ln, not hi
+        kind = r.integers(0, 6)
+        if kind == 0:
+            scans[k] = r.uniform(0.0, 20.0, size)
+        elif kind == 1:
+            scans[k, r.integers(0, size)] = np.nan
+        elif kind == 2:
+            scans[k, r.integers(0, size, 3)] = -1.0
+        if r.random() < 0.7:
+            scans[k, int(r.choice([0, 1, 5, size - 1, size - 2, size - 6, int(r.integers(0, size))]))] = 0.25
+    fg = PyFollowGap(10, md, ma, inc)
+    got = fg.eval_many(scans)
+    want = np.array([O.followgap_eval(scans[i], md, ma, inc) for i in range(n)], np.float32)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), "FollowGap size %d md %g ma %g inc %g: scans %s" % (size, md, ma, inc, np.where(~same)[0][:5])
+
+
 def one_case(seed):
     if True:
         if os.environ.get("FUZZ_TRACE"):
             print("case", seed, flush=True)
         r = np.random.default_rng(seed)
+        try:
+            followgap_case(np.random.default_rng(seed ^ 0x5F0))
+        except AssertionError as e:
+            raise AssertionError("MISMATCH seed=%d: %s" % (seed, e))
         rows, cols = int(r.integers(1, 400)), int(r.integers(1, 400))
         kind = r.integers(0, 4)
         if kind == 0:
