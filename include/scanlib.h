@@ -288,7 +288,10 @@ int rl_last_kernel_ms(rl_method *h, float *ms_out);
  *              cddt_bins (one look-up per pose and table bin), cddt_theta_min (poses from which the look-ups
  *              run theta-major: all poses against one table bin at a time), cddt_lds_sort
  *   binning    inline_prep, inline_max, inline_map_kb, stripe_max, order_inline, bin_multi_min,
- *              bin_generic, bin_ppw (poses per workgroup of the grid-wide binning kernels)
+ *              bin_generic, bin_ppw (poses per workgroup of the grid-wide binning kernels), tile_stripe (order of the map
+ *              tiles the poses are binned by: N > 0 = tile rows in stripes of N, a stripe walked column by column, so that
+ *              a band of the pose list sweeps its part of the map once; 0 = row-major; -1, the default = the tile rows
+ *              one of xcd_bands bands of evenly spread poses holds)
  *   launches   slice_log2 (pose slices below 2^n rays), pinned_max_rays (zero-copy host calls), direct_max_rays (a result
  *              buffer in a block of rl_host_alloc is written by the kernel itself up to this many rays, by DMA beyond),
  *              overlap_min_rays (plain host-pointer scans of at least this many rays — default 2^24 — run as four pose

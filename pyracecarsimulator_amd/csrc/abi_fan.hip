@@ -192,6 +192,7 @@ extern "C" int rl_method_set_option(rl_method *h, const char *name, int value)
     else if (!strcmp(name, "timing")) h->timing = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "bin_multi_min")) h->bin_multi_min = value;
     else if (!strcmp(name, "bin_ppw")) h->bin_ppw = value < 256 ? 256 : (value > 8192 ? 8192 : value);
+    else if (!strcmp(name, "tile_stripe")) h->tile_stripe = value < 0 ? -1 : (value > 4096 ? 4096 : value);
     else if (!strcmp(name, "inline_prep")) h->inline_prep = value != 0;
     else if (!strcmp(name, "bin_generic")) h->bin_generic = value != 0;
     else if (!strcmp(name, "tiled")) h->tiled = value != 0;
@@ -256,6 +257,7 @@ extern "C" int rl_method_get_info(rl_method *h, const char *name, int64_t *value
     else if (!strcmp(name, "timing")) *value_out = h->timing;
     else if (!strcmp(name, "bin_multi_min")) *value_out = h->bin_multi_min;
     else if (!strcmp(name, "bin_ppw")) *value_out = h->bin_ppw;
+    else if (!strcmp(name, "tile_stripe")) *value_out = h->tile_stripe;
     else if (!strcmp(name, "inline_prep")) *value_out = h->inline_prep;
     else if (!strcmp(name, "bin_generic")) *value_out = h->bin_generic;
     else if (!strcmp(name, "tiled")) *value_out = h->tiled;
@@ -644,8 +646,15 @@ static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_po
     const int do_sort = (binning == RL_BIN_GRID_UNSORTED || (binning == RL_BIN_GENERIC && !(h->sort_poses && n_poses >= 64))) ? 0 : 1;
     int shift = 6;
     while ((long)((m->cols >> shift) + 1) * ((m->rows >> shift) + 1) > 8192) ++shift;
-    const int tiles_x = (m->cols >> shift) + 1;
-    const int n_tiles = tiles_x * ((m->rows >> shift) + 1);
+    // (tile_key: tile rows in stripes walked column by column; -1: as many tile rows as an XCD band of evenly spread poses holds)
+    auto striped = [&](int tx, int sh) {
+        const int tiles_y = (m->rows >> sh) + 1;
+        int rps = h->tile_stripe < 0 ? std::max(1, (m->rows >> sh) / std::max(1, h->xcd_bands)) : h->tile_stripe;
+        if (rps >= tiles_y || !do_sort) rps = 0;
+        return tx | (rps << 16);
+    };
+    const int tiles_x = striped((m->cols >> shift) + 1, shift);
+    const int n_tiles = ((m->cols >> shift) + 1) * ((m->rows >> shift) + 1);
     if (binning == RL_BIN_GRID_SORT || binning == RL_BIN_GRID_UNSORTED) {
         const int ppw = h->bin_ppw;
         const int n_wg = (n_poses + ppw - 1) / ppw;
@@ -654,8 +663,8 @@ static int bin_poses(rl_method *h, LaunchCtx &cx, const float *d_poses, int n_po
             // one scan over (tile, workgroup) -> scatter from LDS cursors
             int cshift = shift;
             while ((long)((m->cols >> cshift) + 1) * ((m->rows >> cshift) + 1) > 1024) ++cshift;
-            const int ctx = (m->cols >> cshift) + 1;
-            const int cnt = ctx * ((m->rows >> cshift) + 1);
+            const int ctx = striped((m->cols >> cshift) + 1, cshift);
+            const int cnt = ((m->cols >> cshift) + 1) * ((m->rows >> cshift) + 1);
             const size_t n_ctr = (size_t)cnt * n_wg;
             if ((rc = cx.hist.ensure((n_ctr + cnt) * sizeof(uint32_t)))) return rc;     // counters, then tile totals
             hipLaunchKernelGGL(pose_prep_kernel, dim3(n_wg), dim3(256), (size_t)cnt * 4, stream,

@@ -354,6 +354,7 @@ struct rl_method {
     std::vector<double> edge_host; // the car-outline table last uploaded to `edge` (re-sent only when it changes)
     int *pin_flag = nullptr;       // pinned landing slot for the crash index
     int bin_multi_min = 8192;    // batches at least this large bin poses with grid-wide kernels
+    int tile_stripe = -1;        // binning order: tile rows per stripe walked column-major (rm_kernels.h tile_key); 0: row-major, -1: by xcd_bands
     int bin_ppw = POSES_PER_WG;  // ... poses per workgroup of those kernels
     int order_inline = 1;        // big maps, stripe_max..8192 poses: keys-only binning launch + INLINE march
     int stripe_max = 1536;       // big maps, inline_max..stripe_max poses: no binning launch, workgroups compact

@@ -338,6 +338,20 @@ __device__ __forceinline__ float pose_first_step(const MapParams &m, float gx, f
     return v <= 0.0f ? 0.0f : __builtin_fmaxf(v * coeff, 1.0f);
 }
 
+// Tile (ty, tx) -> its rank in the binning order.  `tiles_xs` = tiles_x | stripe << 16.  stripe == 0: row-major.  Else the
+// tile rows are grouped in stripes of `stripe` rows and a stripe is walked COLUMN by column: a band of the sorted pose
+// list (an XCD's share) then sweeps its part of the map once, left to right, with a window one stripe tall — in row-major
+// order every tile row of the band sweeps the whole map width again and re-reads what the row above it read (the step
+// map of one sweep plus its max_range halo is larger than what an L2 shared by several launches keeps).
+__device__ __forceinline__ uint32_t tile_key(int ty, int tx, int tiles_xs, int n_tiles)
+{
+    const int tiles_x = tiles_xs & 0xffff, rps = tiles_xs >> 16;
+    if (rps == 0) return (uint32_t)(ty * tiles_x + tx);
+    const int tiles_y = n_tiles / tiles_x;
+    const int y0 = (ty / rps) * rps, h = min(rps, tiles_y - y0);
+    return (uint32_t)(y0 * tiles_x + tx * h + (ty - y0));
+}
+
 __device__ __forceinline__ uint32_t pose_record(const MapParams &m, const float *__restrict__ poses,
                                                 int p, int tile_shift, int tiles_x, int n_tiles,
                                                 PoseRec &r, bool walk_outside = false)
@@ -361,7 +375,7 @@ __device__ __forceinline__ uint32_t pose_record(const MapParams &m, const float 
         r.gx = 0.0f; r.gy = 0.0f; r.ct = 1.0f; r.st = 0.0f;
         return ((uint32_t)n_tiles - 1) | POSE_INVALID;
     }
-    return (uint32_t)(((int)r.gy >> tile_shift) * tiles_x + ((int)r.gx >> tile_shift));
+    return tile_key((int)r.gy >> tile_shift, (int)r.gx >> tile_shift, tiles_x, n_tiles);
 }
 
 // The record of a pose in the UPSTREAM-LITERAL arithmetic (variant 3, stream kernel template argument LIT):
@@ -486,8 +500,7 @@ __global__ __launch_bounds__(1024) void pose_bin_small_kernel(MapParams m, const
                 float gx, gy, thg;
                 world_to_grid(m, poses[3 * (size_t)p], poses[3 * (size_t)p + 1], 0.0f, gx, gy, thg);
                 const bool inb = gx > -1.0f && gx < m.fcols && gy > -1.0f && gy < m.frows;   // (NaN -> false)
-                kf[u] = inb ? (uint32_t)(((int)gy >> tile_shift) * tiles_x + ((int)gx >> tile_shift))
-                            : (uint32_t)n_tiles - 1;
+                kf[u] = inb ? tile_key((int)gy >> tile_shift, (int)gx >> tile_shift, tiles_x, n_tiles) : (uint32_t)n_tiles - 1;
             } else {
                 kf[u] = pose_record(m, poses, p, tile_shift, tiles_x, n_tiles, r[u], walk_outside != 0);
             }

@@ -117,7 +117,7 @@ def one_case(seed):
                                  "tiled": int(r.integers(0, 2)), "low_water": int(r.choice([0, 5, 12, 24, 40])),
                                  "run_log2": int(r.choice([-1, 0, 2, 5])), "xcd_bands": int(r.choice([1, 3, 8])),
                                  "grid_mult": int(r.choice([1, 8])), "wg_threads": int(r.choice([256, 512, 1024])),
-                                 "bin_multi_min": int(r.choice([64, 8192])), "bin_ppw": int(r.choice([256, 512, 2048])), "pinned_max_rays": int(r.choice([0, 262144])),
+                                 "bin_multi_min": int(r.choice([64, 8192])), "bin_ppw": int(r.choice([256, 512, 2048])), "tile_stripe": int(r.choice([-1, 0, 1, 3, 100])), "pinned_max_rays": int(r.choice([0, 262144])),
                                  "slots": int(r.choice([1, 2, 3])), "spec_drain": int(r.choice([0, 8, 64])),
                                  "spec_stretch": int(r.choice([1, 4, 16])), "drain_cap": int(r.choice([1, 24, 64])),
                                  "drain_stretch": int(r.choice([1, 8])), "handoff": int(r.integers(0, 2)), "group_drain": int(r.choice([0, 2, 16])),

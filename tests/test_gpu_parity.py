@@ -93,6 +93,12 @@ def test_device_edt_bit_equal_to_oracle(oracle_mod, case):
     {"variant": 1, "slots": 2, "grid_mult": 1, "tail_pct": 25},                  # two generations of workgroups (round 6 A/B: off by default)
     {"variant": 1, "slots": 2, "grid_mult": 1, "tail_pct": 40, "tail_wg_pct": 200, "inline_prep": 0, "code_min_rays": 0},
     {"variant": 1, "slots": 1, "grid_mult": 1, "tail_pct": 15, "inline_map_kb": 0, "stripe_max": 0},
+    {"variant": 1, "slots": 2, "tile_stripe": 0, "inline_map_kb": 0, "stripe_max": 0},          # binning tiles row-major (default: stripes of tile rows, column by column)
+    {"variant": 1, "slots": 2, "tile_stripe": 3, "inline_map_kb": 0, "stripe_max": 0, "xcd_bands": 3},
+    {"variant": 1, "slots": 2, "tile_stripe": 1, "inline_prep": 0},
+    {"variant": 1, "slots": 2, "tile_stripe": 2, "inline_prep": 0, "bin_generic": 1},
+    {"variant": 1, "slots": 2, "tile_stripe": 5, "inline_prep": 0, "bin_multi_min": 64, "code_map": 2, "code_min_rays": 0},
+    {"variant": 1, "tile_stripe": 4096, "inline_prep": 0, "bin_multi_min": 64},                 # (more rows than the map has tiles: row-major)
 ])
 def test_every_kernel_schedule_is_bit_identical(oracle_mod, opts):
     g = maps.make_maze(400, cell=40, wall=3, p=0.45, seed=21, origin=(-7.0, 3.0, -0.4))
