@@ -13,6 +13,7 @@ run cfg2_variant3_literal_serial --variant 3 --pipeline 1
 run cfg2_RM_canonical --method RM --variant 1
 run cfg2_crash --gather crash
 run cfg2_steer --gather steer
+run cfg2_steer_serial --gather steer --pipeline 1
 run cfg2_f32map --opt code_map=0
 run cfg3_CDDT112 --workload cfg3 --method CDDT --theta-disc 112 --steps 40
 run cfg2_serial --pipeline 1
@@ -31,6 +32,7 @@ run cfg3_CDDT_serial --workload cfg3 --method CDDT --steps 40 --pipeline 1
 run cfg3_RMGPU --workload cfg3 --method RMGPU --steps 40
 run cfg4_1M --workload cfg4 --steps 10 --warmup 2
 run cfg4_shard131072 --workload cfg4 --poses 131072 --steps 40 --warmup 4
+run cfg4_shard131072_steer --workload cfg4 --poses 131072 --steps 10 --warmup 2 --gather steer
 run cfg4_4096 --workload cfg4 --poses 4096
 run cfg5 --workload cfg5 --steps 20 --warmup 3
 run cfg5_shard32768 --workload cfg5 --poses 32768 --steps 60
