@@ -19,7 +19,7 @@ rows = [
  ("cfg2, `--method RM --variant 1` (canonical)", "RM, 4 in flight", "cfg2_RM_canonical"),
  ("cfg2 on the float32 step map (`--opt code_map=0`: round 5's kernel)", "RMGPU, 4 in flight", "cfg2_f32map"),
  ("cfg2, `--gather crash` (fused `Car::isCrashed`)", "RMGPU, 4 in flight", "cfg2_crash"),
- ("cfg2, `--gather steer` (scan + FollowGap)", "RMGPU, 4 in flight", "cfg2_steer"),
+ ("cfg2, `--gather steer` (scan + FollowGap, one bit per beam)", "RMGPU, 4 in flight", "cfg2_steer"),
  ("cfg2", "Bresenham (K2b), 4 in flight", "cfg2_BL"),
  ("cfg2", "CDDT θ 108 (pose-major), 4 in flight", "cfg2_CDDT"),
  ("cfg2, 2048 poses", "RMGPU, 4 in flight / serial", ("cfg2_2048", "cfg2_2048_serial")),
