@@ -216,7 +216,9 @@ int rl_check_collision_groups_device(rl_method *h, const float *d_poses_p3, int 
  * steering angle per scan out, one wave per scan.  Bit-identical to the reference's compiled
  * header (tests/golden/followgap_ref.npz).  size < 10 -> RL_ERR_INVALID (the reference indexes
  * out of bounds there); a gap consisting of the single last beam reads beam size-1 where the
- * reference reads one past the array.                                                           */
+ * reference reads one past the array.  Scans of up to 1280 beams run the one-bit-per-beam kernel
+ * (consumer_kernels.h: followgap_bits_kernel), longer ones the per-beam walk (followgap_kernel);
+ * RL_FOLLOWGAP_WALK=1 in the environment at create time forces the walk (A/B, diagnostics).      */
 typedef struct rl_followgap rl_followgap;
 int rl_followgap_create(int device, int window_size, float max_distance, float max_angle,
                         float angle_inc, rl_followgap **out);
